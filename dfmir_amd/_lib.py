@@ -1,0 +1,100 @@
+"""ctypes binding of libdfmir_hip.so (the C ABI declared in include/dfmir_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel launch fails the
+call raises.  Nothing here imports `oracle/`.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_void_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfmir_hip.so")
+
+
+class DfConvGeom(Structure):
+    """Mirror of `struct DfConvGeom` (include/dfmir_hip.h)."""
+    _fields_ = [(n, c_int) for n in (
+        "N", "Cin", "Cout", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "KD", "KH", "KW",
+        "stride", "dil", "pd", "ph", "pw", "pad_mode", "act")] + [("slope", c_float)]
+
+
+P = c_void_p
+_GP = POINTER(DfConvGeom)
+_SIGS = {
+    "dfmir_abi_version": [],
+    "dfmir_conv_fwd": [_GP, P, P, P, P, P],
+    "dfmir_conv_wgrad": [_GP, P, P, P, P],
+    "dfmir_bias_grad": [P, P, c_int, c_int, c_longlong, P],
+    "dfmir_weight_pack": [P, P, c_int, c_int, c_int, c_int, P],
+    "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],
+    "dfmir_instnorm_fwd": [P, P, P, P, P, c_int, c_longlong, c_float, c_int, P],
+    "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P],
+    "dfmir_act_bwd": [P, P, P, c_longlong, c_int, c_float, P],
+    "dfmir_blur_down_fwd": [P, P, c_int, c_int, c_int, P],
+    "dfmir_blur_down_bwd": [P, P, c_int, c_int, c_int, P],
+    "dfmir_blur_up_fwd": [P, P, c_int, c_int, c_int, P],
+    "dfmir_blur_up_bwd": [P, P, c_int, c_int, c_int, P],
+    "dfmir_reflect_pad2d_fwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "dfmir_reflect_pad2d_bwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "dfmir_upcat_fwd": [P, P, P] + [c_int] * 7 + [P],
+    "dfmir_upcat_bwd": [P, P, P] + [c_int] * 7 + [P],
+    "dfmir_cat_channels_fwd": [P, P, P, c_longlong, c_longlong, c_longlong, P],
+    "dfmir_cat_channels_bwd": [P, P, P, c_longlong, c_longlong, c_longlong, P],
+    "dfmir_scale": [P, P, c_longlong, c_float, P],
+    "dfmir_warp2d_fwd": [P, P, P] + [c_int] * 6 + [P],
+    "dfmir_warp2d_bwd": [P, P, P, P, P] + [c_int] * 6 + [P],
+    "dfmir_warp3d_fwd": [P, P, P] + [c_int] * 7 + [P],
+    "dfmir_warp3d_bwd": [P, P, P, P, P] + [c_int] * 7 + [P],
+    "dfmir_resize_fwd": [P, P] + [c_int] * 7 + [c_float, P],
+    "dfmir_resize_bwd": [P, P] + [c_int] * 7 + [c_float, P],
+    "dfmir_patch_gather_fwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
+    "dfmir_patch_gather_bwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
+    "dfmir_l2norm_fwd": [P, P, P, c_int, c_longlong, c_float, P],
+    "dfmir_l2norm_bwd": [P, P, P, P, c_int, c_longlong, c_float, P],
+    "dfmir_patchnce_fwd": [P, P, P, P, c_longlong, c_int, c_int, c_float, P],
+    "dfmir_patchnce_bwd": [P, P, P, P, c_longlong, c_int, c_int, c_float, P],
+    "dfmir_masked_l1_fwd": [P, P, P, c_float, P, P, c_longlong, P],
+    "dfmir_masked_l1_bwd": [P, P, P, c_float, P, P, P, P, c_longlong, P],
+    "dfmir_flow_smooth_fwd": [P, P, P] + [c_int] * 5 + [P],
+    "dfmir_flow_smooth_bwd": [P, P, P] + [c_int] * 5 + [P],
+    "dfmir_ncc_fwd": [P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
+    "dfmir_ncc_bwd": [P, P, P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
+    "dfmir_sum_scaled": [P, P, c_longlong, c_float, P],
+    "dfmir_fill_from_scalar": [P, P, c_longlong, c_float, P],
+    "dfmir_adam_step": [P, P, P, P, c_longlong] + [c_float] * 7 + [P],
+}
+
+_lib = None
+
+
+class DfmirHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfmirHipError(
+                "libdfmir_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C dfmir_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        h.dfmir_last_error.argtypes = []
+        h.dfmir_last_error.restype = ctypes.c_char_p
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dfmir_last_error()
+        raise DfmirHipError(msg.decode() if msg else "dfmir_hip error %d" % rc)
+
+
+def exported_symbols():
+    return sorted(list(_SIGS.keys()) + ["dfmir_last_error"])

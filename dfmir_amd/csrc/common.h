@@ -1,0 +1,92 @@
+// Shared device helpers for the dfmir_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dfmir_hip.h"
+
+#define DF_LAUNCH_CHECK()                                  \
+  do {                                                     \
+    hipError_t e_ = hipGetLastError();                     \
+    if (e_ != hipSuccess) return df_set_error((int)e_, __FILE__, __LINE__); \
+  } while (0)
+#define DF_ARG_CHECK(cond)                                 \
+  do {                                                     \
+    if (!(cond)) return df_set_error(-1, __FILE__, __LINE__); \
+  } while (0)
+
+int df_set_error(int code, const char* file, int line);
+
+static inline unsigned df_grid(long long n, int bs, long long cap = 1LL << 20) {
+  long long b = (n + bs - 1) / bs;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+// 64-wide wavefront reductions (CDNA wave = 64 lanes).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). Result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* sm /* >= 17 floats */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  if (wid == 0) {
+    float t = (lane < nw) ? sm[lane] : 0.f;
+    t = wave_sum(t);
+    if (lane == 0) sm[16] = t;
+  }
+  __syncthreads();
+  return sm[16];
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  if (wid == 0) {
+    float t = (lane < nw) ? sm[lane] : -3.0e38f;
+    t = wave_max(t);
+    if (lane == 0) sm[16] = t;
+  }
+  __syncthreads();
+  return sm[16];
+}
+
+// Input coordinate of output index o / tap t along one axis.
+//   c = o*stride - pad + t ; dil>1 means the input is (virtually) zero-dilated
+//   (transposed convolution == dgrad of a strided conv).
+// pad_mode 0 = zero padding (returns false when outside), 1 = reflect (always inside).
+__device__ __forceinline__ bool df_in_coord(int o, int t, int stride, int pad, int dil, int size,
+                                            int pad_mode, int& idx) {
+  int c = o * stride - pad + t;
+  if (dil == 1) {
+    if (pad_mode == 1) {
+      if (c < 0) c = -c;
+      if (c >= size) c = 2 * (size - 1) - c;
+      c = c < 0 ? 0 : (c >= size ? size - 1 : c);
+      idx = c;
+      return true;
+    }
+    idx = c;
+    return (unsigned)c < (unsigned)size;
+  }
+  if (c < 0) { idx = 0; return false; }
+  int q = c / dil;
+  idx = q;
+  return (q * dil == c) && (q < size);
+}

@@ -1,0 +1,529 @@
+// Implicit-GEMM convolutions on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view (NCHW / NCDHW, "weights-stationary" orientation):
+//     Y[co][p] = sum_k  Wt[k][co] * Xg[k][p],   k = (tap, ci),  p = (n, oz, oy, ox)
+// MFMA A operand = weights (rows = output channels), B operand = gathered input pixels (cols =
+// pixels), so that one accumulator register holds 32 CONSECUTIVE PIXELS of one channel across
+// lanes 0..31 -> every store instruction writes two fully-coalesced 128-byte runs of an NCHW plane.
+//
+// K is walked tap-major: for each filter tap the input offset / padding predicate of a pixel is
+// computed ONCE and reused for a chunk of `kc` (<=16, even) input channels, which are Cin/nchunks
+// rounded to even so that odd channel counts (34, 48, 2 ...) waste < 6 % of the MFMA issue slots.
+// Tiles go global -> registers -> LDS (double buffered, one barrier per K step); fp32 MFMA is
+// 64 cycles per 32x32x2 so the per-element gather arithmetic hides under the matrix pipe.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+  DfConvGeom g;
+  int kc, nchunks;
+};
+
+static inline void df_chunking(int Cin, int& kc, int& nchunks) {
+  nchunks = (Cin + 15) / 16;
+  int per = (Cin + nchunks - 1) / nchunks;
+  kc = (per + 1) & ~1;
+  if (kc < 2) kc = 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / dgrad kernel
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
+                                                   const float* __restrict__ wt,
+                                                   const float* __restrict__ bias,
+                                                   float* __restrict__ y, ConvK k) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
+  constexpr int NA = BK * BM / 256, NB = BK * BN / 256;
+  constexpr int RSB = 256 / BN;            // B rows covered per pass (BN<=256)
+  constexpr int RSA = 256 / BM;            // A rows covered per pass (BM<=256)
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BN <= 256 && BM <= 256, "tile");
+  __shared__ float As[2][BK][BM];
+  __shared__ float Bs[2][BK][BN];
+
+  const DfConvGeom& g = k.g;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const long long DHWi = (long long)g.Di * g.Hi * g.Wi;
+  const long long DHWo = (long long)g.Do * g.Ho * g.Wo;
+  const long long P = (long long)g.N * DHWo;
+  const long long p0 = (long long)blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+
+  // ---- the pixel this thread gathers for the B tile
+  const int bcol = tid % BN, brow0 = tid / BN;
+  const long long pp = p0 + bcol;
+  const bool pv = pp < P;
+  int ox = 0, oy = 0, oz = 0, n = 0;
+  if (pv) {
+    long long t = pp;
+    ox = (int)(t % g.Wo); t /= g.Wo;
+    oy = (int)(t % g.Ho); t /= g.Ho;
+    oz = (int)(t % g.Do); n = (int)(t / g.Do);
+  }
+  const float* xin = x + (long long)n * g.Cin * DHWi;
+  const int acol = tid % BM, arow0 = tid / BM;
+  const int aco = m0 + acol;
+  const bool av = aco < g.Cout;
+
+  float ra[NA], rb[NB];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nks = g.KD * g.KH * g.KW * k.nchunks;
+
+#define CONV_GLOAD(ks_)                                                                          \
+  {                                                                                              \
+    const int tap = (ks_) / k.nchunks;                                                           \
+    const int ci0 = ((ks_) - tap * k.nchunks) * k.kc;                                            \
+    const int kw_ = tap % g.KW;                                                                  \
+    const int t2_ = tap / g.KW;                                                                  \
+    const int kh_ = t2_ % g.KH;                                                                  \
+    const int kd_ = t2_ / g.KH;                                                                  \
+    int iz, iy, ix;                                                                              \
+    bool v = pv;                                                                                 \
+    v &= df_in_coord(oz, kd_, g.stride, g.pd, g.dil, g.Di, g.pad_mode, iz);                      \
+    v &= df_in_coord(oy, kh_, g.stride, g.ph, g.dil, g.Hi, g.pad_mode, iy);                      \
+    v &= df_in_coord(ox, kw_, g.stride, g.pw, g.dil, g.Wi, g.pad_mode, ix);                      \
+    const long long sp = ((long long)iz * g.Hi + iy) * g.Wi + ix;                                \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                             \
+      const int row = brow0 + RSB * j;                                                           \
+      const int ci = ci0 + row;                                                                  \
+      rb[j] = (v && row < k.kc && ci < g.Cin) ? xin[(long long)ci * DHWi + sp] : 0.f;            \
+    }                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                             \
+      const int row = arow0 + RSA * j;                                                           \
+      const int ci = ci0 + row;                                                                  \
+      ra[j] = (av && row < k.kc && ci < g.Cin)                                                   \
+                  ? wt[((long long)tap * g.Cin + ci) * g.Cout + aco]                             \
+                  : 0.f;                                                                         \
+    }                                                                                            \
+  }
+#define CONV_LSTORE(buf_)                                                                        \
+  {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) Bs[buf_][brow0 + RSB * j][bcol] = rb[j];      \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) As[buf_][arow0 + RSA * j][acol] = ra[j];      \
+  }
+
+  CONV_GLOAD(0);
+  CONV_LSTORE(0);
+  __syncthreads();
+
+  const int kpairs = k.kc >> 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int buf = ks & 1;
+    const bool more = (ks + 1) < nks;
+    if (more) CONV_GLOAD(ks + 1);
+#pragma unroll 2
+    for (int kk = 0; kk < kpairs; ++kk) {
+      const int kr = 2 * kk + lhi;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][kr][(wm * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kr][(wn * TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) CONV_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef CONV_GLOAD
+#undef CONV_LSTORE
+
+  // ---- epilogue: D[i = co][j = pixel]; lane holds pixel (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long long pq = p0 + (wn * TN + j) * 32 + l31;
+    if (pq >= P) continue;
+    const long long nn = pq / DHWo;
+    const long long so = pq - nn * DHWo;
+    float* yb = y + nn * g.Cout * DHWo + so;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int cb = m0 + (wm * TM + i) * 32 + 4 * lhi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb + (r & 3) + 8 * (r >> 2);
+        if (co < g.Cout) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[co];
+          if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+          else if (g.act == 2) v = tanhf(v);
+          yb[(long long)co * DHWo] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-Cout direct kernel (Cout <= 4): 7x7 64->1 (+tanh), flow convs 16->2/3, dgrad into 1-3 ch.
+// One thread per output voxel, lanes along x -> coalesced input reads; weights are wave-uniform.
+// ---------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv_small_k(const float* __restrict__ x,
+                                                    const float* __restrict__ wt,
+                                                    const float* __restrict__ bias,
+                                                    float* __restrict__ y, DfConvGeom g) {
+  const long long DHWi = (long long)g.Di * g.Hi * g.Wi;
+  const long long DHWo = (long long)g.Do * g.Ho * g.Wo;
+  const long long P = (long long)g.N * DHWo;
+  const long long pp = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pp >= P) return;
+  long long t = pp;
+  const int ox = (int)(t % g.Wo); t /= g.Wo;
+  const int oy = (int)(t % g.Ho); t /= g.Ho;
+  const int oz = (int)(t % g.Do);
+  const int n = (int)(t / g.Do);
+  const float* xin = x + (long long)n * g.Cin * DHWi;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  int tap = 0;
+  for (int kd = 0; kd < g.KD; ++kd) {
+    int iz;
+    const bool vz = df_in_coord(oz, kd, g.stride, g.pd, g.dil, g.Di, g.pad_mode, iz);
+    for (int kh = 0; kh < g.KH; ++kh) {
+      int iy;
+      const bool vy = df_in_coord(oy, kh, g.stride, g.ph, g.dil, g.Hi, g.pad_mode, iy);
+      for (int kw = 0; kw < g.KW; ++kw, ++tap) {
+        int ix;
+        const bool v = df_in_coord(ox, kw, g.stride, g.pw, g.dil, g.Wi, g.pad_mode, ix) && vy && vz;
+        if (v) {
+          const float* xp = xin + ((long long)iz * g.Hi + iy) * g.Wi + ix;
+          const float* wp = wt + (long long)tap * g.Cin * g.Cout;
+          for (int ci = 0; ci < g.Cin; ++ci) {
+            const float xv = xp[(long long)ci * DHWi];
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+              if (c < g.Cout) acc[c] = fmaf(xv, wp[ci * g.Cout + c], acc[c]);
+          }
+        }
+      }
+    }
+  }
+  const long long so = pp - (long long)n * DHWo;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (c < g.Cout) {
+      float v = acc[c] + (bias ? bias[c] : 0.f);
+      if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+      else if (g.act == 2) v = tanhf(v);
+      y[((long long)n * g.Cout + c) * DHWo + so] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dWt[j][co] += sum_p Xg[j][p] * dY[co][p],  j = tap*Cin + ci
+// MFMA A operand = gathered input (rows = j), B operand = dY (cols = co): lanes 0..31 of one
+// accumulator register hold 32 consecutive `co` of one j -> coalesced atomics into [tap][ci][co].
+// The pixel reduction is split over blockIdx.x; partial tiles are combined with fp32 atomics.
+// ---------------------------------------------------------------------------------------------
+template <int WJ, int WC, int TJ, int TC, int BP>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict__ x,
+                                                         const float* __restrict__ dy,
+                                                         float* __restrict__ dwt, DfConvGeom g,
+                                                         long long pchunk) {
+  constexpr int BJ = WJ * TJ * 32, BC = WC * TC * 32;
+  constexpr int RS = 256 / BP;
+  constexpr int NA = BJ / RS, NB = (BC + RS - 1) / RS;
+  static_assert(WJ * WC == 4, "4 waves");
+  __shared__ float As[2][BP][BJ + 1];
+  __shared__ float Bs[2][BP][BC + 1];
+  __shared__ int jinfo[BJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wj = wid / WC, wc = wid % WC;
+  const long long DHWi = (long long)g.Di * g.Hi * g.Wi;
+  const long long DHWo = (long long)g.Do * g.Ho * g.Wo;
+  const long long P = (long long)g.N * DHWo;
+  const int J = g.KD * g.KH * g.KW * g.Cin;
+  const int j0 = blockIdx.y * BJ, c0 = blockIdx.z * BC;
+  const long long pbeg = (long long)blockIdx.x * pchunk;
+  long long pend = pbeg + pchunk;
+  if (pend > P) pend = P;
+
+  for (int i = tid; i < BJ; i += 256) {
+    const int j = j0 + i;
+    int info = -1;
+    if (j < J) {
+      const int tap = j / g.Cin, ci = j - tap * g.Cin;
+      const int kw = tap % g.KW, t2 = tap / g.KW, kh = t2 % g.KH, kd = t2 / g.KH;
+      info = (ci << 12) | (kd << 8) | (kh << 4) | kw;
+    }
+    jinfo[i] = info;
+  }
+  __syncthreads();
+
+  const int pl = tid % BP, r0 = tid / BP;
+  float ra[NA], rb[NB];
+  f32x16 acc[TJ][TC];
+#pragma unroll
+  for (int i = 0; i < TJ; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define WG_GLOAD(pb_)                                                                            \
+  {                                                                                              \
+    const long long pq = (pb_) + pl;                                                             \
+    const bool pv = pq < pend;                                                                   \
+    int ox = 0, oy = 0, oz = 0, n = 0;                                                           \
+    if (pv) {                                                                                    \
+      long long t = pq;                                                                          \
+      ox = (int)(t % g.Wo); t /= g.Wo;                                                           \
+      oy = (int)(t % g.Ho); t /= g.Ho;                                                           \
+      oz = (int)(t % g.Do); n = (int)(t / g.Do);                                                 \
+    }                                                                                            \
+    const float* xin = x + (long long)n * g.Cin * DHWi;                                          \
+    _Pragma("unroll") for (int jj = 0; jj < NA; ++jj) {                                          \
+      const int info = jinfo[r0 + RS * jj];                                                      \
+      float val = 0.f;                                                                           \
+      if (pv && info >= 0) {                                                                     \
+        const int ci = info >> 12, kd = (info >> 8) & 15, kh = (info >> 4) & 15, kw = info & 15; \
+        int iz, iy, ix;                                                                          \
+        bool v = df_in_coord(oz, kd, g.stride, g.pd, 1, g.Di, g.pad_mode, iz);                   \
+        v &= df_in_coord(oy, kh, g.stride, g.ph, 1, g.Hi, g.pad_mode, iy);                       \
+        v &= df_in_coord(ox, kw, g.stride, g.pw, 1, g.Wi, g.pad_mode, ix);                       \
+        if (v) val = xin[(long long)ci * DHWi + ((long long)iz * g.Hi + iy) * g.Wi + ix];        \
+      }                                                                                          \
+      ra[jj] = val;                                                                              \
+    }                                                                                            \
+    const long long so = pq - (long long)n * DHWo;                                               \
+    _Pragma("unroll") for (int jj = 0; jj < NB; ++jj) {                                          \
+      const int cr = r0 + RS * jj;                                                               \
+      const int co = c0 + cr;                                                                    \
+      rb[jj] = (pv && cr < BC && co < g.Cout) ? dy[((long long)n * g.Cout + co) * DHWo + so] : 0.f; \
+    }                                                                                            \
+  }
+#define WG_LSTORE(buf_)                                                                          \
+  {                                                                                              \
+    _Pragma("unroll") for (int jj = 0; jj < NA; ++jj) As[buf_][pl][r0 + RS * jj] = ra[jj];       \
+    _Pragma("unroll") for (int jj = 0; jj < NB; ++jj) {                                          \
+      const int cr = r0 + RS * jj;                                                               \
+      if (cr < BC) Bs[buf_][pl][cr] = rb[jj];                                                    \
+    }                                                                                            \
+  }
+
+  if (pbeg < pend) {
+    WG_GLOAD(pbeg);
+    WG_LSTORE(0);
+  }
+  __syncthreads();
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int it = 0;
+  for (long long pb = pbeg; pb < pend; pb += BP, ++it) {
+    const int buf = it & 1;
+    const bool more = (pb + BP) < pend;
+    if (more) WG_GLOAD(pb + BP);
+#pragma unroll 2
+    for (int kk = 0; kk < BP / 2; ++kk) {
+      const int kr = 2 * kk + lhi;
+      float a[TJ], b[TC];
+#pragma unroll
+      for (int i = 0; i < TJ; ++i) a[i] = As[buf][kr][(wj * TJ + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TC; ++j) b[j] = Bs[buf][kr][(wc * TC + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TJ; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) WG_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef WG_GLOAD
+#undef WG_LSTORE
+
+#pragma unroll
+  for (int j = 0; j < TC; ++j) {
+    const int co = c0 + (wc * TC + j) * 32 + l31;
+    if (co >= g.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TJ; ++i) {
+      const int jb = j0 + (wj * TJ + i) * 32 + 4 * lhi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jr = jb + (r & 3) + 8 * (r >> 2);
+        if (jr < J) atomicAdd(&dwt[(long long)jr * g.Cout + co], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
+                            long long S, int nsplit) {
+  __shared__ float sm[17];
+  const int c = blockIdx.x, part = blockIdx.y;
+  const long long total = (long long)N * S;
+  const long long per = (total + nsplit - 1) / nsplit;
+  long long beg = part * per, end = beg + per;
+  if (end > total) end = total;
+  float s = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const long long n = i / S, sp = i - n * S;
+    s += dy[(n * C + c) * S + sp];
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) atomicAdd(&db[c], s);
+}
+
+__global__ void weight_pack_k(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin,
+                              int T, int mode) {
+  const long long total = (long long)Cout * Cin * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    // i indexes the OUTPUT
+    if (mode == 0) {  // o[t][ci][co]
+      const int co = (int)(i % Cout);
+      long long r = i / Cout;
+      const int ci = (int)(r % Cin);
+      const int t = (int)(r / Cin);
+      o[i] = w[((long long)co * Cin + ci) * T + t];
+    } else {  // o[t][co][ci] = w[co][ci][T-1-t]
+      const int ci = (int)(i % Cin);
+      long long r = i / Cin;
+      const int co = (int)(r % Cout);
+      const int t = (int)(r / Cout);
+      o[i] = w[((long long)co * Cin + ci) * T + (T - 1 - t)];
+    }
+  }
+}
+__global__ void weight_unpack_k(const float* __restrict__ gt, float* __restrict__ g, int Cout, int Cin,
+                                int T) {
+  const long long total = (long long)Cout * Cin * T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    // i indexes g[co][ci][t]
+    const int t = (int)(i % T);
+    long long r = i / T;
+    const int ci = (int)(r % Cin);
+    const int co = (int)(r / Cin);
+    g[i] = gt[((long long)t * Cin + ci) * Cout + co];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static int check_geom(const DfConvGeom* g) {
+  if (!g) return -1;
+  if (g->N <= 0 || g->Cin <= 0 || g->Cout <= 0) return -1;
+  if (g->Di <= 0 || g->Hi <= 0 || g->Wi <= 0 || g->Do <= 0 || g->Ho <= 0 || g->Wo <= 0) return -1;
+  if (g->KD <= 0 || g->KH <= 0 || g->KW <= 0 || g->KD > 15 || g->KH > 15 || g->KW > 15) return -1;
+  if (g->stride < 1 || g->dil < 1) return -1;
+  if (g->pad_mode != 0 && g->pad_mode != 1) return -1;
+  if (g->pad_mode == 1 && g->dil != 1) return -1;
+  return 0;
+}
+
+extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc,
+                              const float* bias, float* y, void* stream) {
+  DF_ARG_CHECK(check_geom(g) == 0 && x && w_tcc && y);
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
+  if (g->Cout <= 4) {
+    const unsigned grid = (unsigned)((P + 255) / 256);
+    if (g->Cout == 1) conv_small_k<1><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    else if (g->Cout == 2) conv_small_k<2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    else conv_small_k<4><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
+  ConvK k;
+  k.g = *g;
+  df_chunking(g->Cin, k.kc, k.nchunks);
+  if (g->Cout > 64) {
+    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((g->Cout + 127) / 128));
+    conv_mfma_k<2, 2, 2, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  } else if (g->Cout > 32) {
+    dim3 grid((unsigned)((P + 255) / 256), 1);
+    conv_mfma_k<1, 4, 2, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  } else {
+    dim3 grid((unsigned)((P + 255) / 256), 1);
+    conv_mfma_k<1, 4, 1, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  }
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                                void* stream) {
+  DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
+  DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
+  const int J = g->KD * g->KH * g->KW * g->Cin;
+  auto plan = [&](int BJ, int BC, int BP, unsigned& nP, long long& pchunk, dim3& grid) {
+    const unsigned nJ = (J + BJ - 1) / BJ, nC = (g->Cout + BC - 1) / BC;
+    long long want = 2048 / ((long long)nJ * nC);
+    if (want < 1) want = 1;
+    long long maxp = (P + (long long)BP * 8 - 1) / ((long long)BP * 8);  // >= 8 steps per block
+    if (maxp < 1) maxp = 1;
+    if (want > maxp) want = maxp;
+    pchunk = (P + want - 1) / want;
+    pchunk = ((pchunk + BP - 1) / BP) * BP;
+    nP = (unsigned)((P + pchunk - 1) / pchunk);
+    grid = dim3(nP, nJ, nC);
+  };
+  unsigned nP;
+  long long pchunk;
+  dim3 grid;
+  if (g->Cout > 64) {
+    plan(128, 128, 16, nP, pchunk, grid);
+    conv_wgrad_mfma_k<2, 2, 2, 2, 16><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
+  } else if (g->Cout > 32) {
+    plan(128, 64, 16, nP, pchunk, grid);
+    conv_wgrad_mfma_k<4, 1, 1, 2, 16><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
+  } else {
+    plan(128, 32, 32, nP, pchunk, grid);
+    conv_wgrad_mfma_k<4, 1, 1, 1, 32><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
+  }
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream) {
+  DF_ARG_CHECK(dy && db && N > 0 && C > 0 && S > 0);
+  const long long total = (long long)N * S;
+  int nsplit = (int)((total + 65535) / 65536);
+  if (nsplit > 64) nsplit = 64;
+  if (nsplit < 1) nsplit = 1;
+  bias_grad_k<<<dim3(C, nsplit), 256, 0, (hipStream_t)stream>>>(dy, db, N, C, S, nsplit);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, int mode,
+                                 void* stream) {
+  DF_ARG_CHECK(w && w_tcc && Cout > 0 && Cin > 0 && T > 0 && (mode == 0 || mode == 1));
+  const long long total = (long long)Cout * Cin * T;
+  weight_pack_k<<<df_grid(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(w, w_tcc, Cout, Cin, T, mode);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T,
+                                   void* stream) {
+  DF_ARG_CHECK(g_tcc && g && Cout > 0 && Cin > 0 && T > 0);
+  const long long total = (long long)Cout * Cin * T;
+  weight_unpack_k<<<df_grid(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(g_tcc, g, Cout, Cin, T);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,373 @@
+// Scalar losses of the registration step (masked L1, flow smoothness, windowed NCC), a generic
+// scaled sum, and the fused Adam update.  All reductions: per-wave shuffle -> per-block LDS ->
+// one fp32 atomic per block into a tiny workspace; a 1-thread finaliser forms the scalar on device
+// so the host never synchronises.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------- masked L1
+__device__ __forceinline__ float l1_mask(const float a, const float b, const unsigned char* mask,
+                                         long long i, float thr) {
+  if (mask) return mask[i] ? 1.f : 0.f;
+  return (a > thr || b > thr) ? 1.f : 0.f;
+}
+__global__ __launch_bounds__(256) void masked_l1_fwd_k(const float* __restrict__ a,
+                                                       const float* __restrict__ b,
+                                                       const unsigned char* __restrict__ mask, float thr,
+                                                       float* __restrict__ ws, long long n) {
+  __shared__ float sm[17];
+  float s = 0.f, m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float av = a[i], bv = b[i];
+    const float mk = l1_mask(av, bv, mask, i, thr);
+    s += fabsf(av - bv) * mk;
+    m += mk;
+  }
+  s = block_sum(s, sm);
+  m = block_sum(m, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[0], s);
+    atomicAdd(&ws[1], m);
+  }
+}
+__global__ void masked_l1_fin_k(const float* ws, float* out) {
+  out[0] = ws[1] > 0.f ? (1.f / ws[1]) * ws[0] : 0.f;
+}
+__global__ __launch_bounds__(256) void masked_l1_bwd_k(const float* __restrict__ a,
+                                                       const float* __restrict__ b,
+                                                       const unsigned char* __restrict__ mask, float thr,
+                                                       const float* __restrict__ ws,
+                                                       const float* __restrict__ gout,
+                                                       float* __restrict__ da, float* __restrict__ db,
+                                                       long long n) {
+  const float sc = ws[1] > 0.f ? gout[0] / ws[1] : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float av = a[i], bv = b[i];
+    const float mk = l1_mask(av, bv, mask, i, thr);
+    const float d = av - bv;
+    const float g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * mk * sc;
+    if (da) da[i] = g;
+    if (db) db[i] = -g;
+  }
+}
+
+// ------------------------------------------------------------------------------ flow smoothness
+__global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict__ f, float* __restrict__ ws,
+                                                         long long planes, int D, int H, int W) {
+  __shared__ float sm[17];
+  const long long S = (long long)D * H * W, total = planes * S;
+  float sd = 0.f, sh = 0.f, sw = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    long long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const float v = f[i];
+    if (x + 1 < W) { const float d = f[i + 1] - v; sw += d * d; }
+    if (y + 1 < H) { const float d = f[i + W] - v; sh += d * d; }
+    if (z + 1 < D) { const float d = f[i + (long long)H * W] - v; sd += d * d; }
+  }
+  sd = block_sum(sd, sm);
+  sh = block_sum(sh, sm);
+  sw = block_sum(sw, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[0], sd);
+    atomicAdd(&ws[1], sh);
+    atomicAdd(&ws[2], sw);
+  }
+}
+__global__ void flow_smooth_fin_k(const float* ws, float* out, float cd, float ch, float cw, float nd) {
+  float s = 0.f;
+  if (cd > 0.f) s += ws[0] / cd;
+  if (ch > 0.f) s += ws[1] / ch;
+  if (cw > 0.f) s += ws[2] / cw;
+  out[0] = s / nd;
+}
+__global__ __launch_bounds__(256) void flow_smooth_bwd_k(const float* __restrict__ f,
+                                                         const float* __restrict__ gout,
+                                                         float* __restrict__ df, long long planes, int D,
+                                                         int H, int W, float kd, float kh, float kw) {
+  const long long S = (long long)D * H * W, total = planes * S;
+  const float g = gout[0];
+  const long long HW = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    long long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const float v = f[i];
+    float acc = 0.f;
+    if (W > 1) {
+      float t = 0.f;
+      if (x > 0) t += v - f[i - 1];
+      if (x + 1 < W) t -= f[i + 1] - v;
+      acc += kw * t;
+    }
+    if (H > 1) {
+      float t = 0.f;
+      if (y > 0) t += v - f[i - W];
+      if (y + 1 < H) t -= f[i + W] - v;
+      acc += kh * t;
+    }
+    if (D > 1) {
+      float t = 0.f;
+      if (z > 0) t += v - f[i - HW];
+      if (z + 1 < D) t -= f[i + HW] - v;
+      acc += kd * t;
+    }
+    df[i] = g * acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------- NCC
+// box sums are separable: W pass fused with the 5 products, then H, then D.
+__global__ __launch_bounds__(256) void ncc_prod_boxw_k(const float* __restrict__ I, const float* __restrict__ J,
+                                                       float* __restrict__ o, long long N, int W, int r) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int x = (int)(i % W);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+  for (int d = -r; d <= r; ++d) {
+    const int xx = x + d;
+    if ((unsigned)xx < (unsigned)W) {
+      const float a = I[i + d], b = J[i + d];
+      s0 += a; s1 += b; s2 += a * a; s3 += b * b; s4 += a * b;
+    }
+  }
+  o[i] = s0; o[N + i] = s1; o[2 * N + i] = s2; o[3 * N + i] = s3; o[4 * N + i] = s4;
+}
+// out[f][v] = sum_{d} in[f][v + d*stride] over the axis of length `len` (coordinate = (v/stride)%len)
+__global__ __launch_bounds__(256) void box_axis_k(const float* __restrict__ in, float* __restrict__ out,
+                                                  int nf, long long N, long long stride, int len, int r) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int c = (int)((i / stride) % len);
+  for (int f = 0; f < nf; ++f) {
+    const float* p = in + f * N + i;
+    float s = 0.f;
+    for (int d = -r; d <= r; ++d) {
+      const int cc = c + d;
+      if ((unsigned)cc < (unsigned)len) s += p[d * stride];
+    }
+    out[f * N + i] = s;
+  }
+}
+struct NccTerms { float cross, Iv, Jv, uI, uJ, den; };
+__device__ __forceinline__ NccTerms ncc_terms(const float* s, long long N, long long i, float wn, float eps) {
+  const float Is = s[i], Js = s[N + i], I2 = s[2 * N + i], J2 = s[3 * N + i], IJ = s[4 * N + i];
+  NccTerms t;
+  t.uI = Is / wn;
+  t.uJ = Js / wn;
+  t.cross = IJ - t.uJ * Is - t.uI * Js + t.uI * t.uJ * wn;
+  t.Iv = I2 - 2.f * t.uI * Is + t.uI * t.uI * wn;
+  t.Jv = J2 - 2.f * t.uJ * Js + t.uJ * t.uJ * wn;
+  t.den = t.Iv * t.Jv + eps;
+  return t;
+}
+__global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__ s, float* __restrict__ ws,
+                                                       long long N, float wn, float eps) {
+  __shared__ float sm[17];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
+    const NccTerms t = ncc_terms(s, N, i, wn, eps);
+    acc += t.cross * t.cross / t.den;
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) atomicAdd(&ws[0], acc);
+}
+__global__ void ncc_fin_k(const float* ws, float* out, float n) { out[0] = -sqrtf(ws[0] / n); }
+// fields: A = dL/dIJsum, Bq = dL/dI2sum, Cq = dL/dIsum
+__global__ __launch_bounds__(256) void ncc_fields_k(const float* __restrict__ s, const float* __restrict__ ws,
+                                                    const float* __restrict__ gout, float* __restrict__ fld,
+                                                    long long N, float wn, float eps) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float m = ws[0] / (float)N;
+  const float kappa = m > 0.f ? gout[0] * (-0.5f / sqrtf(m)) / (float)N : 0.f;
+  const NccTerms t = ncc_terms(s, N, i, wn, eps);
+  const float A = kappa * (2.f * t.cross / t.den);
+  const float Bq = kappa * (-(t.cross * t.cross) * t.Jv / (t.den * t.den));
+  const float Cq = -A * t.uJ - 2.f * Bq * t.uI;
+  fld[i] = A; fld[N + i] = Bq; fld[2 * N + i] = Cq;
+}
+__global__ __launch_bounds__(256) void ncc_combine_k(const float* __restrict__ I, const float* __restrict__ J,
+                                                     const float* __restrict__ bx, float* __restrict__ dI,
+                                                     long long N) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  dI[i] = J[i] * bx[i] + 2.f * I[i] * bx[N + i] + bx[2 * N + i];
+}
+
+// ---------------------------------------------------------------------------------- misc
+__global__ __launch_bounds__(256) void sum_scaled_k(const float* __restrict__ x, float* __restrict__ out,
+                                                    long long n, float scale) {
+  __shared__ float sm[17];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+__global__ void fill_from_scalar_k(const float* __restrict__ g, float* __restrict__ dx, long long n, float scale) {
+  const float v = g[0] * scale;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = v;
+}
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, long long n,
+                                              float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                              float gs) {
+  const float step = lr / bc1;
+  const float sb2 = sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gr = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    const float den = sqrtf(vi) / sb2 + eps;
+    p[i] -= step * (mi / den);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfmir_masked_l1_fwd(const float* a, const float* b, const unsigned char* mask, float thr,
+                                   float* ws, float* out, long long n, void* stream) {
+  DF_ARG_CHECK(a && b && ws && out && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
+  masked_l1_fwd_k<<<df_grid(n, 256, 1024), 256, 0, st>>>(a, b, mask, thr, ws, n);
+  DF_LAUNCH_CHECK();
+  masked_l1_fin_k<<<1, 1, 0, st>>>(ws, out);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_masked_l1_bwd(const float* a, const float* b, const unsigned char* mask, float thr,
+                                   const float* ws, const float* gout, float* da, float* db, long long n,
+                                   void* stream) {
+  DF_ARG_CHECK(a && b && ws && gout && n > 0);
+  masked_l1_bwd_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(a, b, mask, thr, ws, gout, da, db, n);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C, int D, int H,
+                                     int W, void* stream) {
+  DF_ARG_CHECK(flow && ws && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
+  const long long planes = (long long)B * C;
+  flow_smooth_fwd_k<<<df_grid(planes * D * H * W, 256, 1024), 256, 0, st>>>(flow, ws, planes, D, H, W);
+  DF_LAUNCH_CHECK();
+  const float cd = (float)((double)planes * (D - 1) * H * W), ch = (float)((double)planes * D * (H - 1) * W),
+              cw = (float)((double)planes * D * H * (W - 1));
+  const float nd = (D > 1) ? 3.f : 2.f;
+  flow_smooth_fin_k<<<1, 1, 0, st>>>(ws, out, cd, ch, cw, nd);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,
+                                     int H, int W, void* stream) {
+  DF_ARG_CHECK(flow && gout && dflow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  const long long planes = (long long)B * C;
+  const double cd = (double)planes * (D - 1) * H * W, ch = (double)planes * D * (H - 1) * W,
+               cw = (double)planes * D * H * (W - 1);
+  const double nd = (D > 1) ? 3.0 : 2.0;
+  const float kd = cd > 0 ? (float)(2.0 / (cd * nd)) : 0.f, kh = ch > 0 ? (float)(2.0 / (ch * nd)) : 0.f,
+              kw = cw > 0 ? (float)(2.0 / (cw * nd)) : 0.f;
+  flow_smooth_bwd_k<<<df_grid(planes * D * H * W, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+// fwd: final 5 box sums are left in `tmp`.
+extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float* ws, float* out,
+                             int B, int D, int H, int W, int win, float eps, void* stream) {
+  DF_ARG_CHECK(I && J && tmp && tmp2 && ws && out && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1));
+  hipStream_t st = (hipStream_t)stream;
+  const long long N = (long long)B * D * H * W;
+  const int r = win / 2;
+  const unsigned grid = (unsigned)((N + 255) / 256);
+  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
+  float wn;
+  if (D > 1) {
+    ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp, N, W, r);
+    DF_LAUNCH_CHECK();
+    box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 5, N, W, H, r);
+    DF_LAUNCH_CHECK();
+    box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 5, N, (long long)H * W, D, r);
+    DF_LAUNCH_CHECK();
+    wn = (float)win * win * win;
+  } else {
+    ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp2, N, W, r);
+    DF_LAUNCH_CHECK();
+    box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 5, N, W, H, r);
+    DF_LAUNCH_CHECK();
+    wn = (float)win * win;
+  }
+  ncc_cc_reduce_k<<<df_grid(N, 256, 1024), 256, 0, st>>>(tmp, ws, N, wn, eps);
+  DF_LAUNCH_CHECK();
+  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+// bwd: sums = the 5N box sums of the forward; tmp, tmp2 = 3N floats of scratch each.
+extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
+                             const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
+                             int win, float eps, void* stream) {
+  DF_ARG_CHECK(I && J && sums && tmp && tmp2 && ws && gout && dI && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1));
+  hipStream_t st = (hipStream_t)stream;
+  const long long N = (long long)B * D * H * W;
+  const int r = win / 2;
+  const unsigned grid = (unsigned)((N + 255) / 256);
+  const float wn = (D > 1) ? (float)win * win * win : (float)win * win;
+  ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps);
+  DF_LAUNCH_CHECK();
+  box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 3, N, 1, W, r);
+  DF_LAUNCH_CHECK();
+  box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 3, N, W, H, r);
+  DF_LAUNCH_CHECK();
+  const float* fin = tmp;
+  if (D > 1) {
+    box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 3, N, (long long)H * W, D, r);
+    DF_LAUNCH_CHECK();
+    fin = tmp2;
+  }
+  ncc_combine_k<<<grid, 256, 0, st>>>(I, J, fin, dI, N);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void* stream) {
+  DF_ARG_CHECK(x && out && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
+  sum_scaled_k<<<df_grid(n, 256, 1024), 256, 0, st>>>(x, out, n, scale);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_fill_from_scalar(const float* gout, float* dx, long long n, float scale, void* stream) {
+  DF_ARG_CHECK(gout && dx && n > 0);
+  fill_from_scalar_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(gout, dx, n, scale);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                               float beta2, float eps, float bc1, float bc2, float grad_scale, void* stream) {
+  DF_ARG_CHECK(p && g && m && v && n > 0);
+  adam_k<<<df_grid(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2,
+                                                                grad_scale);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+int df_set_error(int code, const char* file, int line) {
+  const char* msg = code > 0 ? hipGetErrorString((hipError_t)code) : "invalid argument";
+  snprintf(g_err, sizeof(g_err), "dfmir_hip: %s (code %d) at %s:%d", msg, code, file, line);
+  return code;
+}
+extern "C" const char* dfmir_last_error(void) { return g_err; }
+extern "C" int dfmir_abi_version(void) { return DFMIR_ABI_VERSION; }

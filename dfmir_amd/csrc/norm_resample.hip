@@ -1,0 +1,493 @@
+// HBM-bound per-plane kernels of the translation generator: InstanceNorm(+ReLU,+residual),
+// activation backward, anti-aliased 2x down/up-sampling, reflection pad, nearest-up + concat.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm: one (n,c) plane per workgroup; two-pass (mean, then centred variance) so the
+// result tracks torch's numerics instead of the cancellation-prone E[x^2]-E[x]^2 form.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instnorm_fwd_k(const float* __restrict__ x,
+                                                      const float* __restrict__ res,
+                                                      float* __restrict__ y, float* __restrict__ mean_o,
+                                                      float* __restrict__ rstd_o, long long S,
+                                                      float eps, int relu) {
+  __shared__ float sm[17];
+  const long long base = (long long)blockIdx.x * S;
+  const float* xp = x + base;
+  const bool vec = (S & 3) == 0;
+  float s = 0.f;
+  if (vec) {
+    const float4* x4 = reinterpret_cast<const float4*>(xp);
+    for (long long i = threadIdx.x; i < (S >> 2); i += 256) {
+      const float4 v = x4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long i = threadIdx.x; i < S; i += 256) s += xp[i];
+  }
+  const float mean = block_sum(s, sm) / (float)S;
+  float q = 0.f;
+  if (vec) {
+    const float4* x4 = reinterpret_cast<const float4*>(xp);
+    for (long long i = threadIdx.x; i < (S >> 2); i += 256) {
+      const float4 v = x4[i];
+      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (long long i = threadIdx.x; i < S; i += 256) {
+      const float a = xp[i] - mean;
+      q += a * a;
+    }
+  }
+  const float var = block_sum(q, sm) / (float)S;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[blockIdx.x] = mean;
+    rstd_o[blockIdx.x] = rstd;
+  }
+  float* yp = y + base;
+  const float* rp = res ? res + base : nullptr;
+  if (vec) {
+    const float4* x4 = reinterpret_cast<const float4*>(xp);
+    const float4* r4 = reinterpret_cast<const float4*>(rp);
+    float4* y4 = reinterpret_cast<float4*>(yp);
+    for (long long i = threadIdx.x; i < (S >> 2); i += 256) {
+      float4 v = x4[i];
+      v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd;
+      v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (rp) {
+        const float4 r = r4[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      y4[i] = v;
+    }
+  } else {
+    for (long long i = threadIdx.x; i < S; i += 256) {
+      float v = (xp[i] - mean) * rstd;
+      if (relu) v = fmaxf(v, 0.f);
+      if (rp) v += rp[i];
+      yp[i] = v;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
+__global__ __launch_bounds__(256) void instnorm_bwd_k(const float* __restrict__ dy,
+                                                      const float* __restrict__ x,
+                                                      const float* __restrict__ mean_i,
+                                                      const float* __restrict__ rstd_i,
+                                                      float* __restrict__ dx, long long S, int relu) {
+  __shared__ float sm[17];
+  const long long base = (long long)blockIdx.x * S;
+  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
+  const float* xp = x + base;
+  const float* gp = dy + base;
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = threadIdx.x; i < S; i += 256) {
+    const float xh = (xp[i] - mean) * rstd;
+    float g = gp[i];
+    if (relu && !(xh > 0.f)) g = 0.f;
+    s1 += g;
+    s2 += g * xh;
+  }
+  const float m1 = block_sum(s1, sm) / (float)S;
+  const float m2 = block_sum(s2, sm) / (float)S;
+  float* dp = dx + base;
+  for (long long i = threadIdx.x; i < S; i += 256) {
+    const float xh = (xp[i] - mean) * rstd;
+    float g = gp[i];
+    if (relu && !(xh > 0.f)) g = 0.f;
+    dp[i] = rstd * (g - m1 - xh * m2);
+  }
+}
+
+__global__ void act_bwd_k(const float* __restrict__ dy, const float* __restrict__ y,
+                          float* __restrict__ dx, long long n, int act, float slope) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float yv = y[i], g = dy[i];
+    dx[i] = (act == 2) ? g * (1.f - yv * yv) : (yv > 0.f ? g : g * slope);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Downsample: y[oy][ox] = sum_{a,b} f[a]f[b] x[refl(2oy+a-1)][refl(2ox+b-1)], f = [1,2,1]/4
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int refl1(int c, int n) {
+  if (c < 0) c = -c;
+  if (c >= n) c = 2 * (n - 1) - c;
+  return c < 0 ? 0 : c;
+}
+__global__ void blur_down_fwd_k(const float* __restrict__ x, float* __restrict__ y, int planes, int H,
+                                int W, int Ho, int Wo) {
+  const long long total = (long long)planes * Ho * Wo;
+  const float f[3] = {0.25f, 0.5f, 0.25f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const long long pl = r / Ho;
+    const float* xp = x + pl * H * W;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int iy = refl1(2 * oy + a - 1, H);
+      float rs = 0.f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) rs += f[b] * xp[(long long)iy * W + refl1(2 * ox + b - 1, W)];
+      s += f[a] * rs;
+    }
+    y[i] = s;
+  }
+}
+// adjoint weights of the 1-D operator above for input index i: list of (o, w)
+__device__ __forceinline__ int blur_down_adj(int i, int n, int no, int* oo, float* ww) {
+  const float f[3] = {0.25f, 0.5f, 0.25f};
+  int cnt = 0;
+  // padded coordinates q in [-1, n] that reflect onto i: q = i, q = -1 (-> 1), q = n (-> n-2)
+  int qs[3];
+  int nq = 0;
+  qs[nq++] = i;
+  if (i == 1) qs[nq++] = -1;
+  if (i == n - 2) qs[nq++] = n;
+  for (int k = 0; k < nq; ++k) {
+    const int q = qs[k];
+    for (int a = 0; a < 3; ++a) {
+      const int t = q + 1 - a;  // = 2*o
+      if (t >= 0 && (t & 1) == 0) {
+        const int o = t >> 1;
+        if (o < no) {
+          oo[cnt] = o;
+          ww[cnt] = f[a];
+          ++cnt;
+        }
+      }
+    }
+  }
+  return cnt;
+}
+__global__ void blur_down_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int planes, int H,
+                                int W, int Ho, int Wo) {
+  const long long total = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    long long r = i / W;
+    const int iy = (int)(r % H);
+    const long long pl = r / H;
+    const float* gp = dy + pl * Ho * Wo;
+    int oy[9], oxx[9];
+    float wy[9], wx[9];
+    const int ny = blur_down_adj(iy, H, Ho, oy, wy);
+    const int nx = blur_down_adj(ix, W, Wo, oxx, wx);
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      float rs = 0.f;
+      for (int b = 0; b < nx; ++b) rs += wx[b] * gp[(long long)oy[a] * Wo + oxx[b]];
+      s += wy[a] * rs;
+    }
+    dx[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Upsample (replicate pad 1 + conv_transpose 4x4 stride 2 pad 2, cropped) == per axis
+//   out[2m]   = 0.75 x[m] + 0.25 x[max(m-1,0)]
+//   out[2m+1] = 0.75 x[m] + 0.25 x[min(m+1,L-1)]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blur_up_src(int o, int L, int& i0, int& i1) {
+  const int m = o >> 1;
+  i0 = m;
+  i1 = (o & 1) ? (m + 1 < L ? m + 1 : L - 1) : (m > 0 ? m - 1 : 0);
+}
+__global__ void blur_up_fwd_k(const float* __restrict__ x, float* __restrict__ y, int planes, int H,
+                              int W) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)planes * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const long long pl = r / Ho;
+    const float* xp = x + pl * H * W;
+    int y0, y1, x0, x1;
+    blur_up_src(oy, H, y0, y1);
+    blur_up_src(ox, W, x0, x1);
+    const float r0 = 0.75f * xp[(long long)y0 * W + x0] + 0.25f * xp[(long long)y0 * W + x1];
+    const float r1 = 0.75f * xp[(long long)y1 * W + x0] + 0.25f * xp[(long long)y1 * W + x1];
+    y[i] = 0.75f * r0 + 0.25f * r1;
+  }
+}
+__device__ __forceinline__ int blur_up_adj(int m, int L, int* oo, float* ww) {
+  int cnt = 0;
+  oo[cnt] = 2 * m; ww[cnt++] = 0.75f;
+  oo[cnt] = 2 * m + 1; ww[cnt++] = 0.75f;
+  if (m + 1 <= L - 1) { oo[cnt] = 2 * m + 2; ww[cnt++] = 0.25f; }   // out[2(m+1)] uses x[m]
+  if (m == 0) { oo[cnt] = 0; ww[cnt++] = 0.25f; }                    // clamp at the low edge
+  if (m >= 1) { oo[cnt] = 2 * m - 1; ww[cnt++] = 0.25f; }            // out[2(m-1)+1] uses x[m]
+  if (m == L - 1) { oo[cnt] = 2 * L - 1; ww[cnt++] = 0.25f; }        // clamp at the high edge
+  return cnt;
+}
+__global__ void blur_up_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int planes, int H,
+                              int W) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    long long r = i / W;
+    const int iy = (int)(r % H);
+    const long long pl = r / H;
+    const float* gp = dy + pl * Ho * Wo;
+    int oy[6], oxx[6];
+    float wy[6], wx[6];
+    const int ny = blur_up_adj(iy, H, oy, wy);
+    const int nx = blur_up_adj(ix, W, oxx, wx);
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a) {
+      float rs = 0.f;
+      for (int b = 0; b < nx; ++b) rs += wx[b] * gp[(long long)oy[a] * Wo + oxx[b]];
+      s += wy[a] * rs;
+    }
+    dx[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void reflect_pad2d_fwd_k(const float* __restrict__ x, float* __restrict__ y, int planes,
+                                    int H, int W, int p) {
+  const int Ho = H + 2 * p, Wo = W + 2 * p;
+  const long long total = (long long)planes * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const long long pl = r / Ho;
+    y[i] = x[pl * H * W + (long long)refl1(oy - p, H) * W + refl1(ox - p, W)];
+  }
+}
+// padded positions q (in padded coords) that read input index i
+__device__ __forceinline__ int reflect_adj(int i, int n, int p, int* qq) {
+  int cnt = 0;
+  qq[cnt++] = i + p;
+  if (i >= 1 && i <= p) qq[cnt++] = p - i;
+  if (i <= n - 2 && i >= n - 1 - p) qq[cnt++] = p + 2 * (n - 1) - i;
+  return cnt;
+}
+__global__ void reflect_pad2d_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int planes,
+                                    int H, int W, int p) {
+  const int Ho = H + 2 * p, Wo = W + 2 * p;
+  const long long total = (long long)planes * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W);
+    long long r = i / W;
+    const int iy = (int)(r % H);
+    const long long pl = r / H;
+    const float* gp = dy + pl * Ho * Wo;
+    int qy[3], qx[3];
+    const int ny = reflect_adj(iy, H, p, qy);
+    const int nx = reflect_adj(ix, W, p, qx);
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += gp[(long long)qy[a] * Wo + qx[b]];
+    dx[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y[n][c] = c < Ca ? a[n][c][z/sd][y/2][x/2] : b[n][c-Ca][z][y][x]
+// ---------------------------------------------------------------------------------------------
+__global__ void upcat_fwd_k(const float* __restrict__ a, const float* __restrict__ b,
+                            float* __restrict__ y, int N, int Ca, int Cb, int Da, int Ha, int Wa, int sd) {
+  const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb;
+  const long long So = (long long)Do * Ho * Wo, Sa = (long long)Da * Ha * Wa;
+  const long long total = (long long)N * C * So;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wo);
+    long long r = i / Wo;
+    const int yy = (int)(r % Ho); r /= Ho;
+    const int z = (int)(r % Do); r /= Do;
+    const int c = (int)(r % C);
+    const long long n = r / C;
+    float v;
+    if (c < Ca) v = a[(n * Ca + c) * Sa + ((long long)(z / sd) * Ha + (yy >> 1)) * Wa + (x >> 1)];
+    else v = b[(n * Cb + (c - Ca)) * So + ((long long)z * Ho + yy) * Wo + x];
+    y[i] = v;
+  }
+}
+__global__ void upcat_bwd_a_k(const float* __restrict__ dy, float* __restrict__ da, int N, int Ca, int Cb,
+                              int Da, int Ha, int Wa, int sd) {
+  const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb;
+  const long long So = (long long)Do * Ho * Wo, Sa = (long long)Da * Ha * Wa;
+  const long long total = (long long)N * Ca * Sa;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wa);
+    long long r = i / Wa;
+    const int yy = (int)(r % Ha); r /= Ha;
+    const int z = (int)(r % Da); r /= Da;
+    const int c = (int)(r % Ca);
+    const long long n = r / Ca;
+    const float* gp = dy + (n * C + c) * So;
+    float s = 0.f;
+    for (int dz = 0; dz < sd; ++dz)
+      for (int dyy = 0; dyy < 2; ++dyy) {
+        const float* row = gp + ((long long)(z * sd + dz) * Ho + (2 * yy + dyy)) * Wo + 2 * x;
+        s += row[0] + row[1];
+      }
+    da[i] = s;
+  }
+}
+__global__ void upcat_bwd_b_k(const float* __restrict__ dy, float* __restrict__ db, int N, int Ca, int Cb,
+                              long long So) {
+  const int C = Ca + Cb;
+  const long long total = (long long)N * Cb * So;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % So;
+    long long r = i / So;
+    const int c = (int)(r % Cb);
+    const long long n = r / Cb;
+    db[i] = dy[(n * C + Ca + c) * So + s];
+  }
+}
+
+// y[n] = cat(a[n], b[n]) along channels; bwd = the two slice copies.  `scale`: y = mult*x.
+__global__ void cat_channels_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                               long long N, long long SA, long long SB, int dir) {
+  // SA = Ca*S, SB = Cb*S (per-sample element counts); dir 0: a,b -> y ; dir 1: y -> a,b
+  const long long ST = SA + SB, total = N * ST;
+  float* aw = const_cast<float*>(a);
+  float* bw = const_cast<float*>(b);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / ST, r = i - n * ST;
+    if (dir == 0) y[i] = r < SA ? a[n * SA + r] : b[n * SB + (r - SA)];
+    else if (r < SA) { if (aw) aw[n * SA + r] = y[i]; }
+    else { if (bw) bw[n * SB + (r - SA)] = y[i]; }
+  }
+}
+__global__ void scale_k(const float* __restrict__ x, float* __restrict__ y, long long n, float mult) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = mult * x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
+                                  int planes, long long S, float eps, int relu, void* stream) {
+  DF_ARG_CHECK(x && y && mean && rstd && planes > 0 && S > 0);
+  instnorm_fwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(x, res, y, mean, rstd, S, eps, relu);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                  float* dx, int planes, long long S, int relu, void* stream) {
+  DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
+  instnorm_bwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(dy, x, mean, rstd, dx, S, relu);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act,
+                             float slope, void* stream) {
+  DF_ARG_CHECK(dy && y && dx && n > 0 && (act == 1 || act == 2));
+  act_bwd_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, slope);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_blur_down_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
+  DF_ARG_CHECK(x && y && planes > 0 && H > 1 && W > 1);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  blur_down_fwd_k<<<df_grid((long long)planes * Ho * Wo, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+      x, y, planes, H, W, Ho, Wo);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_blur_down_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream) {
+  DF_ARG_CHECK(dy && dx && planes > 0 && H > 1 && W > 1);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  blur_down_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+      dy, dx, planes, H, W, Ho, Wo);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_blur_up_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
+  DF_ARG_CHECK(x && y && planes > 0 && H > 0 && W > 0);
+  blur_up_fwd_k<<<df_grid((long long)planes * H * W * 4, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+      x, y, planes, H, W);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_blur_up_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream) {
+  DF_ARG_CHECK(dy && dx && planes > 0 && H > 0 && W > 0);
+  blur_up_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+      dy, dx, planes, H, W);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_reflect_pad2d_fwd(const float* x, float* y, int planes, int H, int W, int p,
+                                       void* stream) {
+  DF_ARG_CHECK(x && y && planes > 0 && p >= 0 && p < H && p < W);
+  reflect_pad2d_fwd_k<<<df_grid((long long)planes * (H + 2 * p) * (W + 2 * p), 256, 8192), 256, 0,
+                        (hipStream_t)stream>>>(x, y, planes, H, W, p);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p,
+                                       void* stream) {
+  DF_ARG_CHECK(dy && dx && planes > 0 && p >= 0 && p < H && p < W);
+  reflect_pad2d_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+      dy, dx, planes, H, W, p);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, int Ca, int Cb, int Da,
+                               int Ha, int Wa, int sd, void* stream) {
+  DF_ARG_CHECK(a && b && y && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));
+  const long long total = (long long)N * (Ca + Cb) * Da * sd * Ha * 2 * Wa * 2;
+  upcat_fwd_k<<<df_grid(total, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_upcat_bwd(const float* dy, float* da, float* db, int N, int Ca, int Cb, int Da,
+                               int Ha, int Wa, int sd, void* stream) {
+  DF_ARG_CHECK(dy && da && db && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));
+  const long long Sa = (long long)Da * Ha * Wa, So = Sa * sd * 4;
+  upcat_bwd_a_k<<<df_grid((long long)N * Ca * Sa, 256, 16384), 256, 0, (hipStream_t)stream>>>(
+      dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+  DF_LAUNCH_CHECK();
+  upcat_bwd_b_k<<<df_grid((long long)N * Cb * So, 256, 16384), 256, 0, (hipStream_t)stream>>>(
+      dy, db, N, Ca, Cb, So);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_cat_channels_fwd(const float* a, const float* b, float* y, long long N, long long SA,
+                                      long long SB, void* stream) {
+  DF_ARG_CHECK(a && b && y && N > 0 && SA > 0 && SB > 0);
+  cat_channels_k<<<df_grid(N * (SA + SB), 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, SA, SB, 0);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_cat_channels_bwd(const float* dy, float* da, float* db, long long N, long long SA,
+                                      long long SB, void* stream) {
+  DF_ARG_CHECK(dy && N > 0 && SA > 0 && SB > 0);
+  cat_channels_k<<<df_grid(N * (SA + SB), 256, 16384), 256, 0, (hipStream_t)stream>>>(
+      da, db, const_cast<float*>(dy), N, SA, SB, 1);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_scale(const float* x, float* y, long long n, float mult, void* stream) {
+  DF_ARG_CHECK(x && y && n > 0);
+  scale_k<<<df_grid(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(x, y, n, mult);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

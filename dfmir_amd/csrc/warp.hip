@@ -1,0 +1,366 @@
+// Displacement-field warps (SpatialTransformer), the fused VecInt step and ResizeTransform.
+// All HBM-bound gathers: one thread per output voxel, lanes along x (coalesced flow / output
+// streams, L1/L2-served neighbourhood reads of src), channel loop inside the thread so the
+// interpolation weights are computed once per voxel.  The kernels take the voxel displacement
+// directly -- the reference's normalise-to-[-1,1] / permute / grid_sample round trip
+// (torchvoxelmorph/layers.py:36-48) is never materialised.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ 2-D
+__global__ __launch_bounds__(256) void warp2d_fwd_k(const float* __restrict__ src,
+                                                    const float* __restrict__ flow,
+                                                    float* __restrict__ out, int B, int C, int H, int W,
+                                                    int mode, int add_identity) {
+  const long long HW = (long long)H * W;
+  const long long total = (long long)B * HW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long long r = i / W;
+  const int y = (int)(r % H);
+  const long long b = r / H;
+  const long long sp = (long long)y * W + x;
+  const float fy = (float)y + flow[(b * 2 + 0) * HW + sp];
+  const float fx = (float)x + flow[(b * 2 + 1) * HW + sp];
+  const float* sb = src + b * C * HW;
+  float* ob = out + b * C * HW + sp;
+  if (mode == 1) {
+    const int yy = (int)nearbyintf(fy), xx = (int)nearbyintf(fx);
+    const bool v = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    for (int c = 0; c < C; ++c) {
+      float val = v ? sb[c * HW + (long long)yy * W + xx] : 0.f;
+      if (add_identity) val += sb[c * HW + sp];
+      ob[c * HW] = val;
+    }
+    return;
+  }
+  const float y0f = floorf(fy), x0f = floorf(fx);
+  const int y0 = (int)y0f, x0 = (int)x0f;
+  const float wy1 = fy - y0f, wx1 = fx - x0f, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+  const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const long long o00 = (long long)y0 * W + x0;
+  for (int c = 0; c < C; ++c) {
+    const float* sc = sb + c * HW;
+    const float v00 = (vy0 && vx0) ? sc[o00] : 0.f;
+    const float v01 = (vy0 && vx1) ? sc[o00 + 1] : 0.f;
+    const float v10 = (vy1 && vx0) ? sc[o00 + W] : 0.f;
+    const float v11 = (vy1 && vx1) ? sc[o00 + W + 1] : 0.f;
+    float val = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+    if (add_identity) val += sc[sp];
+    ob[c * HW] = val;
+  }
+}
+
+__global__ __launch_bounds__(256) void warp2d_bwd_k(const float* __restrict__ dout,
+                                                    const float* __restrict__ src,
+                                                    const float* __restrict__ flow,
+                                                    float* __restrict__ dsrc, float* __restrict__ dflow,
+                                                    int B, int C, int H, int W, int add_identity,
+                                                    int flow_into_src) {
+  const long long HW = (long long)H * W;
+  const long long total = (long long)B * HW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long long r = i / W;
+  const int y = (int)(r % H);
+  const long long b = r / H;
+  const long long sp = (long long)y * W + x;
+  const float fy = (float)y + flow[(b * 2 + 0) * HW + sp];
+  const float fx = (float)x + flow[(b * 2 + 1) * HW + sp];
+  const float y0f = floorf(fy), x0f = floorf(fx);
+  const int y0 = (int)y0f, x0 = (int)x0f;
+  const float wy1 = fy - y0f, wx1 = fx - x0f, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+  const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const long long o00 = (long long)y0 * W + x0;
+  const float* sb = src + b * C * HW;
+  float* db = dsrc ? dsrc + b * C * HW : nullptr;
+  const float* gb = dout + b * C * HW + sp;
+  float gy = 0.f, gx = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gb[c * HW];
+    const float* sc = sb + c * HW;
+    const float v00 = (vy0 && vx0) ? sc[o00] : 0.f;
+    const float v01 = (vy0 && vx1) ? sc[o00 + 1] : 0.f;
+    const float v10 = (vy1 && vx0) ? sc[o00 + W] : 0.f;
+    const float v11 = (vy1 && vx1) ? sc[o00 + W + 1] : 0.f;
+    gy += g * (wx0 * (v10 - v00) + wx1 * (v11 - v01));
+    gx += g * (wy0 * (v01 - v00) + wy1 * (v11 - v10));
+    if (db) {
+      float* dc = db + c * HW;
+      if (vy0 && vx0) atomicAdd(dc + o00, g * wy0 * wx0);
+      if (vy0 && vx1) atomicAdd(dc + o00 + 1, g * wy0 * wx1);
+      if (vy1 && vx0) atomicAdd(dc + o00 + W, g * wy1 * wx0);
+      if (vy1 && vx1) atomicAdd(dc + o00 + W + 1, g * wy1 * wx1);
+      if (add_identity) atomicAdd(dc + sp, g);
+    }
+  }
+  if (flow_into_src) {
+    atomicAdd(db + 0 * HW + sp, gy);
+    atomicAdd(db + 1 * HW + sp, gx);
+  } else if (dflow) {
+    dflow[(b * 2 + 0) * HW + sp] = gy;
+    dflow[(b * 2 + 1) * HW + sp] = gx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ 3-D
+__global__ __launch_bounds__(256) void warp3d_fwd_k(const float* __restrict__ src,
+                                                    const float* __restrict__ flow,
+                                                    float* __restrict__ out, int B, int C, int D, int H,
+                                                    int W, int mode, int add_identity) {
+  const long long HW = (long long)H * W, S = HW * D;
+  const long long total = (long long)B * S;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  long long r = i / W;
+  const int y = (int)(r % H); r /= H;
+  const int z = (int)(r % D);
+  const long long b = r / D;
+  const long long sp = ((long long)z * H + y) * W + x;
+  const float fz = (float)z + flow[(b * 3 + 0) * S + sp];
+  const float fy = (float)y + flow[(b * 3 + 1) * S + sp];
+  const float fx = (float)x + flow[(b * 3 + 2) * S + sp];
+  const float* sb = src + b * C * S;
+  float* ob = out + b * C * S + sp;
+  if (mode == 1) {
+    const int zz = (int)nearbyintf(fz), yy = (int)nearbyintf(fy), xx = (int)nearbyintf(fx);
+    const bool v = (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    for (int c = 0; c < C; ++c) {
+      float val = v ? sb[c * S + ((long long)zz * H + yy) * W + xx] : 0.f;
+      if (add_identity) val += sb[c * S + sp];
+      ob[c * S] = val;
+    }
+    return;
+  }
+  const float z0f = floorf(fz), y0f = floorf(fy), x0f = floorf(fx);
+  const int z0 = (int)z0f, y0 = (int)y0f, x0 = (int)x0f;
+  const float wz1 = fz - z0f, wy1 = fy - y0f, wx1 = fx - x0f;
+  const float wz0 = 1.f - wz1, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+  const bool vz0 = (unsigned)z0 < (unsigned)D, vz1 = (unsigned)(z0 + 1) < (unsigned)D;
+  const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const long long o000 = ((long long)z0 * H + y0) * W + x0;
+  for (int c = 0; c < C; ++c) {
+    const float* sc = sb + c * S;
+    const float v000 = (vz0 && vy0 && vx0) ? sc[o000] : 0.f;
+    const float v001 = (vz0 && vy0 && vx1) ? sc[o000 + 1] : 0.f;
+    const float v010 = (vz0 && vy1 && vx0) ? sc[o000 + W] : 0.f;
+    const float v011 = (vz0 && vy1 && vx1) ? sc[o000 + W + 1] : 0.f;
+    const float v100 = (vz1 && vy0 && vx0) ? sc[o000 + HW] : 0.f;
+    const float v101 = (vz1 && vy0 && vx1) ? sc[o000 + HW + 1] : 0.f;
+    const float v110 = (vz1 && vy1 && vx0) ? sc[o000 + HW + W] : 0.f;
+    const float v111 = (vz1 && vy1 && vx1) ? sc[o000 + HW + W + 1] : 0.f;
+    float val = wz0 * (wy0 * (wx0 * v000 + wx1 * v001) + wy1 * (wx0 * v010 + wx1 * v011)) +
+                wz1 * (wy0 * (wx0 * v100 + wx1 * v101) + wy1 * (wx0 * v110 + wx1 * v111));
+    if (add_identity) val += sc[sp];
+    ob[c * S] = val;
+  }
+}
+
+__global__ __launch_bounds__(256) void warp3d_bwd_k(const float* __restrict__ dout,
+                                                    const float* __restrict__ src,
+                                                    const float* __restrict__ flow,
+                                                    float* __restrict__ dsrc, float* __restrict__ dflow,
+                                                    int B, int C, int D, int H, int W, int add_identity,
+                                                    int flow_into_src) {
+  const long long HW = (long long)H * W, S = HW * D;
+  const long long total = (long long)B * S;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  long long r = i / W;
+  const int y = (int)(r % H); r /= H;
+  const int z = (int)(r % D);
+  const long long b = r / D;
+  const long long sp = ((long long)z * H + y) * W + x;
+  const float fz = (float)z + flow[(b * 3 + 0) * S + sp];
+  const float fy = (float)y + flow[(b * 3 + 1) * S + sp];
+  const float fx = (float)x + flow[(b * 3 + 2) * S + sp];
+  const float z0f = floorf(fz), y0f = floorf(fy), x0f = floorf(fx);
+  const int z0 = (int)z0f, y0 = (int)y0f, x0 = (int)x0f;
+  const float wz1 = fz - z0f, wy1 = fy - y0f, wx1 = fx - x0f;
+  const float wz0 = 1.f - wz1, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+  const bool vz0 = (unsigned)z0 < (unsigned)D, vz1 = (unsigned)(z0 + 1) < (unsigned)D;
+  const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const long long o000 = ((long long)z0 * H + y0) * W + x0;
+  const float* sb = src + b * C * S;
+  float* db = dsrc ? dsrc + b * C * S : nullptr;
+  const float* gb = dout + b * C * S + sp;
+  float gz = 0.f, gy = 0.f, gx = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gb[c * S];
+    const float* sc = sb + c * S;
+    const float v000 = (vz0 && vy0 && vx0) ? sc[o000] : 0.f;
+    const float v001 = (vz0 && vy0 && vx1) ? sc[o000 + 1] : 0.f;
+    const float v010 = (vz0 && vy1 && vx0) ? sc[o000 + W] : 0.f;
+    const float v011 = (vz0 && vy1 && vx1) ? sc[o000 + W + 1] : 0.f;
+    const float v100 = (vz1 && vy0 && vx0) ? sc[o000 + HW] : 0.f;
+    const float v101 = (vz1 && vy0 && vx1) ? sc[o000 + HW + 1] : 0.f;
+    const float v110 = (vz1 && vy1 && vx0) ? sc[o000 + HW + W] : 0.f;
+    const float v111 = (vz1 && vy1 && vx1) ? sc[o000 + HW + W + 1] : 0.f;
+    const float p0 = wy0 * (wx0 * v000 + wx1 * v001) + wy1 * (wx0 * v010 + wx1 * v011);
+    const float p1 = wy0 * (wx0 * v100 + wx1 * v101) + wy1 * (wx0 * v110 + wx1 * v111);
+    gz += g * (p1 - p0);
+    gy += g * (wz0 * (wx0 * (v010 - v000) + wx1 * (v011 - v001)) +
+               wz1 * (wx0 * (v110 - v100) + wx1 * (v111 - v101)));
+    gx += g * (wz0 * (wy0 * (v001 - v000) + wy1 * (v011 - v010)) +
+               wz1 * (wy0 * (v101 - v100) + wy1 * (v111 - v110)));
+    if (db) {
+      float* dc = db + c * S;
+      if (vz0 && vy0 && vx0) atomicAdd(dc + o000, g * wz0 * wy0 * wx0);
+      if (vz0 && vy0 && vx1) atomicAdd(dc + o000 + 1, g * wz0 * wy0 * wx1);
+      if (vz0 && vy1 && vx0) atomicAdd(dc + o000 + W, g * wz0 * wy1 * wx0);
+      if (vz0 && vy1 && vx1) atomicAdd(dc + o000 + W + 1, g * wz0 * wy1 * wx1);
+      if (vz1 && vy0 && vx0) atomicAdd(dc + o000 + HW, g * wz1 * wy0 * wx0);
+      if (vz1 && vy0 && vx1) atomicAdd(dc + o000 + HW + 1, g * wz1 * wy0 * wx1);
+      if (vz1 && vy1 && vx0) atomicAdd(dc + o000 + HW + W, g * wz1 * wy1 * wx0);
+      if (vz1 && vy1 && vx1) atomicAdd(dc + o000 + HW + W + 1, g * wz1 * wy1 * wx1);
+      if (add_identity) atomicAdd(dc + sp, g);
+    }
+  }
+  if (flow_into_src) {
+    atomicAdd(db + 0 * S + sp, gz);
+    atomicAdd(db + 1 * S + sp, gy);
+    atomicAdd(db + 2 * S + sp, gx);
+  } else if (dflow) {
+    dflow[(b * 3 + 0) * S + sp] = gz;
+    dflow[(b * 3 + 1) * S + sp] = gy;
+    dflow[(b * 3 + 2) * S + sp] = gx;
+  }
+}
+
+// --------------------------------------------------------------------------------- resize
+// F.interpolate(mode=(bi|tri)linear, align_corners=True): src = dst*(in-1)/(out-1).
+__device__ __forceinline__ void lin_src(int o, float scale, int in, int& i0, int& i1, float& l1) {
+  const float f = scale * (float)o;
+  i0 = (int)f;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = f - (float)i0;
+}
+__global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                    int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                                                    int Wo, float sd, float sh, float sw, float mult) {
+  const long long So = (long long)Do * Ho * Wo, Si = (long long)Di * Hi * Wi;
+  const long long total = (long long)planes * So;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % Wo);
+  long long r = i / Wo;
+  const int oy = (int)(r % Ho); r /= Ho;
+  const int oz = (int)(r % Do);
+  const long long pl = r / Do;
+  int z0, z1, y0, y1, x0, x1;
+  float lz, ly, lx;
+  lin_src(oz, sd, Di, z0, z1, lz);
+  lin_src(oy, sh, Hi, y0, y1, ly);
+  lin_src(ox, sw, Wi, x0, x1, lx);
+  const float* xp = x + pl * Si;
+#define XR(z_, y_, x_) xp[((long long)(z_) * Hi + (y_)) * Wi + (x_)]
+  const float a0 = (1.f - lx) * XR(z0, y0, x0) + lx * XR(z0, y0, x1);
+  const float a1 = (1.f - lx) * XR(z0, y1, x0) + lx * XR(z0, y1, x1);
+  const float b0 = (1.f - lx) * XR(z1, y0, x0) + lx * XR(z1, y0, x1);
+  const float b1 = (1.f - lx) * XR(z1, y1, x0) + lx * XR(z1, y1, x1);
+#undef XR
+  const float v = (1.f - lz) * ((1.f - ly) * a0 + ly * a1) + lz * ((1.f - ly) * b0 + ly * b1);
+  y[i] = mult * v;
+}
+__global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy, float* __restrict__ dx,
+                                                    int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                                                    int Wo, float sd, float sh, float sw, float mult) {
+  const long long So = (long long)Do * Ho * Wo, Si = (long long)Di * Hi * Wi;
+  const long long total = (long long)planes * So;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % Wo);
+  long long r = i / Wo;
+  const int oy = (int)(r % Ho); r /= Ho;
+  const int oz = (int)(r % Do);
+  const long long pl = r / Do;
+  int z0, z1, y0, y1, x0, x1;
+  float lz, ly, lx;
+  lin_src(oz, sd, Di, z0, z1, lz);
+  lin_src(oy, sh, Hi, y0, y1, ly);
+  lin_src(ox, sw, Wi, x0, x1, lx);
+  float* xp = dx + pl * Si;
+  const float g = mult * dy[i];
+  const int zz[2] = {z0, z1}, yy[2] = {y0, y1}, xx[2] = {x0, x1};
+  const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float w = wz[a] * wy[bq] * wx[c];
+        if (w != 0.f) atomicAdd(&xp[((long long)zz[a] * Hi + yy[bq]) * Wi + xx[c]], g * w);
+      }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dfmir_warp2d_fwd(const float* src, const float* flow, float* out, int B, int C, int H,
+                                int W, int mode, int add_identity, void* stream) {
+  DF_ARG_CHECK(src && flow && out && B > 0 && C > 0 && H > 0 && W > 0);
+  DF_ARG_CHECK(!add_identity || C == 2);
+  const long long total = (long long)B * H * W;
+  warp2d_fwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, flow, out, B, C, H,
+                                                                                W, mode, add_identity);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_warp2d_bwd(const float* dout, const float* src, const float* flow, float* dsrc,
+                                float* dflow, int B, int C, int H, int W, int add_identity,
+                                int flow_into_src, void* stream) {
+  DF_ARG_CHECK(dout && src && flow && B > 0 && C > 0 && H > 0 && W > 0);
+  DF_ARG_CHECK(!flow_into_src || (dsrc && C == 2));
+  const long long total = (long long)B * H * W;
+  warp2d_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      dout, src, flow, dsrc, dflow, B, C, H, W, add_identity, flow_into_src);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C, int D,
+                                int H, int W, int mode, int add_identity, void* stream) {
+  DF_ARG_CHECK(src && flow && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  DF_ARG_CHECK(!add_identity || C == 3);
+  const long long total = (long long)B * D * H * W;
+  warp3d_fwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      src, flow, out, B, C, D, H, W, mode, add_identity);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_warp3d_bwd(const float* dout, const float* src, const float* flow, float* dsrc,
+                                float* dflow, int B, int C, int D, int H, int W, int add_identity,
+                                int flow_into_src, void* stream) {
+  DF_ARG_CHECK(dout && src && flow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  DF_ARG_CHECK(!flow_into_src || (dsrc && C == 3));
+  const long long total = (long long)B * D * H * W;
+  warp3d_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+static inline float lin_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+extern "C" int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do,
+                                int Ho, int Wo, float mult, void* stream) {
+  DF_ARG_CHECK(x && y && planes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0);
+  const long long total = (long long)planes * Do * Ho * Wo;
+  resize_fwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      x, y, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_resize_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do,
+                                int Ho, int Wo, float mult, void* stream) {
+  DF_ARG_CHECK(dy && dx && planes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0);
+  const long long total = (long long)planes * Do * Ho * Wo;
+  resize_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      dy, dx, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,724 @@
+"""torch.autograd.Function wrappers over the C ABI of libdfmir_hip.so.
+
+Every op here launches hand-written gfx950 kernels on torch's *current* HIP stream with raw device
+pointers; torch is used only for memory, streams and the autograd tape.  There is no CPU or
+eager-PyTorch fallback: a non-CUDA tensor raises.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import DfConvGeom, DfmirHipError, check, lib
+
+_VP = ctypes.c_void_p
+
+
+def _p(t):
+    return None if t is None else _VP(t.data_ptr())
+
+
+def _st():
+    return _VP(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise DfmirHipError("dfmir_amd ops run only on the HIP device (got a %s tensor); "
+                                "there is no CPU fallback" % t.device)
+        if t.dtype not in (torch.float32, torch.int64, torch.bool, torch.uint8):
+            raise DfmirHipError("unsupported dtype %s" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches
+# ------------------------------------------------------------------------------------------------
+def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp):
+    N, Cin, Di, Hi, Wi = x5.shape
+    y = torch.empty((N, Cout) + tuple(out_sp), device=x5.device, dtype=torch.float32)
+    g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, out_sp[0], out_sp[1], out_sp[2], K[0], K[1], K[2],
+                   stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
+    check(lib().dfmir_conv_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _st()))
+    return y
+
+
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode):
+    N, Cin, Di, Hi, Wi = x5.shape
+    _, Cout, Do, Ho, Wo = dy5.shape
+    T = K[0] * K[1] * K[2]
+    dw = torch.zeros((T, Cin, Cout), device=x5.device, dtype=torch.float32)
+    g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
+                   pad[2], pad_mode, 0, 0.0)
+    check(lib().dfmir_conv_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+    return dw
+
+
+def weight_pack(w, mode):
+    Cout, Cin = w.shape[0], w.shape[1]
+    T = w.numel() // (Cout * Cin)
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    check(lib().dfmir_weight_pack(_p(_c(w)), _p(out), Cout, Cin, T, mode, _st()))
+    return out
+
+
+def weight_unpack(g_tcc, shape):
+    Cout, Cin = shape[0], shape[1]
+    T = g_tcc.numel() // (Cout * Cin)
+    out = torch.empty(shape, device=g_tcc.device, dtype=torch.float32)
+    check(lib().dfmir_weight_unpack(_p(g_tcc), _p(out), Cout, Cin, T, _st()))
+    return out
+
+
+# A global "weights epoch": the fused Adam kernel updates parameters through raw pointers, which
+# torch's version counters cannot see; packed-weight caches are keyed on (version, epoch).
+_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    _EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _EPOCH[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class ConvFn(Function):
+    """y = act(conv(x, w) + b).  `owner` supplies cached packed weights (owner.packed(mode))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner, stride, pad, pad_mode, act, slope):
+        _need(x, weight, bias)
+        nd = x.dim() - 2
+        x5 = _c(x) if nd == 3 else _c(x).unsqueeze(2)
+        K = tuple(weight.shape[2:]) if nd == 3 else (1,) + tuple(weight.shape[2:])
+        p3 = (pad,) * 3 if nd == 3 else (0, pad, pad)
+        sp = x5.shape[2:]
+        out_sp = tuple((sp[i] + 2 * p3[i] - K[i]) // stride + 1 for i in range(3))
+        w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
+        y5 = conv_raw(x5, w_tcc, bias, weight.shape[0], K, stride, p3, 1, pad_mode, act, slope, out_sp)
+        ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
+        ctx.save_for_backward(x5, weight, y5 if act else None)
+        ctx.has_bias = bias is not None
+        return y5 if nd == 3 else y5.squeeze(2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        nd, K, stride, p3, pad_mode, act, slope, owner = ctx.cfg
+        x5, weight, y5 = ctx.saved_tensors
+        dy5 = _c(dy) if nd == 3 else _c(dy).unsqueeze(2)
+        if act:
+            dpre = torch.empty_like(dy5)
+            check(lib().dfmir_act_bwd(_p(dy5), _p(y5), _p(dpre), dy5.numel(), act, float(slope), _st()))
+            dy5 = dpre
+        dx = dw = db = None
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if ctx.needs_input_grad[0]:
+            wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
+            in_sp = tuple(x5.shape[2:])
+            if stride == 1 and pad_mode == 1:
+                # full correlation onto the reflect-padded frame, then fold the halo back
+                padp = tuple(K[i] - 1 for i in range(3))
+                out_sp = tuple(in_sp[i] + 2 * p3[i] for i in range(3))
+                dxp = conv_raw(dy5, wd, None, Cin, K, 1, padp, 1, 0, 0, 0.0, out_sp)
+                if p3[0] != 0 or p3[1] != p3[2]:
+                    raise DfmirHipError("reflect padding is 2-D, symmetric only")
+                dx5 = torch.empty_like(x5)
+                check(lib().dfmir_reflect_pad2d_bwd(_p(dxp), _p(dx5), x5.shape[0] * Cin, in_sp[1], in_sp[2],
+                                                    p3[1], _st()))
+            else:
+                padp = tuple(K[i] - 1 - p3[i] for i in range(3))
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp)
+            dx = dx5 if nd == 3 else dx5.squeeze(2)
+        if ctx.needs_input_grad[1]:
+            dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode)
+            dw = weight_unpack(dwt, tuple(weight.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
+            S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
+            check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, S, _st()))
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0):
+    return ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope)
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm (+ReLU, +residual)
+# ------------------------------------------------------------------------------------------------
+class InstNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, res, relu, eps):
+        _need(x, res)
+        x = _c(x)
+        planes = x.shape[0] * x.shape[1]
+        S = x.numel() // planes
+        y = torch.empty_like(x)
+        mean = torch.empty(planes, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        r = _c(res) if res is not None else None
+        check(lib().dfmir_instnorm_fwd(_p(x), _p(r), _p(y), _p(mean), _p(rstd), planes, S, float(eps),
+                                       int(relu), _st()))
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.relu = int(relu)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        planes = x.shape[0] * x.shape[1]
+        S = x.numel() // planes
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu, _st()))
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        return dx, dres, None, None
+
+
+def instance_norm(x, res=None, relu=False, eps=1e-5):
+    return InstNormFn.apply(x, res, relu, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# plane-wise resampling
+# ------------------------------------------------------------------------------------------------
+def _plane_op(fwd_name, bwd_name, out_hw):
+    class _Fn(Function):
+        @staticmethod
+        def forward(ctx, x, *extra):
+            _need(x)
+            x = _c(x)
+            N, C, H, W = x.shape
+            Ho, Wo = out_hw(H, W, *extra)
+            y = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32)
+            check(getattr(lib(), fwd_name)(_p(x), _p(y), N * C, H, W, *extra, _st()))
+            ctx.shape = (N, C, H, W)
+            ctx.extra = extra
+            return y
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, dy):
+            N, C, H, W = ctx.shape
+            dy = _c(dy)
+            dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+            check(getattr(lib(), bwd_name)(_p(dy), _p(dx), N * C, H, W, *ctx.extra, _st()))
+            return (dx,) + (None,) * len(ctx.extra)
+
+    _Fn.__name__ = fwd_name
+    return _Fn
+
+
+BlurDownFn = _plane_op("dfmir_blur_down_fwd", "dfmir_blur_down_bwd",
+                       lambda H, W: ((H - 1) // 2 + 1, (W - 1) // 2 + 1))
+BlurUpFn = _plane_op("dfmir_blur_up_fwd", "dfmir_blur_up_bwd", lambda H, W: (2 * H, 2 * W))
+ReflectPadFn = _plane_op("dfmir_reflect_pad2d_fwd", "dfmir_reflect_pad2d_bwd",
+                         lambda H, W, p: (H + 2 * p, W + 2 * p))
+
+
+def blur_down(x):
+    return BlurDownFn.apply(x)
+
+
+def blur_up(x):
+    return BlurUpFn.apply(x)
+
+
+def reflect_pad2d(x, p):
+    return ReflectPadFn.apply(x, int(p))
+
+
+class UpCatFn(Function):
+    """cat([nearest_up2(a), b], dim=1)  (torchvoxelmorph/networks.py:97-100)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need(a, b)
+        a, b = _c(a), _c(b)
+        nd = a.dim() - 2
+        N, Ca = a.shape[0], a.shape[1]
+        Cb = b.shape[1]
+        Da, Ha, Wa = (a.shape[2:] if nd == 3 else (1,) + tuple(a.shape[2:]))
+        sd = 2 if nd == 3 else 1
+        exp = (Da * sd, Ha * 2, Wa * 2) if nd == 3 else (Ha * 2, Wa * 2)
+        if tuple(b.shape[2:]) != tuple(exp):
+            raise DfmirHipError("upcat: skip tensor %s does not match upsampled %s" % (tuple(b.shape), exp))
+        y = torch.empty((N, Ca + Cb) + tuple(b.shape[2:]), device=a.device, dtype=torch.float32)
+        check(lib().dfmir_upcat_fwd(_p(a), _p(b), _p(y), N, Ca, Cb, Da, Ha, Wa, sd, _st()))
+        ctx.meta = (a.shape, b.shape, N, Ca, Cb, Da, Ha, Wa, sd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ash, bsh, N, Ca, Cb, Da, Ha, Wa, sd = ctx.meta
+        dy = _c(dy)
+        da = torch.empty(ash, device=dy.device, dtype=torch.float32)
+        db = torch.empty(bsh, device=dy.device, dtype=torch.float32)
+        check(lib().dfmir_upcat_bwd(_p(dy), _p(da), _p(db), N, Ca, Cb, Da, Ha, Wa, sd, _st()))
+        return da, db
+
+
+def upcat(a, b):
+    return UpCatFn.apply(a, b)
+
+
+class CatChannelsFn(Function):
+    """torch.cat([a, b], dim=1) for same-shape-but-channels tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need(a, b)
+        a, b = _c(a), _c(b)
+        if a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+            raise DfmirHipError("cat: shapes %s / %s differ outside dim 1" % (tuple(a.shape), tuple(b.shape)))
+        N = a.shape[0]
+        SA, SB = a.numel() // N, b.numel() // N
+        y = torch.empty((N, a.shape[1] + b.shape[1]) + tuple(a.shape[2:]), device=a.device, dtype=torch.float32)
+        check(lib().dfmir_cat_channels_fwd(_p(a), _p(b), _p(y), N, SA, SB, _st()))
+        ctx.meta = (a.shape, b.shape, N, SA, SB)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ash, bsh, N, SA, SB = ctx.meta
+        dy = _c(dy)
+        da = torch.empty(ash, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        db = torch.empty(bsh, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            check(lib().dfmir_cat_channels_bwd(_p(dy), _p(da), _p(db), N, SA, SB, _st()))
+        return da, db
+
+
+def upcat_channels(a, b):
+    return CatChannelsFn.apply(a, b)
+
+
+class CatBatchFn(Function):
+    """torch.cat([a, b], dim=0) (registration_model.py:187) as one copy launch."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need(a, b)
+        a, b = _c(a), _c(b)
+        if a.shape[1:] != b.shape[1:]:
+            raise DfmirHipError("cat_batch: shapes %s / %s differ outside dim 0" % (tuple(a.shape), tuple(b.shape)))
+        y = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+        check(lib().dfmir_cat_channels_fwd(_p(a), _p(b), _p(y), 1, a.numel(), b.numel(), _st()))
+        ctx.meta = (a.shape, b.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        ash, bsh = ctx.meta
+        dy = _c(dy)
+        na = 1
+        for s in ash:
+            na *= s
+        da = dy[:ash[0]] if ctx.needs_input_grad[0] else None
+        db = dy[ash[0]:] if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def cat_batch(a, b):
+    return CatBatchFn.apply(a, b)
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, mult):
+        _need(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib().dfmir_scale(_p(x), _p(y), x.numel(), float(mult), _st()))
+        ctx.mult = float(mult)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().dfmir_scale(_p(dy), _p(dx), dy.numel(), ctx.mult, _st()))
+        return dx, None
+
+
+def scale(x, mult):
+    return ScaleFn.apply(x, mult)
+
+
+# ------------------------------------------------------------------------------------------------
+# warps
+# ------------------------------------------------------------------------------------------------
+def _warp_fwd(src, flow, mode, add_identity):
+    nd = src.dim() - 2
+    out = torch.empty_like(src)
+    if nd == 2:
+        B, C, H, W = src.shape
+        check(lib().dfmir_warp2d_fwd(_p(src), _p(flow), _p(out), B, C, H, W, mode, add_identity, _st()))
+    else:
+        B, C, D, H, W = src.shape
+        check(lib().dfmir_warp3d_fwd(_p(src), _p(flow), _p(out), B, C, D, H, W, mode, add_identity, _st()))
+    return out
+
+
+def _warp_bwd(dout, src, flow, dsrc, dflow, add_identity, into_src):
+    nd = src.dim() - 2
+    if nd == 2:
+        B, C, H, W = src.shape
+        check(lib().dfmir_warp2d_bwd(_p(dout), _p(src), _p(flow), _p(dsrc), _p(dflow), B, C, H, W,
+                                     add_identity, into_src, _st()))
+    else:
+        B, C, D, H, W = src.shape
+        check(lib().dfmir_warp3d_bwd(_p(dout), _p(src), _p(flow), _p(dsrc), _p(dflow), B, C, D, H, W,
+                                     add_identity, into_src, _st()))
+
+
+class WarpFn(Function):
+    @staticmethod
+    def forward(ctx, src, flow, mode):
+        _need(src, flow)
+        src, flow = _c(src), _c(flow)
+        nd = src.dim() - 2
+        if flow.shape[1] != nd or flow.shape[0] != src.shape[0] or flow.shape[2:] != src.shape[2:]:
+            raise DfmirHipError("warp: src %s / flow %s mismatch (expected grid and input to have same "
+                                "batch size and spatial shape)" % (tuple(src.shape), tuple(flow.shape)))
+        ctx.save_for_backward(src, flow)
+        ctx.mode = mode
+        return _warp_fwd(src, flow, mode, 0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        src, flow = ctx.saved_tensors
+        dout = _c(dout)
+        dsrc = torch.zeros_like(src) if ctx.needs_input_grad[0] else None
+        dflow = None
+        if ctx.needs_input_grad[1]:
+            dflow = torch.zeros_like(flow) if ctx.mode == 1 else torch.empty_like(flow)
+        if ctx.mode == 1:
+            if dsrc is not None:
+                raise DfmirHipError("nearest-mode warp backward is not implemented (inference only)")
+            return dsrc, dflow, None
+        _warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
+        return dsrc, dflow, None
+
+
+def warp(src, flow, mode="bilinear"):
+    return WarpFn.apply(src, flow, 1 if mode == "nearest" else 0)
+
+
+class VecIntStepFn(Function):
+    """v -> v + warp(v, v)   (one scaling-and-squaring step, layers.py:66-67)."""
+
+    @staticmethod
+    def forward(ctx, v):
+        _need(v)
+        v = _c(v)
+        ctx.save_for_backward(v)
+        return _warp_fwd(v, v, 0, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (v,) = ctx.saved_tensors
+        dout = _c(dout)
+        dv = torch.zeros_like(v)
+        _warp_bwd(dout, v, v, dv, None, 1, 1)
+        return dv
+
+
+def vecint_step(v):
+    return VecIntStepFn.apply(v)
+
+
+class ResizeFn(Function):
+    @staticmethod
+    def forward(ctx, x, out_sp, mult):
+        _need(x)
+        x = _c(x)
+        nd = x.dim() - 2
+        isp = tuple(x.shape[2:]) if nd == 3 else (1,) + tuple(x.shape[2:])
+        osp = tuple(out_sp) if nd == 3 else (1,) + tuple(out_sp)
+        planes = x.shape[0] * x.shape[1]
+        y = torch.empty(tuple(x.shape[:2]) + tuple(out_sp), device=x.device, dtype=torch.float32)
+        check(lib().dfmir_resize_fwd(_p(x), _p(y), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
+                                     float(mult), _st()))
+        ctx.meta = (x.shape, planes, isp, osp, float(mult))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xs, planes, isp, osp, mult = ctx.meta
+        dy = _c(dy)
+        dx = torch.zeros(xs, device=dy.device, dtype=torch.float32)
+        check(lib().dfmir_resize_bwd(_p(dy), _p(dx), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
+                                     mult, _st()))
+        return dx, None, None
+
+
+def resize_linear(x, out_sp, mult=1.0):
+    return ResizeFn.apply(x, tuple(int(s) for s in out_sp), mult)
+
+
+# ------------------------------------------------------------------------------------------------
+# PatchNCE
+# ------------------------------------------------------------------------------------------------
+class PatchGatherFn(Function):
+    """feat [B,C,*sp], ids int64 [P] -> channel-major rows [C, B*P]."""
+
+    @staticmethod
+    def forward(ctx, feat, ids):
+        _need(feat, ids)
+        feat = _c(feat)
+        ids = _c(ids.to(torch.int64))
+        B, C = feat.shape[0], feat.shape[1]
+        S = feat.numel() // (B * C)
+        Pn = ids.numel()
+        out = torch.empty((C, B * Pn), device=feat.device, dtype=torch.float32)
+        check(lib().dfmir_patch_gather_fwd(_p(feat), _p(ids), _p(out), B, C, S, Pn, _st()))
+        ctx.save_for_backward(ids)
+        ctx.meta = (feat.shape, B, C, S, Pn)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        shape, B, C, S, Pn = ctx.meta
+        dout = _c(dout)
+        dfeat = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, _st()))
+        return dfeat, None
+
+
+def patch_gather(feat, ids):
+    return PatchGatherFn.apply(feat, ids)
+
+
+class L2NormFn(Function):
+    """x [C, rows] -> x / (||x||_2 over C + eps)   (networks.py:499-502)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _need(x)
+        x = _c(x)
+        C, rows = x.shape
+        y = torch.empty_like(x)
+        nrm = torch.empty(rows, device=x.device, dtype=torch.float32)
+        check(lib().dfmir_l2norm_fwd(_p(x), _p(y), _p(nrm), C, rows, float(eps), _st()))
+        ctx.save_for_backward(x, nrm)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, nrm = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib().dfmir_l2norm_bwd(_p(dy), _p(x), _p(nrm), _p(dx), x.shape[0], x.shape[1], ctx.eps, _st()))
+        return dx, None
+
+
+def l2norm_rows(x, eps=1e-7):
+    return L2NormFn.apply(x, eps)
+
+
+class PatchNCEFn(Function):
+    """q, k [C, rows] -> per-row InfoNCE loss [rows]; gradient flows to q only (k is detached,
+    patchnce.py:17)."""
+
+    @staticmethod
+    def forward(ctx, q, k, groups, T):
+        _need(q, k)
+        q, k = _c(q), _c(k)
+        C, rows = q.shape
+        if rows % groups != 0:
+            raise DfmirHipError("patchnce: rows %d not divisible by groups %d" % (rows, groups))
+        R = rows // groups
+        loss = torch.empty(rows, device=q.device, dtype=torch.float32)
+        probs = torch.empty((rows, R + 1), device=q.device, dtype=torch.float32)
+        check(lib().dfmir_patchnce_fwd(_p(q), _p(k), _p(loss), _p(probs), rows, C, groups, float(T), _st()))
+        ctx.save_for_backward(probs, k)
+        ctx.meta = (rows, C, groups, float(T))
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        probs, k = ctx.saved_tensors
+        rows, C, groups, T = ctx.meta
+        dloss = _c(dloss)
+        dq = torch.empty_like(k)
+        check(lib().dfmir_patchnce_bwd(_p(dloss), _p(probs), _p(k), _p(dq), rows, C, groups, T, _st()))
+        return dq, None, None, None
+
+
+def patchnce_rows(q, k, groups, T):
+    return PatchNCEFn.apply(q, k, groups, T)
+
+
+# ------------------------------------------------------------------------------------------------
+# scalar losses
+# ------------------------------------------------------------------------------------------------
+class MaskedL1Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, mask, thr):
+        _need(a, b, mask)
+        a, b = _c(a), _c(b)
+        m = None
+        if mask is not None:
+            m = _c(mask.to(torch.bool))
+            if m.shape != a.shape:
+                m = _c(m.expand_as(a))
+        ws = torch.empty(8, device=a.device, dtype=torch.float32)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        check(lib().dfmir_masked_l1_fwd(_p(a), _p(b), _p(m), float(thr), _p(ws), _p(out), a.numel(), _st()))
+        ctx.save_for_backward(a, b, m, ws)
+        ctx.thr = float(thr)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b, m, ws = ctx.saved_tensors
+        g = _c(g)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            check(lib().dfmir_masked_l1_bwd(_p(a), _p(b), _p(m), ctx.thr, _p(ws), _p(g), _p(da), _p(db),
+                                            a.numel(), _st()))
+        return da, db, None, None
+
+
+def masked_l1(a, b, mask=None, thr=-0.95):
+    """sum(|a-b|*m)/sum(m); m = mask if given else (a>thr)|(b>thr)."""
+    return MaskedL1Fn.apply(a, b, mask, thr)
+
+
+class FlowSmoothFn(Function):
+    @staticmethod
+    def forward(ctx, flow):
+        _need(flow)
+        flow = _c(flow)
+        nd = flow.dim() - 2
+        B, C = flow.shape[0], flow.shape[1]
+        D, H, W = flow.shape[2:] if nd == 3 else (1,) + tuple(flow.shape[2:])
+        ws = torch.empty(8, device=flow.device, dtype=torch.float32)
+        out = torch.empty((), device=flow.device, dtype=torch.float32)
+        check(lib().dfmir_flow_smooth_fwd(_p(flow), _p(ws), _p(out), B, C, D, H, W, _st()))
+        ctx.save_for_backward(flow)
+        ctx.meta = (B, C, D, H, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (flow,) = ctx.saved_tensors
+        B, C, D, H, W = ctx.meta
+        g = _c(g)
+        df = torch.empty_like(flow)
+        check(lib().dfmir_flow_smooth_bwd(_p(flow), _p(g), _p(df), B, C, D, H, W, _st()))
+        return df
+
+
+def flow_smoothness(flow):
+    return FlowSmoothFn.apply(flow)
+
+
+class NCCFn(Function):
+    """-sqrt(mean(cc)) with a win^nd mean window (util/losses.py:248-256); gradient w.r.t. the
+    prediction I only (J is the fixed target)."""
+
+    @staticmethod
+    def forward(ctx, I, J, win, eps):
+        _need(I, J)
+        I, J = _c(I), _c(J)
+        if I.shape[1] != 1:
+            raise DfmirHipError("NCC expects single-channel volumes")
+        nd = I.dim() - 2
+        B = I.shape[0]
+        D, H, W = I.shape[2:] if nd == 3 else (1,) + tuple(I.shape[2:])
+        N = I.numel()
+        sums = torch.empty(5 * N, device=I.device, dtype=torch.float32)
+        tmp2 = torch.empty(5 * N, device=I.device, dtype=torch.float32)
+        ws = torch.empty(8, device=I.device, dtype=torch.float32)
+        out = torch.empty((), device=I.device, dtype=torch.float32)
+        check(lib().dfmir_ncc_fwd(_p(I), _p(J), _p(sums), _p(tmp2), _p(ws), _p(out), B, D, H, W, int(win),
+                                  float(eps), _st()))
+        ctx.save_for_backward(I, J, sums, ws)
+        ctx.meta = (B, D, H, W, int(win), float(eps))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        I, J, sums, ws = ctx.saved_tensors
+        B, D, H, W, win, eps = ctx.meta
+        g = _c(g)
+        N = I.numel()
+        t1 = torch.empty(3 * N, device=I.device, dtype=torch.float32)
+        t2 = torch.empty(3 * N, device=I.device, dtype=torch.float32)
+        dI = torch.empty_like(I)
+        check(lib().dfmir_ncc_bwd(_p(I), _p(J), _p(sums), _p(t1), _p(t2), _p(ws), _p(g), _p(dI), B, D, H, W,
+                                  win, eps, _st()))
+        return dI, None, None, None
+
+
+def ncc_loss(I, J, win=9, eps=1e-5):
+    return NCCFn.apply(I, J, win, eps)
+
+
+class MeanFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need(x)
+        x = _c(x)
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        check(lib().dfmir_sum_scaled(_p(x), _p(out), x.numel(), 1.0 / x.numel(), _st()))
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g)
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        check(lib().dfmir_fill_from_scalar(_p(g), _p(dx), n, 1.0 / n, _st()))
+        return dx
+
+
+def mean(x):
+    return MeanFn.apply(x)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _need(p, g, m, v)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(lib().dfmir_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                float(eps), float(bc1), float(bc2), float(grad_scale), _st()))
+    bump_weights_epoch()

@@ -1,0 +1,23 @@
+"""Namespace with the option fields the registration plugin reads, at the reference's defaults
+(options/base_options.py:26-70, options/train_options.py:13-41, registration_model.py:35-71 with
+CUT_mode=CUT).  train.py users pass their own parsed `opt`; this is for tests / bench / smoke."""
+import argparse
+
+
+def default_options(**overrides):
+    opt = argparse.Namespace(
+        # base_options.py
+        name='experiment_name', gpu_ids=[0], checkpoints_dir='./checkpoints', model='registration',
+        input_nc=1, output_nc=1, ngf=64, netG='resnet_9blocks', normG='instance', init_type='xavier',
+        init_gain=0.02, no_dropout=True, no_antialias=False, no_antialias_up=False, direction='AtoB',
+        batch_size=1, load_size=256, crop_size=256, preprocess='resize_and_crop', epoch='latest', verbose=False,
+        # train_options.py
+        isTrain=True, continue_train=False, epoch_count=1, pretrained_name=None, n_epochs=150, n_epochs_decay=150,
+        beta1=0.5, beta2=0.999, lr=0.0002, gan_mode='lsgan', pool_size=0, lr_policy='linear', lr_decay_iters=50,
+        # registration_model.py (CUT defaults)
+        CUT_mode='CUT', lambda_GAN=0.0, lambda_NCE=0.25, nce_idt=True, nce_layers='0,4,8,12,16',
+        nce_includes_all_negatives_from_minibatch=False, netF='mlp_sample', netF_nc=256, nce_T=0.07,
+        num_patches=256, flip_equivariance=False, dvf_image=None)
+    for k, v in overrides.items():
+        setattr(opt, k, v)
+    return opt

@@ -1,0 +1,228 @@
+"""REGISTRATIONModel -- the `--model registration` plugin (reference
+models/registration_model.py:34-263) on the MI355X-native kernels.
+
+Same class name, option setter, attribute names (netG/netF/netR, loss_*, visuals), call order and
+loss algebra as the reference, including its quirks (double lambda_NCE on loss_local,
+PatchNCELoss grouping by opt.batch_size, NCE layer 0 = the reflection-padded input).  Deliberate
+differences, all outside the arithmetic of the losses:
+  * `.cuda()` hard-codes become `self.device`;
+  * the `dvf` checkerboard is decoded once and expanded to the batch (the reference re-reads
+    ./deform256.jpg every step and crashes for batch_size > 1, registration_model.py:148-149);
+  * Adam runs as one fused launch per network over a flat parameter arena (dfmir_amd.optim);
+  * multi-GPU = one process per GPU + one RCCL all-reduce per network after backward.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import networks, ops
+from . import voxelmorph as vxm
+from .base_model import BaseModel
+from .losses import NCC_Loss, smooothing_loss
+from .optim import FlatAdam
+from .patchnce import PatchNCELoss
+from .voxelmorph import SpatialTransformer
+
+
+def str2bool(v):
+    """util/util.py:13-21."""
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if v.lower() in ('no', 'false', 'f', 'n', '0'):
+        return False
+    import argparse
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+def open_image_to_torch(path, size):
+    """CenterCrop(size) + ToTensor + Normalize(0.5, 0.5) of an image file -> [1,C,size,size]
+    (registration_model.py:14-23), without torchvision."""
+    from PIL import Image
+    im = Image.open(path)
+    w, h = im.size
+    left, top = int(round((w - size) / 2.0)), int(round((h - size) / 2.0))
+    im = im.crop((left, top, left + size, top + size))
+    a = np.asarray(im, dtype=np.float32) / 255.0
+    if a.ndim == 2:
+        a = a[:, :, None]
+    t = torch.from_numpy(a).permute(2, 0, 1).contiguous()
+    return ((t - 0.5) / 0.5).unsqueeze(0)
+
+
+def synthetic_checkerboard(size, channels=3, cell=16):
+    """Stand-in for the reference's deform256.jpg asset when it is not in the working directory."""
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing='ij')
+    board = (((yy // cell) + (xx // cell)) % 2).float() * 2.0 - 1.0
+    return board[None, None].repeat(1, channels, 1, 1)
+
+
+class REGISTRATIONModel(BaseModel):
+    @staticmethod
+    def modify_commandline_options(parser, is_train=True):
+        """registration_model.py:35-71."""
+        parser.add_argument('--CUT_mode', type=str, default="CUT", choices='(CUT, cut, FastCUT, fastcut)')
+        parser.add_argument('--lambda_GAN', type=float, default=0.0, help='weight for GAN loss：GAN(G(X))')
+        parser.add_argument('--lambda_NCE', type=float, default=0.25, help='weight for NCE loss: NCE(G(X), X)')
+        parser.add_argument('--nce_idt', type=str2bool, nargs='?', const=True, default=False)
+        parser.add_argument('--nce_layers', type=str, default='0,4,8,12,16')
+        parser.add_argument('--nce_includes_all_negatives_from_minibatch', type=str2bool, nargs='?', const=True, default=False)
+        parser.add_argument('--netF', type=str, default='mlp_sample', choices=['sample', 'reshape', 'mlp_sample'])
+        parser.add_argument('--netF_nc', type=int, default=256)
+        parser.add_argument('--nce_T', type=float, default=0.07)
+        parser.add_argument('--num_patches', type=int, default=256)
+        parser.add_argument('--flip_equivariance', type=str2bool, nargs='?', const=True, default=False)
+        parser.set_defaults(pool_size=0)
+        opt, _ = parser.parse_known_args()
+        if opt.CUT_mode.lower() == "cut":
+            parser.set_defaults(nce_idt=True, lambda_NCE=0.25)
+        elif opt.CUT_mode.lower() == "fastcut":
+            parser.set_defaults(nce_idt=False, lambda_NCE=10.0, flip_equivariance=True, n_epochs=150, n_epochs_decay=50)
+        else:
+            raise ValueError(opt.CUT_mode)
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        self.loss_names = ['G', 'NCE', 'R', 'smooth', 'local']
+        self.visual_names = ['real_A', 'fake_B', 'real_B', 'dvf', 'registered', 'regA']
+        self.nce_layers = [int(i) for i in self.opt.nce_layers.split(',')]
+        if opt.nce_idt and self.isTrain:
+            self.loss_names += ['NCE_Y']
+            self.visual_names += ['idt_B']
+        self.model_names = ['G', 'F', 'R'] if self.isTrain else ['G', 'R']
+
+        self.netG = networks.define_G(opt.input_nc, opt.output_nc, opt.ngf, opt.netG, opt.normG, not opt.no_dropout,
+                                      opt.init_type, opt.init_gain, opt.no_antialias, opt.no_antialias_up, self.gpu_ids, opt)
+        self.netF = networks.define_F(opt.input_nc, opt.netF, opt.normG, not opt.no_dropout, opt.init_type,
+                                      opt.init_gain, opt.no_antialias, self.gpu_ids, opt)
+        nb_features = [[16, 32, 32, 64, 64, 64], [64, 64, 64, 32, 32, 32, 16]]
+        vol_shape = (opt.crop_size, opt.crop_size)
+        self.netR = vxm.networks.VxmDense(vol_shape, nb_features, int_steps=7, bidir=True).to(self.device)
+        self.netR.train()
+        self.spatialTransformer = SpatialTransformer(vol_shape).to(self.device)
+        self._dvf_image = None
+
+        if self.isTrain:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode).to(self.device)
+            self.criterionNCE = [PatchNCELoss(opt).to(self.device) for _ in self.nce_layers]
+            self.criterionIdt = None  # torch.nn.L1Loss in the reference; constructed, never called
+            self.criterionNCC = NCC_Loss(self.device, name='ncc', kernel_var=[9, 9], kernel_type='mean')
+            self.optimizer_G = FlatAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2))
+            self.optimizer_R = FlatAdam(self.netR.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2))
+            self.optimizers.append(self.optimizer_G)
+            self.optimizers.append(self.optimizer_R)
+
+    # -- registration_model.py:119-136
+    def data_dependent_initialize(self, data):
+        self.set_input(data)
+        bs_per_gpu = self.real_A.size(0) // max(len(self.opt.gpu_ids), 1)
+        self.real_A = self.real_A[:bs_per_gpu]
+        self.real_B = self.real_B[:bs_per_gpu]
+        self.forward()
+        if self.opt.isTrain:
+            self.compute_G_loss().backward()
+            if self.opt.lambda_NCE > 0.0:
+                self.optimizer_F = FlatAdam(self.netF.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, self.opt.beta2))
+                self.optimizers.append(self.optimizer_F)
+
+    def _checkerboard(self, batch):
+        """The visual-only test pattern warped into `dvf` (registration_model.py:148-149)."""
+        if self._dvf_image is None:
+            size = self.opt.crop_size
+            path = getattr(self.opt, 'dvf_image', None) or "./deform256.jpg"
+            if os.path.exists(path) and size <= 256:
+                img = open_image_to_torch(path, size)
+            else:
+                img = synthetic_checkerboard(size)
+            self._dvf_image = img.to(self.device)
+        return self._dvf_image.expand(batch, -1, -1, -1).contiguous()
+
+    # -- registration_model.py:138-171
+    def optimize_parameters(self):
+        self.forward()
+
+        y_output = self.netR(self.real_A, self.real_B)
+        y_pred = [self.spatialTransformer(self.fake_B, y_output[2]), y_output[2]]
+        self.registered = y_pred[0]
+        self.regA = y_output[0]
+        with torch.no_grad():
+            self.dvf = self.spatialTransformer(self._checkerboard(self.real_A.size(0)), y_pred[1].detach())
+
+        self.optimizer_G.zero_grad()
+        self.optimizer_R.zero_grad()
+        if self.opt.netF == 'mlp_sample':
+            self.optimizer_F.zero_grad()
+
+        self.loss_G = self.compute_G_loss()
+
+        # masks (registration_model.py:160-161) are evaluated inside the fused masked-L1 kernel:
+        # mask = (real_B > -0.95) | (registered > -0.95);  mask2 = (idt_B > -0.95) | (registered > -0.95)
+        self.loss_local = self.calculate_NCE_loss(self.real_B, y_output[0]) * 0.25
+        self.loss_R = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold') * 1.0 \
+            + self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold') * 1.0 + self.loss_local * 1.0
+        self.loss_smooth = smooothing_loss(y_pred[1]) * 0.20
+        all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
+        all_G_loss.backward()
+        self.sync_gradients()
+        self.optimizer_G.step()
+        self.optimizer_R.step()
+        if self.opt.netF == 'mlp_sample':
+            self.optimizer_F.step()
+
+    # -- registration_model.py:174-183
+    def set_input(self, input):
+        AtoB = self.opt.direction == 'AtoB'
+        self.real_A = input['A' if AtoB else 'B'].to(self.device, non_blocking=True)
+        self.real_B = input['B' if AtoB else 'A'].to(self.device, non_blocking=True)
+        self.image_paths = input['A_paths' if AtoB else 'B_paths']
+
+    # -- registration_model.py:185-196
+    def forward(self):
+        self.real = ops.cat_batch(self.real_A, self.real_B)
+        if self.opt.flip_equivariance:
+            raise NotImplementedError("flip_equivariance (FastCUT) is not on the registration path")
+        self.fake = self.netG(self.real)
+        self.fake_B = self.fake[:self.real_A.size(0)]
+        self.idt_B = self.fake[self.real_A.size(0):]
+
+    # -- registration_model.py:213-235
+    def compute_G_loss(self):
+        if self.opt.lambda_GAN > 0.0:
+            raise NotImplementedError("the registration model is discriminator-free (lambda_GAN must be 0)")
+        self.loss_G_GAN = 0.0
+        if self.opt.lambda_NCE > 0.0:
+            self.loss_NCE = self.calculate_NCE_loss(self.real_A, self.fake_B)
+        else:
+            self.loss_NCE, self.loss_NCE_bd = 0.0, 0.0
+        if self.opt.nce_idt and self.opt.lambda_NCE > 0.0:
+            self.loss_NCE_Y = self.calculate_NCE_loss(self.real_B, self.idt_B)
+            loss_NCE_both = (self.loss_NCE + self.loss_NCE_Y) * 0.5
+        else:
+            loss_NCE_both = self.loss_NCE
+        self.loss_G = self.loss_G_GAN + loss_NCE_both
+        return self.loss_G
+
+    # -- registration_model.py:237-253
+    def calculate_NCE_loss(self, src, tgt):
+        n_layers = len(self.nce_layers)
+        feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
+        with torch.no_grad():  # feat_k is detached inside PatchNCELoss (patchnce.py:17): forward only
+            feat_k = self.netG(src, self.nce_layers, encode_only=True)
+            feat_k_pool, sample_ids = self.netF(feat_k, self.opt.num_patches, None)
+        feat_q_pool, _ = self.netF(feat_q, self.opt.num_patches, sample_ids)
+        total_nce_loss = 0.0
+        for f_q, f_k, crit, nce_layer in zip(feat_q_pool, feat_k_pool, self.criterionNCE, self.nce_layers):
+            loss = crit(f_q, f_k)                      # [B*P], reduction='none'
+            total_nce_loss += ops.mean(loss) * self.opt.lambda_NCE
+        return total_nce_loss / n_layers
+
+    # -- registration_model.py:255-263
+    def calculate_L1_loss(self, src, tgt, mask):
+        if mask is None:
+            return ops.masked_l1(src, tgt, torch.ones_like(src, dtype=torch.bool))
+        if isinstance(mask, str):  # fused (src > -0.95) | (tgt > -0.95)
+            return ops.masked_l1(src, tgt, None, -0.95)
+        return ops.masked_l1(src, tgt, mask)

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's VoxelMorph pieces on the hot path
+(models/voxelmorph/torchvoxelmorph/layers.py:6-97, networks.py:9-106, 1028-1165, 1506-1521,
+modelio.py:7-76): SpatialTransformer, VecInt, ResizeTransform, ConvBlock, Unet, VxmDense.
+
+Same constructor signatures, forward semantics and state_dict keys; compute = libdfmir_hip.so.
+2-D and 3-D share every kernel (a 2-D tensor is the D == 1 case).
+"""
+import inspect
+
+import torch
+import torch.nn as nn
+from torch.distributions.normal import Normal
+
+from . import ops
+from .networks import Conv2d, Conv3d
+
+
+class SpatialTransformer(nn.Module):
+    """N-D spatial transformer: out = grid_sample(src, grid + flow, align_corners=True, zeros).
+    `flow` is a displacement in voxels, channel d along axis d (layers.py:30-48).  The `grid`
+    buffer is kept only for state_dict compatibility -- the kernel adds the identity itself."""
+
+    def __init__(self, size, mode='bilinear'):
+        super().__init__()
+        self.mode = mode
+        vectors = [torch.arange(0, s) for s in size]
+        grids = torch.meshgrid(vectors, indexing='ij')
+        grid = torch.stack(grids).unsqueeze(0).type(torch.FloatTensor)
+        self.register_buffer('grid', grid)
+
+    def forward(self, src, flow):
+        if tuple(flow.shape[2:]) != tuple(self.grid.shape[2:]):
+            raise RuntimeError("SpatialTransformer built for %s got flow %s" %
+                               (tuple(self.grid.shape[2:]), tuple(flow.shape[2:])))
+        return ops.warp(src, flow, self.mode)
+
+
+class VecInt(nn.Module):
+    """Scaling and squaring (layers.py:51-68): vec/2^n, then n fused `v + warp(v, v)` steps."""
+
+    def __init__(self, inshape, nsteps):
+        super().__init__()
+        assert nsteps >= 0, 'nsteps should be >= 0, found: %d' % nsteps
+        self.nsteps = nsteps
+        self.scale = 1.0 / (2 ** self.nsteps)
+        self.transformer = SpatialTransformer(inshape)
+
+    def forward(self, vec, scale_folded=False):
+        if not scale_folded:
+            vec = ops.scale(vec, self.scale)
+        for _ in range(self.nsteps):
+            vec = ops.vecint_step(vec)
+        return vec
+
+
+class ResizeTransform(nn.Module):
+    """Resize + rescale a vector field (layers.py:71-97); the scalar factor is fused."""
+
+    def __init__(self, vel_resize, ndims):
+        super().__init__()
+        self.factor = 1.0 / vel_resize
+        self.mode = {2: 'bilinear', 3: 'trilinear'}.get(ndims, 'linear')
+
+    def forward(self, x, extra_mult=1.0):
+        if self.factor == 1 and extra_mult == 1.0:
+            return x
+        out_sp = [int(s * self.factor) for s in x.shape[2:]]  # floor(size*scale), as F.interpolate
+        return ops.resize_linear(x, out_sp, self.factor * extra_mult)
+
+
+def store_config_args(func):
+    """modelio.py:7-35 (getargspec replaced by getfullargspec)."""
+    spec = inspect.getfullargspec(func)
+    attrs, defaults = spec.args, spec.defaults
+
+    def wrapper(self, *args, **kwargs):
+        self.config = {}
+        if defaults:
+            for attr, val in zip(reversed(attrs), reversed(defaults)):
+                self.config[attr] = val
+        for attr, val in zip(attrs[1:], args):
+            self.config[attr] = val
+        for attr, val in kwargs.items():
+            self.config[attr] = val
+        return func(self, *args, **kwargs)
+    wrapper.__wrapped__ = func
+    return wrapper
+
+
+class LoadableModel(nn.Module):
+    """modelio.py:38-76."""
+
+    def __init__(self, *args, **kwargs):
+        if not hasattr(self, 'config'):
+            raise RuntimeError('models that inherit from LoadableModel must decorate the constructor with @store_config_args')
+        super().__init__(*args, **kwargs)
+
+    def save(self, path):
+        sd = self.state_dict().copy()
+        for key in [k for k in sd.keys() if k.endswith('.grid')]:
+            sd.pop(key)
+        torch.save({'config': self.config, 'model_state': sd}, path)
+
+    @classmethod
+    def load(cls, path, device):
+        checkpoint = torch.load(path, map_location=torch.device(device))
+        model = cls(**checkpoint['config'])
+        model.load_state_dict(checkpoint['model_state'], strict=False)
+        return model
+
+
+def default_unet_features():
+    return [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
+
+
+class ConvBlock(nn.Module):
+    """Conv{2,3}d(3, stride, pad 1) + LeakyReLU(0.2) in one launch (networks.py:1506-1521)."""
+
+    def __init__(self, ndims, in_channels, out_channels, stride=1):
+        super().__init__()
+        Conv = {2: Conv2d, 3: Conv3d}[ndims]
+        self.main = Conv(in_channels, out_channels, 3, stride, 1)
+        self.activation = nn.LeakyReLU(0.2)  # parameter-free marker; fused into the conv epilogue
+
+    def forward(self, x):
+        return self.main(x, act=1, slope=0.2)
+
+
+class Unet(nn.Module):
+    """networks.py:16-106."""
+
+    def __init__(self, inshape, nb_features=None, nb_levels=None, feat_mult=1):
+        super().__init__()
+        ndims = len(inshape)
+        assert ndims in [2, 3], 'ndims should be 2 or 3 on this path. found: %d' % ndims
+        if nb_features is None:
+            nb_features = default_unet_features()
+        if isinstance(nb_features, int):
+            raise NotImplementedError("integer nb_features is not on the path (lists are always passed)")
+        if nb_levels is not None:
+            raise ValueError('cannot use nb_levels if nb_features is not an integer')
+        self.enc_nf, self.dec_nf = nb_features
+        self.upsample = nn.Upsample(scale_factor=2, mode='nearest')  # marker; fused with the concat
+        prev_nf = 2
+        self.downarm = nn.ModuleList()
+        for nf in self.enc_nf:
+            self.downarm.append(ConvBlock(ndims, prev_nf, nf, stride=2))
+            prev_nf = nf
+        enc_history = list(reversed(self.enc_nf))
+        self.uparm = nn.ModuleList()
+        for i, nf in enumerate(self.dec_nf[:len(self.enc_nf)]):
+            channels = prev_nf + enc_history[i] if i > 0 else prev_nf
+            self.uparm.append(ConvBlock(ndims, channels, nf, stride=1))
+            prev_nf = nf
+        prev_nf += 2
+        self.extras = nn.ModuleList()
+        for nf in self.dec_nf[len(self.enc_nf):]:
+            self.extras.append(ConvBlock(ndims, prev_nf, nf, stride=1))
+            prev_nf = nf
+
+    def forward(self, x):
+        x_enc = [x]
+        for layer in self.downarm:
+            x_enc.append(layer(x_enc[-1]))
+        x = x_enc.pop()
+        for layer in self.uparm:
+            x = layer(x)
+            x = ops.upcat(x, x_enc.pop())
+        for layer in self.extras:
+            x = layer(x)
+        return x
+
+
+class VxmDense(LoadableModel):
+    """networks.py:1028-1145 (this fork returns the INTEGRATED full-resolution pos_flow when
+    bidir=True, networks.py:1143)."""
+
+    @store_config_args
+    def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1, int_steps=7,
+                 int_downsize=2, bidir=False, use_probs=False):
+        super().__init__()
+        self.training = True
+        ndims = len(inshape)
+        assert ndims in [2, 3], 'ndims should be 2 or 3 on this path. found: %d' % ndims
+        self.unet_model = Unet(inshape, nb_features=nb_unet_features, nb_levels=nb_unet_levels,
+                               feat_mult=unet_feat_mult)
+        Conv = {2: Conv2d, 3: Conv3d}[ndims]
+        self.flow = Conv(self.unet_model.dec_nf[-1], ndims, 3, padding=1)
+        self.flow.weight = nn.Parameter(Normal(0, 1e-5).sample(self.flow.weight.shape))
+        self.flow.bias = nn.Parameter(torch.zeros(self.flow.bias.shape))
+        if use_probs:
+            raise NotImplementedError('Flow variance has not been implemented in pytorch - set use_probs to False')
+        resize = int_steps > 0 and int_downsize > 1
+        self.resize = ResizeTransform(int_downsize, ndims) if resize else None
+        self.fullsize = ResizeTransform(1 / int_downsize, ndims) if resize else None
+        self.bidir = bidir
+        down_shape = [int(dim / int_downsize) for dim in inshape]
+        self.integrate = VecInt(down_shape, int_steps) if int_steps > 0 else None
+        self.transformer = SpatialTransformer(inshape)
+
+    def forward(self, source, target, registration=False):
+        x = ops.upcat_channels(source, target)
+        x = self.unet_model(x)
+        flow_field = self.flow(x)
+        pos_flow = flow_field
+        if self.resize:
+            pos_flow = self.resize(pos_flow)
+        preint_flow = pos_flow
+        neg_flow = None
+        if self.integrate:
+            sc = self.integrate.scale
+            # negate + 2^-n scale folded into one launch per direction
+            if self.bidir:
+                neg_flow = ops.scale(pos_flow, -sc)
+                neg_flow = self.integrate(neg_flow, scale_folded=True)
+            pos_flow = ops.scale(pos_flow, sc)
+            pos_flow = self.integrate(pos_flow, scale_folded=True)
+            if self.fullsize:
+                pos_flow = self.fullsize(pos_flow)
+                neg_flow = self.fullsize(neg_flow) if self.bidir else None
+        elif self.bidir:
+            neg_flow = ops.scale(pos_flow, -1.0)
+        y_source = self.transformer(source, pos_flow)
+        y_target = self.transformer(target, neg_flow) if self.bidir else None
+        if not registration:
+            return (y_source, y_target, pos_flow) if self.bidir else (y_source, preint_flow)
+        return y_source, pos_flow
+
+
+class _Namespace(object):
+    pass
+
+
+# `vxm.networks.VxmDense`, `vxm.layers.SpatialTransformer` as in the reference's imports
+# (models/registration_model.py:7-8,98).
+networks = _Namespace()
+networks.VxmDense = VxmDense
+networks.Unet = Unet
+networks.ConvBlock = ConvBlock
+networks.default_unet_features = default_unet_features
+layers = _Namespace()
+layers.SpatialTransformer = SpatialTransformer
+layers.VecInt = VecInt
+layers.ResizeTransform = ResizeTransform

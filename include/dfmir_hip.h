@@ -1,0 +1,203 @@
+/*
+ * dfmir_hip.h -- C ABI of libdfmir_hip.so: the MI355X (gfx950) compute library behind the
+ * DFMIR `--model registration` training step.
+ *
+ * The reference (heyblackC/DFMIR) has no native boundary: its hot path calls torch.nn /
+ * torch.nn.functional ops from Python.  Each entry point below replaces ONE such torch op call
+ * site on the path REGISTRATIONModel.set_input -> optimize_parameters
+ * (reference models/registration_model.py:138-183); the reference line each one stands in for is
+ * cited next to it.  The host side (the dfmir_amd Python package) binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-allocated, contiguous fp32 memory laid out
+ *     NCHW / NCDHW exactly like the reference's tensors (2-D tensors are D == 1);
+ *   - `stream` is a hipStream_t passed as void*; nothing allocates, nothing synchronises, no
+ *     global state except the last-error string -> re-entrant across streams / processes;
+ *   - return value 0 = launched; >0 = hipError_t; <0 = bad argument.  dfmir_last_error() gives text;
+ *   - "accumulates" means the kernel atomically adds into a buffer the caller has zeroed/initialised.
+ */
+#ifndef DFMIR_HIP_H
+#define DFMIR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFMIR_ABI_VERSION 1
+
+int dfmir_abi_version(void);
+const char* dfmir_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
+ * Replaces nn.Conv2d / nn.Conv3d (+ the ReflectionPad2d in front of it, + the LeakyReLU/Tanh
+ * behind it) at: models/networks.py:982-983, 995, 1016-1023 (ResnetGenerator),
+ * models/networks.py:1201,1214 (ResnetBlock), models/networks.py:587-595 (PatchSampleF MLP,
+ * as 1x1 convs), models/voxelmorph/torchvoxelmorph/networks.py:1506-1521 (ConvBlock),
+ * :1077-1081 (flow conv).
+ *
+ * Weights are consumed in "tap-major" packing  w_tcc[tap][Cin][Cout]  (tap = (kd*KH+kh)*KW+kw),
+ * produced from the reference's [Cout][Cin][KD][KH][KW] by dfmir_weight_pack.
+ * Input index along an axis:  c = o*stride - pad + t ;  dil>1 treats the input as zero-dilated
+ * (transposed convolution = dgrad of a strided conv).  pad_mode: 0 zeros, 1 reflect.
+ * act: 0 none, 1 leaky-relu(slope) (slope 0 = ReLU), 2 tanh.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct DfConvGeom {
+  int N, Cin, Cout;
+  int Di, Hi, Wi;
+  int Do, Ho, Wo;
+  int KD, KH, KW;
+  int stride, dil;
+  int pd, ph, pw;
+  int pad_mode;
+  int act;
+  float slope;
+} DfConvGeom;
+
+/* y[N,Cout,Do,Ho,Wo] = act(conv(x[N,Cin,Di,Hi,Wi], w) + bias).  bias may be NULL. */
+int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
+                   float* y, void* stream);
+/* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
+int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                     void* stream);
+/* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
+int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
+/* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
+ * mode 1: w_tcc[t][co][ci] = w[co][ci][T-1-t]       (dgrad packing: roles of Cin/Cout swapped, taps flipped) */
+int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, int mode, void* stream);
+/* g[co][ci][t] = g_tcc[t][ci][co]  (gradient back to the reference's parameter layout). */
+int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False, eps) [+ ReLU] [+ residual add]  -- models/networks.py:113-131,
+ * 984-985, 1190-1221 (x + conv_block(x)).  One (n,c) plane of S elements per workgroup.
+ * y = res + relu?((x-mean)*rstd) ; mean/rstd [planes] are saved for backward.
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
+                       int planes, long long S, float eps, int relu, void* stream);
+int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                       float* dx, int planes, long long S, int relu, void* stream);
+
+/* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
+int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Anti-aliased resampling of the generator -- models/networks.py:37-60 (Downsample: reflect pad 1,
+ * depthwise [1 2 1]x[1 2 1]/16, stride 2) and :73-93 (Upsample: replicate pad 1, depthwise
+ * conv_transpose 4x4 [1 3 3 1]^2/16 stride 2, cropped to 2H x 2W).
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_blur_down_fwd(const float* x, float* y, int planes, int H, int W, void* stream);
+int dfmir_blur_down_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream);
+int dfmir_blur_up_fwd(const float* x, float* y, int planes, int H, int W, void* stream);
+int dfmir_blur_up_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream);
+/* nn.ReflectionPad2d(p) -- models/networks.py:982,1022 (materialised only for NCE layer 0). */
+int dfmir_reflect_pad2d_fwd(const float* x, float* y, int planes, int H, int W, int p, void* stream);
+int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p, void* stream);
+
+/* nn.Upsample(scale 2, nearest) + torch.cat([up(a), b], 1) -- torchvoxelmorph/networks.py:64,97-100.
+ * a[N,Ca,Da,Ha,Wa] -> factor sd (1 for 2-D, 2 for 3-D) in D and 2 in H,W; b[N,Cb,Da*sd,2Ha,2Wa]. */
+int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, int Ca, int Cb, int Da, int Ha,
+                    int Wa, int sd, void* stream);
+int dfmir_upcat_bwd(const float* dy, float* da, float* db, int N, int Ca, int Cb, int Da, int Ha,
+                    int Wa, int sd, void* stream);
+
+/* torch.cat([a, b], dim=1) -- torchvoxelmorph/networks.py:1110 (source|target into the U-Net).
+ * SA = Ca*S, SB = Cb*S elements per sample.  bwd: da/db may be NULL. */
+int dfmir_cat_channels_fwd(const float* a, const float* b, float* y, long long N, long long SA,
+                           long long SB, void* stream);
+int dfmir_cat_channels_bwd(const float* dy, float* da, float* db, long long N, long long SA,
+                           long long SB, void* stream);
+/* y = mult * x -- `vec * self.scale` (layers.py:65), `-pos_flow` (networks.py:1125). */
+int dfmir_scale(const float* x, float* y, long long n, float mult, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SpatialTransformer.forward  (torchvoxelmorph/layers.py:30-48): out = grid_sample(src, grid+flow)
+ * with align_corners=True, padding_mode='zeros'; flow is a displacement in voxels, channel d =
+ * axis d.  mode 0 bilinear/trilinear, 1 nearest.  add_identity: out += src (VecInt step
+ * v + warp(v,v), layers.py:64-68; needs C == ndims).
+ * Backward: dsrc accumulates (atomic scatter); dflow is written, or (flow_into_src) accumulated
+ * into dsrc for the VecInt self-warp where src == flow.
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_warp2d_fwd(const float* src, const float* flow, float* out, int B, int C, int H, int W,
+                     int mode, int add_identity, void* stream);
+int dfmir_warp2d_bwd(const float* dout, const float* src, const float* flow, float* dsrc,
+                     float* dflow, int B, int C, int H, int W, int add_identity, int flow_into_src,
+                     void* stream);
+int dfmir_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C, int D, int H,
+                     int W, int mode, int add_identity, void* stream);
+int dfmir_warp3d_bwd(const float* dout, const float* src, const float* flow, float* dsrc,
+                     float* dflow, int B, int C, int D, int H, int W, int add_identity,
+                     int flow_into_src, void* stream);
+
+/* ResizeTransform (layers.py:71-97): F.interpolate(align_corners=True, bi/tri-linear) fused with the
+ * scalar rescale `mult`.  D == 1 for 2-D.  bwd accumulates into dx. */
+int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                     int Wo, float mult, void* stream);
+int dfmir_resize_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                     int Wo, float mult, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PatchNCE path -- models/networks.py:602-619 (PatchSampleF.forward), :493-502 (Normalize),
+ * models/patchnce.py:14-55 (PatchNCELoss.forward).
+ * Sampled features are kept channel-major [C][rows] (rows = B*P, row r = b*P + p) so the 2-layer
+ * MLP runs as 1x1 convs over `rows` pixels; the reference's [B*P, C] tensors are the transposed
+ * VIEW of this buffer.
+ * ---------------------------------------------------------------------------------------- */
+/* out[c][b*P+p] = feat[b][c][ids[p]]   (feat [B,C,S], ids int64 [P] shared by the batch). */
+int dfmir_patch_gather_fwd(const float* feat, const long long* ids, float* out, int B, int C,
+                           long long S, int P, void* stream);
+int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
+                           long long S, int P, void* stream); /* accumulates */
+/* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
+int dfmir_l2norm_fwd(const float* x, float* y, float* norm, int C, long long rows, float eps, void* stream);
+int dfmir_l2norm_bwd(const float* dy, const float* x, const float* norm, float* dx, int C,
+                     long long rows, float eps, void* stream);
+/* q,k: [C][rows]; G consecutive groups of R = rows/G rows share negatives (R % 16 == 0).
+ * loss[rows]; probs[rows][R+1] = softmax of [pos | neg]/T, saved for backward. */
+int dfmir_patchnce_fwd(const float* q, const float* k, float* loss, float* probs, long long rows,
+                       int C, int G, float T, void* stream);
+int dfmir_patchnce_bwd(const float* dloss, const float* probs, const float* k, float* dq,
+                       long long rows, int C, int G, float T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scalar losses.  `out` is a 1-float device scalar; `ws` is a small zero-able workspace (8 floats).
+ * ---------------------------------------------------------------------------------------- */
+/* calculate_L1_loss (registration_model.py:255-263) with mask = (a>thr)|(b>thr)
+ * (registration_model.py:160-161) when mask == NULL, else the given byte mask.
+ * out = sum(|a-b|*m)/sum(m)  (0 when sum(m)==0). */
+int dfmir_masked_l1_fwd(const float* a, const float* b, const unsigned char* mask, float thr,
+                        float* ws, float* out, long long n, void* stream);
+int dfmir_masked_l1_bwd(const float* a, const float* b, const unsigned char* mask, float thr,
+                        const float* ws, const float* gout, float* da, float* db, long long n,
+                        void* stream);
+/* smooothing_loss (registration_model.py:25-32) / Grad_Loss l2 (util/losses.py:81-130):
+ * mean over axes of mean(squared forward difference) (D==1: 2 axes). flow [B,C,D,H,W]. */
+int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C, int D, int H,
+                          int W, void* stream);
+int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,
+                          int H, int W, void* stream);
+/* NCC_Loss (util/losses.py:183-261), mean kernel of `win` per axis (odd), zero padding:
+ * out = -sqrt(mean(cross^2/(Ivar*Jvar+eps))).  tmp: 5*numel floats of scratch (box sums, kept for
+ * backward). I = prediction, J = target, [B,1,D,H,W]. */
+int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float* ws, float* out,
+                  int B, int D, int H, int W, int win, float eps, void* stream);
+int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
+                  const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
+                  int win, float eps, void* stream);
+/* out = scale * sum(x) (out zeroed by this call). */
+int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void* stream);
+/* dx[i] = gout[0]*scale */
+int dfmir_fill_from_scalar(const float* gout, float* dx, long long n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * torch.optim.Adam(lr, betas) step over one flat parameter arena
+ * (registration_model.py:114-117,135,168-171).  grad is pre-scaled by grad_scale (1/world under DDP).
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                    float beta2, float eps, float bc1, float bc2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFMIR_HIP_H */

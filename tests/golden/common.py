@@ -1,0 +1,53 @@
+"""Deterministic inputs shared by the golden-vector generator (make_golden.py, runs only where
+/root/reference exists) and the tests that replay the vectors.  Pure torch CPU RNG."""
+import hashlib
+
+import numpy as np
+import torch
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(int(seed))
+    return g
+
+
+def randn(seed, *shape):
+    return torch.randn(*shape, generator=gen(seed))
+
+
+def rand(seed, *shape):
+    return torch.rand(*shape, generator=gen(seed))
+
+
+def image_pair(seed, B, H, W):
+    """Synthetic [-1,1] pairs with a -1 background so the (>-0.95) masks are non-trivial."""
+    a = rand(seed, B, 1, H, W) * 2 - 1
+    b = rand(seed + 1, B, 1, H, W) * 2 - 1
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    r = ((yy - H / 2.0) ** 2 + (xx - W / 2.0) ** 2).sqrt()
+    bg = (r > 0.42 * min(H, W))[None, None]
+    a = torch.where(bg, torch.full_like(a, -1.0), a)
+    b = torch.where(bg.roll(3, -1), torch.full_like(b, -1.0), b)
+    return a.contiguous(), b.contiguous()
+
+
+def patch_ids(call, layer, S, P):
+    """Patch ids of NCE call `call` (0,1 = data-dependent init; 2,3,4 = step 0; ...) at `layer`."""
+    return torch.randperm(S, generator=gen(1000003 * (call + 1) + 7919 * layer))[:min(P, S)]
+
+
+def checksum(tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def state_checksum(module):
+    sd = module.state_dict()
+    return checksum([sd[k] for k in sorted(sd.keys())])
+
+
+def multi_state_checksum(modules):
+    return hashlib.sha256("".join(state_checksum(m) for m in modules).encode()).hexdigest()
