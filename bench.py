@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the DFMIR `--model registration` train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" = REGISTRATIONModel.set_input + optimize_parameters (reference train.py:46-47): forward,
+backward and Adam of G/F/R on one batch of synthetic pairs already resident in HBM.  Workload at
+every N: BASELINE.json configs[1] geometry -- 2-D 256x256, batch 16 PER GPU, ngf 64, fp32 (weak
+scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with `roofline`
+(dominant kernel = the 128x128-tile fp32-MFMA implicit-GEMM conv, timed live with HIP events on
+its launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle = a port of the reference's
+PyTorch-CPU path, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+
+
+def synth_pairs(B, H, W, device, seed):
+    """Uniform [-1,1] slices with a -1 background disc complement (non-trivial >-0.95 masks)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    a = torch.rand(B, 1, H, W, generator=g) * 2 - 1
+    b = torch.rand(B, 1, H, W, generator=g) * 2 - 1
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    bg = (((yy - H / 2.0) ** 2 + (xx - W / 2.0) ** 2).sqrt() > 0.45 * min(H, W))[None, None]
+    a = torch.where(bg, torch.full_like(a, -1.0), a)
+    b = torch.where(bg, torch.full_like(b, -1.0), b)
+    return a.to(device), b.to(device)
+
+
+class KernelTimer(object):
+    """Brackets selected kernel launches with HIP events on the launch (= torch current) stream."""
+
+    def __init__(self, kinds):
+        self.kinds = set(kinds)
+        self.records = {}
+        self.enabled = False
+
+    def __call__(self, kind, flops, launch):
+        if not self.enabled or kind not in self.kinds:
+            launch()
+            return
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        self.records.setdefault(kind, []).append((s, e, flops))
+
+    def summary(self):
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[kind] = dict(launches=len(recs), ms=ms, flops=fl)
+        return out
+
+
+def pick_cpu_threads():
+    """Threads for the CPU baseline: the host cores this process may actually use (affinity and
+    cgroup quota), refined by a 1-second calibration of the path's dominant conv shape -- a box that
+    advertises 256 CPUs but schedules far fewer is 100x slower when oversubscribed."""
+    import torch.nn.functional as F
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = max(1, min(avail, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    x = torch.randn(1, 256, 64, 64)
+    w = torch.randn(256, 256, 3, 3)
+    best, best_t = 1, float("inf")
+    for n in sorted(set(min(c, avail) for c in (avail, 128, 64, 32, 16, 8))):
+        torch.set_num_threads(n)
+        F.conv2d(x, w, padding=1)
+        t0 = time.time()
+        for _ in range(3):
+            F.conv2d(x, w, padding=1)
+        dt = time.time() - t0
+        if dt < best_t * 0.95:
+            best, best_t = n, dt
+    return best
+
+
+def cpu_baseline(size, max_steps=3):
+    """The oracle (CPU port of the reference path) at the same 256x256 geometry, batch 1."""
+    from oracle import dfmir_oracle as O
+    cores = pick_cpu_threads()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    st = O.RegistrationStep(size, 1, ngf=64)
+    a, b = synth_pairs(1, size, size, "cpu", 1)
+    st.data_dependent_initialize(a, b)      # warm-up (also creates netF), like train.py:43
+    t0 = time.time()
+    n = 0
+    while n < max_steps:
+        a, b = synth_pairs(1, size, size, "cpu", 2 + n)
+        st.step(a, b)
+        n += 1
+        if time.time() - t0 > 30.0:
+            break
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="image-pairs/s", cores=cores, kind="port",
+                sample="%d train steps of the CPU oracle (PyTorch fp32, %d threads) at 2-D %dx%d batch 1, ngf 64, "
+                       "after 1 warm-up fwd+bwd" % (n, cores, size, size))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--ngf", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from dfmir_amd import ops
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+
+    B, S = args.batch, args.size
+    opt = default_options(batch_size=B, crop_size=S, load_size=S, ngf=args.ngf, gpu_ids=[dev.index],
+                          checkpoints_dir="/tmp/dfmir_bench", name="bench")
+    torch.manual_seed(0)                      # same weights on every rank (also broadcast in parallelize())
+    model = REGISTRATIONModel(opt)
+    timer = KernelTimer(["conv_mfma_L", "conv_wgrad_L"])
+    ops.set_conv_profiler(timer)
+
+    batches = [synth_pairs(B, S, S, dev, 1000 * rank + i) for i in range(4)]   # resident in HBM
+    paths = [""] * B
+
+    def feed(i):
+        a, b = batches[i % len(batches)]
+        return {"A": a, "B": b, "A_paths": paths, "B_paths": paths}
+
+    model.data_dependent_initialize(feed(0))
+    model.setup(opt)
+    model.parallelize()
+    for i in range(args.warmup):
+        model.set_input(feed(i))
+        model.optimize_parameters()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.set_input(feed(i))
+        model.optimize_parameters()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    losses = model.get_current_losses()
+    assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ks = timer.summary()
+    result = None
+    if rank == 0:
+        pairs = B * world * args.steps
+        dom = ks.get("conv_mfma_L", dict(launches=0, ms=0.0, flops=0.0))
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        wg = ks.get("conv_wgrad_L", dict(launches=0, ms=0.0, flops=0.0))
+        wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
+        step_tflop = 1581e9 * B / 1e12      # algorithmic conv FLOPs per step per GPU
+        result = {
+            "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
+            "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "2-D %dx%d T1<->T2-shaped synthetic slice pairs, batch %d per GPU, ngf %d: "
+                                   "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
+                                   "VoxelMorph + bilinear warps, fwd+bwd+Adam), BASELINE configs[1]" % (S, S, B, args.ngf),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "conv_mfma_k<2,2,2,2> (128x128 tile, v_mfma_f32_32x32x2_f32; fwd + dgrad of every "
+                                   "Cout>64 conv)",
+                         "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                         "wgrad_kernel_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
+                         "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},
+            "losses": {k: round(v, 6) for k, v in losses.items()},
+        }
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            ops.set_conv_profiler(None)
+            result["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

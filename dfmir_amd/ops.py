@@ -41,12 +41,31 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
+# Optional launch profiler (bench.py): called as prof(kind, flops, launch) where launch() issues
+# the kernel; lets the bench bracket the dominant kernel with HIP events on the launch stream.
+_CONV_PROFILER = [None]
+
+
+def set_conv_profiler(fn):
+    _CONV_PROFILER[0] = fn
+
+
 def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp):
     N, Cin, Di, Hi, Wi = x5.shape
     y = torch.empty((N, Cout) + tuple(out_sp), device=x5.device, dtype=torch.float32)
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, out_sp[0], out_sp[1], out_sp[2], K[0], K[1], K[2],
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
-    check(lib().dfmir_conv_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _st()))
+
+    def launch():
+        check(lib().dfmir_conv_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _st()))
+
+    prof = _CONV_PROFILER[0]
+    if prof is None:
+        launch()
+    else:
+        flops = 2.0 * N * Cout * out_sp[0] * out_sp[1] * out_sp[2] * Cin * K[0] * K[1] * K[2] / (dil ** 3 if K[0] > 1 else dil ** 2)
+        prof("conv_mfma_L" if Cout > 64 else ("conv_mfma_M" if Cout > 32 else ("conv_mfma_S" if Cout > 4 else "conv_small")),
+             flops, launch)
     return y
 
 
@@ -57,7 +76,15 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode):
     dw = torch.zeros((T, Cin, Cout), device=x5.device, dtype=torch.float32)
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
-    check(lib().dfmir_conv_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+    def launch():
+        check(lib().dfmir_conv_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+
+    prof = _CONV_PROFILER[0]
+    if prof is None:
+        launch()
+    else:
+        prof("conv_wgrad_L" if Cout > 64 else ("conv_wgrad_M" if Cout > 32 else "conv_wgrad_S"),
+             2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
     return dw
 
 

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dfmir_hip.h declares, and the
+ctypes table covers exactly that set (no compute calls here -- there is no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import dfmir_amd
+from dfmir_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "dfmir_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfmir_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    syms = header_symbols()
+    assert len(syms) >= 40
+    h = ctypes.CDLL(dfmir_amd.LIB_PATH)
+    for s in syms:
+        assert hasattr(h, s), "libdfmir_hip.so does not export %s" % s
+
+
+def test_ctypes_table_matches_header():
+    assert header_symbols() == _lib.exported_symbols()
+
+
+def test_abi_version_and_error_string():
+    h = dfmir_amd.lib()
+    assert h.dfmir_abi_version() == 1
+    # a bad-argument call must fail loudly without touching a device
+    rc = h.dfmir_scale(None, None, 0, 1.0, None)
+    assert rc != 0
+    assert b"invalid argument" in h.dfmir_last_error()
+
+
+def test_geom_struct_layout():
+    assert ctypes.sizeof(_lib.DfConvGeom) == 20 * 4

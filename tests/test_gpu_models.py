@@ -1,0 +1,261 @@
+"""GPU parity at module / whole-step level: the host mirror (dfmir_amd.networks / voxelmorph /
+registration_model) on the HIP kernels against (a) the golden vectors captured from the reference
+and (b) the CPU oracle on the same seeded weights and inputs.  Tolerance 1e-4 relative on outputs
+(north_star), 1e-3 on gradients that pass through long reductions / many layers.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import common as C
+from tests.test_gpu_ops import DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import dfmir_oracle
+    return dfmir_oracle
+
+
+def _load(dst, src_module):
+    """Copy an oracle module's weights into the HIP mirror (same state_dict keys; `grid` buffers
+    exist only on the HIP side for checkpoint compatibility)."""
+    missing, unexpected = dst.load_state_dict(src_module.state_dict(), strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith(".grid") for k in missing), missing
+    from dfmir_amd import ops
+    ops.bump_weights_epoch()
+
+
+def test_resblock_golden(golden, O):
+    from dfmir_amd import networks as N
+    g = golden("resblock.npz")
+    torch.manual_seed(41)
+    ob = O.ResBlock(16)
+    assert C.state_checksum(ob) == str(g["wsum"])
+    hb = N.ResnetBlock(16, 'reflect', N.get_norm_layer('instance'), False, True).to(DEV)
+    _load(hb, ob)
+    x = C.randn(42, 2, 16, 10, 14).to(DEV).requires_grad_()
+    y = hb(x)
+    (y * C.randn(43, *y.shape).to(DEV)).sum().backward()
+    close(y, g["out"], what="out"); close(x.grad, g["dx"], rtol=3e-4, what="dx")
+    close(hb.conv_block[1].weight.grad, g["dw1"], rtol=1e-3, what="dw1")
+    close(hb.conv_block[1].bias.grad, g["db1"], rtol=1e-3, atol=1e-4, what="db1")
+    close(hb.conv_block[5].weight.grad, g["dw5"], rtol=1e-3, what="dw5")
+    close(hb.conv_block[5].bias.grad, g["db5"], rtol=1e-3, atol=1e-4, what="db5")
+
+
+def test_generator_golden(golden, O):
+    from dfmir_amd import networks as N
+    from tests.test_oracle_golden import make_tiny_generator
+    g = golden("generator.npz")
+    og = make_tiny_generator()
+    assert C.state_checksum(og) == str(g["wsum"])
+    hg = N.define_G(1, 1, 8, 'resnet_9blocks', 'instance', False, 'xavier', 0.02, False, False, [0], None)
+    assert sorted(hg.state_dict().keys()) == sorted(og.state_dict().keys())
+    _load(hg, og)
+    x = C.image_pair(52, 2, 64, 64)[0].to(DEV).requires_grad_()
+    y, feats = hg(x, [0, 4, 8, 12, 16], encode_only=False)
+    fc = [C.randn(54 + i, *f.shape).to(DEV) for i, f in enumerate(feats)]
+    ((y * C.randn(53, *y.shape).to(DEV)).sum() + sum((f * c).sum() for f, c in zip(feats, fc))).backward()
+    close(y, g["out"], what="gen out")
+    for i, f in enumerate(feats):
+        close(f, g["feat%d" % i], what="feat%d" % i)
+    close(x.grad, g["dx"], rtol=1e-3, what="gen dx")
+    for k, p in hg.named_parameters():
+        if k.endswith(".bias") and k != "model.30.bias":
+            continue  # a bias in front of InstanceNorm has an exactly-zero true gradient: both sides are rounding noise
+        ref = float(g["gnorm_" + k.replace(".", "_")])
+        assert abs(float(p.grad.norm()) - ref) <= 2e-3 * max(ref, 1e-6), (k, float(p.grad.norm()), ref)
+    enc = hg(x.detach(), [0, 4, 8, 12, 16], encode_only=True)
+    assert len(enc) == 5
+    close(enc[4], g["feat4"], what="encode_only feat4")
+    close(hg(x.detach()), g["out"], what="plain forward")
+
+
+def test_patch_sampler_golden(golden, O):
+    from dfmir_amd import networks as N
+    from dfmir_amd.patchnce import PatchNCELoss
+    from dfmir_amd.options import default_options
+    from dfmir_amd import ops
+    from tests.test_oracle_golden import make_patch_sampler
+    g = golden("patchnce.npz")
+    opf, feats = make_patch_sampler()
+    hpf = N.PatchSampleF(use_mlp=True, init_type='xavier', init_gain=0.02, nc=32, gpu_ids=[0])
+    hpf.create_mlp([f.to(DEV) for f in feats])
+    _load(hpf, opf)
+    ids = [C.patch_ids(0, i, f.shape[2] * f.shape[3], 48).to(DEV) for i, f in enumerate(feats)]
+    fq = [f.clone().to(DEV).requires_grad_() for f in feats]
+    fk = [C.randn(65 + i, *f.shape).to(DEV) for i, f in enumerate(feats)]
+    kpool, _ = hpf(fk, 48, ids)
+    qpool, rid = hpf(fq, 48, ids)
+    assert qpool[1].shape == (2 * 48, 32)
+    crit = PatchNCELoss(default_options(batch_size=2))
+    tot = 0
+    for i, (q, k) in enumerate(zip(qpool, kpool)):
+        l = crit(q, k)
+        close(l, g["loss%d" % i], what="nce loss %d" % i)
+        close(q, g["q%d" % i], what="q%d" % i)
+        tot = tot + ops.mean(l)
+    tot.backward()
+    for i, f in enumerate(fq):
+        close(f.grad, g["dfeat%d" % i], rtol=1e-3, what="dfeat%d" % i)
+    for k_, p in hpf.named_parameters():
+        close(p.grad, g["dparam_" + k_.replace(".", "_")], rtol=1e-3, atol=1e-5, what=k_)
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_vxm_golden(golden, O, tag):
+    from dfmir_amd import voxelmorph as V
+    from tests.test_oracle_golden import make_vxm
+    g = golden("vxm.npz")
+    ov, shp = make_vxm(tag)
+    feats_ = O.PLUGIN_UNET_FEATURES if tag == "2d" else None
+    hv = V.VxmDense(shp, feats_, int_steps=7, bidir=True).to(DEV)
+    _load(hv, ov)
+    B = 2 if tag == "2d" else 1
+    s_ = C.rand(83, B, 1, *shp).to(DEV).requires_grad_()
+    t_ = C.rand(84, B, 1, *shp).to(DEV)
+    ys, yt, fl = hv(s_, t_)
+    ((ys * C.randn(85, *ys.shape).to(DEV)).sum() + (fl * (C.randn(86, *fl.shape) * 0.1).to(DEV)).sum()).backward()
+    close(fl, g["flow_" + tag], what="flow"); close(ys, g["ys_" + tag], what="ys"); close(yt, g["yt_" + tag], what="yt")
+    close(s_.grad, g["dsrc_" + tag], rtol=1e-3, what="dsrc")
+    close(hv.flow.weight.grad, g["gflow_w_" + tag], rtol=1e-3, what="dflow.w")
+    close(hv.unet_model.downarm[0].main.weight.grad, g["gdown0_w_" + tag], rtol=1e-3, what="ddown0.w")
+    close(hv.unet_model.uparm[1].main.weight.grad, g["gup1_w_" + tag], rtol=1e-3, what="dup1.w")
+    y2, f2 = hv(s_.detach(), t_, registration=True)
+    close(y2, g["reg_ys_" + tag], what="registration=True")
+
+
+def _hip_model_from_oracle(st, size, B, ngf):
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=ngf, gpu_ids=[0],
+                          checkpoints_dir="/tmp/dfmir_ckpt", name="t")
+    model = REGISTRATIONModel(opt)
+    _load(model.netG, st.netG)
+    _load(model.netR, st.netR)
+    return model, opt
+
+
+def test_whole_step_golden(golden, O):
+    """Config 1 geometry (64x64, batch 2): 3 consecutive train steps against the reference's own
+    losses / outputs (fixture S1), patch ids pinned."""
+    from tests.test_oracle_golden import make_step
+    g = golden("step.npz")
+    st, size, B = make_step()          # oracle with the fixture's seeded weights (post data-dependent init)
+    assert C.multi_state_checksum((st.netG, st.netF, st.netR)) == str(g["wsum"])
+    model, opt = _hip_model_from_oracle(st, size, B, 8)
+    call = [0]
+    base_forward = model.netF.forward
+
+    def netF_forward(feats, num_patches=64, patch_ids=None):
+        if patch_ids is None:
+            patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
+            call[0] += 1
+        return base_forward(feats, num_patches, patch_ids)
+
+    model.netF.forward = netF_forward
+    A0, B0 = C.image_pair(93, B, size, size)
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    for it in range(3):
+        A_, B_ = C.image_pair(100 + 2 * it, B, size, size)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        ls = model.get_current_losses()
+        got = np.array([ls[k] for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y")])
+        np.testing.assert_allclose(got, g["losses_%d" % it], rtol=3e-4 * (it + 1), atol=1e-6, err_msg="step %d" % it)
+        if it == 0:
+            close(model.fake_B, g["fake_B"], what="fake_B"); close(model.registered, g["registered"], what="registered")
+            close(model.regA, g["regA"], what="regA"); close(model.idt_B, g["idt_B"], what="idt_B")
+            for nm, o_ in (("G", model.optimizer_G), ("F", model.optimizer_F), ("R", model.optimizer_R)):
+                n2 = float(o_.flat_g.double().pow(2).sum().sqrt())
+                ref = float(g["gradnorm_" + nm])
+                assert abs(n2 - ref) <= 2e-3 * ref, (nm, n2, ref)
+    vis = model.get_current_visuals()
+    assert list(vis.keys()) == ['real_A', 'fake_B', 'real_B', 'dvf', 'registered', 'regA', 'idt_B']
+    assert vis['dvf'].shape == (B, 3, size, size)
+
+
+def test_full_size_step_vs_oracle(O):
+    """256x256, ngf=64 (BASELINE config 2 geometry at batch 1): one step of the HIP path against the
+    oracle on identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""
+    size, B = 256, 1
+    torch.manual_seed(7)
+    st = O.RegistrationStep(size, B, ngf=64)
+    with torch.no_grad():
+        st.netR.flow.weight.mul_(1e5)
+        st.netR.flow.bias.copy_(C.randn(8, 2) * 1.0)
+    st.ids_hook = lambda c, feats: [C.patch_ids(c, i, f.shape[2] * f.shape[3], 256) for i, f in enumerate(feats)]
+    A0, B0 = C.image_pair(9, B, size, size)
+    st.data_dependent_initialize(A0, B0)
+    with torch.no_grad():
+        for p in st.netF.parameters():
+            if p.dim() == 1:
+                p.add_(0.01)
+    model, opt = _hip_model_from_oracle(st, size, B, 64)
+    call = [0]
+    base_forward = model.netF.forward
+
+    def netF_forward(feats, num_patches=64, patch_ids=None):
+        if patch_ids is None:
+            patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
+            call[0] += 1
+        return base_forward(feats, num_patches, patch_ids)
+
+    model.netF.forward = netF_forward
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""], "B_paths": [""]})
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    A_, B_ = C.image_pair(11, B, size, size)
+    ref = st.step(A_, B_)
+    model.set_input({"A": A_, "B": B_, "A_paths": [""], "B_paths": [""]})
+    model.optimize_parameters()
+    ls = model.get_current_losses()
+    close(model.fake_B, st.fake_B, what="fake_B"); close(model.regA, st.regA, what="regA")
+    close(model.registered, st.registered, what="registered")
+    for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
+        assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
+    # gradients of the step (Adam's first update is lr*sign(g), so parameters are compared through g)
+    for (k, po), (k2, ph) in zip(st.netG.named_parameters(), model.netG.named_parameters()):
+        assert k == k2
+        if k.endswith(".bias") and k != "model.30.bias":
+            continue  # zero true gradient (bias in front of InstanceNorm)
+        close(ph.grad, po.grad, rtol=3e-3, what="grad " + k)
+    for (k, po), (k2, ph) in zip(st.netR.named_parameters(), model.netR.named_parameters()):
+        close(ph.grad, po.grad, rtol=3e-3, what="grad R " + k)
+    for (k, po), (k2, ph) in zip(st.netF.named_parameters(), model.netF.named_parameters()):
+        close(ph.grad, po.grad, rtol=3e-3, atol=1e-7, what="grad F " + k)
+    moved = (model.netG.state_dict()["model.12.conv_block.1.weight"].cpu() - st.netG.state_dict()["model.12.conv_block.1.weight"]).abs().max()
+    assert float(moved) <= 2.0 * 2e-4 * 1.001   # both took one Adam step of size <= lr
+
+
+@pytest.mark.parametrize("shape,plugin", [((32, 32, 32), False), ((64, 64, 64), True)])
+def test_registration3d_step_vs_oracle(O, shape, plugin):
+    """The 3-D step (VxmDense 3-D + NCC[9,9,9] + Grad l2): two consecutive steps against the oracle."""
+    from dfmir_amd.registration3d import Registration3DModel
+    feats = O.PLUGIN_UNET_FEATURES if plugin else None
+    torch.manual_seed(21)
+    st = O.Registration3DStep(shape, feats)
+    with torch.no_grad():
+        st.netR.flow.weight.mul_(3e4)
+    model = Registration3DModel(shape, feats, device=DEV)
+    _load(model.netR, st.netR)
+    for it in range(2):
+        A = C.rand(31 + it, 1, 1, *shape)
+        B = 0.5 * A + 0.5 * C.rand(41 + it, 1, 1, *shape)
+        ref = st.step(A, B)
+        model.set_input({"A": A, "B": B})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        if it == 0:
+            close(model.flow, st.flow, what="flow"); close(model.regA, st.ys, what="warped")
+            for (k, po), (k2, ph) in zip(st.netR.named_parameters(), model.netR.named_parameters()):
+                close(ph.grad, po.grad, rtol=3e-3, atol=1e-9, what="grad " + k)
+        for k in ("ncc", "grad"):
+            assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-7), (it, k, got[k], ref[k])

@@ -1,0 +1,321 @@
+"""GPU parity, op by op: every C-ABI kernel (through dfmir_amd.ops) against the CPU oracle /
+plain torch fp32 ops on the same seeded inputs, forward and backward.  Bar: 1e-4 relative to the
+tensor's max magnitude (fp32; summation order differs), 1e-3 on long-reduction gradients.
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden import common as C
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def close(got, ref, rtol=1e-4, atol=1e-6, what=""):
+    got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    ref = ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), "%s: non-finite values" % what
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    err = float(np.abs(got - ref).max())
+    assert err <= atol + rtol * scale, "%s: max abs err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from dfmir_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV2D = [
+    # Cin, Cout, K, stride, pad, reflect, act(0 none,1 leaky .2,2 tanh), N, H, W
+    (16, 16, 3, 1, 1, True, 0, 2, 12, 20),
+    (8, 40, 3, 1, 1, False, 0, 2, 9, 13),
+    (24, 72, 3, 1, 1, False, 0, 1, 17, 15),
+    (256, 256, 3, 1, 1, True, 0, 1, 16, 16),
+    (130, 136, 3, 1, 1, False, 0, 1, 8, 8),
+    (1, 64, 7, 1, 3, True, 0, 2, 20, 24),
+    (64, 1, 7, 1, 3, True, 2, 2, 20, 24),
+    (2, 16, 3, 2, 1, False, 1, 2, 16, 24),
+    (16, 32, 3, 2, 1, False, 1, 2, 15, 17),
+    (34, 16, 3, 1, 1, False, 1, 1, 16, 16),
+    (16, 2, 3, 1, 1, False, 0, 2, 10, 14),
+    (48, 32, 3, 1, 1, False, 1, 1, 11, 7),
+    (33, 3, 1, 1, 0, False, 0, 1, 6, 50),
+    (256, 256, 1, 1, 0, False, 1, 1, 1, 512),
+]
+
+
+def torch_conv(x, w, b, stride, pad, reflect, act, nd):
+    conv = F.conv2d if nd == 2 else F.conv3d
+    if reflect:
+        x = F.pad(x, (pad,) * (2 * nd), mode='reflect')
+        y = conv(x, w, b, stride=stride)
+    else:
+        y = conv(x, w, b, stride=stride, padding=pad)
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif act == 2:
+        y = torch.tanh(y)
+    return y
+
+
+@pytest.mark.parametrize("cfg", CONV2D, ids=[str(c) for c in CONV2D])
+def test_conv2d(ops, cfg):
+    Cin, Cout, K, stride, pad, reflect, act, N, H, W = cfg
+    x = C.randn(1, N, Cin, H, W)
+    w = C.randn(2, Cout, Cin, K, K) / (Cin * K * K) ** 0.5
+    b = C.randn(3, Cout) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch_conv(xr, wr, br, stride, pad, reflect, act, 2)
+    cot = C.randn(4, *yr.shape)
+    (yr * cot).sum().backward()
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+    yg = ops.conv(xg, wg, bg, None, stride, pad, 1 if reflect else 0, act, 0.2)
+    (yg * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    close(yg, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(wg.grad, wr.grad, rtol=3e-4, what="dw")
+    close(bg.grad, br.grad, rtol=3e-4, what="db")
+
+
+CONV3D = [
+    (2, 16, 3, 2, 1, 1, 12, 10, 14),
+    (16, 32, 3, 2, 1, 1, 9, 11, 13),
+    (34, 32, 3, 1, 1, 1, 6, 10, 12),
+    (32, 16, 3, 1, 1, 1, 8, 8, 8),
+    (16, 3, 3, 1, 1, 1, 7, 9, 11),
+    (64, 32, 3, 1, 1, 2, 4, 6, 5),
+]
+
+
+@pytest.mark.parametrize("cfg", CONV3D, ids=[str(c) for c in CONV3D])
+def test_conv3d(ops, cfg):
+    Cin, Cout, K, stride, pad, N, D, H, W = cfg
+    x = C.randn(1, N, Cin, D, H, W)
+    w = C.randn(2, Cout, Cin, K, K, K) / (Cin * K ** 3) ** 0.5
+    b = C.randn(3, Cout) * 0.1
+    act = 1 if Cout > 3 else 0
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch_conv(xr, wr, br, stride, pad, False, act, 3)
+    cot = C.randn(4, *yr.shape)
+    (yr * cot).sum().backward()
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+    yg = ops.conv(xg, wg, bg, None, stride, pad, 0, act, 0.2)
+    (yg * cot.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    close(yg, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(wg.grad, wr.grad, rtol=3e-4, what="dw")
+    close(bg.grad, br.grad, rtol=3e-4, what="db")
+
+
+# --------------------------------------------------------------------------------- norm / resample
+@pytest.mark.parametrize("shape,relu,res", [((2, 5, 16, 16), True, False), ((2, 7, 9, 11), False, True),
+                                            ((1, 3, 64, 64), True, True), ((3, 4, 5, 5), False, False)])
+def test_instnorm(ops, shape, relu, res):
+    x = C.randn(5, *shape) * 2 + 0.7
+    r = C.randn(6, *shape) if res else None
+    xr = x.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    yr = F.instance_norm(xr, eps=1e-5)
+    if relu:
+        yr = F.relu(yr)
+    if res:
+        yr = rr + yr
+    cot = C.randn(7, *shape)
+    (yr * cot).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_()
+    rg = r.clone().to(DEV).requires_grad_() if res else None
+    yg = ops.instance_norm(xg, rg, relu, 1e-5)
+    (yg * cot.to(DEV)).sum().backward()
+    close(yg, yr, what="y")
+    close(xg.grad, xr.grad, rtol=3e-4, what="dx")
+    if res:
+        close(rg.grad, rr.grad, what="dres")
+
+
+def test_blur_reflect_golden(ops, golden):
+    g = golden("blur.npz")
+    x = C.randn(31, 2, 8, 12, 12).to(DEV).requires_grad_()
+    y = ops.blur_down(x)
+    (y * C.randn(32, *y.shape).to(DEV)).sum().backward()
+    close(y, g["down"], what="down"); close(x.grad, g["ddown"], what="ddown")
+    x = C.randn(33, 2, 8, 12, 12).to(DEV).requires_grad_()
+    y = ops.blur_up(x)
+    (y * C.randn(34, *y.shape).to(DEV)).sum().backward()
+    close(y, g["up"], what="up"); close(x.grad, g["dup"], what="dup")
+    xo = C.randn(35, 1, 3, 7, 9).to(DEV).requires_grad_()
+    yo = ops.blur_down(xo)
+    (yo * C.randn(36, *yo.shape).to(DEV)).sum().backward()
+    close(yo, g["down_odd"], what="down odd"); close(xo.grad, g["ddown_odd"], what="ddown odd")
+    for p, shp in ((3, (2, 1, 9, 12)), (1, (1, 4, 5, 6)), (2, (1, 2, 3, 3))):
+        x = C.randn(37, *shp)
+        xr = x.clone().requires_grad_()
+        yr = F.pad(xr, (p, p, p, p), mode='reflect')
+        cot = C.randn(38, *yr.shape)
+        (yr * cot).sum().backward()
+        xg = x.clone().to(DEV).requires_grad_()
+        yg = ops.reflect_pad2d(xg, p)
+        (yg * cot.to(DEV)).sum().backward()
+        close(yg, yr, what="pad"); close(xg.grad, xr.grad, what="dpad")
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_upcat_cat_scale(ops, nd):
+    sp = (5, 7) if nd == 2 else (3, 4, 5)
+    a = C.randn(41, 2, 6, *sp)
+    b = C.randn(42, 2, 3, *[2 * s for s in sp])
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch.cat([F.interpolate(ar, scale_factor=2, mode='nearest'), br], dim=1)
+    cot = C.randn(43, *yr.shape)
+    (yr * cot).sum().backward()
+    ag, bg = a.clone().to(DEV).requires_grad_(), b.clone().to(DEV).requires_grad_()
+    yg = ops.upcat(ag, bg)
+    (yg * cot.to(DEV)).sum().backward()
+    close(yg, yr, what="upcat"); close(ag.grad, ar.grad, what="da"); close(bg.grad, br.grad, what="db")
+    c = C.randn(44, 2, 2, *sp)
+    ag, cg = a.clone().to(DEV).requires_grad_(), c.clone().to(DEV).requires_grad_()
+    yg = ops.upcat_channels(ag, cg)
+    close(yg, torch.cat([a, c], 1), what="cat")
+    cot = C.randn(45, *yg.shape)
+    (yg * cot.to(DEV)).sum().backward()
+    close(ag.grad, cot[:, :6], what="dcat a"); close(cg.grad, cot[:, 6:], what="dcat c")
+    yb = ops.cat_batch(ag, ag.detach() * 2)
+    close(yb, torch.cat([a, 2 * a], 0), what="cat_batch")
+    sg = ops.scale(ag, -0.125)
+    close(sg, -0.125 * a, what="scale")
+
+
+# ------------------------------------------------------------------------------------------ warps
+def test_warp_golden(ops, golden):
+    g = golden("warp.npz")
+    for tag, shp, C_ in (("2d", (17, 23), 3), ("3d", (9, 11, 13), 2)):
+        B = 2 if tag == "2d" else 1
+        src = C.randn(11, B, C_, *shp).to(DEV).requires_grad_()
+        flow = ((C.rand(12, B, len(shp), *shp) * 12) - 6).to(DEV).requires_grad_()
+        cot = C.randn(13, B, C_, *shp).to(DEV)
+        y = ops.warp(src, flow)
+        (y * cot).sum().backward()
+        close(y, g["out_" + tag], what="warp " + tag)
+        close(src.grad, g["dsrc_" + tag], what="dsrc " + tag)
+        close(flow.grad, g["dflow_" + tag], rtol=3e-4, what="dflow " + tag)
+        yn = ops.warp(src.detach(), flow.detach(), "nearest")
+        gn = g["nearest_" + tag]
+        frac_bad = float((np.abs(yn.cpu().numpy() - gn) > 1e-5).mean())
+        assert frac_bad < 0.01, "nearest warp differs on %.3f of voxels" % frac_bad  # ties may round apart
+
+
+def test_warp_identity_and_oob(ops):
+    x = C.randn(51, 2, 1, 20, 30).to(DEV)
+    z = torch.zeros(2, 2, 20, 30, device=DEV)
+    close(ops.warp(x, z), x, what="identity")
+    far = torch.full((2, 2, 20, 30), 100.0, device=DEV)
+    assert float(ops.warp(x, far).abs().max()) == 0.0
+    one = torch.zeros(2, 2, 20, 30, device=DEV)
+    one[:, 0] = 1.0   # flow channel 0 = +1 row: content moves up, last row -> 0
+    y = ops.warp(x, one)
+    close(y[:, :, :-1], x[:, :, 1:], what="shift")
+    assert float(y[:, :, -1].abs().max()) == 0.0
+
+
+def test_vecint_resize_golden(ops, golden):
+    g = golden("vecint_resize.npz")
+    for tag, shp in (("2d", (32, 32)), ("3d", (8, 10, 12))):
+        v = (C.randn(21, 2 if tag == "2d" else 1, len(shp), *shp) * 2.0).to(DEV).requires_grad_()
+        cot = C.randn(22, *v.shape).to(DEV)
+        y = ops.scale(v, 1.0 / 128)
+        for _ in range(7):
+            y = ops.vecint_step(y)
+        (y * cot).sum().backward()
+        close(y, g["vecint_" + tag], what="vecint " + tag)
+        close(v.grad, g["dvecint_" + tag], rtol=1e-3, what="dvecint " + tag)
+        x = C.randn(23, 1, len(shp), *shp).to(DEV).requires_grad_()
+        half = ops.resize_linear(x, [s // 2 for s in shp], 0.5)
+        (half * C.randn(24, *half.shape).to(DEV)).sum().backward()
+        close(half, g["half_" + tag], what="half"); close(x.grad, g["dhalf_" + tag], what="dhalf")
+        x2 = C.randn(25, 1, len(shp), *shp).to(DEV).requires_grad_()
+        dbl = ops.resize_linear(x2, [s * 2 for s in shp], 2.0)
+        (dbl * C.randn(26, *dbl.shape).to(DEV)).sum().backward()
+        close(dbl, g["double_" + tag], what="double"); close(x2.grad, g["ddouble_" + tag], what="ddouble")
+
+
+# ---------------------------------------------------------------------------------------- PatchNCE
+def test_patch_gather_l2norm_nce(ops):
+    from oracle import dfmir_oracle as O
+    B, Cc, H, W, P = 2, 24, 9, 11, 32
+    feat = C.randn(61, B, Cc, H, W)
+    ids = C.patch_ids(3, 0, H * W, P)
+    fr = feat.clone().requires_grad_()
+    rows_r = fr.permute(0, 2, 3, 1).flatten(1, 2)[:, ids, :].flatten(0, 1)        # [B*P, C]
+    qn_r = O.l2_normalize(rows_r)
+    k = O.l2_normalize(C.randn(62, B * P, Cc))
+    lr_ = O.patchnce_loss(qn_r, k, B, 0.07)
+    cot = C.rand(63, B * P) + 0.5
+    (lr_ * cot).sum().backward()
+    fg = feat.clone().to(DEV).requires_grad_()
+    rows_g = ops.patch_gather(fg, ids.to(DEV))                                      # [C, B*P]
+    close(rows_g.t(), rows_r, what="gather")
+    qn_g = ops.l2norm_rows(rows_g)
+    close(qn_g.t(), qn_r, what="l2norm")
+    lg = ops.patchnce_rows(qn_g, k.t().contiguous().to(DEV), B, 0.07)
+    close(lg, lr_, what="nce loss")
+    (lg * cot.to(DEV)).sum().backward()
+    close(fg.grad, fr.grad, rtol=1e-3, what="dfeat")
+    # all negatives from the minibatch (groups = 1)
+    l1r = O.patchnce_loss(qn_r.detach(), k, 1, 0.07)
+    l1g = ops.patchnce_rows(qn_g.detach(), k.t().contiguous().to(DEV), 1, 0.07)
+    close(l1g, l1r, what="nce loss G=1")
+    m = ops.mean(lg.detach())
+    close(m, lr_.mean(), what="mean")
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_losses_golden(ops, golden):
+    g = golden("losses.npz")
+    a, b = C.image_pair(71, 2, 20, 24)
+    a, b = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    l = ops.masked_l1(a, b, None, -0.95)
+    l.backward()
+    close(l, g["l1"], what="l1"); close(a.grad, g["dl1_a"], what="dl1a"); close(b.grad, g["dl1_b"], what="dl1b")
+    mask = ((b > -0.95) | (a > -0.95)).detach()
+    close(ops.masked_l1(a.detach(), b.detach(), mask), g["l1"], what="l1 explicit mask")
+    z = ops.masked_l1(a.detach() * 0 - 1, b.detach() * 0 - 1, None, -0.95)
+    assert float(z) == 0.0                                     # sum(mask)==0 -> 0 (registration_model.py:259)
+    f2 = (C.randn(72, 2, 2, 18, 22) * 1.5).to(DEV).requires_grad_()
+    l = ops.flow_smoothness(f2); l.backward()
+    close(l, g["smooth2d"], what="smooth2d"); close(f2.grad, g["dsmooth2d"], what="dsmooth2d")
+    f3 = (C.randn(73, 1, 3, 7, 9, 11) * 1.5).to(DEV).requires_grad_()
+    l = ops.flow_smoothness(f3); l.backward()
+    close(l, g["grad3d"], what="grad3d"); close(f3.grad, g["dgrad3d"], what="dgrad3d")
+    for tag, shp in (("2d", (2, 1, 24, 28)), ("3d", (1, 1, 12, 14, 16))):
+        I = C.rand(75, *shp)
+        J = (0.6 * I + 0.4 * C.rand(76, *shp)).to(DEV)
+        I = I.to(DEV).requires_grad_()
+        l = ops.ncc_loss(I, J, 9, 1e-5); l.backward()
+        close(l, g["ncc" + tag], what="ncc" + tag); close(I.grad, g["dncc" + tag], rtol=1e-3, what="dncc" + tag)
+
+
+def test_adam_matches_torch(ops):
+    from dfmir_amd.optim import FlatAdam
+    ps = [C.randn(81, 37, 5), C.randn(82, 129)]
+    ref = [p.clone().requires_grad_() for p in ps]
+    got = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    o_got = FlatAdam(got, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(5):
+        o_ref.zero_grad(); o_got.zero_grad()
+        for i, (r, q) in enumerate(zip(ref, got)):
+            gr = C.randn(90 + 10 * it + i, *r.shape) * (0.1 + it)
+            r.grad = gr.clone()
+            q.grad.add_(gr.to(DEV))
+        o_ref.step(); o_got.step()
+    for r, q in zip(ref, got):
+        close(q, r, rtol=1e-6, what="adam params")

@@ -1,0 +1,108 @@
+"""CPU: host-side logic of the plugin mirror -- module structure / state_dict keys against the
+oracle (itself pinned to the reference), option defaults, scheduler rule, the flat Adam arena, and
+the no-fallback guarantee (HIP ops refuse CPU tensors)."""
+import pytest
+import torch
+
+from dfmir_amd import DfmirHipError
+from dfmir_amd import networks as N
+from dfmir_amd import ops
+from dfmir_amd import voxelmorph as V
+from dfmir_amd.optim import FlatAdam
+from dfmir_amd.options import default_options
+from oracle import dfmir_oracle as O
+
+
+def test_generator_structure_matches_reference_indices():
+    hg = N.ResnetGenerator(1, 1, 8, norm_layer=N.get_norm_layer('instance'), n_blocks=9)
+    og = O.Generator(1, 1, 8, 9)
+    assert list(hg.state_dict().keys()) == list(og.state_dict().keys())
+    for k, v in og.state_dict().items():
+        assert tuple(hg.state_dict()[k].shape) == tuple(v.shape), k
+    assert len(hg.model) == 32
+    assert isinstance(hg.model[0], N.ReflectionPad2d) and isinstance(hg.model[4], N.Conv2d)
+    assert isinstance(hg.model[7], N.Downsample) and isinstance(hg.model[12], N.ResnetBlock)
+    assert isinstance(hg.model[21], N.Upsample) and isinstance(hg.model[31], N.Tanh)
+    n = sum(p.numel() for p in N.ResnetGenerator(1, 1, 64, norm_layer=N.InstanceNorm2d, n_blocks=9).parameters())
+    assert n == 11365633
+
+
+def test_blur_buffers_match_reference_filters():
+    assert torch.allclose(N.Downsample(2).filt[0, 0], torch.tensor([[1., 2, 1], [2, 4, 2], [1, 2, 1]]) / 16)
+    assert torch.allclose(N.Upsample(2).filt[0, 0].sum(), torch.tensor(4.0))
+
+
+def test_vxm_structure():
+    hv = V.VxmDense((64, 64), O.PLUGIN_UNET_FEATURES, int_steps=7, bidir=True)
+    ov = O.VxmDense((64, 64), O.PLUGIN_UNET_FEATURES, 7, True)
+    hk = [k for k in hv.state_dict().keys() if not k.endswith('.grid')]
+    assert hk == list(ov.state_dict().keys())
+    assert 'transformer.grid' in hv.state_dict() and 'integrate.transformer.grid' in hv.state_dict()
+    assert sum(p.numel() for p in hv.parameters()) == 356258
+    h3 = V.VxmDense((32, 32, 32), None, int_steps=7, bidir=True)
+    assert sum(p.numel() for p in h3.parameters()) == 301411
+    assert float(hv.flow.weight.abs().max()) < 1e-3 and float(hv.flow.bias.abs().max()) == 0.0
+    assert hv.config['int_steps'] == 7 and hv.config['bidir'] is True
+    assert hv.transformer.grid.shape == (1, 2, 64, 64) and float(hv.transformer.grid[0, 0, 5, 0]) == 5.0
+
+
+def test_patch_sampler_keys():
+    f = N.PatchSampleF(use_mlp=True, nc=32)
+    f.mlp_init = False
+    feats = [torch.zeros(1, 1, 4, 4), torch.zeros(1, 16, 4, 4)]
+    f.create_mlp(feats)
+    o = O.PatchSampler(32, True)
+    o.create_mlp(feats)
+    assert list(f.state_dict().keys()) == list(o.state_dict().keys())
+    assert float(f.mlp_0[0].bias.abs().max()) == 0.0
+
+
+def test_model_class_discovery_and_options():
+    import dfmir_amd.registration_model as rm
+    names = [n for n, c in vars(rm).items() if n.lower() == 'registrationmodel']
+    assert names == ['REGISTRATIONModel']
+    opt = default_options()
+    assert opt.nce_idt is True and opt.lambda_NCE == 0.25 and opt.nce_layers == '0,4,8,12,16'
+    assert opt.lr == 2e-4 and opt.beta1 == 0.5 and opt.num_patches == 256 and opt.nce_T == 0.07
+
+
+def test_scheduler_linear_rule():
+    opt = default_options(n_epochs=2, n_epochs_decay=2, epoch_count=1)
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    o = torch.optim.SGD(p, lr=1.0)
+    s = N.get_scheduler(o, opt)
+    lrs = []
+    for _ in range(4):
+        lrs.append(o.param_groups[0]['lr'])
+        o.step(); s.step()
+    assert lrs == [1.0, 1.0, pytest.approx(2 / 3), pytest.approx(1 / 3)]
+
+
+def test_ops_refuse_cpu_tensors():
+    x = torch.zeros(1, 2, 4, 4)
+    with pytest.raises(DfmirHipError):
+        ops.instance_norm(x)
+    with pytest.raises(DfmirHipError):
+        ops.warp(x, torch.zeros(1, 2, 4, 4))
+    with pytest.raises(DfmirHipError):
+        ops.conv(x, torch.zeros(3, 2, 3, 3), None, None, 1, 1, 0, 0, 0.0)
+
+
+def test_flat_adam_arena_aliases_parameters():
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    ps = list(net.parameters())
+    before = [p.detach().clone() for p in ps]
+    o = FlatAdam(ps, lr=1e-3, betas=(0.5, 0.999))
+    assert o.flat_p.numel() == sum(p.numel() for p in ps)
+    off = 0
+    for p, b in zip(ps, before):
+        assert torch.equal(p.detach(), b)
+        assert p.data_ptr() == o.flat_p.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == o.flat_g.data_ptr() + 4 * off
+        off += p.numel()
+    net(torch.ones(1, 3)).sum().backward()
+    assert float(o.flat_g.abs().sum()) > 0      # autograd accumulated straight into the arena
+    o.zero_grad()
+    assert float(o.flat_g.abs().sum()) == 0
+    with pytest.raises(DfmirHipError):            # the fused Adam kernel is HIP-only: no CPU fallback
+        o.step()
