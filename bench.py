@@ -162,9 +162,11 @@ def main():
         a, b = batches[i % len(batches)]
         return {"A": a, "B": b, "A_paths": paths, "B_paths": paths}
 
-    model.data_dependent_initialize(feed(0))
-    model.setup(opt)
-    model.parallelize()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # keep stdout = the one JSON line
+        model.data_dependent_initialize(feed(0))
+        model.setup(opt)
+        model.parallelize()
     for i in range(args.warmup):
         model.set_input(feed(i))
         model.optimize_parameters()

@@ -133,9 +133,13 @@ class PatchSampler(nn.Module):
             self.create_mlp(feats)
         out, ids = [], []
         for i, f in enumerate(feats):
-            rows = f.permute(0, 2, 3, 1).flatten(1, 2)                       # [B, HW, C]
-            pid = patch_ids[i] if patch_ids is not None else torch.randperm(rows.shape[1])[:min(num_patches, rows.shape[1])]
-            x = rows[:, pid, :].flatten(0, 1)                                # [B*P, C]
+            S = f.shape[2] * f.shape[3]
+            pid = patch_ids[i] if patch_ids is not None else torch.randperm(S)[:min(num_patches, S)]
+            # == f.permute(0,2,3,1).flatten(1,2)[:, pid, :].flatten(0,1) of the reference, written so that
+            # the gradient w.r.t. f is CONTIGUOUS: torch 2.10's CPU instance_norm backward returns wrong
+            # values for a channels-last grad_output at N == 1, which the reference's
+            # formulation produces at batch_size 1.  Values and (correct) gradients are identical.
+            x = f.flatten(2)[:, :, pid].permute(0, 2, 1).flatten(0, 1)       # [B*P, C]
             if self.use_mlp:
                 x = getattr(self, 'mlp_%d' % i)(x)
             ids.append(pid)

@@ -230,3 +230,28 @@ def test_whole_step(golden):
             for nm, net in (("G", st.netG), ("F", st.netF), ("R", st.netR)):
                 n2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters() if p.grad is not None) ** 0.5
                 assert abs(n2 - float(g["gradnorm_" + nm])) <= 1e-3 * float(g["gradnorm_" + nm]), nm
+
+
+def test_patch_gather_formulation_and_torch_cpu_instance_norm_bug():
+    """The oracle gathers patches as f.flatten(2)[:, :, pid] (contiguous gradient).  (a) it equals the
+    reference's permute/flatten/index formulation in value and, at batch 2, in gradient; (b) at batch 1
+    the reference's formulation hands InstanceNorm a channels-last grad_output, for which torch 2.10's
+    CPU backward returns wrong values -- the oracle's gradient instead equals the dense-
+    cotangent gradient, which is formulation-independent."""
+    import torch.nn.functional as F
+    for B in (1, 2):
+        x = C.randn(300 + B, B, 5, 6, 7).requires_grad_()
+        pid = C.patch_ids(0, 0, 42, 20)
+        cot = C.randn(310 + B, B * 20, 5)
+        y = F.instance_norm(x)
+        rows_ref = y.permute(0, 2, 3, 1).flatten(1, 2)[:, pid, :].flatten(0, 1)
+        rows_orc = y.flatten(2)[:, :, pid].permute(0, 2, 1).flatten(0, 1)
+        assert torch.equal(rows_ref, rows_orc)
+        g_orc, = torch.autograd.grad((rows_orc * cot).sum(), x, retain_graph=True)
+        dense = torch.zeros(B, 5, 42)
+        dense[:, :, pid] = cot.view(B, 20, 5).permute(0, 2, 1)
+        g_dense, = torch.autograd.grad((y * dense.view_as(y)).sum(), x, retain_graph=True)
+        close(g_orc, g_dense, what="oracle vs dense, B=%d" % B)
+        if B == 2:
+            g_ref, = torch.autograd.grad((rows_ref * cot).sum(), x)
+            close(g_ref, g_orc, what="reference formulation, B=2")
