@@ -12,6 +12,7 @@
 // Tiles go global -> registers -> LDS (double buffered, one barrier per K step); fp32 MFMA is
 // 64 cycles per 32x32x2 so the per-element gather arithmetic hides under the matrix pipe.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -423,6 +424,19 @@ __global__ void weight_unpack_k(const float* __restrict__ gt, float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
+                        float* y, hipStream_t st, int* rc);
+bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                          hipStream_t st, int* rc);
+static bool use_generic_only() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DFMIR_CONV_GENERIC");   // A/B switch: force the generic gather kernels
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 static int check_geom(const DfConvGeom* g) {
   if (!g) return -1;
   if (g->N <= 0 || g->Cin <= 0 || g->Cout <= 0) return -1;
@@ -439,6 +453,10 @@ extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* 
   DF_ARG_CHECK(check_geom(g) == 0 && x && w_tcc && y);
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
+  if (!use_generic_only()) {
+    int rc = 0;
+    if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
+  }
   if (g->Cout <= 4) {
     const unsigned grid = (unsigned)((P + 255) / 256);
     if (g->Cout == 1) conv_small_k<1><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
@@ -469,6 +487,10 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
   DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
   DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
   hipStream_t st = (hipStream_t)stream;
+  if (!use_generic_only()) {
+    int rc = 0;
+    if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
+  }
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   const int J = g->KD * g->KH * g->KW * g->Cin;
   auto plan = [&](int BJ, int BC, int BP, unsigned& nP, long long& pchunk, dim3& grid) {

@@ -1,0 +1,434 @@
+// 2-D 3x3 stride-1 convolutions -- the shape that carries ~95 % of the generator's FLOPs -- as
+// LDS-resident implicit GEMMs on the fp32 matrix cores, software-pipelined.
+//
+// The generic kernel (conv.hip) re-gathers the input once per filter tap.  Here a workgroup
+// stages, per chunk of 8 input channels, (a) ONE halo patch of the input covering its run of
+// output pixels (+1 ring) and (b) the weights of all 9 taps; the 9 taps then read the SAME patch
+// at shifted LDS addresses.  The global loads of chunk i+1 are issued into registers BEFORE the
+// 144-MFMA phase of chunk i and written to LDS after it, so HBM/L2 latency sits under the matrix
+// pipe instead of in front of it (rocprof: the un-pipelined form idled the pipe 36 % of the time).
+//
+// forward / dgrad :  Y[co][p] = sum_{tap,ci} Wt[tap][ci][co] * X[ci][p + tap]       (conv3x3_mfma_k)
+// wgrad           :  dWt[tap][ci][co] += sum_p X[ci][p + tap] * dY[co][p]           (conv3x3_wgrad_k)
+//   wgrad's MFMA A operand is read straight out of the halo patch: one 32-row tile = 32 input
+//   channels of ONE tap, so the (tap, ci) "im2col" axis is never materialised.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv3P {
+  int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;
+  float slope;
+  int tiles_per_img;
+};
+
+__device__ __forceinline__ int halo_offset(int iy, int ix, int Hi, int Wi, int pad_mode) {
+  if (pad_mode == 1) {
+    if (iy < 0) iy = -iy;
+    if (iy >= Hi) iy = 2 * (Hi - 1) - iy;
+    if (ix < 0) ix = -ix;
+    if (ix >= Wi) ix = 2 * (Wi - 1) - ix;
+    iy = iy < 0 ? 0 : (iy >= Hi ? Hi - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= Wi ? Wi - 1 : ix);
+    return iy * Wi + ix;
+  }
+  return ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) ? iy * Wi + ix : -1;
+}
+
+template <int WM, int WN, int TM, int TN, int XP>
+__global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ x,
+                                                      const float* __restrict__ wt,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ y, Conv3P k) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, CK = 8;
+  constexpr int NS = (XP + 255) / 256;
+  constexpr int W4 = 9 * CK * BM / 4;  // float4 elements of one weight chunk
+  constexpr int NW = (W4 + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float Ws[9 * CK * BM];
+  __shared__ float Xs[CK * XP];
+  __shared__ float bs[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
+  const int n = blockIdx.x / k.tiles_per_img;
+  const int t = blockIdx.x - n * k.tiles_per_img;
+  const int p0 = t * BN;
+  const int pend = (p0 + BN < HWo) ? p0 + BN : HWo;
+  const int m0 = blockIdx.y * BM;
+  const int y0 = p0 / k.Wo, y1 = (pend - 1) / k.Wo;
+  const bool single = (y0 == y1);
+  const int x0 = p0 - y0 * k.Wo, x1 = (pend - 1) - y1 * k.Wo;
+  const int xoff = single ? x0 : 0;
+  const int ncols = single ? (x1 - x0 + 3) : (k.Wo + 2);
+  const int nrows = y1 - y0 + 3;
+  const int npos = nrows * ncols;
+
+  int goff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pos = tid + 256 * s;
+    int off = -1;
+    if (pos < npos) {
+      const int r = pos / ncols, c = pos - r * ncols;
+      off = halo_offset(y0 - k.pad + r, xoff - k.pad + c, k.Hi, k.Wi, k.pad_mode);
+    }
+    goff[s] = off;
+  }
+  if (tid < BM) bs[tid] = (bias && (m0 + tid) < k.Cout) ? bias[m0 + tid] : 0.f;
+
+  int pbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int q = p0 + (wn * TN + j) * 32 + l31;
+    q = q < pend ? q : pend - 1;
+    const int yy = q / k.Wo, xx = q - yy * k.Wo;
+    pbase[j] = (yy - y0) * ncols + (xx - xoff);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Buffer descriptors: out-of-range offsets (zero padding, channel / tile overrun) read as 0 in
+  // hardware, so the staging loads are branch-free and can all be in flight at once.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (long long)n * k.Cin * HWi), 0, (unsigned)(k.Cin * HWi) * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt), 0, (unsigned)(9 * k.Cin * k.Cout) * 4u, 0x00020000);
+  const bool vec4 = (k.Cout & 3) == 0;
+  unsigned gbyte[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) gbyte[s] = goff[s] < 0 ? OOB : (unsigned)goff[s] * 4u;
+  // weight slot -> (row, 4 output channels); byte offset of chunk 0, advanced by CK*Cout*4 per chunk
+  unsigned wbyte[NW];
+  bool wok[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int idx4 = tid + 256 * j;
+    const int row = idx4 / (BM / 4), c4 = idx4 - row * (BM / 4);
+    const int tap = row >> 3, ci = row & 7, co = m0 + c4 * 4;
+    wok[j] = idx4 < W4 && co < k.Cout;
+    wbyte[j] = (unsigned)((tap * k.Cin + ci) * k.Cout + co) * 4u;
+  }
+  const unsigned wstep = (unsigned)(CK * k.Cout) * 4u;
+  const unsigned xstep = (unsigned)HWi * 4u;
+
+  u32x4 rw[NW];
+  unsigned rx[NS][CK];
+
+#define C3_GLOAD(ci0_)                                                                           \
+  {                                                                                              \
+    const unsigned wadd = (unsigned)((ci0_) / CK) * wstep;                                       \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                             \
+      /* rows of this chunk with ci >= Cin lie beyond tap's slab only for the LAST tap; mask */  \
+      const bool ok = wok[j] && ((ci0_) + ((tid + 256 * j) / (BM / 4) & 7)) < k.Cin;             \
+      const unsigned o = ok ? wbyte[j] + wadd : OOB;                                             \
+      if (vec4) {                                                                                \
+        rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw_src, o, 0, 0);                          \
+      } else {                                                                                   \
+        const int co = m0 + ((tid + 256 * j) % (BM / 4)) * 4;                                    \
+        rw[j].x = __builtin_amdgcn_raw_buffer_load_b32(rw_src, o, 0, 0);                         \
+        rw[j].y = __builtin_amdgcn_raw_buffer_load_b32(rw_src, (ok && co + 1 < k.Cout) ? o + 4u : OOB, 0, 0);  \
+        rw[j].z = __builtin_amdgcn_raw_buffer_load_b32(rw_src, (ok && co + 2 < k.Cout) ? o + 8u : OOB, 0, 0);  \
+        rw[j].w = __builtin_amdgcn_raw_buffer_load_b32(rw_src, (ok && co + 3 < k.Cout) ? o + 12u : OOB, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+    const unsigned xadd = (unsigned)(ci0_) * xstep;                                              \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
+      _Pragma("unroll") for (int c = 0; c < CK; ++c)                                             \
+        rx[s][c] = __builtin_amdgcn_raw_buffer_load_b32(rx_src, gbyte[s] + xadd + (unsigned)c * xstep, 0, 0); \
+    }                                                                                            \
+  }
+#define C3_LSTORE()                                                                              \
+  {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                             \
+      const int idx4 = tid + 256 * j;                                                            \
+      if (idx4 < W4) *reinterpret_cast<u32x4*>(&Ws[idx4 * 4]) = rw[j];                           \
+    }                                                                                            \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
+      const int pos = tid + 256 * s;                                                             \
+      if (pos < npos) {                                                                          \
+        _Pragma("unroll") for (int c = 0; c < CK; ++c) Xs[c * XP + pos] = __uint_as_float(rx[s][c]); \
+      }                                                                                          \
+    }                                                                                            \
+  }
+
+  C3_GLOAD(0);
+  C3_LSTORE();
+  __syncthreads();
+
+  for (int ci0 = 0; ci0 < k.Cin; ci0 += CK) {
+    const bool more = (ci0 + CK) < k.Cin;
+    if (more) C3_GLOAD(ci0 + CK);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * ncols + (tap % 3);
+#pragma unroll
+      for (int kk = 0; kk < CK / 2; ++kk) {
+        const int kr = 2 * kk + lhi;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = Ws[(tap * CK + kr) * BM + (wm * TM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Xs[kr * XP + pbase[j] + toff];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      __syncthreads();  // every wave is done reading this chunk
+      C3_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef C3_GLOAD
+#undef C3_LSTORE
+
+  // ---- epilogue
+  float* yb = y + (long long)n * k.Cout * HWo;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int q = p0 + (wn * TN + j) * 32 + l31;
+    if (q >= pend) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int cl = (wm * TM + i) * 32 + 4 * lhi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = cl + (r & 3) + 8 * (r >> 2);
+        const int co = m0 + c;
+        if (co < k.Cout) {
+          float v = acc[i][j][r] + bs[c];
+          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+          else if (k.act == 2) v = tanhf(v);
+          yb[(long long)co * HWo + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  Block tile = (32*WI input channels) x (32*WC output channels) x 9 taps; wave
+// (wi, wc) owns 9 accumulator tiles [32 ci x 32 co], one per tap.  Reduction over runs of BP = 32
+// pixels; LDS double-buffered, next run's loads in flight during the 144-MFMA phase.
+// ---------------------------------------------------------------------------------------------
+struct W3P {
+  int N, Cin, Cout, H, W, pad_mode;
+  int runs_per_img, runs_total, runs_per_block;
+};
+
+template <int WI, int WC>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_k(const float* __restrict__ x,
+                                                       const float* __restrict__ dy,
+                                                       float* __restrict__ dwt, W3P k) {
+  constexpr int BP = 32, XP = 105;            // 105 % 32 == 9: conflict-free channel-strided reads
+  constexpr int CT = 32 * WI, BC = 32 * WC, BCP = BC + 1;
+  constexpr int HC = CT / 2;                  // channels per thread: 2 threads share one halo position
+  constexpr int ND4 = (BP / 4) * BC / 256;    // float4 of dY per thread
+  static_assert(WI * WC == 4, "4 waves");
+  static_assert(ND4 >= 1, "dY tile");
+  __shared__ float Xs[2][CT * XP];
+  __shared__ float Ds[2][BP * BCP];
+  __shared__ int ppos[2][BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wi = wid / WC, wc = wid % WC;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HW = k.H * k.W;
+  const int ci0 = blockIdx.y * CT, co0 = blockIdx.z * BC;
+  const int run_beg = blockIdx.x * k.runs_per_block;
+  int run_end = run_beg + k.runs_per_block;
+  if (run_end > k.runs_total) run_end = k.runs_total;
+
+  // halo position / channel half owned by this thread (geometry is run-invariant up to its origin)
+  const int hpos = tid & 127, hhalf = tid >> 7;
+  const bool single_row = k.W >= BP;          // host guarantees W % BP == 0 or BP % W == 0
+  const int ncols = single_row ? (BP + 2) : (k.W + 2);
+  const int nrows = single_row ? 3 : (BP / k.W + 2);
+  const int npos = nrows * ncols;
+  const int hr = hpos / ncols, hc = hpos - hr * ncols;
+  // dY: lanes along pixels
+  const int p4 = tid % (BP / 4), dcr = tid / (BP / 4);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned rx[HC];
+  u32x4 rd[ND4];
+  int rpp = 0;
+  const unsigned hw4 = (unsigned)HW * 4u;
+
+#define W3_GLOAD(run_)                                                                           \
+  {                                                                                              \
+    const int n_ = (run_) / k.runs_per_img;                                                      \
+    const int p0_ = ((run_) - n_ * k.runs_per_img) * BP;                                         \
+    const int y0_ = p0_ / k.W;                                                                   \
+    const int xo_ = single_row ? (p0_ - y0_ * k.W) : 0;                                          \
+    const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(x + (long long)n_ * k.Cin * HW), 0, (unsigned)(k.Cin * HW) * 4u, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t ds_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, (unsigned)(k.Cout * HW) * 4u, 0x00020000); \
+    int off_ = -1;                                                                               \
+    if (hpos < npos) off_ = halo_offset(y0_ - 1 + hr, xo_ - 1 + hc, k.H, k.W, k.pad_mode);       \
+    const unsigned xb_ = off_ < 0 ? OOB : (unsigned)off_ * 4u + (unsigned)(ci0 + hhalf * HC) * hw4; \
+    _Pragma("unroll") for (int c = 0; c < HC; ++c)                                               \
+      rx[c] = __builtin_amdgcn_raw_buffer_load_b32(xs_, xb_ + (unsigned)c * hw4, 0, 0);          \
+    const unsigned db_ = (unsigned)(co0 + dcr) * hw4 + (unsigned)(p0_ + p4 * 4) * 4u;            \
+    _Pragma("unroll") for (int j = 0; j < ND4; ++j)                                              \
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b128(ds_, db_ + (unsigned)(j * (256 / (BP / 4))) * hw4, 0, 0); \
+    if (tid < BP) {                                                                              \
+      const int q = p0_ + tid;                                                                   \
+      const int yy = q / k.W, xx = q - yy * k.W;                                                 \
+      rpp = (yy - y0_) * ncols + (xx - xo_);                                                     \
+    }                                                                                            \
+  }
+#define W3_LSTORE(buf_)                                                                          \
+  {                                                                                              \
+    if (hpos < npos) {                                                                           \
+      _Pragma("unroll") for (int c = 0; c < HC; ++c) Xs[buf_][(hhalf * HC + c) * XP + hpos] = __uint_as_float(rx[c]); \
+    }                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < ND4; ++j) {                                            \
+      const int c = dcr + j * (256 / (BP / 4));                                                  \
+      Ds[buf_][(p4 * 4 + 0) * BCP + c] = __uint_as_float(rd[j].x);                                               \
+      Ds[buf_][(p4 * 4 + 1) * BCP + c] = __uint_as_float(rd[j].y);                                               \
+      Ds[buf_][(p4 * 4 + 2) * BCP + c] = __uint_as_float(rd[j].z);                                               \
+      Ds[buf_][(p4 * 4 + 3) * BCP + c] = __uint_as_float(rd[j].w);                                               \
+    }                                                                                            \
+    if (tid < BP) ppos[buf_][tid] = rpp;                                                         \
+  }
+
+  if (run_beg < run_end) {
+    W3_GLOAD(run_beg);
+    W3_LSTORE(0);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int run = run_beg; run < run_end; ++run, ++it) {
+    const int buf = it & 1;
+    const bool more = (run + 1) < run_end;
+    if (more) W3_GLOAD(run + 1);
+    const float* xrow = &Xs[buf][(wi * 32 + l31) * XP];
+#pragma unroll 2
+    for (int kk = 0; kk < BP / 2; ++kk) {
+      const int kr = 2 * kk + lhi;
+      const int pp = ppos[buf][kr];
+      const float b = Ds[buf][kr * BCP + wc * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float a = xrow[pp + (t / 3) * ncols + (t % 3)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) W3_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef W3_GLOAD
+#undef W3_LSTORE
+
+  const int co = co0 + wc * 32 + l31;
+  if (co < k.Cout) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch (called from conv.hip); return true when the launch was taken.
+// ---------------------------------------------------------------------------------------------
+static int worst_npos(int Wo, int HWo, int BN) {
+  if (HWo <= BN) {  // one tile per image
+    const int rows = (HWo + Wo - 1) / Wo;
+    return rows == 1 ? 3 * (HWo + 2) : (rows + 2) * (Wo + 2);
+  }
+  if (Wo >= BN) return (Wo % BN == 0) ? 3 * (BN + 2) : 4 * (Wo + 2);
+  const int rows = (BN % Wo == 0) ? BN / Wo : (BN + Wo - 1) / Wo + 1;
+  return (rows + 2) * (Wo + 2);
+}
+
+bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
+                        float* y, hipStream_t st, int* rc) {
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
+    return false;
+  if (g->Cout <= 4 || g->ph != g->pw || g->pd != 0) return false;
+  const int p = g->ph;
+  if (!(p == 1 || (p == 2 && g->pad_mode == 0))) return false;
+  if (g->Ho != g->Hi + 2 * p - 2 || g->Wo != g->Wi + 2 * p - 2) return false;
+  const long long HWo = (long long)g->Ho * g->Wo;
+  if (HWo >= (1LL << 30) || (long long)g->Hi * g->Wi >= (1LL << 30)) return false;
+  Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
+  if (g->Cout > 64) {
+    if (worst_npos(g->Wo, (int)HWo, 128) > 400) return false;
+    k.tiles_per_img = (int)((HWo + 127) / 128);
+    dim3 grid((unsigned)(g->N * k.tiles_per_img), (unsigned)((g->Cout + 127) / 128));
+    conv3x3_mfma_k<2, 2, 2, 2, 400><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  } else if (g->Cout > 32) {
+    if (worst_npos(g->Wo, (int)HWo, 256) > 1056) return false;
+    k.tiles_per_img = (int)((HWo + 255) / 256);
+    dim3 grid((unsigned)(g->N * k.tiles_per_img), 1);
+    conv3x3_mfma_k<1, 4, 2, 2, 1056><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  } else {
+    if (worst_npos(g->Wo, (int)HWo, 256) > 1056) return false;
+    k.tiles_per_img = (int)((HWo + 255) / 256);
+    dim3 grid((unsigned)(g->N * k.tiles_per_img), 1);
+    conv3x3_mfma_k<1, 4, 1, 2, 1056><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  }
+  hipError_t e = hipGetLastError();
+  *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+  return true;
+}
+
+bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                          hipStream_t st, int* rc) {
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
+    return false;
+  if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
+  if (g->Cout < 64 || g->Cin < 32) return false;
+  constexpr int BP = 32;
+  const long long HW = (long long)g->Hi * g->Wi;
+  if (HW % BP != 0 || HW >= (1LL << 30)) return false;
+  const int W = g->Wi;
+  if (!((W % BP == 0) || (W < BP && BP % W == 0))) return false;
+  const int npos = (W >= BP) ? 3 * (BP + 2) : (BP / W + 2) * (W + 2);
+  if (npos > 105) return false;
+  W3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, (int)(HW / BP), 0, 0};
+  k.runs_total = g->N * k.runs_per_img;
+  const bool wide = g->Cout >= 128;
+  const int CT = wide ? 32 : 64, BC = wide ? 128 : 64;
+  const unsigned ny = (g->Cin + CT - 1) / CT, nz = (g->Cout + BC - 1) / BC;
+  long long want = 512 / ((long long)ny * nz);   // one resident round: 2 workgroups per CU
+  if (want < 1) want = 1;
+  long long maxs = (k.runs_total + 3) / 4;       // >= 4 runs per block
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  k.runs_per_block = (int)((k.runs_total + want - 1) / want);
+  const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
+  dim3 grid(nx, ny, nz);
+  if (wide) conv3x3_wgrad_k<1, 4><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
+  else conv3x3_wgrad_k<2, 2><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
+  hipError_t e = hipGetLastError();
+  *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+  return true;
+}

@@ -1,0 +1,35 @@
+"""Micro-benchmark (GPU box): the generator's conv shapes through dfmir_conv_fwd / dfmir_conv_wgrad.
+Usage: python scripts/bench_conv.py [batch]   (set DFMIR_CONV_GENERIC=1 for the generic kernels)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dfmir_amd import ops
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+SHAPES = [  # Cin, Cout, H, reflect
+    (256, 256, 64, True), (64, 128, 256, False), (128, 256, 128, False), (256, 128, 128, False), (128, 64, 256, False)]
+print("generic" if os.environ.get("DFMIR_CONV_GENERIC") == "1" else "specialised", "kernels, n =", n)
+for Cin, Cout, H, refl in SHAPES:
+    x = torch.randn(n, Cin, 1, H, H, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.02
+    b = torch.zeros(Cout, device="cuda")
+    wt = ops.weight_pack(w, 0)
+    dy = torch.randn(n, Cout, 1, H, H, device="cuda")
+    fl = 2.0 * n * Cout * H * H * Cin * 9
+    def fwd():
+        return ops.conv_raw(x, wt, b, Cout, (1, 3, 3), 1, (0, 1, 1), 1, 1 if refl else 0, 0, 0.0, (1, H, H))
+    def wgrad():
+        return ops.conv_wgrad_raw(x, dy, (1, 3, 3), 1, (0, 1, 1), 1 if refl else 0)
+    for name, fn in (("fwd", fwd), ("wgrad", wgrad)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        print("%-5s %3d->%3d @%3d^2 %s  %7.3f ms  %6.1f TFLOP/s" % (name, Cin, Cout, H, "refl" if refl else "zero", ms, fl / ms / 1e9))

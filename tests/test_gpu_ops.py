@@ -49,6 +49,16 @@ CONV2D = [
     (48, 32, 3, 1, 1, False, 1, 1, 11, 7),
     (33, 3, 1, 1, 0, False, 0, 1, 6, 50),
     (256, 256, 1, 1, 0, False, 1, 1, 1, 512),
+    # geometries that take the LDS-resident 3x3 kernels (conv3x3.hip): aligned / unaligned pixel runs,
+    # padded-frame dgrad of reflect convs, W >= tile, partial channel chunks, both wgrad tilings
+    (64, 128, 3, 1, 1, False, 0, 2, 32, 32),
+    (128, 128, 3, 1, 1, True, 0, 2, 64, 64),
+    (32, 64, 3, 1, 1, False, 1, 1, 48, 40),
+    (128, 64, 3, 1, 1, False, 0, 2, 64, 64),
+    (64, 128, 3, 1, 1, False, 0, 1, 16, 256),
+    (36, 132, 3, 1, 1, True, 0, 1, 24, 72),
+    (256, 256, 3, 1, 1, True, 0, 2, 64, 64),
+    (64, 32, 3, 1, 1, False, 1, 1, 64, 256),
 ]
 
 
