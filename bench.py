@@ -7,7 +7,7 @@ A "step" = REGISTRATIONModel.set_input + optimize_parameters (reference train.py
 backward and Adam of G/F/R on one batch of synthetic pairs already resident in HBM.  Workload at
 every N: BASELINE.json configs[1] geometry -- 2-D 256x256, batch 16 PER GPU, ngf 64, fp32 (weak
 scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with `roofline`
-(dominant kernel = the 128x128-tile fp32-MFMA implicit-GEMM conv, timed live with HIP events on
+(dominant kernel = the 128x128-tile fp32-MFMA 3x3 implicit-GEMM conv, timed live with HIP events on
 its launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle = a port of the reference's
 PyTorch-CPU path, timed on the host cores on a bounded sample).
 """
@@ -152,7 +152,7 @@ def main():
                           checkpoints_dir="/tmp/dfmir_bench", name="bench")
     torch.manual_seed(0)                      # same weights on every rank (also broadcast in parallelize())
     model = REGISTRATIONModel(opt)
-    timer = KernelTimer(["conv_mfma_L", "conv_wgrad_L"])
+    timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"])
     ops.set_conv_profiler(timer)
 
     batches = [synth_pairs(B, S, S, dev, 1000 * rank + i) for i in range(4)]   # resident in HBM
@@ -197,9 +197,9 @@ def main():
     result = None
     if rank == 0:
         pairs = B * world * args.steps
-        dom = ks.get("conv_mfma_L", dict(launches=0, ms=0.0, flops=0.0))
+        dom = ks.get("conv3x3_L", dict(launches=0, ms=0.0, flops=0.0))
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        wg = ks.get("conv_wgrad_L", dict(launches=0, ms=0.0, flops=0.0))
+        wg = ks.get("wgrad3x3_L", dict(launches=0, ms=0.0, flops=0.0))
         wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
         step_tflop = 1581e9 * B / 1e12      # algorithmic conv FLOPs per step per GPU
         result = {
@@ -213,8 +213,8 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "conv_mfma_k<2,2,2,2> (128x128 tile, v_mfma_f32_32x32x2_f32; fwd + dgrad of every "
-                                   "Cout>64 conv)",
+                         "kernel": "conv3x3_mfma_k<2,2,2,2,400> (128 couts x 128 pixels, LDS-resident halo + 9-tap weights, "
+                                   "v_mfma_f32_32x32x2_f32): forward + dgrad of every 3x3 conv with Cout > 64",
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "wgrad_kernel_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
                          "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},

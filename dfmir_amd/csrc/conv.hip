@@ -65,7 +65,15 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
     oy = (int)(t % g.Ho); t /= g.Ho;
     oz = (int)(t % g.Do); n = (int)(t / g.Do);
   }
-  const float* xin = x + (long long)n * g.Cin * DHWi;
+  // hardware-bounds-checked buffer loads: padding / tile overrun = an out-of-range offset = 0.0,
+  // so the gather is branch-free (host guarantees every tensor here is < 2 GiB)
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned dhw4 = (unsigned)DHWi * 4u;
+  const unsigned nbase = (unsigned)n * (unsigned)g.Cin * dhw4;
+  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x), 0, (unsigned)((long long)g.N * g.Cin * DHWi * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt), 0, (unsigned)((long long)g.KD * g.KH * g.KW * g.Cin * g.Cout * 4), 0x00020000);
   const int acol = tid % BM, arow0 = tid / BM;
   const int aco = m0 + acol;
   const bool av = aco < g.Cout;
@@ -94,18 +102,19 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
     v &= df_in_coord(oz, kd_, g.stride, g.pd, g.dil, g.Di, g.pad_mode, iz);                      \
     v &= df_in_coord(oy, kh_, g.stride, g.ph, g.dil, g.Hi, g.pad_mode, iy);                      \
     v &= df_in_coord(ox, kw_, g.stride, g.pw, g.dil, g.Wi, g.pad_mode, ix);                      \
-    const long long sp = ((long long)iz * g.Hi + iy) * g.Wi + ix;                                \
+    const unsigned sp = v ? nbase + (unsigned)(((long long)iz * g.Hi + iy) * g.Wi + ix) * 4u : OOB; \
     _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                             \
       const int row = brow0 + RSB * j;                                                           \
       const int ci = ci0 + row;                                                                  \
-      rb[j] = (v && row < k.kc && ci < g.Cin) ? xin[(long long)ci * DHWi + sp] : 0.f;            \
+      const unsigned o = (row < k.kc && ci < g.Cin) ? sp + (unsigned)ci * dhw4 : OOB;            \
+      rb[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_src, o, 0, 0));             \
     }                                                                                            \
     _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                             \
       const int row = arow0 + RSA * j;                                                           \
       const int ci = ci0 + row;                                                                  \
-      ra[j] = (av && row < k.kc && ci < g.Cin)                                                   \
-                  ? wt[((long long)tap * g.Cin + ci) * g.Cout + aco]                             \
-                  : 0.f;                                                                         \
+      const unsigned o = (av && row < k.kc && ci < g.Cin)                                        \
+                             ? (unsigned)((tap * g.Cin + ci) * g.Cout + aco) * 4u : OOB;         \
+      ra[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_src, o, 0, 0));             \
     }                                                                                            \
   }
 #define CONV_LSTORE(buf_)                                                                        \
@@ -270,6 +279,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
   }
   __syncthreads();
 
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned dhwi4 = (unsigned)DHWi * 4u;
+  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x), 0, (unsigned)((long long)g.N * g.Cin * DHWi * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t d_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dy), 0, (unsigned)((long long)g.N * g.Cout * DHWo * 4), 0x00020000);
   const int pl = tid % BP, r0 = tid / BP;
   float ra[NA], rb[NB];
   f32x16 acc[TJ][TC];
@@ -291,25 +306,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
       oy = (int)(t % g.Ho); t /= g.Ho;                                                           \
       oz = (int)(t % g.Do); n = (int)(t / g.Do);                                                 \
     }                                                                                            \
-    const float* xin = x + (long long)n * g.Cin * DHWi;                                          \
+    const unsigned xb = (unsigned)n * (unsigned)g.Cin * dhwi4;                                   \
     _Pragma("unroll") for (int jj = 0; jj < NA; ++jj) {                                          \
       const int info = jinfo[r0 + RS * jj];                                                      \
-      float val = 0.f;                                                                           \
-      if (pv && info >= 0) {                                                                     \
-        const int ci = info >> 12, kd = (info >> 8) & 15, kh = (info >> 4) & 15, kw = info & 15; \
-        int iz, iy, ix;                                                                          \
-        bool v = df_in_coord(oz, kd, g.stride, g.pd, 1, g.Di, g.pad_mode, iz);                   \
-        v &= df_in_coord(oy, kh, g.stride, g.ph, 1, g.Hi, g.pad_mode, iy);                       \
-        v &= df_in_coord(ox, kw, g.stride, g.pw, 1, g.Wi, g.pad_mode, ix);                       \
-        if (v) val = xin[(long long)ci * DHWi + ((long long)iz * g.Hi + iy) * g.Wi + ix];        \
-      }                                                                                          \
-      ra[jj] = val;                                                                              \
+      const int ci = info >> 12, kd = (info >> 8) & 15, kh = (info >> 4) & 15, kw = info & 15;   \
+      int iz, iy, ix;                                                                            \
+      bool v = pv && info >= 0;                                                                  \
+      v &= df_in_coord(oz, kd, g.stride, g.pd, 1, g.Di, g.pad_mode, iz);                         \
+      v &= df_in_coord(oy, kh, g.stride, g.ph, 1, g.Hi, g.pad_mode, iy);                         \
+      v &= df_in_coord(ox, kw, g.stride, g.pw, 1, g.Wi, g.pad_mode, ix);                         \
+      const unsigned o = v ? xb + (unsigned)ci * dhwi4 +                                         \
+                                 (unsigned)(((long long)iz * g.Hi + iy) * g.Wi + ix) * 4u : OOB; \
+      ra[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_src, o, 0, 0));            \
     }                                                                                            \
     const long long so = pq - (long long)n * DHWo;                                               \
     _Pragma("unroll") for (int jj = 0; jj < NB; ++jj) {                                          \
       const int cr = r0 + RS * jj;                                                               \
       const int co = c0 + cr;                                                                    \
-      rb[jj] = (pv && cr < BC && co < g.Cout) ? dy[((long long)n * g.Cout + co) * DHWo + so] : 0.f; \
+      const unsigned o = (pv && cr < BC && co < g.Cout)                                          \
+                             ? (unsigned)(((long long)n * g.Cout + co) * DHWo + so) * 4u : OOB;  \
+      rb[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d_src, o, 0, 0));            \
     }                                                                                            \
   }
 #define WG_LSTORE(buf_)                                                                          \
@@ -465,20 +481,33 @@ extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* 
     DF_LAUNCH_CHECK();
     return 0;
   }
-  ConvK k;
-  k.g = *g;
-  df_chunking(g->Cin, k.kc, k.nchunks);
-  if (g->Cout > 64) {
-    dim3 grid((unsigned)((P + 127) / 128), (unsigned)((g->Cout + 127) / 128));
-    conv_mfma_k<2, 2, 2, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
-  } else if (g->Cout > 32) {
-    dim3 grid((unsigned)((P + 255) / 256), 1);
-    conv_mfma_k<1, 4, 2, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
-  } else {
-    dim3 grid((unsigned)((P + 255) / 256), 1);
-    conv_mfma_k<1, 4, 1, 2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, k);
+  // buffer descriptors address < 2 GiB: split the batch when a tensor is larger
+  const long long in_img = (long long)g->Cin * g->Di * g->Hi * g->Wi * 4;
+  const long long out_img = (long long)g->Cout * g->Do * g->Ho * g->Wo * 4;
+  DF_ARG_CHECK(in_img < 0x7FFFFFFFLL && out_img < 0x7FFFFFFFLL);
+  DF_ARG_CHECK((long long)g->KD * g->KH * g->KW * g->Cin * g->Cout * 4 < 0x7FFFFFFFLL);
+  long long nb = 0x7FFFFFFFLL / (in_img > out_img ? in_img : out_img);
+  if (nb > g->N) nb = g->N;
+  for (int n0 = 0; n0 < g->N; n0 += (int)nb) {
+    ConvK k;
+    k.g = *g;
+    k.g.N = (g->N - n0 < nb) ? g->N - n0 : (int)nb;
+    df_chunking(g->Cin, k.kc, k.nchunks);
+    const float* xs = x + (long long)n0 * (in_img / 4);
+    float* ys = y + (long long)n0 * (out_img / 4);
+    const long long Ps = (long long)k.g.N * g->Do * g->Ho * g->Wo;
+    if (g->Cout > 64) {
+      dim3 grid((unsigned)((Ps + 127) / 128), (unsigned)((g->Cout + 127) / 128));
+      conv_mfma_k<2, 2, 2, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+    } else if (g->Cout > 32) {
+      dim3 grid((unsigned)((Ps + 255) / 256), 1);
+      conv_mfma_k<1, 4, 2, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+    } else {
+      dim3 grid((unsigned)((Ps + 255) / 256), 1);
+      conv_mfma_k<1, 4, 1, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+    }
+    DF_LAUNCH_CHECK();
   }
-  DF_LAUNCH_CHECK();
   return 0;
 }
 
@@ -491,7 +520,7 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
     int rc = 0;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }
-  const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
+  long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   const int J = g->KD * g->KH * g->KW * g->Cin;
   auto plan = [&](int BJ, int BC, int BP, unsigned& nP, long long& pchunk, dim3& grid) {
     const unsigned nJ = (J + BJ - 1) / BJ, nC = (g->Cout + BC - 1) / BC;
@@ -505,20 +534,34 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
     nP = (unsigned)((P + pchunk - 1) / pchunk);
     grid = dim3(nP, nJ, nC);
   };
-  unsigned nP;
-  long long pchunk;
-  dim3 grid;
-  if (g->Cout > 64) {
-    plan(128, 128, 16, nP, pchunk, grid);
-    conv_wgrad_mfma_k<2, 2, 2, 2, 16><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
-  } else if (g->Cout > 32) {
-    plan(128, 64, 16, nP, pchunk, grid);
-    conv_wgrad_mfma_k<4, 1, 1, 2, 16><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
-  } else {
-    plan(128, 32, 32, nP, pchunk, grid);
-    conv_wgrad_mfma_k<4, 1, 1, 1, 32><<<grid, 256, 0, st>>>(x, dy, dw_tcc, *g, pchunk);
+  // buffer descriptors address < 2 GiB: split the batch when a tensor is larger (dw accumulates)
+  const long long in_img = (long long)g->Cin * g->Di * g->Hi * g->Wi * 4;
+  const long long out_img = (long long)g->Cout * g->Do * g->Ho * g->Wo * 4;
+  DF_ARG_CHECK(in_img < 0x7FFFFFFFLL && out_img < 0x7FFFFFFFLL);
+  long long nb = 0x7FFFFFFFLL / (in_img > out_img ? in_img : out_img);
+  if (nb > g->N) nb = g->N;
+  const int Nfull = g->N;
+  for (int n0 = 0; n0 < Nfull; n0 += (int)nb) {
+    DfConvGeom gs = *g;
+    gs.N = (Nfull - n0 < nb) ? Nfull - n0 : (int)nb;
+    const float* xs = x + (long long)n0 * (in_img / 4);
+    const float* ds = dy + (long long)n0 * (out_img / 4);
+    P = (long long)gs.N * g->Do * g->Ho * g->Wo;
+    unsigned nP;
+    long long pchunk;
+    dim3 grid;
+    if (g->Cout > 64) {
+      plan(128, 128, 16, nP, pchunk, grid);
+      conv_wgrad_mfma_k<2, 2, 2, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+    } else if (g->Cout > 32) {
+      plan(128, 64, 16, nP, pchunk, grid);
+      conv_wgrad_mfma_k<4, 1, 1, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+    } else {
+      plan(128, 32, 32, nP, pchunk, grid);
+      conv_wgrad_mfma_k<4, 1, 1, 1, 32><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+    }
+    DF_LAUNCH_CHECK();
   }
-  DF_LAUNCH_CHECK();
   return 0;
 }
 

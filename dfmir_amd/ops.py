@@ -64,8 +64,10 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         launch()
     else:
         flops = 2.0 * N * Cout * out_sp[0] * out_sp[1] * out_sp[2] * Cin * K[0] * K[1] * K[2] / (dil ** 3 if K[0] > 1 else dil ** 2)
-        prof("conv_mfma_L" if Cout > 64 else ("conv_mfma_M" if Cout > 32 else ("conv_mfma_S" if Cout > 4 else "conv_small")),
-             flops, launch)
+        size = "L" if Cout > 64 else ("M" if Cout > 32 else ("S" if Cout > 4 else "small"))
+        is3x3 = (tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and pad[1] == pad[2]
+                 and pad[1] in (1, 2) and Cout > 4)
+        prof(("conv3x3_" if is3x3 else "conv_mfma_") + size, flops, launch)
     return y
 
 
@@ -83,8 +85,10 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode):
     if prof is None:
         launch()
     else:
-        prof("conv_wgrad_L" if Cout > 64 else ("conv_wgrad_M" if Cout > 32 else "conv_wgrad_S"),
-             2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
+        is3x3 = (tuple(K) == (1, 3, 3) and stride == 1 and Di == 1 and pad[1] == 1 and pad[2] == 1
+                 and Cout >= 64 and Cin >= 32 and (Hi * Wi) % 32 == 0 and Wi % 32 == 0)
+        size = "L" if Cout > 64 else ("M" if Cout > 32 else "S")
+        prof(("wgrad3x3_" if is3x3 else "conv_wgrad_") + size, 2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
     return dw
 
 
