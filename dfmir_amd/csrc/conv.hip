@@ -387,19 +387,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 __global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
                             long long S, int nsplit) {
+  // one (n, c) plane segment per workgroup: contiguous float4 stream, one atomic per workgroup
   __shared__ float sm[17];
-  const int c = blockIdx.x, part = blockIdx.y;
-  const long long total = (long long)N * S;
-  const long long per = (total + nsplit - 1) / nsplit;
-  long long beg = part * per, end = beg + per;
-  if (end > total) end = total;
+  const int c = blockIdx.x, n = blockIdx.y, part = blockIdx.z;
+  const long long per = (((S + nsplit - 1) / nsplit) + 3) & ~3LL;
+  const long long beg = part * per;
+  long long end = beg + per;
+  if (end > S) end = S;
+  const float* p = dy + ((long long)n * C + c) * S;
   float s = 0.f;
-  for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const long long n = i / S, sp = i - n * S;
-    s += dy[(n * C + c) * S + sp];
+  if ((S & 3) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (long long i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += blockDim.x) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) s += p[i];
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0) atomicAdd(&db[c], s);
+  if (threadIdx.x == 0 && beg < S) atomicAdd(&db[c], s);
 }
 
 __global__ void weight_pack_k(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin,
@@ -567,11 +574,11 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
 
 extern "C" int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream) {
   DF_ARG_CHECK(dy && db && N > 0 && C > 0 && S > 0);
-  const long long total = (long long)N * S;
-  int nsplit = (int)((total + 65535) / 65536);
+  int nsplit = (int)((S + 65535) / 65536);      // planes larger than 64K elements are split further
   if (nsplit > 64) nsplit = 64;
   if (nsplit < 1) nsplit = 1;
-  bias_grad_k<<<dim3(C, nsplit), 256, 0, (hipStream_t)stream>>>(dy, db, N, C, S, nsplit);
+  DF_ARG_CHECK(N <= 65535);
+  bias_grad_k<<<dim3(C, N, nsplit), S >= 4096 ? 256 : 64, 0, (hipStream_t)stream>>>(dy, db, N, C, S, nsplit);
   DF_LAUNCH_CHECK();
   return 0;
 }

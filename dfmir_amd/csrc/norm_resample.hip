@@ -86,7 +86,45 @@ __global__ __launch_bounds__(256) void instnorm_bwd_k(const float* __restrict__ 
   const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
   const float* xp = x + base;
   const float* gp = dy + base;
+  float* dp = dx + base;
   float s1 = 0.f, s2 = 0.f;
+  if ((S & 3) == 0) {
+    const float4* x4 = reinterpret_cast<const float4*>(xp);
+    const float4* g4 = reinterpret_cast<const float4*>(gp);
+    float4* d4 = reinterpret_cast<float4*>(dp);
+    const long long S4 = S >> 2;
+    for (long long i = threadIdx.x; i < S4; i += 256) {
+      const float4 xv = x4[i];
+      float4 g = g4[i];
+      const float a = (xv.x - mean) * rstd, b = (xv.y - mean) * rstd, c = (xv.z - mean) * rstd, d = (xv.w - mean) * rstd;
+      if (relu) {
+        if (!(a > 0.f)) g.x = 0.f;
+        if (!(b > 0.f)) g.y = 0.f;
+        if (!(c > 0.f)) g.z = 0.f;
+        if (!(d > 0.f)) g.w = 0.f;
+      }
+      s1 += (g.x + g.y) + (g.z + g.w);
+      s2 += (g.x * a + g.y * b) + (g.z * c + g.w * d);
+    }
+    const float m1 = block_sum(s1, sm) / (float)S;
+    const float m2 = block_sum(s2, sm) / (float)S;
+    for (long long i = threadIdx.x; i < S4; i += 256) {
+      const float4 xv = x4[i];
+      float4 g = g4[i];
+      const float a = (xv.x - mean) * rstd, b = (xv.y - mean) * rstd, c = (xv.z - mean) * rstd, d = (xv.w - mean) * rstd;
+      if (relu) {
+        if (!(a > 0.f)) g.x = 0.f;
+        if (!(b > 0.f)) g.y = 0.f;
+        if (!(c > 0.f)) g.z = 0.f;
+        if (!(d > 0.f)) g.w = 0.f;
+      }
+      float4 o;
+      o.x = rstd * (g.x - m1 - a * m2); o.y = rstd * (g.y - m1 - b * m2);
+      o.z = rstd * (g.z - m1 - c * m2); o.w = rstd * (g.w - m1 - d * m2);
+      d4[i] = o;
+    }
+    return;
+  }
   for (long long i = threadIdx.x; i < S; i += 256) {
     const float xh = (xp[i] - mean) * rstd;
     float g = gp[i];
@@ -96,7 +134,6 @@ __global__ __launch_bounds__(256) void instnorm_bwd_k(const float* __restrict__ 
   }
   const float m1 = block_sum(s1, sm) / (float)S;
   const float m2 = block_sum(s2, sm) / (float)S;
-  float* dp = dx + base;
   for (long long i = threadIdx.x; i < S; i += 256) {
     const float xh = (xp[i] - mean) * rstd;
     float g = gp[i];
@@ -145,31 +182,28 @@ __global__ void blur_down_fwd_k(const float* __restrict__ x, float* __restrict__
     y[i] = s;
   }
 }
-// adjoint weights of the 1-D operator above for input index i: list of (o, w)
-__device__ __forceinline__ int blur_down_adj(int i, int n, int no, int* oo, float* ww) {
-  const float f[3] = {0.25f, 0.5f, 0.25f};
-  int cnt = 0;
-  // padded coordinates q in [-1, n] that reflect onto i: q = i, q = -1 (-> 1), q = n (-> n-2)
-  int qs[3];
-  int nq = 0;
-  qs[nq++] = i;
-  if (i == 1) qs[nq++] = -1;
-  if (i == n - 2) qs[nq++] = n;
-  for (int k = 0; k < nq; ++k) {
-    const int q = qs[k];
-    for (int a = 0; a < 3; ++a) {
-      const int t = q + 1 - a;  // = 2*o
-      if (t >= 0 && (t & 1) == 0) {
-        const int o = t >> 1;
-        if (o < no) {
-          oo[cnt] = o;
-          ww[cnt] = f[a];
-          ++cnt;
-        }
-      }
+// Adjoint of the 1-D operator above for input index i: at most 3 (output index, weight) pairs, held
+// in registers (weight 0 = unused slot, index clamped in range).
+//   2o + a - 1 = i  =>  i even: (i/2, 1/2);  i odd: ((i+1)/2, 1/4) and ((i-1)/2, 1/4)
+//   reflected halo: padded -1 -> i == 1 adds (0, 1/4);  padded n -> i == n-2 adds ((n-1)/2, 1/4) for odd n
+__device__ __forceinline__ void blur_down_adj(int i, int n, int no, int (&o)[3], float (&w)[3]) {
+  if ((i & 1) == 0) {
+    o[0] = i >> 1; w[0] = 0.5f;
+    o[1] = 0; w[1] = 0.f;
+  } else {
+    o[0] = (i - 1) >> 1; w[0] = 0.25f;
+    const int o1 = (i + 1) >> 1;
+    o[1] = o1 < no ? o1 : 0; w[1] = o1 < no ? 0.25f : 0.f;
+  }
+  o[2] = 0; w[2] = 0.f;
+  if (i == 1) { o[2] = 0; w[2] = 0.25f; }
+  if (i == n - 2 && (n & 1)) {
+    if (i == 1) {  // n == 3: both halo extras land on the middle sample -> (0, 1/2), (1, 1/2)
+      o[0] = 0; w[0] = 0.5f; o[1] = 1; w[1] = 0.5f; o[2] = 0; w[2] = 0.f;
+    } else {
+      o[2] = (n - 1) >> 1; w[2] = 0.25f;
     }
   }
-  return cnt;
 }
 __global__ void blur_down_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int planes, int H,
                                 int W, int Ho, int Wo) {
@@ -181,15 +215,15 @@ __global__ void blur_down_bwd_k(const float* __restrict__ dy, float* __restrict_
     const int iy = (int)(r % H);
     const long long pl = r / H;
     const float* gp = dy + pl * Ho * Wo;
-    int oy[9], oxx[9];
-    float wy[9], wx[9];
-    const int ny = blur_down_adj(iy, H, Ho, oy, wy);
-    const int nx = blur_down_adj(ix, W, Wo, oxx, wx);
+    int oy[3], oxx[3];
+    float wy[3], wx[3];
+    blur_down_adj(iy, H, Ho, oy, wy);
+    blur_down_adj(ix, W, Wo, oxx, wx);
     float s = 0.f;
-    for (int a = 0; a < ny; ++a) {
-      float rs = 0.f;
-      for (int b = 0; b < nx; ++b) rs += wx[b] * gp[(long long)oy[a] * Wo + oxx[b]];
-      s += wy[a] * rs;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float* row = gp + (long long)oy[a] * Wo;
+      s += wy[a] * (wx[0] * row[oxx[0]] + wx[1] * row[oxx[1]] + wx[2] * row[oxx[2]]);
     }
     dx[i] = s;
   }

@@ -248,7 +248,10 @@ class ResnetBlock(nn.Module):
 
 
 def _reflect_conv(pad, conv, x, act=0):
-    """conv(reflection_pad(x)) with the halo resolved inside the conv's gather."""
+    """conv(reflection_pad(x)) with the halo resolved inside the conv's gather.  The 7x7 ends
+    (Cin == 1 / Cout == 1) run as tap-stack / tap-sum + 1x1 GEMM so that they reach the matrix cores."""
+    if conv.kernel_size >= 5 and conv.stride == 1 and (conv.in_channels == 1 or conv.out_channels <= 4):
+        return ops.conv_taps(x, conv.weight, conv.bias, pad.padding, 1, act, 0.0)
     return ops.conv(x, conv.weight, conv.bias, conv, conv.stride, pad.padding, 1, act, 0.0)
 
 

@@ -187,6 +187,79 @@ def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, s
 
 
 # ------------------------------------------------------------------------------------------------
+# 7x7 convolutions as tap-stack / tap-sum + 1x1 GEMM
+# ------------------------------------------------------------------------------------------------
+class TapStackFn(Function):
+    """x [N,C,H,W] -> S [N, C*K*K, H, W],  S[c*T+tap][p] = x[c][map(p + tap - pad)]."""
+
+    @staticmethod
+    def forward(ctx, x, K, pad, pad_mode):
+        _need(x)
+        x = _c(x)
+        N, C, H, W = x.shape
+        s = torch.empty((N, C * K * K, H, W), device=x.device, dtype=torch.float32)
+        check(lib().dfmir_tapstack_fwd(_p(x), _p(s), N, C, H, W, K, pad, pad_mode, _st()))
+        ctx.meta = (N, C, H, W, K, pad, pad_mode)
+        return s
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        N, C, H, W, K, pad, pad_mode = ctx.meta
+        ds = _c(ds)
+        dx = torch.empty((N, C, H, W), device=ds.device, dtype=torch.float32)
+        check(lib().dfmir_tapstack_bwd(_p(ds), _p(dx), N, C, H, W, K, pad, pad_mode, _st()))
+        return dx, None, None, None
+
+
+class TapSumFn(Function):
+    """Z [N, C*K*K, H, W] -> y [N,C,H,W] = act(bias + sum_tap Z[c*T+tap][map(p + tap - pad)])."""
+
+    @staticmethod
+    def forward(ctx, z, bias, C, K, pad, pad_mode, act, slope):
+        _need(z, bias)
+        z = _c(z)
+        N, CT, H, W = z.shape
+        y = torch.empty((N, C, H, W), device=z.device, dtype=torch.float32)
+        check(lib().dfmir_tapsum_fwd(_p(z), _p(bias), _p(y), N, C, H, W, H, W, K, pad, pad_mode, act, float(slope), _st()))
+        ctx.meta = (N, C, H, W, K, pad, pad_mode, act, float(slope))
+        ctx.save_for_backward(y if act else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        N, C, H, W, K, pad, pad_mode, act, slope = ctx.meta
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        if act:
+            dpre = torch.empty_like(dy)
+            check(lib().dfmir_act_bwd(_p(dy), _p(y), _p(dpre), dy.numel(), act, slope, _st()))
+            dy = dpre
+        dz = db = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty((N, C * K * K, H, W), device=dy.device, dtype=torch.float32)
+            check(lib().dfmir_tapsum_bwd(_p(dy), _p(dz), N, C, H, W, H, W, K, pad, pad_mode, _st()))
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = torch.zeros(C, device=dy.device, dtype=torch.float32)
+            check(lib().dfmir_bias_grad(_p(dy), _p(db), N, C, H * W, _st()))
+        return dz, db, None, None, None, None, None, None
+
+
+def conv_taps(x, weight, bias, pad, pad_mode, act=0, slope=0.0):
+    """KxK conv with Cin == 1 or Cout <= 4 as a 1x1 GEMM over K*K tap planes (see csrc/taps.hip)."""
+    Cout, Cin, K = weight.shape[0], weight.shape[1], weight.shape[2]
+    T = K * K
+    if Cin == 1:
+        s = TapStackFn.apply(x, K, pad, pad_mode)
+        return conv(s, weight.view(Cout, T, 1, 1), bias, None, 1, 0, 0, act, slope)
+    wz = weight.view(Cout, Cin, T).permute(0, 2, 1).reshape(Cout * T, Cin, 1, 1)   # [c*T+tap][ci]
+    z = conv(x, wz, None, None, 1, 0, 0, 0, 0.0)
+    return TapSumFn.apply(z, bias, Cout, K, pad, pad_mode, act, slope)
+
+
+# ------------------------------------------------------------------------------------------------
 # InstanceNorm (+ReLU, +residual)
 # ------------------------------------------------------------------------------------------------
 class InstNormFn(Function):

@@ -68,6 +68,20 @@ int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, in
 /* g[co][ci][t] = g_tcc[t][ci][co]  (gradient back to the reference's parameter layout). */
 int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, void* stream);
 
+/* 7x7 convs of the generator as 1x1 GEMMs (models/networks.py:982-983 Conv2d(1,64,7) and :1022-1024
+ * Conv2d(64,1,7)+Tanh, both behind ReflectionPad2d(3)):
+ *   tapstack: S[n][c*K*K+tap][p] = x[n][c][map(p + tap - pad)]            (then a 1x1 conv K*K -> Cout)
+ *   tapsum  : y[n][c][p] = act(bias[c] + sum_tap Z[n][c*K*K+tap][map(p + tap - opad)])   (after a 1x1 conv Cin -> K*K)
+ * map = reflect (pad_mode 1) or zero (pad_mode 0); *_bwd are the exact adjoints (gather form). */
+int dfmir_tapstack_fwd(const float* x, float* s, int N, int C, int H, int W, int K, int pad,
+                       int pad_mode, void* stream);
+int dfmir_tapstack_bwd(const float* ds, float* dx, int N, int C, int H, int W, int K, int pad,
+                       int pad_mode, void* stream);
+int dfmir_tapsum_fwd(const float* z, const float* bias, float* y, int N, int C, int Hz, int Wz, int Ho,
+                     int Wo, int K, int opad, int pad_mode, int act, float slope, void* stream);
+int dfmir_tapsum_bwd(const float* dy, float* dz, int N, int C, int Hz, int Wz, int Ho, int Wo, int K,
+                     int opad, int pad_mode, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) [+ ReLU] [+ residual add]  -- models/networks.py:113-131,
  * 984-985, 1190-1221 (x + conv_block(x)).  One (n,c) plane of S elements per workgroup.

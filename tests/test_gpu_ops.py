@@ -96,6 +96,28 @@ def test_conv2d(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
 
 
+@pytest.mark.parametrize("cfg", [(1, 64, 7, 3, True, 0, 2, 20, 24), (64, 1, 7, 3, True, 2, 2, 20, 24),
+                                 (1, 8, 5, 2, False, 1, 1, 9, 11), (6, 2, 5, 2, True, 0, 1, 12, 10)],
+                         ids=["1to64_k7_refl", "64to1_k7_refl_tanh", "1to8_k5_zero_leaky", "6to2_k5_refl"])
+def test_conv_taps(ops, cfg):
+    """7x7 / 5x5 convs with Cin == 1 or Cout <= 4 as tap-stack / tap-sum + 1x1 GEMM (csrc/taps.hip)."""
+    Cin, Cout, K, pad, reflect, act, N, H, W = cfg
+    x = C.randn(1, N, Cin, H, W)
+    w = C.randn(2, Cout, Cin, K, K) / (Cin * K * K) ** 0.5
+    b = C.randn(3, Cout) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch_conv(xr, wr, br, 1, pad, reflect, act, 2)
+    cot = C.randn(4, *yr.shape)
+    (yr * cot).sum().backward()
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+    yg = ops.conv_taps(xg, wg, bg, pad, 1 if reflect else 0, act, 0.2)
+    (yg * cot.to(DEV)).sum().backward()
+    close(yg, yr, what="y")
+    close(xg.grad, xr.grad, what="dx")
+    close(wg.grad, wr.grad, rtol=3e-4, what="dw")
+    close(bg.grad, br.grad, rtol=3e-4, what="db")
+
+
 CONV3D = [
     (2, 16, 3, 2, 1, 1, 12, 10, 14),
     (16, 32, 3, 2, 1, 1, 9, 11, 13),
