@@ -120,6 +120,31 @@ def cpu_baseline(size, max_steps=3):
                        "after 1 warm-up fwd+bwd" % (n, cores, size, size))
 
 
+def bench_3d(dev, steps=5, warmup=2):
+    """Auxiliary line: the 3-D step of BASELINE configs[4] geometry on ONE GPU -- 160x192x224, batch 1,
+    VxmDense(default features, int_steps 7, bidir) + NCC[9,9,9] + Grad l2, fwd+bwd+Adam."""
+    from dfmir_amd.registration3d import Registration3DModel
+    shape = (160, 192, 224)
+    torch.manual_seed(0)
+    m = Registration3DModel(shape, None, device=dev)
+    A = torch.rand(1, 1, *shape, device=dev) * 2 - 1
+    B = 0.5 * A + 0.5 * (torch.rand(1, 1, *shape, device=dev) * 2 - 1)
+    for _ in range(warmup):
+        m.set_input({"A": A, "B": B})
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.set_input({"A": A, "B": B})
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "3-D 160x192x224 volume pair, batch 1, VxmDense default features + NCC[9,9,9] + Grad-l2, "
+                        "fwd+bwd+Adam (BASELINE configs[4] geometry, one GPU)",
+            "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
+            "conv_tflops": 2393.0 / dt / 1e3, "dtype": "f32"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +154,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ngf", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-3d", action="store_true", help="skip the auxiliary 3-D (config 5 geometry) measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,8 +249,13 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
+        ops.set_conv_profiler(None)
+        if world == 1 and not args.no_3d:
+            model = None
+            batches.clear()
+            torch.cuda.empty_cache()
+            result["also_3d"] = bench_3d(dev)
         if world == 1 and not args.no_cpu_baseline:
-            ops.set_conv_profiler(None)
             result["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(result))
     if world > 1:
