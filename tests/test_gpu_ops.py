@@ -245,6 +245,18 @@ def test_warp_golden(ops, golden):
         assert frac_bad < 0.01, "nearest warp differs on %.3f of voxels" % frac_bad  # ties may round apart
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 2, 6, 10, 12), (1, 1, 40, 48, 56)])
+def test_warp_vectorised_vs_oracle(ops, shape):
+    """W % 4 == 0 takes the 4-voxels-per-thread kernel; compare with the oracle incl. out-of-bounds samples."""
+    from oracle import dfmir_oracle as O
+    nd = len(shape) - 2
+    src = C.randn(55, *shape)
+    flow = (C.rand(56, shape[0], nd, *shape[2:]) * 14) - 7
+    ref = O.spatial_transform(src, flow)
+    got = ops.warp(src.to(DEV), flow.to(DEV))
+    close(got, ref, what="warp v4")
+
+
 def test_warp_identity_and_oob(ops):
     x = C.randn(51, 2, 1, 20, 30).to(DEV)
     z = torch.zeros(2, 2, 20, 30, device=DEV)
