@@ -451,6 +451,10 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
                         float* y, hipStream_t st, int* rc);
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
+bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
+                       hipStream_t st, int* rc);
+bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
+                         int* rc);
 static bool use_generic_only() {
   static int v = -1;
   if (v < 0) {
@@ -479,6 +483,7 @@ extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* 
   if (!use_generic_only()) {
     int rc = 0;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
+    if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
   if (g->Cout <= 4) {
     const unsigned grid = (unsigned)((P + 255) / 256);
@@ -526,6 +531,7 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
   if (!use_generic_only()) {
     int rc = 0;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
+    if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }
   long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   const int J = g->KD * g->KH * g->KW * g->Cin;

@@ -125,6 +125,14 @@ CONV3D = [
     (32, 16, 3, 1, 1, 1, 8, 8, 8),
     (16, 3, 3, 1, 1, 1, 7, 9, 11),
     (64, 32, 3, 1, 1, 2, 4, 6, 5),
+    # stride-1 shapes that take the 16x16x4-MFMA halo kernels (conv3d.hip): whole + partial patches,
+    # channel groups (Cin > 32), the 34-channel concat layer and its dgrad (Cout' = 34 -> 3 row tiles)
+    (34, 32, 3, 1, 1, 1, 6, 16, 32),
+    (32, 16, 3, 1, 1, 1, 5, 10, 20),
+    (16, 16, 3, 1, 1, 2, 4, 8, 16),
+    (48, 32, 3, 1, 1, 1, 4, 12, 24),
+    (64, 32, 3, 1, 1, 1, 3, 8, 16),
+    (32, 34, 3, 1, 1, 1, 4, 8, 12),
 ]
 
 
