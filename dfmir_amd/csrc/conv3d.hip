@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad16_k(const float* __restrict_
                                                         float* __restrict__ dwt, W3dP k) {
   constexpr int PY = 4, PX = 16, BP = PY * PX, HY = PY + 2, HX = PX + 2;
   constexpr int NPOS = 3 * HY * HX;                 // 324
-  constexpr int XP = NPOS + 1;                      // 325 (odd): rows of different channels spread over banks
+  constexpr int XP = NPOS;                          // dense [c][pos] image: staged element e lands at Xs[e]
   constexpr int DSTR = (NCT == 1) ? 16 : 16 * NCT + 16;
   constexpr int CGMAX = 32;
   constexpr int NXL = (CGMAX * NPOS + 255) / 256;   // halo loads per thread (41)
@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad16_k(const float* __restrict_
         const_cast<float*>(x + ((long long)n_ * k.Cin + c0) * S), 0, (unsigned)(cgn * S) * 4u, 0x00020000); \
     const __amdgpu_buffer_rsrc_t ds_ = __builtin_amdgcn_make_buffer_rsrc(                        \
         const_cast<float*>(dy + (long long)n_ * k.Cout * S), 0, (unsigned)(k.Cout * S) * 4u, 0x00020000);   \
+    int tq_ = tid;                                                                               \
+    asm volatile("" : "+v"(tq_));   /* opaque: keeps the address decode inside the patch loop */  \
     _Pragma("unroll") for (int i = 0; i < NXL; ++i) {                                            \
-      const int e = tid + 256 * i;                                                               \
+      const int e = tq_ + 256 * i;                                                               \
       unsigned o = OOB;                                                                          \
       if (e < nelem) {                                                                           \
         const int c = e / NPOS, pos = e - c * NPOS;                                              \
@@ -301,10 +303,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad16_k(const float* __restrict_
   {                                                                                              \
     _Pragma("unroll") for (int i = 0; i < NXL; ++i) {                                            \
       const int e = tid + 256 * i;                                                               \
-      if (e < nelem) {                                                                           \
-        const int c = e / NPOS, pos = e - c * NPOS;                                              \
-        Xs[c * XP + pos] = __uint_as_float(rxv[i]);                                              \
-      }                                                                                          \
+      if (e < nelem) Xs[e] = __uint_as_float(rxv[i]);                                            \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < ND4; ++i) {                                            \
       const int e = tid + 256 * i;                                                               \
@@ -395,7 +394,7 @@ bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, 
 
 bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
                          int* rc) {
-  if (!is_3x3x3_s1_p1(g) || g->Cout > 32 || g->Cout < 5) return false;
+  if (!is_3x3x3_s1_p1(g) || g->Cout > 32) return false;   // incl. the 16->3 flow conv (padded to one 16-col tile)
   const long long S = (long long)g->Di * g->Hi * g->Wi;
   if ((long long)g->Cin * S * 4 >= 0x7FFFFFFFLL || (long long)g->Cout * S * 4 >= 0x7FFFFFFFLL) return false;
   if ((g->Wi & 3) != 0) return false;                       // float4 dY loads

@@ -350,36 +350,53 @@ __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x,
   const float v = (1.f - lz) * ((1.f - ly) * a0 + ly * a1) + lz * ((1.f - ly) * b0 + ly * b1);
   y[i] = mult * v;
 }
+// Adjoint in GATHER form: input sample i collects from the outputs o whose interpolation window
+// touches it (o in [(i-1)/scale, (i+1)/scale]); the weight is recomputed with the forward's own
+// lin_src(), so forward and backward use bit-identical coefficients.  No atomics, no pre-zeroing.
+__device__ __forceinline__ void lin_range(int i, float scale, int out, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf((float)(i - 1) / scale) - 1;
+  hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+}
+__device__ __forceinline__ float lin_weight(int o, float scale, int in, int i) {
+  int i0, i1;
+  float l1;
+  lin_src(o, scale, in, i0, i1, l1);
+  return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
 __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy, float* __restrict__ dx,
                                                     int planes, int Di, int Hi, int Wi, int Do, int Ho,
                                                     int Wo, float sd, float sh, float sw, float mult) {
   const long long So = (long long)Do * Ho * Wo, Si = (long long)Di * Hi * Wi;
-  const long long total = (long long)planes * So;
+  const long long total = (long long)planes * Si;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int ox = (int)(i % Wo);
-  long long r = i / Wo;
-  const int oy = (int)(r % Ho); r /= Ho;
-  const int oz = (int)(r % Do);
-  const long long pl = r / Do;
-  int z0, z1, y0, y1, x0, x1;
-  float lz, ly, lx;
-  lin_src(oz, sd, Di, z0, z1, lz);
-  lin_src(oy, sh, Hi, y0, y1, ly);
-  lin_src(ox, sw, Wi, x0, x1, lx);
-  float* xp = dx + pl * Si;
-  const float g = mult * dy[i];
-  const int zz[2] = {z0, z1}, yy[2] = {y0, y1}, xx[2] = {x0, x1};
-  const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const float w = wz[a] * wy[bq] * wx[c];
-        if (w != 0.f) atomicAdd(&xp[((long long)zz[a] * Hi + yy[bq]) * Wi + xx[c]], g * w);
-      }
+  const int ix = (int)(i % Wi);
+  long long r = i / Wi;
+  const int iy = (int)(r % Hi); r /= Hi;
+  const int iz = (int)(r % Di);
+  const long long pl = r / Di;
+  const float* gp = dy + pl * So;
+  int zl, zh, yl, yh, xl, xh;
+  lin_range(iz, sd, Do, zl, zh);
+  lin_range(iy, sh, Ho, yl, yh);
+  lin_range(ix, sw, Wo, xl, xh);
+  float acc = 0.f;
+  for (int oz = zl; oz <= zh; ++oz) {
+    const float wz = lin_weight(oz, sd, Di, iz);
+    if (wz == 0.f) continue;
+    for (int oy = yl; oy <= yh; ++oy) {
+      const float wy = lin_weight(oy, sh, Hi, iy);
+      if (wy == 0.f) continue;
+      const float* row = gp + ((long long)oz * Ho + oy) * Wo;
+      float racc = 0.f;
+      for (int ox = xl; ox <= xh; ++ox) racc += lin_weight(ox, sw, Wi, ix) * row[ox];
+      acc += wz * wy * racc;
+    }
+  }
+  dx[i] = mult * acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -452,7 +469,7 @@ extern "C" int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, in
 extern "C" int dfmir_resize_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do,
                                 int Ho, int Wo, float mult, void* stream) {
   DF_ARG_CHECK(dy && dx && planes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0);
-  const long long total = (long long)planes * Do * Ho * Wo;
+  const long long total = (long long)planes * Di * Hi * Wi;
   resize_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       dy, dx, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
   DF_LAUNCH_CHECK();

@@ -574,7 +574,7 @@ class ResizeFn(Function):
     def backward(ctx, dy):
         xs, planes, isp, osp, mult = ctx.meta
         dy = _c(dy)
-        dx = torch.zeros(xs, device=dy.device, dtype=torch.float32)
+        dx = torch.empty(xs, device=dy.device, dtype=torch.float32)
         check(lib().dfmir_resize_bwd(_p(dy), _p(dx), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
                                      mult, _st()))
         return dx, None, None

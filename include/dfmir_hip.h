@@ -145,7 +145,7 @@ int dfmir_warp3d_bwd(const float* dout, const float* src, const float* flow, flo
                      int flow_into_src, void* stream);
 
 /* ResizeTransform (layers.py:71-97): F.interpolate(align_corners=True, bi/tri-linear) fused with the
- * scalar rescale `mult`.  D == 1 for 2-D.  bwd accumulates into dx. */
+ * scalar rescale `mult`.  D == 1 for 2-D.  bwd is the adjoint in gather form (writes dx; no atomics). */
 int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do, int Ho,
                      int Wo, float mult, void* stream);
 int dfmir_resize_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do, int Ho,
