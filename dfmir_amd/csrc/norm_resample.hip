@@ -75,6 +75,95 @@ __global__ __launch_bounds__(256) void instnorm_fwd_k(const float* __restrict__ 
   }
 }
 
+// Register-resident variants for the generator's plane sizes (64^2, 128^2, 256^2): the plane is read
+// from HBM exactly once (float4 per lane, E float4 per thread), both reductions run on registers.
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict__ x,
+                                                         const float* __restrict__ res,
+                                                         float* __restrict__ y, float* __restrict__ mean_o,
+                                                         float* __restrict__ rstd_o, float eps, int relu) {
+  __shared__ float sm[17];
+  constexpr long long S = (long long)NT * 4 * E;
+  const long long base = (long long)blockIdx.x * S;
+  const float4* x4 = reinterpret_cast<const float4*>(x + base);
+  float4 v[E];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    v[i] = x4[threadIdx.x + NT * i];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = block_sum(s, sm) / (float)S;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = block_sum(q, sm) / (float)S;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[blockIdx.x] = mean;
+    rstd_o[blockIdx.x] = rstd;
+  }
+  const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+  float4* y4 = reinterpret_cast<float4*>(y + base);
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    float4 o;
+    o.x = (v[i].x - mean) * rstd; o.y = (v[i].y - mean) * rstd;
+    o.z = (v[i].z - mean) * rstd; o.w = (v[i].w - mean) * rstd;
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    if (r4) {
+      const float4 r = r4[threadIdx.x + NT * i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    y4[threadIdx.x + NT * i] = o;
+  }
+}
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict__ dy,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i,
+                                                         float* __restrict__ dx, int relu) {
+  __shared__ float sm[17];
+  constexpr long long S = (long long)NT * 4 * E;
+  const long long base = (long long)blockIdx.x * S;
+  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
+  const float4* x4 = reinterpret_cast<const float4*>(x + base);
+  const float4* g4 = reinterpret_cast<const float4*>(dy + base);
+  float4 xh[E], g[E];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const float4 xv = x4[threadIdx.x + NT * i];
+    g[i] = g4[threadIdx.x + NT * i];
+    xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
+    xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+    if (relu) {
+      if (!(xh[i].x > 0.f)) g[i].x = 0.f;
+      if (!(xh[i].y > 0.f)) g[i].y = 0.f;
+      if (!(xh[i].z > 0.f)) g[i].z = 0.f;
+      if (!(xh[i].w > 0.f)) g[i].w = 0.f;
+    }
+    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+  }
+  const float m1 = block_sum(s1, sm) / (float)S;
+  const float m2 = block_sum(s2, sm) / (float)S;
+  float4* d4 = reinterpret_cast<float4*>(dx + base);
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    float4 o;
+    o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+    o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+    d4[threadIdx.x + NT * i] = o;
+  }
+}
+
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
 __global__ __launch_bounds__(256) void instnorm_bwd_k(const float* __restrict__ dy,
                                                       const float* __restrict__ x,
@@ -420,6 +509,11 @@ __global__ void scale_k(const float* __restrict__ x, float* __restrict__ y, long
 extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
                                   int planes, long long S, float eps, int relu, void* stream) {
   DF_ARG_CHECK(x && y && mean && rstd && planes > 0 && S > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 4096) instnorm_fwd_reg_k<256, 4><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu);
+  else if (S == 16384) instnorm_fwd_reg_k<256, 16><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu);
+  else if (S == 65536) instnorm_fwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(x, res, y, mean, rstd, eps, relu);
+  else
   instnorm_fwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(x, res, y, mean, rstd, S, eps, relu);
   DF_LAUNCH_CHECK();
   return 0;
@@ -427,6 +521,11 @@ extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, fl
 extern "C" int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                   float* dx, int planes, long long S, int relu, void* stream) {
   DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu);
+  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu);
+  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu);
+  else
   instnorm_bwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(dy, x, mean, rstd, dx, S, relu);
   DF_LAUNCH_CHECK();
   return 0;

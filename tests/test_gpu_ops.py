@@ -159,7 +159,9 @@ def test_conv3d(ops, cfg):
 
 # --------------------------------------------------------------------------------- norm / resample
 @pytest.mark.parametrize("shape,relu,res", [((2, 5, 16, 16), True, False), ((2, 7, 9, 11), False, True),
-                                            ((1, 3, 64, 64), True, True), ((3, 4, 5, 5), False, False)])
+                                            ((1, 3, 64, 64), True, True), ((3, 4, 5, 5), False, False),
+                                            ((2, 2, 128, 128), True, False), ((1, 2, 256, 256), False, True),
+                                            ((1, 3, 256, 256), True, False)])
 def test_instnorm(ops, shape, relu, res):
     x = C.randn(5, *shape) * 2 + 0.7
     r = C.randn(6, *shape) if res else None
