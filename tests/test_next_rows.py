@@ -1,0 +1,139 @@
+"""The rows either side of the hot path: data pipeline and logging on CPU;
+checkpoint interchange, inference path and the training driver on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from dfmir_amd.options import default_options
+from tests.golden import common as C
+
+
+def _make_folders(root, n=5, size=80):
+    rng = np.random.RandomState(0)
+    for d in ("trainA", "trainB"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+        for i in range(n):
+            a = (rng.rand(size, size + 8) * 255).astype(np.uint8)
+            Image.fromarray(a, mode="L").save(os.path.join(root, d, "%s_%02d.png" % (d, i)))
+
+
+def test_dataset_pipeline(tmp_path):
+    from dfmir_amd.data import create_dataset, make_dataset, slice_transform
+    root = str(tmp_path)
+    _make_folders(root)
+    opt = default_options(dataroot=root, phase="train", batch_size=2, load_size=72, crop_size=64, no_flip=True,
+                          serial_batches=True, num_threads=0, max_dataset_size=float("inf"))
+    assert len(make_dataset(os.path.join(root, "trainA"))) == 5
+    ds = create_dataset(opt)
+    assert len(ds) == 5
+    batches = list(ds)
+    assert len(batches) == 2                       # drop_last in training (data/__init__.py:79)
+    b = batches[0]
+    assert b["A"].shape == (2, 1, 64, 64) and b["B"].dtype == torch.float32
+    assert float(b["A"].min()) >= -1.0 and float(b["A"].max()) <= 1.0
+    assert b["A_paths"][0].endswith("trainA_00.png") and b["B_paths"][1].endswith("trainB_01.png")
+    # transform = Grayscale -> bicubic resize -> crop -> (x-0.5)/0.5, checked against the same PIL calls
+    img = Image.open(os.path.join(root, "trainA", "trainA_00.png"))
+    o2 = default_options(load_size=64, crop_size=64, no_flip=True)
+    t = slice_transform(img, o2)
+    ref = np.asarray(img.convert("L").resize((64, 64), Image.BICUBIC), dtype=np.float32) / 255.0
+    assert torch.allclose(t[0], torch.from_numpy((ref - 0.5) / 0.5))
+    # sizes not divisible by 4 are rounded like __make_power_2(base=4)
+    o3 = default_options(load_size=70, crop_size=70, no_flip=True)
+    assert slice_transform(img, o3).shape == (1, 72, 72)
+
+
+def test_visualizer_log_format(tmp_path):
+    from collections import OrderedDict
+    from dfmir_amd.visualizer import Visualizer
+    opt = default_options(checkpoints_dir=str(tmp_path), name="exp")
+    v = Visualizer(opt)
+    msg = v.print_current_losses(3, 200, OrderedDict([("G", 1.23456), ("R", 0.5)]), 0.0123, 0.001)
+    assert msg == "(epoch: 3, iters: 200, time: 0.012, data: 0.001) G: 1.235 R: 0.500 "
+    assert open(os.path.join(str(tmp_path), "exp", "loss_log.txt")).read().strip().endswith(msg.strip())
+
+
+def test_train_option_parser():
+    from dfmir_amd.train import parse
+    opt = parse(["--dataroot", "/x", "--batch_size", "16", "--ngf", "32", "--nce_idt", "false"])
+    assert opt.batch_size == 16 and opt.ngf == 32 and opt.nce_idt is False and opt.lambda_NCE == 0.25
+    assert opt.isTrain and opt.nce_layers == "0,4,8,12,16"
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_checkpoint_interchange(tmp_path):
+    """<epoch>_net_{G,F,R}.pth written by the HIP model load into the oracle modules and back
+    (base_model.py:164-224; key names = the reference's)."""
+    from oracle import dfmir_oracle as O
+    from tests.test_gpu_models import _hip_model_from_oracle, _load
+    torch.manual_seed(5)
+    st = O.RegistrationStep(64, 1, ngf=8)
+    model, opt = _hip_model_from_oracle(st, 64, 1, 8)
+    opt.checkpoints_dir, opt.name = str(tmp_path), "ck"
+    model.save_dir = os.path.join(str(tmp_path), "ck")
+    A0, B0 = C.image_pair(6, 1, 64, 64)
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""], "B_paths": [""]})
+    model.save_networks("latest")
+    for nm in ("G", "F", "R"):
+        assert os.path.exists(os.path.join(model.save_dir, "latest_net_%s.pth" % nm))
+    sdG = torch.load(os.path.join(model.save_dir, "latest_net_G.pth"))
+    og = O.Generator(1, 1, 8, 9)
+    og.load_state_dict(sdG)                                               # strict: identical key set
+    sdR = torch.load(os.path.join(model.save_dir, "latest_net_R.pth"))
+    assert "transformer.grid" in sdR and "integrate.transformer.grid" in sdR   # like the reference's R checkpoints
+    orr = O.VxmDense((64, 64), O.PLUGIN_UNET_FEATURES, 7, True)
+    missing, unexpected = orr.load_state_dict(sdR, strict=False)
+    assert not missing and all(k.endswith(".grid") for k in unexpected)
+    # perturb, reload, compare
+    with torch.no_grad():
+        for p in model.netG.parameters():
+            p.add_(1.0)
+    model.load_networks("latest")
+    for k, v in model.netG.state_dict().items():
+        assert torch.equal(v.cpu(), sdG[k]), k
+
+
+@pytest.mark.gpu
+def test_inference_path_vs_oracle():
+    from oracle import dfmir_oracle as O
+    from dfmir_amd.infer import register_pair
+    from tests.test_gpu_models import _hip_model_from_oracle
+    from tests.test_gpu_ops import close
+    torch.manual_seed(9)
+    st = O.RegistrationStep(64, 2, ngf=8)
+    with torch.no_grad():
+        st.netR.flow.weight.mul_(1e5)
+    model, opt = _hip_model_from_oracle(st, 64, 2, 8)
+    model.eval()
+    A, B = C.image_pair(10, 2, 64, 64)
+    label = (C.rand(11, 2, 1, 64, 64) * 4).floor()
+    out = register_pair(model, {"A": A, "B": B, "A_paths": ["", ""], "B_paths": ["", ""]}, label)
+    with torch.no_grad():
+        tb = st.netG(B)
+        ys, flow = st.netR(A, B, registration=True)
+        lab = O.spatial_transform(label, flow, 'nearest')
+    close(out["translated_B"], tb, what="G(real_B)")
+    close(out["flow"], flow, what="flow"); close(out["warped_A"], ys, what="warped A")
+    frac = float((out["warped_label"].cpu() != lab).float().mean())
+    assert frac < 0.01, "nearest label warp differs on %.3f of pixels (ties only)" % frac
+    assert set(np.unique(out["warped_label"].cpu().numpy())) <= {0.0, 1.0, 2.0, 3.0}
+
+
+@pytest.mark.gpu
+def test_training_driver_two_epochs(tmp_path):
+    """python -m dfmir_amd.train end to end on a synthetic folder dataset (ngf 8, 64x64)."""
+    from dfmir_amd import train
+    root = os.path.join(str(tmp_path), "data")
+    _make_folders(root, n=4, size=72)
+    ck = os.path.join(str(tmp_path), "ck")
+    train.main(["--dataroot", root, "--name", "t", "--checkpoints_dir", ck, "--batch_size", "2", "--ngf", "8",
+                "--load_size", "64", "--crop_size", "64", "--n_epochs", "1", "--n_epochs_decay", "1",
+                "--print_freq", "2", "--save_epoch_freq", "1", "--num_threads", "0"])
+    log = open(os.path.join(ck, "t", "loss_log.txt")).read()
+    assert "(epoch: 2," in log and "NCE_Y:" in log and "nan" not in log.lower()
+    for nm in ("G", "F", "R"):
+        assert os.path.exists(os.path.join(ck, "t", "2_net_%s.pth" % nm))
