@@ -234,86 +234,6 @@ __global__ __launch_bounds__(256) void warp3d_bwd_k(const float* __restrict__ do
   }
 }
 
-// ------------------------------------------------------------- vectorised forward (W % 4 == 0)
-// 4 consecutive x per thread: float4 flow loads / output stores, 32-bit index math, one grid row of
-// workgroups per batch item.  Same arithmetic as the scalar kernels above.
-template <int ND>
-__global__ __launch_bounds__(256) void warp_fwd_v4_k(const float* __restrict__ src,
-                                                     const float* __restrict__ flow,
-                                                     float* __restrict__ out, int C, int D, int H, int W,
-                                                     int add_identity) {
-  const int W4 = W >> 2;
-  const int S = D * H * W;                     // host guarantees < 2^31
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= (S >> 2)) return;
-  const int b = blockIdx.y;
-  const int x0 = (g % W4) << 2;
-  const int t = g / W4;
-  const int y = t % H, z = t / H;
-  const int sp = g << 2;
-  const float* fb = flow + (long long)b * ND * S + sp;
-  float4 fz4 = make_float4(0.f, 0.f, 0.f, 0.f), fy4, fx4;
-  if (ND == 3) {
-    fz4 = *reinterpret_cast<const float4*>(fb);
-    fy4 = *reinterpret_cast<const float4*>(fb + S);
-    fx4 = *reinterpret_cast<const float4*>(fb + 2 * (long long)S);
-  } else {
-    fy4 = *reinterpret_cast<const float4*>(fb);
-    fx4 = *reinterpret_cast<const float4*>(fb + S);
-  }
-  const float dz[4] = {fz4.x, fz4.y, fz4.z, fz4.w}, dy[4] = {fy4.x, fy4.y, fy4.z, fy4.w},
-              dx[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
-  const int HW = H * W;
-  int o000[4];
-  float wz1[4], wy1[4], wx1[4];
-  unsigned vmask[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float fz = (float)z + dz[e], fy = (float)y + dy[e], fx = (float)(x0 + e) + dx[e];
-    const float z0f = floorf(fz), y0f = floorf(fy), x0f = floorf(fx);
-    const int z0 = (ND == 3) ? (int)z0f : 0, y0 = (int)y0f, xx0 = (int)x0f;
-    wz1[e] = (ND == 3) ? fz - z0f : 0.f;
-    wy1[e] = fy - y0f;
-    wx1[e] = fx - x0f;
-    const bool vz0 = (ND == 3) ? ((unsigned)z0 < (unsigned)D) : true;
-    const bool vz1 = (ND == 3) ? ((unsigned)(z0 + 1) < (unsigned)D) : false;
-    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
-    const bool vx0 = (unsigned)xx0 < (unsigned)W, vx1 = (unsigned)(xx0 + 1) < (unsigned)W;
-    vmask[e] = (vz0 ? 1u : 0u) | (vz1 ? 2u : 0u) | (vy0 ? 4u : 0u) | (vy1 ? 8u : 0u) | (vx0 ? 16u : 0u) | (vx1 ? 32u : 0u);
-    o000[e] = (z0 * H + y0) * W + xx0;
-  }
-  for (int c = 0; c < C; ++c) {
-    const float* sc = src + ((long long)b * C + c) * S;
-    float r[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned m = vmask[e];
-      const int o = o000[e];
-      const bool z0v = m & 1u, z1v = m & 2u, y0v = m & 4u, y1v = m & 8u, x0v = m & 16u, x1v = m & 32u;
-      const float v000 = (z0v && y0v && x0v) ? sc[o] : 0.f;
-      const float v001 = (z0v && y0v && x1v) ? sc[o + 1] : 0.f;
-      const float v010 = (z0v && y1v && x0v) ? sc[o + W] : 0.f;
-      const float v011 = (z0v && y1v && x1v) ? sc[o + W + 1] : 0.f;
-      const float wx0 = 1.f - wx1[e], wy0 = 1.f - wy1[e];
-      float val = wy0 * (wx0 * v000 + wx1[e] * v001) + wy1[e] * (wx0 * v010 + wx1[e] * v011);
-      if (ND == 3) {
-        const float v100 = (z1v && y0v && x0v) ? sc[o + HW] : 0.f;
-        const float v101 = (z1v && y0v && x1v) ? sc[o + HW + 1] : 0.f;
-        const float v110 = (z1v && y1v && x0v) ? sc[o + HW + W] : 0.f;
-        const float v111 = (z1v && y1v && x1v) ? sc[o + HW + W + 1] : 0.f;
-        const float p1 = wy0 * (wx0 * v100 + wx1[e] * v101) + wy1[e] * (wx0 * v110 + wx1[e] * v111);
-        val = (1.f - wz1[e]) * val + wz1[e] * p1;
-      }
-      r[e] = val;
-    }
-    if (add_identity) {
-      const float4 id = *reinterpret_cast<const float4*>(sc + sp);
-      r[0] += id.x; r[1] += id.y; r[2] += id.z; r[3] += id.w;
-    }
-    *reinterpret_cast<float4*>(out + ((long long)b * C + c) * S + sp) = make_float4(r[0], r[1], r[2], r[3]);
-  }
-}
-
 // --------------------------------------------------------------------------------- resize
 // F.interpolate(mode=(bi|tri)linear, align_corners=True): src = dst*(in-1)/(out-1).
 __device__ __forceinline__ void lin_src(int o, float scale, int in, int& i0, int& i1, float& l1) {
@@ -400,15 +320,18 @@ __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-windowed kernels (warp_win.hip): taken whenever W % 4 == 0 in linear mode.
+int df_warp_win_fwd_try(int nd, const float* src, const float* flow, float* out, int B, int C, int D, int H, int W,
+                        int add_identity, hipStream_t st);
+int df_warp_win_bwd_try(int nd, const float* dout, const float* src, const float* flow, float* dsrc, float* dflow,
+                        int B, int C, int D, int H, int W, int add_identity, int flow_into_src, hipStream_t st);
+
 extern "C" int dfmir_warp2d_fwd(const float* src, const float* flow, float* out, int B, int C, int H,
                                 int W, int mode, int add_identity, void* stream) {
   DF_ARG_CHECK(src && flow && out && B > 0 && C > 0 && H > 0 && W > 0);
   DF_ARG_CHECK(!add_identity || C == 2);
   const long long total = (long long)B * H * W;
-  if (mode == 0 && (W & 3) == 0 && (long long)H * W < (1LL << 31) && B <= 65535) {
-    const int S4 = (int)(((long long)H * W) >> 2);
-    warp_fwd_v4_k<2><<<dim3((unsigned)((S4 + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
-        src, flow, out, C, 1, H, W, add_identity);
+  if (mode == 0 && df_warp_win_fwd_try(2, src, flow, out, B, C, 1, H, W, add_identity, (hipStream_t)stream)) {
     DF_LAUNCH_CHECK();
     return 0;
   }
@@ -423,6 +346,10 @@ extern "C" int dfmir_warp2d_bwd(const float* dout, const float* src, const float
   DF_ARG_CHECK(dout && src && flow && B > 0 && C > 0 && H > 0 && W > 0);
   DF_ARG_CHECK(!flow_into_src || (dsrc && C == 2));
   const long long total = (long long)B * H * W;
+  if (df_warp_win_bwd_try(2, dout, src, flow, dsrc, dflow, B, C, 1, H, W, add_identity, flow_into_src, (hipStream_t)stream)) {
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   warp2d_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       dout, src, flow, dsrc, dflow, B, C, H, W, add_identity, flow_into_src);
   DF_LAUNCH_CHECK();
@@ -433,10 +360,7 @@ extern "C" int dfmir_warp3d_fwd(const float* src, const float* flow, float* out,
   DF_ARG_CHECK(src && flow && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
   DF_ARG_CHECK(!add_identity || C == 3);
   const long long total = (long long)B * D * H * W;
-  if (mode == 0 && (W & 3) == 0 && (long long)D * H * W < (1LL << 31) && B <= 65535) {
-    const int S4 = (int)(((long long)D * H * W) >> 2);
-    warp_fwd_v4_k<3><<<dim3((unsigned)((S4 + 255) / 256), (unsigned)B), 256, 0, (hipStream_t)stream>>>(
-        src, flow, out, C, D, H, W, add_identity);
+  if (mode == 0 && df_warp_win_fwd_try(3, src, flow, out, B, C, D, H, W, add_identity, (hipStream_t)stream)) {
     DF_LAUNCH_CHECK();
     return 0;
   }
@@ -451,6 +375,10 @@ extern "C" int dfmir_warp3d_bwd(const float* dout, const float* src, const float
   DF_ARG_CHECK(dout && src && flow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
   DF_ARG_CHECK(!flow_into_src || (dsrc && C == 3));
   const long long total = (long long)B * D * H * W;
+  if (df_warp_win_bwd_try(3, dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src, (hipStream_t)stream)) {
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   warp3d_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src);
   DF_LAUNCH_CHECK();

@@ -184,9 +184,27 @@ class REGISTRATIONModel(BaseModel):
         self.real = ops.cat_batch(self.real_A, self.real_B)
         if self.opt.flip_equivariance:
             raise NotImplementedError("flip_equivariance (FastCUT) is not on the registration path")
-        self.fake = self.netG(self.real)
-        self.fake_B = self.fake[:self.real_A.size(0)]
-        self.idt_B = self.fake[self.real_A.size(0):]
+        nb = self.real_A.size(0)
+        self._key_feats = None
+        if self.isTrain and self.opt.lambda_NCE > 0.0 and getattr(self.opt, 'reuse_key_features', True):
+            # The reference re-runs G's encoder on real_A / real_B for the (detached) key side of every
+            # NCE term (registration_model.py:244) with the weights this very pass used.  Every
+            # kernel on the path is per-sample and batch-size independent, so those activations are
+            # bit-identical to the ones this pass produces: tap them here instead of recomputing
+            # (ResnetGenerator.forward(layers, encode_only=False) returns them, networks.py:1028-1047).
+            self.fake, feats = self.netG(self.real, self.nce_layers, encode_only=False)
+            self._key_feats = ((self.real_A, [f[:nb].detach() for f in feats]),
+                               (self.real_B, [f[nb:].detach() for f in feats]))
+        else:
+            self.fake = self.netG(self.real)
+        self.fake_B = self.fake[:nb]
+        self.idt_B = self.fake[nb:]
+
+    def _encode_keys(self, src):
+        for owner, feats in (self._key_feats or ()):
+            if owner is src:
+                return feats
+        return self.netG(src, self.nce_layers, encode_only=True)
 
     # -- registration_model.py:213-235
     def compute_G_loss(self):
@@ -210,7 +228,7 @@ class REGISTRATIONModel(BaseModel):
         n_layers = len(self.nce_layers)
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
         with torch.no_grad():  # feat_k is detached inside PatchNCELoss (patchnce.py:17): forward only
-            feat_k = self.netG(src, self.nce_layers, encode_only=True)
+            feat_k = self._encode_keys(src)
             feat_k_pool, sample_ids = self.netF(feat_k, self.opt.num_patches, None)
         feat_q_pool, _ = self.netF(feat_q, self.opt.num_patches, sample_ids)
         total_nce_loss = 0.0

@@ -21,18 +21,26 @@ def report(name, nbytes, ms):
 
 dev = "cuda"
 # ---- warps (fwd 4*(C+nd+C)*N, bwd 4*(C + 2C + 2nd)*N)
-for name, shp, C in (("warp3d 160x192x224 C=1", (1, 160, 192, 224), 1), ("warp3d half-res self C=3", (1, 80, 96, 112), 3),
-                     ("warp2d 256^2 B=16 C=1", (16, 256, 256), 1), ("warp2d 128^2 B=16 self C=2", (16, 128, 128), 2)):
+# field regimes: "smooth" = a regularised registration field (control points every 32 voxels, ~1 voxel
+# rms, what VoxelMorph's smoothness loss produces); "rough" = control points every 16 voxels, 3 voxels rms
+# (local variation beyond the LDS window: exercises the per-voxel fallback of warp_win.hip)
+for name, shp, C, cell, amp in (("warp3d 160x192x224 C=1 smooth", (1, 160, 192, 224), 1, 32, 1.0),
+                                ("warp3d 160x192x224 C=1 rough", (1, 160, 192, 224), 1, 16, 3.0),
+                                ("warp3d half-res self C=3 smooth", (1, 80, 96, 112), 3, 16, 1.0),
+                                ("warp2d 256^2 B=16 C=1 smooth", (16, 256, 256), 1, 32, 1.0),
+                                ("warp2d 128^2 B=16 self C=2 smooth", (16, 128, 128), 2, 16, 1.0)):
     B, sp = shp[0], shp[1:]
     nd = len(sp)
     src = torch.randn(B, C, *sp, device=dev)
-    coarse = torch.randn(B, nd, *[max(2, s_ // 16) for s_ in sp], device=dev) * 3.0   # smooth field, |phi| ~ 3 px
+    coarse = torch.randn(B, nd, *[max(2, s_ // cell) for s_ in sp], device=dev) * amp
     flow = torch.nn.functional.interpolate(coarse, size=sp, mode='trilinear' if nd == 3 else 'bilinear', align_corners=True).contiguous()
     nv = src.numel() // C
     ms = timeit(lambda: ops._warp_fwd(src, flow, 0, 0))
     report(name + " fwd", 4 * (C + nd + C) * nv, ms)
     dout = torch.randn_like(src)
     dsrc = torch.zeros_like(src); dflow = torch.empty_like(flow)
+    ms = timeit(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0))
+    report(name + " bwd d(flow) only", 4 * (C + C + 2 * nd) * nv, ms)
     def bwd():
         dsrc.zero_()
         ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)

@@ -182,6 +182,50 @@ def test_whole_step_golden(golden, O):
     assert vis['dvf'].shape == (B, 3, size, size)
 
 
+def test_key_feature_reuse_is_bit_identical(O):
+    """forward() taps the key-side encoder features instead of re-running the encoder three times
+    (registration_model.py:244): losses, gradients and updated weights must not change by one bit."""
+    from tests.test_oracle_golden import make_step
+    res = []
+    for reuse in (True, False):
+        st, size, B = make_step()
+        model, opt = _hip_model_from_oracle(st, size, B, 8)
+        opt.reuse_key_features = reuse
+        base_forward = model.netF.forward
+        call = [0]
+
+        def netF_forward(feats, num_patches=64, patch_ids=None, base_forward=base_forward, call=call):
+            if patch_ids is None:
+                patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
+                call[0] += 1
+            return base_forward(feats, num_patches, patch_ids)
+
+        model.netF.forward = netF_forward
+        A0, B0 = C.image_pair(93, B, size, size)
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+        _load(model.netF, st.netF)
+        model.setup(opt)
+        model.parallelize()
+        A_, B_ = C.image_pair(100, B, size, size)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        assert (model._key_feats is not None) == reuse
+        res.append(([v for v in model.get_current_losses().values()], [o_.flat_g.clone() for o_ in model.optimizers]))
+        if reuse:   # the tapped activations are the encoder's, bit for bit (forward kernels hold no atomics)
+            with torch.no_grad():
+                model.forward()   # re-tap with the weights as they are now
+                for owner, feats in model._key_feats:
+                    again = model.netG(owner, model.nce_layers, encode_only=True)
+                    assert len(again) == len(feats)
+                    for f0, f1 in zip(feats, again):
+                        assert torch.equal(f0, f1)
+    # the step's losses are identical; its gradients differ only by the float-atomic ordering noise of the
+    # warp backward (one step only: Adam's g/sqrt(v) turns that noise into lr-sized differences later)
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm())
+
+
 def test_full_size_step_vs_oracle(O):
     """256x256, ngf=64 (BASELINE config 2 geometry at batch 1): one step of the HIP path against the
     oracle on identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""

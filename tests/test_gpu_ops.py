@@ -267,6 +267,30 @@ def test_warp_vectorised_vs_oracle(ops, shape):
     close(got, ref, what="warp v4")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (2, 2, 50, 44), (1, 2, 6, 10, 12), (1, 3, 13, 21, 36), (1, 1, 40, 48, 56)])
+@pytest.mark.parametrize("amp", [1.5, 5.0, 30.0])
+def test_warp_windowed_fwd_bwd_vs_oracle(ops, shape, amp):
+    """The LDS-windowed kernels (warp_win.hip) on ragged tile edges, with displacement fields that stay
+    inside the window (amp 1.5), mix window hits with the global fallback (5) and mostly leave it (30):
+    output, d(src) and d(flow) against the oracle's grid_sample + autograd."""
+    from oracle import dfmir_oracle as O
+    nd = len(shape) - 2
+    src = C.randn(61, *shape).requires_grad_()
+    coarse = (C.rand(62, shape[0], nd, *[max(2, s // 6) for s in shape[2:]]) * 2 - 1) * amp
+    flow = torch.nn.functional.interpolate(coarse, size=shape[2:], mode="trilinear" if nd == 3 else "bilinear",
+                                           align_corners=True)
+    flow = (flow + (C.rand(63, *flow.shape) - 0.5) * 0.5).requires_grad_()
+    cot = C.randn(64, *shape)
+    ref = O.spatial_transform(src, flow)
+    (ref * cot).sum().backward()
+    s_, f_ = src.detach().to(DEV).requires_grad_(), flow.detach().to(DEV).requires_grad_()
+    got = ops.warp(s_, f_)
+    (got * cot.to(DEV)).sum().backward()
+    close(got, ref.detach(), what="warp win fwd")
+    close(s_.grad, src.grad, what="warp win dsrc")
+    close(f_.grad, flow.grad, rtol=3e-4, what="warp win dflow")
+
+
 def test_warp_identity_and_oob(ops):
     x = C.randn(51, 2, 1, 20, 30).to(DEV)
     z = torch.zeros(2, 2, 20, 30, device=DEV)
