@@ -26,6 +26,7 @@ _SIGS = {
     "dfmir_conv_wgrad": [_GP, P, P, P, P],
     "dfmir_bias_grad": [P, P, c_int, c_int, c_longlong, P],
     "dfmir_weight_pack": [P, P, c_int, c_int, c_int, c_int, P],
+    "dfmir_weight_pack_floats": [c_int, c_int, c_int],
     "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],
     "dfmir_tapstack_fwd": [P, P] + [c_int] * 7 + [P],
     "dfmir_tapstack_bwd": [P, P] + [c_int] * 7 + [P],
@@ -88,6 +89,7 @@ def lib():
             fn = getattr(h, name)
             fn.argtypes = args
             fn.restype = c_int
+        h.dfmir_weight_pack_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []
         h.dfmir_last_error.restype = ctypes.c_char_p
         _lib = h

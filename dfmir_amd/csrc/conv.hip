@@ -11,7 +11,7 @@
 // rounded to even so that odd channel counts (34, 48, 2 ...) waste < 6 % of the MFMA issue slots.
 // Tiles go global -> registers -> LDS (double buffered, one barrier per K step); fp32 MFMA is
 // 64 cycles per 32x32x2 so the per-element gather arithmetic hides under the matrix pipe.
-#include "common.h"
+#include "conv3x3_common.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -451,6 +451,9 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
                         float* y, hipStream_t st, int* rc);
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* w_packed, const float* bias,
+                              float* y, hipStream_t st, int* rc);
+void df_weight_split_launch(const float* w_tcc, float* split, int K, int M, hipStream_t st);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc);
 bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
@@ -482,6 +485,7 @@ extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* 
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   if (!use_generic_only()) {
     int rc = 0;
+    if (df_conv3x3_split_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
@@ -595,7 +599,18 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
   const long long total = (long long)Cout * Cin * T;
   weight_pack_k<<<df_grid(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(w, w_tcc, Cout, Cin, T, mode);
   DF_LAUNCH_CHECK();
+  if (T == 9) {   // split-bf16 section for the 3x3 kernels (conv3x3s.hip); K = reduction, M = produced channels
+    const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
+    df_weight_split_launch(w_tcc, w_tcc + df_pack_tcc_floats(K, M, T), K, M, (hipStream_t)stream);
+    DF_LAUNCH_CHECK();
+  }
   return 0;
+}
+extern "C" long long dfmir_weight_pack_floats(int Cout, int Cin, int T) {
+  if (Cout <= 0 || Cin <= 0 || T <= 0) return -1;
+  // [T][K][M] fp32 (rounded up to 16 B) + the split section when T == 9; one size for both packings
+  const long long s0 = df_pack_split_floats(Cin, Cout, T), s1 = df_pack_split_floats(Cout, Cin, T);
+  return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1);
 }
 extern "C" int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T,
                                    void* stream) {

@@ -12,29 +12,7 @@
 // wgrad           :  dWt[tap][ci][co] += sum_p X[ci][p + tap] * dY[co][p]           (conv3x3_wgrad_k)
 //   wgrad's MFMA A operand is read straight out of the halo patch: one 32-row tile = 32 input
 //   channels of ONE tap, so the (tap, ci) "im2col" axis is never materialised.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct Conv3P {
-  int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;
-  float slope;
-  int tiles_per_img;
-};
-
-__device__ __forceinline__ int halo_offset(int iy, int ix, int Hi, int Wi, int pad_mode) {
-  if (pad_mode == 1) {
-    if (iy < 0) iy = -iy;
-    if (iy >= Hi) iy = 2 * (Hi - 1) - iy;
-    if (ix < 0) ix = -ix;
-    if (ix >= Wi) ix = 2 * (Wi - 1) - ix;
-    iy = iy < 0 ? 0 : (iy >= Hi ? Hi - 1 : iy);
-    ix = ix < 0 ? 0 : (ix >= Wi ? Wi - 1 : ix);
-    return iy * Wi + ix;
-  }
-  return ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) ? iy * Wi + ix : -1;
-}
+#include "conv3x3_common.h"
 
 template <int WM, int WN, int TM, int TN, int XP>
 __global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ x,
@@ -358,16 +336,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_k(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch (called from conv.hip); return true when the launch was taken.
 // ---------------------------------------------------------------------------------------------
-static int worst_npos(int Wo, int HWo, int BN) {
-  if (HWo <= BN) {  // one tile per image
-    const int rows = (HWo + Wo - 1) / Wo;
-    return rows == 1 ? 3 * (HWo + 2) : (rows + 2) * (Wo + 2);
-  }
-  if (Wo >= BN) return (Wo % BN == 0) ? 3 * (BN + 2) : 4 * (Wo + 2);
-  const int rows = (BN % Wo == 0) ? BN / Wo : (BN + Wo - 1) / Wo + 1;
-  return (rows + 2) * (Wo + 2);
-}
-
 bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
                         float* y, hipStream_t st, int* rc) {
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))

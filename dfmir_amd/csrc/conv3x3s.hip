@@ -1,0 +1,362 @@
+// 2-D 3x3 stride-1 convolution, fp32 in / fp32 out, on the bf16 matrix cores by exact 3-way operand
+// splitting ("bf16x3", the scheme behind fp32-emulating GEMMs):
+//
+//     a = a0 + a1 + a2,  b = b0 + b1 + b2      (each term bf16, round-to-nearest: 3 x 8+1 bits >= fp32's 24)
+//     a*b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0          (dropped terms are <= 2^-24 |ab|)
+//
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs replace sixteen-K's worth of
+// v_mfma_f32_32x32x2_f32: 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
+// Measured deviation from the fp32-MFMA kernel is at fp32 rounding level (tests/test_gpu_ops.py,
+// scripts/bf16_split_precision.py); the fp32-MFMA kernels stay available with DFMIR_CONV_FP32=1.
+//
+// Tiling follows the fp32 kernel (conv3x3.hip): 128 output channels x a run of 128 output pixels per
+// group of 4 waves, one LDS halo patch per chunk of 8 input channels shared by all 9 taps, next chunk's
+// global loads in flight during the MFMA phase.  What changes is the operand format:
+//   * weights arrive pre-split from dfmir_weight_pack (16-B units of 8 input channels, layout
+//     [chunk][split][tap][cout]) and are copied to LDS as they are;
+//   * the patch is split when it is written to LDS: [split][position] x (8 channels = 16 B), so a
+//     lane's MFMA B operand is one ds_read_b128;
+//   * K = 16 of one MFMA = 2 taps x 8 channels: lanes 0-31 feed tap 2j, lanes 32-63 tap 2j+1 (their B
+//     reads differ by the tap's patch shift).  The ninth tap pairs with a zero operand (10 % idle).
+#include "conv3x3_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), a in the low half
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 fp32 -> three 16-B vectors of 8 bf16 (hi, mid, lo)
+__device__ __forceinline__ void split8(const float v[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float x0 = v[2 * w], x1 = v[2 * w + 1];
+    const unsigned ph = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+    const unsigned pm = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+    h[w] = ph; m[w] = pm; l[w] = pk_bf16(s0, s1);
+  }
+}
+
+// ---- weight splitting: w_tcc [9][K][M] fp32 -> [ceil(K/8)][3][9][M] x 16 B
+__global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ w_tcc, u32x4* __restrict__ out,
+                                                      int K, int M) {
+  const int chunks = (K + 7) >> 3;
+  const long long total = (long long)chunks * 9 * M;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i % M);
+    const int tap = (int)((i / M) % 9);
+    const int ch = (int)(i / ((long long)9 * M));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = ch * 8 + j;
+      v[j] = kk < K ? w_tcc[((long long)tap * K + kk) * M + m] : 0.f;
+    }
+    u32x4 h, md, l;
+    split8(v, h, md, l);
+    const long long base = (long long)ch * 27 * M + (long long)tap * M + m;
+    out[base] = h;
+    out[base + (long long)9 * M] = md;
+    out[base + (long long)18 * M] = l;
+  }
+}
+
+void df_weight_split_launch(const float* w_tcc, float* split, int K, int M, hipStream_t st) {
+  const long long total = (long long)((K + 7) / 8) * 9 * M;
+  weight_split_k<<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(split), K, M);
+}
+
+// ---- the 120-MFMA phase of one 8-channel chunk for a wave tile of TM x TN 32x32 blocks.
+// Ab: weight chunk [split][tap][BM] (16-B units), Xb: halo patch [split][XP]; aoff[pr] / bidx[pr][j] are
+// this lane's unit indices for tap pair pr.  Operands of pair pr+1 are read from LDS while the matrix pipe
+// works on pair pr (two register sets); the sched_group_barriers pin that interleave -- left to itself the
+// scheduler issued each ds_read right before its first use and the pipe idled ~45 % of the phase.
+template <int BM, int XP, int TM, int TN, int NV>
+__device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb,
+                                                const int (&aoff)[5], const int (&bidx)[5][TN],
+                                                f32x16 (&acc)[TM][TN]) {
+  u32x4 a[2][TM][3], b[2][TN][3];
+#define SPLIT_LOAD(set_, pr_)                                                                    \
+  {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
+      _Pragma("unroll") for (int s = 0; s < 3; ++s) a[set_][i][s] = Ab[s * 9 * BM + aoff[pr_] + i * 32]; \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+      _Pragma("unroll") for (int s = 0; s < 3; ++s) b[set_][j][s] = Xb[s * XP + bidx[pr_][j]];   \
+  }
+#define SPLIT_MMA(set_, sa_, sb_)                                                                \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[set_][i][sa_]), \
+                                                          __builtin_bit_cast(bf16x8, b[set_][j][sb_]), acc[i][j], 0, 0, 0);
+  SPLIT_LOAD(0, 0)
+#pragma unroll
+  for (int pr = 0; pr < 5; ++pr) {
+    if (pr < 4) SPLIT_LOAD((pr + 1) & 1, pr + 1)
+    SPLIT_MMA(pr & 1, 2, 0) SPLIT_MMA(pr & 1, 0, 2) SPLIT_MMA(pr & 1, 1, 1)
+    SPLIT_MMA(pr & 1, 1, 0) SPLIT_MMA(pr & 1, 0, 1) SPLIT_MMA(pr & 1, 0, 0)
+  }
+#undef SPLIT_LOAD
+#undef SPLIT_MMA
+  // schedule: the NL ds_reads of the next pair ride behind the first NL MFMAs of a pair; the caller's NV
+  // prefetch loads (global -> registers, issued in the same basic block) behind the following ones
+  constexpr int NL = 3 * (TM + TN), NM = 6 * TM * TN, VP = (NV + 3) / 4;
+  static_assert(NL + VP <= NM, "interleave pattern");
+  __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NL - VP, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel: ping-pong over two wave groups.  A first version with two independent 256-thread workgroups
+// per CU left the matrix pipe 64 % busy (profiles/r01_conv3x3s_pmc.md): fair MFMA arbitration makes the
+// co-resident workgroups finish their MFMA phases together, then both convert/store with the pipe idle.
+// Here ONE 512-thread workgroup holds two groups of 4 waves (one wave of each group per SIMD) that
+// alternate by construction: in every
+// half-step one group runs the 120-MFMA phase of a chunk while the other converts + stores its next
+// halo patch and half of the next weight chunk, then a barrier swaps the roles.  The weight chunk is
+// shared by both groups (128 output channels x 2 x 128 pixels per workgroup) and double-buffered.
+//   half-step h, chunk c = h >> 1:   group A (0) computes on even h, group B (1) on odd h.
+//   A prefetches X_A(c+1), W_A-half(c+1) while computing c and stores them at h = 2c+1;
+//   B prefetches X_B(c+1), W_B-half(c+2) while computing c and stores them at h = 2c+2.
+//   W(c+1) is therefore complete at the end of h = 2c+1, and its buffer was last read (chunk c-1) at
+//   h = 2c-1: every hand-over is ordered by the per-half-step barrier.
+template <int XP>
+__global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __restrict__ x,
+                                                              const u32x4* __restrict__ ws,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, Conv3P k) {
+  constexpr int BM = 128, BNG = 128, CK = 8, TM = 2, TN = 2, WN = 2;
+  constexpr int NS = (XP + 255) / 256;
+  constexpr int WU = 27 * BM, WH = WU / 2;    // 16-B units of one weight chunk / of one group's share
+  constexpr int NW = (WH + 255) / 256;
+  constexpr int ZPOS = XP - 1;
+  __shared__ __attribute__((aligned(16))) u32x4 As[2][WU];
+  __shared__ __attribute__((aligned(16))) u32x4 Xs[2][3 * XP];
+  __shared__ float bs[BM];
+
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
+  const int n = blockIdx.x / k.tiles_per_img;
+  const int t = blockIdx.x - n * k.tiles_per_img;
+  const int p0 = t * (2 * BNG) + grp * BNG;
+  const bool gvalid = p0 < HWo;               // the last tile of an image may leave group B without pixels
+  const int pend = (p0 + BNG < HWo) ? p0 + BNG : HWo;
+  const int m0 = blockIdx.y * BM;
+  const int y0 = p0 / k.Wo, y1 = (pend - 1) / k.Wo;
+  const bool single = (y0 == y1);
+  const int x0 = p0 - y0 * k.Wo, x1 = (pend - 1) - y1 * k.Wo;
+  const int xoff = single ? x0 : 0;
+  const int ncols = single ? (x1 - x0 + 3) : (k.Wo + 2);
+  const int nrows = y1 - y0 + 3;
+  const int npos = gvalid ? nrows * ncols : 0;
+  u32x4* __restrict__ Xg = Xs[grp];
+
+  constexpr unsigned OOB = 0x80000000u;
+  // byte offsets of this thread's patch positions within one 8-channel slab, per channel: constant over
+  // the chunk loop (the slab base moves in the scalar buffer descriptor instead), so the prefetch issues
+  // no vector ALU work -- on this chip every VALU instruction delays the matrix pipe by its 4 cycles
+  // (scripts/ubench/mfma_peak.hip).
+  unsigned gvo[NS][CK];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pos = tid + 256 * s;
+    int off = -1;
+    if (pos < npos) {
+      const int r = pos / ncols, c = pos - r * ncols;
+      off = halo_offset(y0 - k.pad + r, xoff - k.pad + c, k.Hi, k.Wi, k.pad_mode);
+    }
+#pragma unroll
+    for (int c = 0; c < CK; ++c) gvo[s][c] = off < 0 ? OOB : (unsigned)(off + c * HWi) * 4u;
+  }
+  if (threadIdx.x < BM) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
+  if (tid < 3) Xg[tid * XP + ZPOS] = u32x4{0u, 0u, 0u, 0u};
+
+  int pbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int q = p0 + (wn * TN + j) * 32 + l31;
+    q = q < pend ? q : pend - 1;
+    const int yy = q / k.Wo, xx = q - yy * k.Wo;
+    pbase[j] = (yy - y0) * ncols + (xx - xoff);
+  }
+  // per tap pair: this half-wave's A unit offset and B patch index (tap 8 pairs with the zero position)
+  int aoff[5], bidx[5][TN];
+#pragma unroll
+  for (int pr = 0; pr < 5; ++pr) {
+    const int tp = (pr == 4) ? 8 : 2 * pr + lhi;
+    aoff[pr] = tp * BM + wm * TM * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      bidx[pr][j] = ((pr == 4) && lhi) ? ZPOS : pbase[j] + (tp / 3) * ncols + (tp % 3);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* xn = x + (long long)n * k.Cin * HWi;
+  const int chunks = (k.Cin + CK - 1) / CK;
+  unsigned wbyte[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int loc = tid + 256 * j;
+    const int idx = grp * WH + loc;
+    const int seg = idx >> 7, co = m0 + (idx & 127);
+    wbyte[j] = (loc < WH && co < k.Cout) ? (unsigned)(seg * k.Cout + co) * 16u : OOB;
+  }
+  const int wunits = 27 * k.Cout;
+
+  u32x4 rw[NW];
+  unsigned rx[NS][CK];
+
+  // chunk ch_ = its own descriptor (base advanced, extent = what is left of the tensor, 0 past the end)
+#define P3_GLOADW(ch_)                                                                           \
+  {                                                                                              \
+    const int c_ = (ch_);                                                                        \
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<u32x4*>(ws + (long long)c_ * wunits), 0, c_ < chunks ? (unsigned)wunits * 16u : 0u, 0x00020000); \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j)                                               \
+      rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wbyte[j], 0, 0);                        \
+  }
+#define P3_GLOADX(ch_)                                                                           \
+  {                                                                                              \
+    const int c0_ = (ch_) * CK;                                                                  \
+    const int left_ = k.Cin - c0_;                                                               \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(xn + (long long)c0_ * HWi), 0,                                        \
+        left_ > 0 ? (unsigned)((left_ < CK ? left_ : CK) * HWi) * 4u : 0u, 0x00020000);          \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
+      _Pragma("unroll") for (int c = 0; c < CK; ++c)                                             \
+        rx[s][c] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[s][c], 0, 0);                   \
+    }                                                                                            \
+  }
+#define P3_LSTOREW(buf_)                                                                         \
+  {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                             \
+      const int loc = tid + 256 * j;                                                             \
+      if (loc < WH) As[buf_][grp * WH + loc] = rw[j];                                            \
+    }                                                                                            \
+  }
+#define P3_LSTOREX()                                                                             \
+  {                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
+      const int pos = tid + 256 * s;                                                             \
+      if (pos < npos) {                                                                          \
+        float v[8];                                                                              \
+        _Pragma("unroll") for (int c = 0; c < CK; ++c) v[c] = __uint_as_float(rx[s][c]);         \
+        u32x4 h, m, l;                                                                           \
+        split8(v, h, m, l);                                                                      \
+        Xg[pos] = h; Xg[XP + pos] = m; Xg[2 * XP + pos] = l;                                     \
+      }                                                                                          \
+    }                                                                                            \
+  }
+
+  // prologue: W(0) (each group its half) + own X(0); group B also fetches its half of W(1)
+  P3_GLOADW(0);
+  P3_GLOADX(0);
+  P3_LSTOREW(0);
+  P3_LSTOREX();
+  if (grp == 1 && chunks > 1) P3_GLOADW(1);
+  __syncthreads();
+
+  for (int h = 0; h < 2 * chunks; ++h) {
+    const int c = h >> 1;
+    if ((h & 1) == grp) {
+      // ---- compute half-step: 120 MFMAs on chunk c with the prefetch loads interleaved.  Chunks past
+      // the end lie beyond the buffer descriptors and read 0, so the loads need no guard.
+      if (gvalid) {
+        P3_GLOADX(c + 1);
+        P3_GLOADW(c + 1 + grp);
+        split_mma_chunk<BM, XP, TM, TN, NW + NS * CK>(As[c & 1], Xg, aoff, bidx, acc);
+      } else {
+        P3_GLOADW(c + 1 + grp);
+      }
+    } else {
+      // ---- store half-step: what this group prefetched during its last compute half-step
+      const int cx = c + 1 - grp;               // A: X(c+1);  B: X(c)  (B's X(0) is already in place)
+      if (cx < chunks && h > 0) P3_LSTOREX();
+      if (c + 1 < chunks) P3_LSTOREW((c + 1) & 1);
+    }
+    __syncthreads();
+  }
+#undef P3_GLOADW
+#undef P3_GLOADX
+#undef P3_LSTOREW
+#undef P3_LSTOREX
+
+  if (!gvalid) return;
+  float* yb = y + (long long)n * k.Cout * HWo;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int q = p0 + (wn * TN + j) * 32 + l31;
+    if (q >= pend) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int cl = (wm * TM + i) * 32 + 4 * lhi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = cl + (r & 3) + 8 * (r >> 2);
+        const int co = m0 + cc;
+        if (co < k.Cout) {
+          float v = acc[i][j][r] + bs[cc];
+          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+          else if (k.act == 2) v = tanhf(v);
+          yb[(long long)co * HWo + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static bool split_enabled() {
+  static const bool on = getenv("DFMIR_CONV_FP32") == nullptr;   // A/B switch: keep the fp32-MFMA kernels
+  return on;
+}
+
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* w_packed, const float* bias,
+                              float* y, hipStream_t st, int* rc) {
+  if (!split_enabled()) return false;
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
+    return false;
+  if (g->Cout <= 64 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
+  const int p = g->ph;
+  if (!(p == 1 || (p == 2 && g->pad_mode == 0))) return false;
+  if (g->Ho != g->Hi + 2 * p - 2 || g->Wo != g->Wi + 2 * p - 2) return false;
+  const long long HWo = (long long)g->Ho * g->Wo;
+  if (HWo >= (1LL << 30) || (long long)g->Hi * g->Wi >= (1LL << 30)) return false;
+  if ((long long)((g->Cin + 7) / 8) * 27 * g->Cout * 16 >= (1LL << 31)) return false;
+  if (worst_npos(g->Wo, (int)HWo, 128) > 399) return false;
+  Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
+  const u32x4* ws = reinterpret_cast<const u32x4*>(w_packed + df_pack_tcc_floats(g->Cin, g->Cout, 9));
+  k.tiles_per_img = (int)((HWo + 255) / 256);
+  dim3 grid((unsigned)(g->N * k.tiles_per_img), (unsigned)((g->Cout + 127) / 128));
+  conv3x3_bf16x3_pp_k<400><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+  hipError_t e = hipGetLastError();
+  *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+  return true;
+}

@@ -95,7 +95,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode):
 def weight_pack(w, mode):
     Cout, Cin = w.shape[0], w.shape[1]
     T = w.numel() // (Cout * Cin)
-    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    out = torch.empty(lib().dfmir_weight_pack_floats(Cout, Cin, T), device=w.device, dtype=torch.float32)
     check(lib().dfmir_weight_pack(_p(_c(w)), _p(out), Cout, Cin, T, mode, _st()))
     return out
 

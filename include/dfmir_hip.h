@@ -29,7 +29,10 @@ int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
- * Convolutions (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
+ * Convolutions (implicit GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, and -- for the
+ * 2-D 3x3 stride-1 layers with more than 64 output channels -- fp32 emulated exactly on
+ * v_mfma_f32_32x32x16_bf16 by 3-way operand splitting, csrc/conv3x3s.hip; DFMIR_CONV_FP32=1 keeps the
+ * fp32 instruction there too).
  * Replaces nn.Conv2d / nn.Conv3d (+ the ReflectionPad2d in front of it, + the LeakyReLU/Tanh
  * behind it) at: models/networks.py:982-983, 995, 1016-1023 (ResnetGenerator),
  * models/networks.py:1201,1214 (ResnetBlock), models/networks.py:587-595 (PatchSampleF MLP,
@@ -63,7 +66,11 @@ int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float
 /* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
 int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
 /* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
- * mode 1: w_tcc[t][co][ci] = w[co][ci][T-1-t]       (dgrad packing: roles of Cin/Cout swapped, taps flipped) */
+ * mode 1: w_tcc[t][co][ci] = w[co][ci][T-1-t]       (dgrad packing: roles of Cin/Cout swapped, taps flipped)
+ * The packed buffer holds dfmir_weight_pack_floats(Cout, Cin, T) floats: the tap-major fp32 weights, then
+ * (T == 9 only) the same weights pre-split into bf16 triples for the 3x3 kernels.  Callers treat it as
+ * opaque and hand it to dfmir_conv_fwd unchanged. */
+long long dfmir_weight_pack_floats(int Cout, int Cin, int T);
 int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, int mode, void* stream);
 /* g[co][ci][t] = g_tcc[t][ci][co]  (gradient back to the reference's parameter layout). */
 int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, void* stream);
