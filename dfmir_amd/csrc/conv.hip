@@ -453,6 +453,8 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
                           hipStream_t st, int* rc);
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* w_packed, const float* bias,
                               float* y, hipStream_t st, int* rc);
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                                hipStream_t st, int* rc);
 void df_weight_split_launch(const float* w_tcc, float* split, int K, int M, hipStream_t st);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc);
@@ -534,6 +536,7 @@ extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
+    if (df_conv3x3_split_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }

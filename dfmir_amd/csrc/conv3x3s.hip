@@ -360,3 +360,209 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;
 }
+
+// =================================================================================================
+// Weight gradient on the bf16 pipe:   dWt[tap][ci][co] += sum_{n,p} X[n][ci][p + tap] * dY[n][co][p]
+//
+// The reduction index is the PIXEL, so an MFMA lane must hold 8 consecutive pixels of one channel (16 B
+// of bf16).  dY needs no shift; X is needed at the 9 tap shifts, and a +-1 pixel shift of a 16-B unit is
+// a 2-byte misalignment that ds_read_b128 / ds_write_b128 only serve at ~1/4 rate
+// (scripts/ubench/lds_unaligned.hip).  The shift is therefore applied once, in registers, when the patch
+// is converted: a thread loads its 8 pixels plus the pixel on either side, splits the 10 values, and stores
+// three aligned units per split -- patch columns [-1..6], [0..7], [1..8] of its group -- so that all nine
+// taps read aligned units (dy is a whole row = a different LDS row).  The neighbour pixels of the edge
+// groups are the conv padding (reflected or zero), so there is no separate halo path.
+//
+// Workgroup = 512 threads = 8 waves = (2 tiles of 32 input channels) x (4 tiles of 32 output channels),
+// each wave holding the 9 tap accumulators [32 ci x 32 co].  One "run" = 2 image rows x 16 pixels
+// (2 MFMA K-steps, patch = 4 rows x 18 columns); global loads of the next run are in flight during the
+// 108-MFMA phase, conversion + LDS stores follow it.  The 6 products of a tap chain on one accumulator
+// (a dependent MFMA chain issues at full rate, scripts/ubench/mfma_peak.hip), so only one tap's operands
+// are live and the next tap's are read from LDS meanwhile.  Runs are split over blockIdx.x (split-K, fp32
+// atomics at the end, as conv3x3_wgrad_k).
+//   LDS  Xc[split][dx][row 0..3][half][ci 64], Dy[split][kstep][half][co 128] : 16-B units of 8 pixels
+struct WS3P {
+  int N, Cin, Cout, H, W, pad_mode;
+  int runs_per_row, runs_per_img, runs_total, runs_per_block;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ dwt, WS3P k) {
+  constexpr int CT = 64, BC = 128;
+  constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
+  __shared__ __attribute__((aligned(16))) u32x4 Xc[3 * 3 * 4 * XSLAB];   // 73,728 B
+  __shared__ __attribute__((aligned(16))) u32x4 Dy[3 * 2 * 2 * BC];      // 24,576 B
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wi = wid >> 2, wc = wid & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HW = k.H * k.W;
+  const int ci0 = blockIdx.y * CT, co0 = blockIdx.z * BC;
+  const int run_beg = blockIdx.x * k.runs_per_block;
+  int run_end = run_beg + k.runs_per_block;
+  if (run_end > k.runs_total) run_end = k.runs_total;
+
+  // loader roles (512 threads): X group (patch row xr 0..3, half xu 0..1, channel xc 0..63) and
+  // dY group (k-step dk, half du, channel dc 0..127)
+  const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
+  const int dc = tid & 127, du = (tid >> 7) & 1, dk = tid >> 8;
+  const unsigned hw4 = (unsigned)HW * 4u;
+  constexpr unsigned OOB = 0x80000000u;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  u32x4 rxa, rxb, rda, rdb;   // 8 px of X, 8 px of dY
+  unsigned rxl, rxr;          // the pixel left / right of the X group
+
+#define WS_GLOAD(run_)                                                                           \
+  {                                                                                              \
+    const int n_ = (run_) / k.runs_per_img;                                                      \
+    const int q_ = (run_) - n_ * k.runs_per_img;                                                 \
+    const int yp_ = q_ / k.runs_per_row, xs_ = q_ - yp_ * k.runs_per_row;                        \
+    const int y0_ = 2 * yp_, x0_ = 16 * xs_ + 8 * xu;                                            \
+    const __amdgpu_buffer_rsrc_t bx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(x + (long long)n_ * k.Cin * HW), 0, (unsigned)(k.Cin * HW) * 4u, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t bd_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, (unsigned)(k.Cout * HW) * 4u, 0x00020000); \
+    const bool cok_ = ci0 + xc < k.Cin;                                                          \
+    const unsigned cb_ = (unsigned)(ci0 + xc) * hw4;                                             \
+    const int o1_ = halo_offset(y0_ - 1 + xr, x0_, k.H, k.W, k.pad_mode);                        \
+    const int ol_ = halo_offset(y0_ - 1 + xr, x0_ - 1, k.H, k.W, k.pad_mode);                    \
+    const int or_ = halo_offset(y0_ - 1 + xr, x0_ + 8, k.H, k.W, k.pad_mode);                    \
+    const unsigned xb_ = (o1_ < 0 || !cok_) ? OOB : cb_ + (unsigned)o1_ * 4u;                    \
+    rxa = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_, 0, 0);                                 \
+    rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
+    rxl = __builtin_amdgcn_raw_buffer_load_b32(bx_, (ol_ < 0 || !cok_) ? OOB : cb_ + (unsigned)ol_ * 4u, 0, 0); \
+    rxr = __builtin_amdgcn_raw_buffer_load_b32(bx_, (or_ < 0 || !cok_) ? OOB : cb_ + (unsigned)or_ * 4u, 0, 0); \
+    const unsigned db_ = (co0 + dc >= k.Cout) ? OOB                                              \
+        : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + dk) * k.W + 16 * xs_ + 8 * du) * 4u;    \
+    rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
+    rdb = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_ == OOB ? OOB : db_ + 16u, 0, 0);        \
+  }
+  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour.  Per split level: pairs
+  // (0,1)(2,3)(4,5)(6,7)(8,9) -> units dx=0 (cols -1..6) and dx=2 (cols 1..8); pairs (1,2)..(7,8) -> dx=1.
+#define WS_LSTORE()                                                                              \
+  {                                                                                              \
+    float r[10];                                                                                 \
+    r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
+      unsigned pa[5], pb[4];                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 5; ++i) pa[i] = pk_bf16(r[2 * i], r[2 * i + 1]);     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) pb[i] = pk_bf16(r[2 * i + 1], r[2 * i + 2]); \
+      u32x4* dst = Xc + ((s * 3 * 4 + xr) * 2 + xu) * CT + xc;                                   \
+      dst[0] = u32x4{pa[0], pa[1], pa[2], pa[3]};                                                \
+      dst[4 * XSLAB] = u32x4{pb[0], pb[1], pb[2], pb[3]};                                        \
+      dst[8 * XSLAB] = u32x4{pa[1], pa[2], pa[3], pa[4]};                                        \
+      if (s < 2) {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                          \
+          r[2 * i] -= __uint_as_float(pa[i] << 16);                                              \
+          r[2 * i + 1] -= __uint_as_float(pa[i] & 0xffff0000u);                                  \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+    float v[8];                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
+    u32x4 sp[3];                                                                                 \
+    split8(v, sp[0], sp[1], sp[2]);                                                              \
+    _Pragma("unroll") for (int s = 0; s < 3; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
+  }
+
+  if (run_beg < run_end) {
+    WS_GLOAD(run_beg);
+    WS_LSTORE();
+  }
+  __syncthreads();
+
+  // operand unit indices of this lane: A = Xc[((s*3 + dx)*4 + row)*2 + lhi][ci], B = Dy[(s*2 + ks)*2 + lhi][co]
+  const int abase = lhi * CT + wi * 32 + l31;
+  const int bbase = lhi * BC + wc * 32 + l31;
+  for (int run = run_beg; run < run_end; ++run) {
+    const bool more = (run + 1) < run_end;
+    if (more) WS_GLOAD(run + 1);
+    u32x4 b[3], a[2][3];
+#define WS_LOADA(set_, step_)                                                                    \
+  _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                  \
+    a[set_][s] = Xc[((s * 3 + ((step_) % 3)) * 4 + (step_) / 9 + ((step_) % 9) / 3) * XSLAB + abase];
+#define WS_MMA(set_, t_, sa_, sb_)                                                               \
+  acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[set_][sa_]),    \
+                                                    __builtin_bit_cast(bf16x8, b[sb_]), acc[t_], 0, 0, 0);
+    // 18 steps = (k-step ks, tap): step = ks*9 + ty*3 + dx; operands of step+1 are read during step
+    WS_LOADA(0, 0)
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      if (step % 9 == 0) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) b[s] = Dy[(s * 2 + step / 9) * 2 * BC + bbase];
+      }
+      if (step + 1 < 18) WS_LOADA((step + 1) & 1, step + 1)
+      WS_MMA(step & 1, step % 9, 2, 0) WS_MMA(step & 1, step % 9, 0, 2) WS_MMA(step & 1, step % 9, 1, 1)
+      WS_MMA(step & 1, step % 9, 1, 0) WS_MMA(step & 1, step % 9, 0, 1) WS_MMA(step & 1, step % 9, 0, 0)
+    }
+#undef WS_LOADA
+#undef WS_MMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      const int nr = (step + 1 < 18 ? 3 : 0) + ((step + 1) % 9 == 0 && step + 1 < 18 ? 3 : 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    if (more) {
+      __syncthreads();
+      WS_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef WS_GLOAD
+#undef WS_LSTORE
+
+  const int co = co0 + wc * 32 + l31;
+  if (co < k.Cout) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r]);
+      }
+    }
+  }
+}
+
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
+                                hipStream_t st, int* rc) {
+  if (!split_enabled()) return false;
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
+    return false;
+  if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
+  if (g->Cout < 128 || g->Cin < 64) return false;
+  if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
+  const long long HW = (long long)g->Hi * g->Wi;
+  if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0};
+  k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
+  const long long total = (long long)g->N * k.runs_per_img;
+  if (total >= (1LL << 30)) return false;
+  k.runs_total = (int)total;
+  const unsigned ny = (g->Cin + 63) / 64, nz = (g->Cout + 127) / 128;
+  long long want = 256 / ((long long)ny * nz);    // one resident round: 1 workgroup per CU
+  if (want < 1) want = 1;
+  long long maxs = (k.runs_total + 7) / 8;        // >= 8 runs per block
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  k.runs_per_block = (int)((k.runs_total + want - 1) / want);
+  const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
+  conv3x3_wgrad_bf16x3_k<<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
+  hipError_t e = hipGetLastError();
+  *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+  return true;
+}

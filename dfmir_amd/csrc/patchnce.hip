@@ -27,36 +27,53 @@ __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long lo
 }
 
 // y = x / (sqrt(sum_c x^2) + eps)     (models/networks.py:499-502)
-__global__ void l2norm_fwd_k(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm,
-                             int C, long long P, float eps) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const float* xp = x + i;
+// x is channel-major [C][P] with only a few thousand rows P: a workgroup takes 16 rows x 16 channel
+// groups (thread = row r, channels cg, cg+16, ...), so 256 rows already fill 16 CUs and the per-thread
+// dependent-load chain is C/16 long instead of C (the one-thread-per-row form was pure latency: 94 us).
+__global__ __launch_bounds__(256) void l2norm_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                    float* __restrict__ nrm, int C, long long P, float eps) {
+  __shared__ float red[16][17];
+  const int r = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + r;
+  const bool ok = i < P;
   float s = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float v = xp[(long long)c * P];
-    s += v * v;
-  }
-  const float n = sqrtf(s);
-  nrm[i] = n;
+  if (ok)
+    for (int c = cg; c < C; c += 16) {
+      const float v = x[(long long)c * P + i];
+      s += v * v;
+    }
+  red[cg][r] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) tot += red[g][r];
+  if (!ok) return;
+  const float n = sqrtf(tot);
+  if (cg == 0) nrm[i] = n;
   const float inv = 1.f / (n + eps);
-  float* yp = y + i;
-  for (int c = 0; c < C; ++c) yp[(long long)c * P] = xp[(long long)c * P] * inv;
+  for (int c = cg; c < C; c += 16) y[(long long)c * P + i] = x[(long long)c * P + i] * inv;
 }
-__global__ void l2norm_bwd_k(const float* __restrict__ dy, const float* __restrict__ x,
-                             const float* __restrict__ nrm, float* __restrict__ dx, int C, long long P,
-                             float eps) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const float* xp = x + i;
-  const float* gp = dy + i;
+__global__ __launch_bounds__(256) void l2norm_bwd_k(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ nrm, float* __restrict__ dx, int C,
+                                                    long long P, float eps) {
+  __shared__ float red[16][17];
+  const int r = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + r;
+  const bool ok = i < P;
+  float s = 0.f;
+  if (ok)
+    for (int c = cg; c < C; c += 16) s += dy[(long long)c * P + i] * x[(long long)c * P + i];
+  red[cg][r] = s;
+  __syncthreads();
   float dot = 0.f;
-  for (int c = 0; c < C; ++c) dot += gp[(long long)c * P] * xp[(long long)c * P];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) dot += red[g][r];
+  if (!ok) return;
   const float n = nrm[i];
   const float inv = 1.f / (n + eps);
   const float k2 = n > 0.f ? dot * inv * inv / n : 0.f;
-  float* dp = dx + i;
-  for (int c = 0; c < C; ++c) dp[(long long)c * P] = gp[(long long)c * P] * inv - xp[(long long)c * P] * k2;
+  for (int c = cg; c < C; c += 16)
+    dx[(long long)c * P + i] = dy[(long long)c * P + i] * inv - x[(long long)c * P + i] * k2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -243,14 +260,14 @@ extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, f
 extern "C" int dfmir_l2norm_fwd(const float* x, float* y, float* norm, int C, long long rows, float eps,
                                 void* stream) {
   DF_ARG_CHECK(x && y && norm && C > 0 && rows > 0);
-  l2norm_fwd_k<<<df_grid(rows, 256), 256, 0, (hipStream_t)stream>>>(x, y, norm, C, rows, eps);
+  l2norm_fwd_k<<<(unsigned)((rows + 15) / 16), 256, 0, (hipStream_t)stream>>>(x, y, norm, C, rows, eps);
   DF_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int dfmir_l2norm_bwd(const float* dy, const float* x, const float* norm, float* dx, int C,
                                 long long rows, float eps, void* stream) {
   DF_ARG_CHECK(dy && x && norm && dx && C > 0 && rows > 0);
-  l2norm_bwd_k<<<df_grid(rows, 256), 256, 0, (hipStream_t)stream>>>(dy, x, norm, dx, C, rows, eps);
+  l2norm_bwd_k<<<(unsigned)((rows + 15) / 16), 256, 0, (hipStream_t)stream>>>(dy, x, norm, dx, C, rows, eps);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -46,5 +46,11 @@ for Cin, Cout, H, refl in SHAPES:
     xp = F.pad(x[:, :, 0].double(), (1, 1, 1, 1), mode="reflect" if refl else "constant")
     ref = F.conv2d(xp, w.double())
     d = (y[:, :, 0].double() - ref)
-    print("  %3d->%3d @%3d^2  rel L2 %.2e   max|err|/max|ref| %.2e" % (
-        Cin, Cout, Hh, float(d.norm() / ref.norm()), float(d.abs().max() / ref.abs().max())))
+    dyy = torch.randn(2, Cout, 1, Hh, Hh, device="cuda")
+    dwt = ops.conv_wgrad_raw(x, dyy, (1, 3, 3), 1, (0, 1, 1), 1 if refl else 0)
+    dw = ops.weight_unpack(dwt, (Cout, Cin, 3, 3)).double()
+    dwr = torch.nn.grad.conv2d_weight(xp, (Cout, Cin, 3, 3), dyy[:, :, 0].double())
+    dd = dw - dwr
+    print("  %3d->%3d @%3d^2  fwd rel L2 %.2e max %.2e   wgrad rel L2 %.2e max %.2e" % (
+        Cin, Cout, Hh, float(d.norm() / ref.norm()), float(d.abs().max() / ref.abs().max()),
+        float(dd.norm() / dwr.norm()), float(dd.abs().max() / dwr.abs().max())))

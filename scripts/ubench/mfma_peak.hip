@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     for (int p = 0; p < 6; ++p)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        if (MODE == 2) {
+        if (MODE == 5) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[p]), __builtin_bit_cast(bf16x8, bv[(p + a) % 6]), acc[0], 0, 0, 0);
+        } else if (MODE == 2) {
 #pragma unroll
           for (int q = 0; q < 1; ++q)
             acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[p][a]), __uint_as_float(bv[p][a]), acc[a], 0, 0, 0);
@@ -76,6 +78,7 @@ int main() {
     run<2>("fp32 32x32x2, registers only", 4096.0, w);
     run<3>("bf16 32x32x16 + 2 VALU per MFMA", 32768.0, w);
     run<4>("bf16 32x32x16 + 4 VALU per MFMA", 32768.0, w);
+    run<5>("bf16 32x32x16, ONE accumulator chain", 32768.0, w);
   }
   return 0;
 }

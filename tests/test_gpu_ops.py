@@ -59,6 +59,11 @@ CONV2D = [
     (36, 132, 3, 1, 1, True, 0, 1, 24, 72),
     (256, 256, 3, 1, 1, True, 0, 2, 64, 64),
     (64, 32, 3, 1, 1, False, 1, 1, 64, 256),
+    # split-bf16 kernels (conv3x3s.hip) with ragged channel tiles / image rows shorter than a pixel run /
+    # a last pixel tile that leaves the second wave group empty; wgrad runs of 2 rows x 16 px
+    (72, 136, 3, 1, 1, True, 1, 2, 10, 48),
+    (64, 160, 3, 1, 1, False, 0, 1, 6, 16),
+    (200, 129, 3, 1, 1, True, 0, 1, 18, 32),
 ]
 
 
