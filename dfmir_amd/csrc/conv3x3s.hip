@@ -104,8 +104,9 @@ __device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, co
 #undef SPLIT_MMA
   // schedule: the NL ds_reads of the next pair ride behind the first NL MFMAs of a pair; the caller's NV
   // prefetch loads (global -> registers, issued in the same basic block) behind the following ones
-  constexpr int NL = 3 * (TM + TN), NM = 6 * TM * TN, VP = (NV + 3) / 4;
-  static_assert(NL + VP <= NM, "interleave pattern");
+  constexpr int NL = 3 * (TM + TN), NM = 6 * TM * TN;
+  constexpr int VP = ((NV + 3) / 4 < NM - NL) ? (NV + 3) / 4 : NM - NL;
+  static_assert(NL <= NM, "interleave pattern");
   __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
@@ -138,12 +139,13 @@ __device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, co
 //   B prefetches X_B(c+1), W_B-half(c+2) while computing c and stores them at h = 2c+2.
 //   W(c+1) is therefore complete at the end of h = 2c+1, and its buffer was last read (chunk c-1) at
 //   h = 2c-1: every hand-over is ordered by the per-half-step barrier.
-template <int XP>
+template <int XP, int BM>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __restrict__ x,
                                                               const u32x4* __restrict__ ws,
                                                               const float* __restrict__ bias,
                                                               float* __restrict__ y, Conv3P k) {
-  constexpr int BM = 128, BNG = 128, CK = 8, TM = 2, TN = 2, WN = 2;
+  // BM = 128: waves 2 x 2, each 64 couts x 64 pixels;  BM = 64: waves 1 x 4, each 64 couts x 32 pixels
+  constexpr int BNG = 128, CK = 8, TM = 2, TN = (BM == 128) ? 2 : 1, WN = (BM == 128) ? 2 : 4;
   constexpr int NS = (XP + 255) / 256;
   constexpr int WU = 27 * BM, WH = WU / 2;    // 16-B units of one weight chunk / of one group's share
   constexpr int NW = (WH + 255) / 256;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
 #pragma unroll
     for (int c = 0; c < CK; ++c) gvo[s][c] = off < 0 ? OOB : (unsigned)(off + c * HWi) * 4u;
   }
-  if (threadIdx.x < BM) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
+  if ((int)threadIdx.x < BM) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
   if (tid < 3) Xg[tid * XP + ZPOS] = u32x4{0u, 0u, 0u, 0u};
 
   int pbase[TN];
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
   for (int j = 0; j < NW; ++j) {
     const int loc = tid + 256 * j;
     const int idx = grp * WH + loc;
-    const int seg = idx >> 7, co = m0 + (idx & 127);
+    const int seg = idx / BM, co = m0 + (idx % BM);
     wbyte[j] = (loc < WH && co < k.Cout) ? (unsigned)(seg * k.Cout + co) * 16u : OOB;
   }
   const int wunits = 27 * k.Cout;
@@ -343,7 +345,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   if (!split_enabled()) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
-  if (g->Cout <= 64 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
+  if (g->Cout <= 32 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
   const int p = g->ph;
   if (!(p == 1 || (p == 2 && g->pad_mode == 0))) return false;
   if (g->Ho != g->Hi + 2 * p - 2 || g->Wo != g->Wi + 2 * p - 2) return false;
@@ -354,8 +356,13 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
   const u32x4* ws = reinterpret_cast<const u32x4*>(w_packed + df_pack_tcc_floats(g->Cin, g->Cout, 9));
   k.tiles_per_img = (int)((HWo + 255) / 256);
-  dim3 grid((unsigned)(g->N * k.tiles_per_img), (unsigned)((g->Cout + 127) / 128));
-  conv3x3_bf16x3_pp_k<400><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+  if (g->Cout > 64) {
+    dim3 grid((unsigned)(g->N * k.tiles_per_img), (unsigned)((g->Cout + 127) / 128));
+    conv3x3_bf16x3_pp_k<400, 128><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+  } else {
+    dim3 grid((unsigned)(g->N * k.tiles_per_img), 1);
+    conv3x3_bf16x3_pp_k<400, 64><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+  }
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;
