@@ -5,6 +5,7 @@ pointers; torch is used only for memory, streams and the autograd tape.  There i
 eager-PyTorch fallback: a non-CUDA tensor raises.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -71,11 +72,12 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     return y
 
 
-def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode):
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None):
+    """dW in the tap-major packing; `out` (same packing) is accumulated into when given."""
     N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
     T = K[0] * K[1] * K[2]
-    dw = torch.zeros((T, Cin, Cout), device=x5.device, dtype=torch.float32)
+    dw = torch.zeros((T, Cin, Cout), device=x5.device, dtype=torch.float32) if out is None else out
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
     def launch():
@@ -115,6 +117,40 @@ _EPOCH = [0]
 
 def bump_weights_epoch():
     _EPOCH[0] += 1
+
+
+# Deferred weight gradients.  A train step back-propagates through the same conv modules several times
+# (G once, its encoder three more times for the NCE terms).  Inside `with deferred_weight_grads():` the
+# wgrad kernels of all those passes accumulate into ONE persistent tap-major buffer per module and the
+# bias gradients straight into `bias.grad`; the buffers are unpacked into `weight.grad` once, on exit.
+# Without it every pass pays a zero-fill, an unpack and an autograd `add` per parameter (~900 tiny launches).
+_DEFER = {"on": False, "pending": {}}
+
+
+class deferred_weight_grads:
+    def __enter__(self):
+        _DEFER["on"] = os.environ.get("DFMIR_NO_DEFER") is None   # A/B switch
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER["on"] = False
+        pending, _DEFER["pending"] = _DEFER["pending"], {}
+        if exc[0] is None:
+            with torch.no_grad():
+                for owner, buf, shape in pending.values():
+                    g = owner.weight.grad
+                    g.add_(weight_unpack(buf, shape).view_as(g))
+                    buf.zero_()
+        return False
+
+
+def _deferred_buffer(owner, T, Cin, Cout, shape, device):
+    buf = getattr(owner, "_dw_tcc", None)
+    if buf is None or buf.shape != (T, Cin, Cout) or buf.device != device:
+        buf = torch.zeros((T, Cin, Cout), device=device, dtype=torch.float32)
+        owner._dw_tcc = buf
+    _DEFER["pending"][id(owner)] = (owner, buf, shape)
+    return buf
 
 
 def weights_epoch():
@@ -172,13 +208,24 @@ class ConvFn(Function):
                 padp = tuple(K[i] - 1 - p3[i] for i in range(3))
                 dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp)
             dx = dx5 if nd == 3 else dx5.squeeze(2)
+        defer = (_DEFER["on"] and owner is not None and getattr(owner, "weight", None) is not None
+                 and owner.weight.grad is not None and owner.weight.grad.is_contiguous())
         if ctx.needs_input_grad[1]:
-            dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode)
-            dw = weight_unpack(dwt, tuple(weight.shape))
+            if defer:
+                T = K[0] * K[1] * K[2]
+                conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode,
+                               out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device))
+            else:
+                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode)
+                dw = weight_unpack(dwt, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
-            check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, S, _st()))
+            bg = getattr(owner, "bias", None).grad if defer and getattr(owner, "bias", None) is not None else None
+            if bg is not None and bg.is_contiguous():
+                check(lib().dfmir_bias_grad(_p(dy5), _p(bg), dy5.shape[0], Cout, S, _st()))   # accumulates
+            else:
+                db = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
+                check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, S, _st()))
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -10,6 +10,7 @@ reference does ship: `VxmDense(ndims=3, int_steps=7, bidir=True)`
 import torch
 
 from . import distributed as dfdist
+from . import ops
 from .losses import Grad_Loss, NCC_Loss
 from .optim import FlatAdam
 from .voxelmorph import VxmDense
@@ -41,7 +42,8 @@ class Registration3DModel(object):
         self.optimizer_R.zero_grad()
         self.loss_ncc = self.criterionNCC(y_source, self.real_B)
         self.loss_grad = self.criterionGrad(flow)
-        (self.loss_ncc + self.loss_grad * self.lam).backward()
+        with ops.deferred_weight_grads():
+            (self.loss_ncc + self.loss_grad * self.lam).backward()
         if self._ddp:
             dfdist.allreduce_arenas([self.optimizer_R.flat_g])
         self.optimizer_R.step()

@@ -165,7 +165,8 @@ class REGISTRATIONModel(BaseModel):
             + self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold') * 1.0 + self.loss_local * 1.0
         self.loss_smooth = smooothing_loss(y_pred[1]) * 0.20
         all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
-        all_G_loss.backward()
+        with ops.deferred_weight_grads():
+            all_G_loss.backward()
         self.sync_gradients()
         self.optimizer_G.step()
         self.optimizer_R.step()
