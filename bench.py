@@ -231,7 +231,9 @@ def main():
         # passes recompute activations the forward pass already holds and are not re-executed here (349 G)
         step_tflop = (1581e9 - 349e9) * B / 1e12
         split = os.environ.get("DFMIR_CONV_FP32") is None
-        issued = ach * 6.0 * 10.0 / 9.0 if split else ach     # 6 bf16 products, 5 k-steps for 9 taps
+        nprod = 6.0 if os.environ.get("DFMIR_CONV_SPLIT", "f").startswith("b") else 3.0   # bf16x3 / fp16x2 (default)
+        form = "bf16x3 (6 products)" if nprod == 6.0 else "scaled fp16x2 (3 products)"
+        issued = ach * nprod * 10.0 / 9.0 if split else ach     # 5 k-steps for 9 taps
         result = {
             "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -243,20 +245,20 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": ("conv3x3_bf16x3_pp_k<400> (fp32 operands split exactly into bf16 triples, 6 x "
-                                    "v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate; 128 couts x 2x128 pixels, "
-                                    "ping-pong wave groups)" if split else
+                         "kernel": ("conv3x3_split_pp_k (fp32 operands split into 16-bit terms, %s on "
+                                    "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; 128 couts x 2x128 pixels, "
+                                    "ping-pong wave groups)" % form if split else
                                     "conv3x3_mfma_k<2,2,2,2,400> (v_mfma_f32_32x32x2_f32; 128 couts x 128 pixels)") +
                                    ": forward + dgrad of every 3x3 conv with Cout > 64",
                          "peak_note": "peak = dense fp32 MFMA (dtype f32); achieved = algorithmic fp32 FLOP/s" +
-                                      (", above it because the products run on the bf16 pipe" if split else ""),
+                                      (", above it because the products run on the 16-bit matrix pipe" if split else ""),
                          "issued_mfma_tflops": issued, "issued_mfma_peak": 2500.0 if split else FP32_MFMA_PEAK_TFLOPS,
                          "issued_mfma_frac": issued / (2500.0 if split else FP32_MFMA_PEAK_TFLOPS),
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                         "wgrad_kernel": ("conv3x3_wgrad_bf16x3_k (same split; 64 ci x 128 co x 9 taps per workgroup, "
+                         "wgrad_kernel": ("conv3x3_wgrad_split_k (same split; 64 ci x 128 co x 9 taps per workgroup, "
                                           "runs of 2 rows x 16 px)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
                          "wgrad_kernel_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
-                         "wgrad_issued_mfma_frac": (wg_tf * 6.0 / 2500.0) if split else wg_tf / FP32_MFMA_PEAK_TFLOPS,
+                         "wgrad_issued_mfma_frac": (wg_tf * nprod / 2500.0) if split else wg_tf / FP32_MFMA_PEAK_TFLOPS,
                          "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},
             "losses": {k: round(v, 6) for k, v in losses.items()},
         }

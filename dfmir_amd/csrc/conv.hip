@@ -451,11 +451,12 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
                         float* y, hipStream_t st, int* rc);
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
-bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* w_packed, const float* bias,
-                              float* y, hipStream_t st, int* rc);
-bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
-                                hipStream_t st, int* rc);
-void df_weight_split_launch(const float* w_tcc, float* split, int K, int M, hipStream_t st);
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_packed,
+                              const float* bias, float* y, hipStream_t st, int* rc);
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                                const float* dy_amax, float* dw_tcc, hipStream_t st, int* rc);
+int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st);
+int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc);
 bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
@@ -480,14 +481,30 @@ static int check_geom(const DfConvGeom* g) {
   return 0;
 }
 
+static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+                         const float* bias, float* y, void* stream);
 extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc,
                               const float* bias, float* y, void* stream) {
+  return conv_fwd_impl(g, x, nullptr, w_tcc, bias, y, stream);
+}
+extern "C" int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+                                     const float* bias, float* y, void* stream) {
+  return conv_fwd_impl(g, x, x_amax, w_tcc, bias, y, stream);
+}
+extern "C" int dfmir_absmax(const float* x, long long n, float* out, void* stream) {
+  DF_ARG_CHECK(x && out && n > 0);
+  const int rc = df_absmax_launch(x, n, out, (hipStream_t)stream);
+  if (rc) return df_set_error(rc, __FILE__, __LINE__);
+  return 0;
+}
+static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+                         const float* bias, float* y, void* stream) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && w_tcc && y);
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
+    if (df_conv3x3_split_fwd_try(g, x, x_amax, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
@@ -529,14 +546,24 @@ extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* 
   return 0;
 }
 
+static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                           const float* dy_amax, float* dw_tcc, void* stream);
 extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                                 void* stream) {
+  return conv_wgrad_impl(g, x, nullptr, dy, nullptr, dw_tcc, stream);
+}
+extern "C" int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                                       const float* dy_amax, float* dw_tcc, void* stream) {
+  return conv_wgrad_impl(g, x, x_amax, dy, dy_amax, dw_tcc, stream);
+}
+static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                           const float* dy_amax, float* dw_tcc, void* stream) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
   DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
+    if (df_conv3x3_split_wgrad_try(g, x, x_amax, dy, dy_amax, dw_tcc, st, &rc)) return rc;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }
@@ -604,8 +631,8 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
   DF_LAUNCH_CHECK();
   if (T == 9) {   // split-bf16 section for the 3x3 kernels (conv3x3s.hip); K = reduction, M = produced channels
     const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
-    df_weight_split_launch(w_tcc, w_tcc + df_pack_tcc_floats(K, M, T), K, M, (hipStream_t)stream);
-    DF_LAUNCH_CHECK();
+    const int rc = df_weight_split_launch(w_tcc, w_tcc, K, M, (hipStream_t)stream);
+    if (rc) return df_set_error(rc, __FILE__, __LINE__);
   }
   return 0;
 }
@@ -613,7 +640,7 @@ extern "C" long long dfmir_weight_pack_floats(int Cout, int Cin, int T) {
   if (Cout <= 0 || Cin <= 0 || T <= 0) return -1;
   // [T][K][M] fp32 (rounded up to 16 B) + the split section when T == 9; one size for both packings
   const long long s0 = df_pack_split_floats(Cin, Cout, T), s1 = df_pack_split_floats(Cout, Cin, T);
-  return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1);
+  return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1) + (T == 9 ? 4 : 0);   // + scale trailer
 }
 extern "C" int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T,
                                    void* stream) {

@@ -1,13 +1,19 @@
-// 2-D 3x3 stride-1 convolution, fp32 in / fp32 out, on the bf16 matrix cores by exact 3-way operand
-// splitting ("bf16x3", the scheme behind fp32-emulating GEMMs):
+// 2-D 3x3 stride-1 convolution (forward, dgrad, wgrad), fp32 in / fp32 out, on the 16-bit matrix cores by
+// operand splitting -- the scheme behind fp32-emulating GEMMs.  Two forms share every kernel here (NSP):
 //
-//     a = a0 + a1 + a2,  b = b0 + b1 + b2      (each term bf16, round-to-nearest: 3 x 8+1 bits >= fp32's 24)
-//     a*b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0          (dropped terms are <= 2^-24 |ab|)
+//   NSP = 3, "bf16x3":  a = a0 + a1 + a2 (bf16, round-to-nearest residuals: 3 x (8+1) bits >= fp32's 24)
+//        a*b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0        6 MFMAs, dropped terms <= 2^-24 |ab|
+//        bf16 has fp32's exponent range: no scaling, exact for any input.
+//   NSP = 2, "fp16x2":  a = (a0 + a1) / s  with  a0 = fp16(s*a), a1 = fp16(s*a - a0)   (11 + 11 bits, +-2^-23)
+//        a*b ~= a0b0 + a0b1 + a1b0                              3 MFMAs, dropped a1b1 <= 2^-22 |ab|
+//        fp16 has 5 exponent bits, so each tensor is scaled by a power of two s = 2^(13 - ilogb(max|a|))
+//        taken from a device-side max|a| (dfmir_absmax; weights: at pack time); elements more than 2^16
+//        below the tensor maximum keep a fixed absolute error of 2^-38 max|a| instead of a relative one.
+//        The result is rescaled by 2^-(ea+eb) in the epilogue.  Half the matrix-pipe work of bf16x3.
 //
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs replace sixteen-K's worth of
-// v_mfma_f32_32x32x2_f32: 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512.
-// Measured deviation from the fp32-MFMA kernel is at fp32 rounding level (tests/test_gpu_ops.py,
-// scripts/bf16_split_precision.py); the fp32-MFMA kernels stay available with DFMIR_CONV_FP32=1.
+// Products are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.  Against an fp64 convolution both forms
+// land at the fp32-MFMA kernels' error level (scripts/bench_conv.py, tests/test_gpu_ops.py); those kernels
+// (conv3x3.hip) remain under DFMIR_CONV_FP32=1, and DFMIR_CONV_SPLIT=bf16x3 selects the unscaled form.
 //
 // Tiling follows the fp32 kernel (conv3x3.hip): 128 output channels x a run of 128 output pixels per
 // group of 4 waves, one LDS halo patch per chunk of 8 input channels shared by all 9 taps, next chunk's
@@ -22,6 +28,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), a in the low half
@@ -29,24 +37,99 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-// 8 fp32 -> three 16-B vectors of 8 bf16 (hi, mid, lo)
-__device__ __forceinline__ void split8(const float v[8], u32x4& h, u32x4& m, u32x4& l) {
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float x0 = v[2 * w], x1 = v[2 * w + 1];
-    const unsigned ph = pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
-    const unsigned pm = pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
-    h[w] = ph; m[w] = pm; l[w] = pk_bf16(s0, s1);
+// one pair of fp32 values -> NSP packed 16-bit pairs (term 0 = leading term)
+template <int NSP>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&p)[NSP]) {
+  if constexpr (NSP == 3) {
+    p[0] = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(p[0] << 16), r1 = x1 - __uint_as_float(p[0] & 0xffff0000u);
+    p[1] = pk_bf16(r0, r1);
+    p[2] = pk_bf16(r0 - __uint_as_float(p[1] << 16), r1 - __uint_as_float(p[1] & 0xffff0000u));
+  } else {
+    const f32x2 v = {x0, x1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);            // v_cvt_pk_f16_f32 (RNE)
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);        // exact
+    p[0] = __builtin_bit_cast(unsigned, h);
+    p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
 }
+// 8 fp32 -> NSP 16-B vectors of 8 halves
+template <int NSP>
+__device__ __forceinline__ void split8(const float v[8], u32x4 (&out)[NSP]) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned p[NSP];
+    split_pair<NSP>(v[2 * w], v[2 * w + 1], p);
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) out[s][w] = p[s];
+  }
+}
+template <int NSP>
+__device__ __forceinline__ f32x16 mma16(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (NSP == 3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// products kept, smallest first: (A term, B term)
+template <int NSP> struct Prod;
+template <> struct Prod<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct Prod<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
 
-// ---- weight splitting: w_tcc [9][K][M] fp32 -> [ceil(K/8)][3][9][M] x 16 B
+// power-of-two scale exponent of a tensor whose max |.| is amax: |a| * 2^e < 2^14
+__device__ __forceinline__ int scale_exp(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  int e = (amax > 0.f) ? 13 - be : 0;
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  return e;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+// ---- max |x| of a tensor (device scalar, must be zeroed by the caller: dfmir_absmax does)
+__global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  __shared__ float red[8];
+  float m = 0.f;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(m == m)) m = __uint_as_float(0x7f800000u);   // NaN -> +inf so that it survives the integer max
+    atomicMax(out, __float_as_uint(m));                // non-negative floats order like their bit patterns
+  }
+}
+int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  absmax_k<<<(unsigned)blocks, 256, 0, st>>>(x, n, reinterpret_cast<unsigned*>(out));
+  return (int)hipGetLastError();
+}
+
+// ---- weight splitting: w_tcc [9][K][M] fp32 -> [ceil(K/8)][NSP][9][M] x 16 B.
+// NSP = 2: trailer[0] = max|w| (from absmax_k), trailer[1] <- the scale exponent used (as a float)
+template <int NSP>
 __global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ w_tcc, u32x4* __restrict__ out,
-                                                      int K, int M) {
+                                                      float* __restrict__ trailer, int K, int M) {
   const int chunks = (K + 7) >> 3;
   const long long total = (long long)chunks * 9 * M;
+  int e = 0;
+  if (NSP == 2) {
+    e = scale_exp(trailer[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = (float)e;
+  }
+  const float sc = pow2f(e);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int m = (int)(i % M);
     const int tap = (int)((i / M) % 9);
@@ -55,74 +138,110 @@ __global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kk = ch * 8 + j;
-      v[j] = kk < K ? w_tcc[((long long)tap * K + kk) * M + m] : 0.f;
+      v[j] = kk < K ? w_tcc[((long long)tap * K + kk) * M + m] * sc : 0.f;
     }
-    u32x4 h, md, l;
-    split8(v, h, md, l);
-    const long long base = (long long)ch * 27 * M + (long long)tap * M + m;
-    out[base] = h;
-    out[base + (long long)9 * M] = md;
-    out[base + (long long)18 * M] = l;
+    u32x4 sp[NSP];
+    split8<NSP>(v, sp);
+    const long long base = (long long)ch * 9 * NSP * M + (long long)tap * M + m;
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) out[base + (long long)s * 9 * M] = sp[s];
   }
 }
 
-void df_weight_split_launch(const float* w_tcc, float* split, int K, int M, hipStream_t st) {
-  const long long total = (long long)((K + 7) / 8) * 9 * M;
-  weight_split_k<<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(split), K, M);
+// which split form the library runs with (read once): 0 = none (fp32 MFMA), 2 = fp16x2 (default), 3 = bf16x3
+int df_split_mode() {
+  static const int mode = [] {
+    if (getenv("DFMIR_CONV_FP32")) return 0;
+    const char* s = getenv("DFMIR_CONV_SPLIT");
+    if (s && s[0] == 'b') return 3;
+    return 2;
+  }();
+  return mode;
 }
 
-// ---- the 120-MFMA phase of one 8-channel chunk for a wave tile of TM x TN 32x32 blocks.
+// split section of a packed weight buffer (K = reduction channels, M = produced channels)
+static inline float* split_section(const float* packed, int K, int M) {
+  return const_cast<float*>(packed) + df_pack_tcc_floats(K, M, 9);
+}
+static inline float* split_trailer(const float* packed, int K, int M, int nsp) {
+  return split_section(packed, K, M) + (long long)((K + 7) / 8) * 9 * nsp * M * 4;
+}
+
+int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st) {
+  const int mode = df_split_mode();
+  if (mode == 0) return 0;
+  const long long total = (long long)((K + 7) / 8) * 9 * M;
+  u32x4* sec = reinterpret_cast<u32x4*>(split_section(packed, K, M));
+  float* tr = split_trailer(packed, K, M, mode);
+  if (mode == 2) {
+    const int rc = df_absmax_launch(w_tcc, (long long)9 * K * M, tr, st);
+    if (rc) return rc;
+    weight_split_k<2><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, K, M);
+  } else {
+    weight_split_k<3><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, K, M);
+  }
+  return (int)hipGetLastError();
+}
+
+// ---- the MFMA phase of one 8-channel chunk for a wave tile of TM x TN 32x32 blocks.
 // Ab: weight chunk [split][tap][BM] (16-B units), Xb: halo patch [split][XP]; aoff[pr] / bidx[pr][j] are
 // this lane's unit indices for tap pair pr.  Operands of pair pr+1 are read from LDS while the matrix pipe
 // works on pair pr (two register sets); the sched_group_barriers pin that interleave -- left to itself the
 // scheduler issued each ds_read right before its first use and the pipe idled ~45 % of the phase.
-template <int BM, int XP, int TM, int TN, int NV>
+template <int NSP, int BM, int XP, int TM, int TN, int NV>
 __device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb,
                                                 const int (&aoff)[5], const int (&bidx)[5][TN],
                                                 f32x16 (&acc)[TM][TN]) {
-  u32x4 a[2][TM][3], b[2][TN][3];
+  using P = Prod<NSP>;
+  u32x4 a[2][TM][NSP], b[2][TN][NSP];
 #define SPLIT_LOAD(set_, pr_)                                                                    \
   {                                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
-      _Pragma("unroll") for (int s = 0; s < 3; ++s) a[set_][i][s] = Ab[s * 9 * BM + aoff[pr_] + i * 32]; \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s) a[set_][i][s] = Ab[s * 9 * BM + aoff[pr_] + i * 32]; \
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
-      _Pragma("unroll") for (int s = 0; s < 3; ++s) b[set_][j][s] = Xb[s * XP + bidx[pr_][j]];   \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s) b[set_][j][s] = Xb[s * XP + bidx[pr_][j]]; \
   }
-#define SPLIT_MMA(set_, sa_, sb_)                                                                \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[set_][i][sa_]), \
-                                                          __builtin_bit_cast(bf16x8, b[set_][j][sb_]), acc[i][j], 0, 0, 0);
   SPLIT_LOAD(0, 0)
 #pragma unroll
   for (int pr = 0; pr < 5; ++pr) {
     if (pr < 4) SPLIT_LOAD((pr + 1) & 1, pr + 1)
-    SPLIT_MMA(pr & 1, 2, 0) SPLIT_MMA(pr & 1, 0, 2) SPLIT_MMA(pr & 1, 1, 1)
-    SPLIT_MMA(pr & 1, 1, 0) SPLIT_MMA(pr & 1, 0, 1) SPLIT_MMA(pr & 1, 0, 0)
+#pragma unroll
+    for (int q = 0; q < P::N; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = mma16<NSP>(a[pr & 1][i][P::A[q]], b[pr & 1][j][P::B[q]], acc[i][j]);
   }
 #undef SPLIT_LOAD
-#undef SPLIT_MMA
-  // schedule: the NL ds_reads of the next pair ride behind the first NL MFMAs of a pair; the caller's NV
+  // schedule: the NL ds_reads of the next pair ride behind the first MFMAs of a pair; the caller's NV
   // prefetch loads (global -> registers, issued in the same basic block) behind the following ones
-  constexpr int NL = 3 * (TM + TN), NM = 6 * TM * TN;
-  constexpr int VP = ((NV + 3) / 4 < NM - NL) ? (NV + 3) / 4 : NM - NL;
-  static_assert(NL <= NM, "interleave pattern");
-  __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
+  constexpr int NL = NSP * (TM + TN), NM = P::N * TM * TN;
+  constexpr int LP = NL < NM ? NL : NM;                   // reads interleaved one per MFMA
+  constexpr int VP = ((NV + 3) / 4 < NM - LP) ? (NV + 3) / 4 : NM - LP;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < LP; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i == LP - 1) {
+#pragma unroll
+        for (int e = 0; e < NL - LP; ++e) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM - NL - VP, 0);
+#pragma unroll
+    for (int i = 0; i < NM - LP - VP; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
   }
-  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+#pragma unroll
+  for (int i = 0; i < NM; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,28 +249,33 @@ __device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, co
 // per CU left the matrix pipe 64 % busy (profiles/r01_conv3x3s_pmc.md): fair MFMA arbitration makes the
 // co-resident workgroups finish their MFMA phases together, then both convert/store with the pipe idle.
 // Here ONE 512-thread workgroup holds two groups of 4 waves (one wave of each group per SIMD) that
-// alternate by construction: in every
-// half-step one group runs the 120-MFMA phase of a chunk while the other converts + stores its next
-// halo patch and half of the next weight chunk, then a barrier swaps the roles.  The weight chunk is
-// shared by both groups (128 output channels x 2 x 128 pixels per workgroup) and double-buffered.
+// alternate by construction: in every half-step one group runs the MFMA phase of a chunk while the other
+// converts + stores its next halo patch and half of the next weight chunk, then a barrier swaps the roles.
+// The weight chunk is shared by both groups (BM output channels x 2 x 128 pixels per workgroup) and
+// double-buffered.
 //   half-step h, chunk c = h >> 1:   group A (0) computes on even h, group B (1) on odd h.
 //   A prefetches X_A(c+1), W_A-half(c+1) while computing c and stores them at h = 2c+1;
 //   B prefetches X_B(c+1), W_B-half(c+2) while computing c and stores them at h = 2c+2.
 //   W(c+1) is therefore complete at the end of h = 2c+1, and its buffer was last read (chunk c-1) at
 //   h = 2c-1: every hand-over is ordered by the per-half-step barrier.
-template <int XP, int BM>
-__global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __restrict__ x,
-                                                              const u32x4* __restrict__ ws,
-                                                              const float* __restrict__ bias,
-                                                              float* __restrict__ y, Conv3P k) {
+struct SplitScale {
+  const float* x_amax;    // device: max |x| of the input tensor (NSP = 2 only)
+  const float* w_trailer; // device: [1] = weight scale exponent (NSP = 2 only)
+};
+
+template <int NSP, int XP, int BM>
+__global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __restrict__ x,
+                                                             const u32x4* __restrict__ ws,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ y, Conv3P k, SplitScale sc) {
   // BM = 128: waves 2 x 2, each 64 couts x 64 pixels;  BM = 64: waves 1 x 4, each 64 couts x 32 pixels
   constexpr int BNG = 128, CK = 8, TM = 2, TN = (BM == 128) ? 2 : 1, WN = (BM == 128) ? 2 : 4;
   constexpr int NS = (XP + 255) / 256;
-  constexpr int WU = 27 * BM, WH = WU / 2;    // 16-B units of one weight chunk / of one group's share
+  constexpr int WU = 9 * NSP * BM, WH = WU / 2;   // 16-B units of one weight chunk / of one group's share
   constexpr int NW = (WH + 255) / 256;
-  constexpr int ZPOS = XP - 1;
+  constexpr int ZPOS = XP - 1;                    // a patch position that always holds zeros
   __shared__ __attribute__((aligned(16))) u32x4 As[2][WU];
-  __shared__ __attribute__((aligned(16))) u32x4 Xs[2][3 * XP];
+  __shared__ __attribute__((aligned(16))) u32x4 Xs[2][NSP * XP];
   __shared__ float bs[BM];
 
   const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
@@ -173,6 +297,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
   const int npos = gvalid ? nrows * ncols : 0;
   u32x4* __restrict__ Xg = Xs[grp];
 
+  // scales (NSP = 2): input scaled by 2^ex when it is split, result rescaled by 2^-(ex+ew)
+  float xscale = 1.f, oscale = 1.f;
+  if (NSP == 2) {
+    const int ex = scale_exp(sc.x_amax[0]);
+    const int ew = (int)sc.w_trailer[1];
+    xscale = pow2f(ex);
+    oscale = pow2f(-(ex + ew));
+  }
+
   constexpr unsigned OOB = 0x80000000u;
   // byte offsets of this thread's patch positions within one 8-channel slab, per channel: constant over
   // the chunk loop (the slab base moves in the scalar buffer descriptor instead), so the prefetch issues
@@ -191,7 +324,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
     for (int c = 0; c < CK; ++c) gvo[s][c] = off < 0 ? OOB : (unsigned)(off + c * HWi) * 4u;
   }
   if ((int)threadIdx.x < BM) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
-  if (tid < 3) Xg[tid * XP + ZPOS] = u32x4{0u, 0u, 0u, 0u};
+  if (tid < NSP) Xg[tid * XP + ZPOS] = u32x4{0u, 0u, 0u, 0u};
 
   int pbase[TN];
 #pragma unroll
@@ -230,7 +363,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
     const int seg = idx / BM, co = m0 + (idx % BM);
     wbyte[j] = (loc < WH && co < k.Cout) ? (unsigned)(seg * k.Cout + co) * 16u : OOB;
   }
-  const int wunits = 27 * k.Cout;
+  const int wunits = 9 * NSP * k.Cout;
 
   u32x4 rw[NW];
   unsigned rx[NS][CK];
@@ -269,10 +402,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
       const int pos = tid + 256 * s;                                                             \
       if (pos < npos) {                                                                          \
         float v[8];                                                                              \
-        _Pragma("unroll") for (int c = 0; c < CK; ++c) v[c] = __uint_as_float(rx[s][c]);         \
-        u32x4 h, m, l;                                                                           \
-        split8(v, h, m, l);                                                                      \
-        Xg[pos] = h; Xg[XP + pos] = m; Xg[2 * XP + pos] = l;                                     \
+        _Pragma("unroll") for (int c = 0; c < CK; ++c)                                           \
+          v[c] = (NSP == 2) ? __uint_as_float(rx[s][c]) * xscale : __uint_as_float(rx[s][c]);    \
+        u32x4 sp[NSP];                                                                           \
+        split8<NSP>(v, sp);                                                                      \
+        _Pragma("unroll") for (int q = 0; q < NSP; ++q) Xg[q * XP + pos] = sp[q];                \
       }                                                                                          \
     }                                                                                            \
   }
@@ -288,12 +422,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
   for (int h = 0; h < 2 * chunks; ++h) {
     const int c = h >> 1;
     if ((h & 1) == grp) {
-      // ---- compute half-step: 120 MFMAs on chunk c with the prefetch loads interleaved.  Chunks past
+      // ---- compute half-step: the MFMAs of chunk c with the prefetch loads interleaved.  Chunks past
       // the end lie beyond the buffer descriptors and read 0, so the loads need no guard.
       if (gvalid) {
         P3_GLOADX(c + 1);
         P3_GLOADW(c + 1 + grp);
-        split_mma_chunk<BM, XP, TM, TN, NW + NS * CK>(As[c & 1], Xg, aoff, bidx, acc);
+        split_mma_chunk<NSP, BM, XP, TM, TN, NW + NS * CK>(As[c & 1], Xg, aoff, bidx, acc);
       } else {
         P3_GLOADW(c + 1 + grp);
       }
@@ -324,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
         const int cc = cl + (r & 3) + 8 * (r >> 2);
         const int co = m0 + cc;
         if (co < k.Cout) {
-          float v = acc[i][j][r] + bs[cc];
+          float v = (NSP == 2 ? acc[i][j][r] * oscale : acc[i][j][r]) + bs[cc];
           if (k.act == 1) v = v > 0.f ? v : v * k.slope;
           else if (k.act == 2) v = tanhf(v);
           yb[(long long)co * HWo + q] = v;
@@ -335,14 +469,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16x3_pp_k(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-static bool split_enabled() {
-  static const bool on = getenv("DFMIR_CONV_FP32") == nullptr;   // A/B switch: keep the fp32-MFMA kernels
-  return on;
-}
-
-bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* w_packed, const float* bias,
-                              float* y, hipStream_t st, int* rc) {
-  if (!split_enabled()) return false;
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_packed,
+                              const float* bias, float* y, hipStream_t st, int* rc) {
+  const int mode = df_split_mode();
+  if (mode == 0 || (mode == 2 && !x_amax)) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->Cout <= 32 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
@@ -354,14 +484,17 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   if ((long long)((g->Cin + 7) / 8) * 27 * g->Cout * 16 >= (1LL << 31)) return false;
   if (worst_npos(g->Wo, (int)HWo, 128) > 399) return false;
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
-  const u32x4* ws = reinterpret_cast<const u32x4*>(w_packed + df_pack_tcc_floats(g->Cin, g->Cout, 9));
+  const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
+  const SplitScale sc{x_amax, split_trailer(w_packed, g->Cin, g->Cout, mode)};
   k.tiles_per_img = (int)((HWo + 255) / 256);
-  if (g->Cout > 64) {
-    dim3 grid((unsigned)(g->N * k.tiles_per_img), (unsigned)((g->Cout + 127) / 128));
-    conv3x3_bf16x3_pp_k<400, 128><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+  const bool big = g->Cout > 64;
+  dim3 grid((unsigned)(g->N * k.tiles_per_img), big ? (unsigned)((g->Cout + 127) / 128) : 1u);
+  if (mode == 2) {
+    if (big) conv3x3_split_pp_k<2, 400, 128><<<grid, 512, 0, st>>>(x, ws, bias, y, k, sc);
+    else conv3x3_split_pp_k<2, 400, 64><<<grid, 512, 0, st>>>(x, ws, bias, y, k, sc);
   } else {
-    dim3 grid((unsigned)(g->N * k.tiles_per_img), 1);
-    conv3x3_bf16x3_pp_k<400, 64><<<grid, 512, 0, st>>>(x, ws, bias, y, k);
+    if (big) conv3x3_split_pp_k<3, 400, 128><<<grid, 512, 0, st>>>(x, ws, bias, y, k, sc);
+    else conv3x3_split_pp_k<3, 400, 64><<<grid, 512, 0, st>>>(x, ws, bias, y, k, sc);
   }
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
@@ -369,10 +502,10 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
 }
 
 // =================================================================================================
-// Weight gradient on the bf16 pipe:   dWt[tap][ci][co] += sum_{n,p} X[n][ci][p + tap] * dY[n][co][p]
+// Weight gradient on the 16-bit pipe:   dWt[tap][ci][co] += sum_{n,p} X[n][ci][p + tap] * dY[n][co][p]
 //
 // The reduction index is the PIXEL, so an MFMA lane must hold 8 consecutive pixels of one channel (16 B
-// of bf16).  dY needs no shift; X is needed at the 9 tap shifts, and a +-1 pixel shift of a 16-B unit is
+// of halves).  dY needs no shift; X is needed at the 9 tap shifts, and a +-1 pixel shift of a 16-B unit is
 // a 2-byte misalignment that ds_read_b128 / ds_write_b128 only serve at ~1/4 rate
 // (scripts/ubench/lds_unaligned.hip).  The shift is therefore applied once, in registers, when the patch
 // is converted: a thread loads its 8 pixels plus the pixel on either side, splits the 10 values, and stores
@@ -383,7 +516,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
 // Workgroup = 512 threads = 8 waves = (2 tiles of 32 input channels) x (4 tiles of 32 output channels),
 // each wave holding the 9 tap accumulators [32 ci x 32 co].  One "run" = 2 image rows x 16 pixels
 // (2 MFMA K-steps, patch = 4 rows x 18 columns); global loads of the next run are in flight during the
-// 108-MFMA phase, conversion + LDS stores follow it.  The 6 products of a tap chain on one accumulator
+// MFMA phase, conversion + LDS stores follow it.  The products of a tap chain on one accumulator
 // (a dependent MFMA chain issues at full rate, scripts/ubench/mfma_peak.hip), so only one tap's operands
 // are live and the next tap's are read from LDS meanwhile.  Runs are split over blockIdx.x (split-K, fp32
 // atomics at the end, as conv3x3_wgrad_k).
@@ -391,15 +524,19 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
 struct WS3P {
   int N, Cin, Cout, H, W, pad_mode;
   int runs_per_row, runs_per_img, runs_total, runs_per_block;
+  const float* x_amax;    // NSP = 2: device max |x|, max |dy|
+  const float* dy_amax;
 };
 
-__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __restrict__ x,
-                                                                 const float* __restrict__ dy,
-                                                                 float* __restrict__ dwt, WS3P k) {
+template <int NSP>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __restrict__ x,
+                                                                const float* __restrict__ dy,
+                                                                float* __restrict__ dwt, WS3P k) {
+  using P = Prod<NSP>;
   constexpr int CT = 64, BC = 128;
   constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
-  __shared__ __attribute__((aligned(16))) u32x4 Xc[3 * 3 * 4 * XSLAB];   // 73,728 B
-  __shared__ __attribute__((aligned(16))) u32x4 Dy[3 * 2 * 2 * BC];      // 24,576 B
+  __shared__ __attribute__((aligned(16))) u32x4 Xc[NSP * 3 * 4 * XSLAB];
+  __shared__ __attribute__((aligned(16))) u32x4 Dy[NSP * 2 * 2 * BC];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wi = wid >> 2, wc = wid & 3;
@@ -409,6 +546,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __
   const int run_beg = blockIdx.x * k.runs_per_block;
   int run_end = run_beg + k.runs_per_block;
   if (run_end > k.runs_total) run_end = k.runs_total;
+
+  float xscale = 1.f, dscale = 1.f, oscale = 1.f;
+  if (NSP == 2) {
+    const int ex = scale_exp(k.x_amax[0]), ed = scale_exp(k.dy_amax[0]);
+    xscale = pow2f(ex); dscale = pow2f(ed); oscale = pow2f(-(ex + ed));
+  }
 
   // loader roles (512 threads): X group (patch row xr 0..3, half xu 0..1, channel xc 0..63) and
   // dY group (k-step dk, half du, channel dc 0..127)
@@ -451,33 +594,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __
     rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
     rdb = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_ == OOB ? OOB : db_ + 16u, 0, 0);        \
   }
-  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour.  Per split level: pairs
-  // (0,1)(2,3)(4,5)(6,7)(8,9) -> units dx=0 (cols -1..6) and dx=2 (cols 1..8); pairs (1,2)..(7,8) -> dx=1.
+  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour.  Pairs (0,1)(2,3)(4,5)(6,7)(8,9)
+  // make the units dx=0 (cols -1..6) and dx=2 (cols 1..8); pairs (1,2)..(7,8) make dx=1.  The residual of a
+  // pixel does not depend on which pair it was rounded in, so the second pairing only costs its conversions.
 #define WS_LSTORE()                                                                              \
   {                                                                                              \
     float r[10];                                                                                 \
     r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
-    _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                              \
-      unsigned pa[5], pb[4];                                                                     \
-      _Pragma("unroll") for (int i = 0; i < 5; ++i) pa[i] = pk_bf16(r[2 * i], r[2 * i + 1]);     \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) pb[i] = pk_bf16(r[2 * i + 1], r[2 * i + 2]); \
+    if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 10; ++e) r[e] *= xscale; }             \
+    unsigned pa[5][NSP], pb[4][NSP];                                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair<NSP>(r[2 * i], r[2 * i + 1], pa[i]); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) split_pair<NSP>(r[2 * i + 1], r[2 * i + 2], pb[i]); \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
       u32x4* dst = Xc + ((s * 3 * 4 + xr) * 2 + xu) * CT + xc;                                   \
-      dst[0] = u32x4{pa[0], pa[1], pa[2], pa[3]};                                                \
-      dst[4 * XSLAB] = u32x4{pb[0], pb[1], pb[2], pb[3]};                                        \
-      dst[8 * XSLAB] = u32x4{pa[1], pa[2], pa[3], pa[4]};                                        \
-      if (s < 2) {                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                          \
-          r[2 * i] -= __uint_as_float(pa[i] << 16);                                              \
-          r[2 * i + 1] -= __uint_as_float(pa[i] & 0xffff0000u);                                  \
-        }                                                                                        \
-      }                                                                                          \
+      dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
+      dst[4 * XSLAB] = u32x4{pb[0][s], pb[1][s], pb[2][s], pb[3][s]};                            \
+      dst[8 * XSLAB] = u32x4{pa[1][s], pa[2][s], pa[3][s], pa[4][s]};                            \
     }                                                                                            \
     float v[8];                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
-    u32x4 sp[3];                                                                                 \
-    split8(v, sp[0], sp[1], sp[2]);                                                              \
-    _Pragma("unroll") for (int s = 0; s < 3; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
+    if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] *= dscale; }              \
+    u32x4 sp[NSP];                                                                               \
+    split8<NSP>(v, sp);                                                                          \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
   }
 
   if (run_beg < run_end) {
@@ -492,35 +632,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __
   for (int run = run_beg; run < run_end; ++run) {
     const bool more = (run + 1) < run_end;
     if (more) WS_GLOAD(run + 1);
-    u32x4 b[3], a[2][3];
+    u32x4 b[NSP], a[2][NSP];
 #define WS_LOADA(set_, step_)                                                                    \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                  \
+  _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                                \
     a[set_][s] = Xc[((s * 3 + ((step_) % 3)) * 4 + (step_) / 9 + ((step_) % 9) / 3) * XSLAB + abase];
-#define WS_MMA(set_, t_, sa_, sb_)                                                               \
-  acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[set_][sa_]),    \
-                                                    __builtin_bit_cast(bf16x8, b[sb_]), acc[t_], 0, 0, 0);
     // 18 steps = (k-step ks, tap): step = ks*9 + ty*3 + dx; operands of step+1 are read during step
     WS_LOADA(0, 0)
 #pragma unroll
     for (int step = 0; step < 18; ++step) {
       if (step % 9 == 0) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) b[s] = Dy[(s * 2 + step / 9) * 2 * BC + bbase];
+        for (int s = 0; s < NSP; ++s) b[s] = Dy[(s * 2 + step / 9) * 2 * BC + bbase];
       }
       if (step + 1 < 18) WS_LOADA((step + 1) & 1, step + 1)
-      WS_MMA(step & 1, step % 9, 2, 0) WS_MMA(step & 1, step % 9, 0, 2) WS_MMA(step & 1, step % 9, 1, 1)
-      WS_MMA(step & 1, step % 9, 1, 0) WS_MMA(step & 1, step % 9, 0, 1) WS_MMA(step & 1, step % 9, 0, 0)
+#pragma unroll
+      for (int q = 0; q < P::N; ++q)
+        acc[step % 9] = mma16<NSP>(a[step & 1][P::A[q]], b[P::B[q]], acc[step % 9]);
     }
 #undef WS_LOADA
-#undef WS_MMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * NSP; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
     for (int step = 0; step < 18; ++step) {
-      const int nr = (step + 1 < 18 ? 3 : 0) + ((step + 1) % 9 == 0 && step + 1 < 18 ? 3 : 0);
+      const int nr = (step + 1 < 18 ? NSP : 0) + ((step + 1) % 9 == 0 && step + 1 < 18 ? NSP : 0);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < P::N; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i == P::N - 1) {
+#pragma unroll
+          for (int e = P::N; e < nr; ++e) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
       }
     }
     if (more) {
@@ -539,15 +681,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r]);
+        if (ci < k.Cin)
+          atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], NSP == 2 ? acc[t][r] * oscale : acc[t][r]);
       }
     }
   }
 }
 
-bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
-                                hipStream_t st, int* rc) {
-  if (!split_enabled()) return false;
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                                const float* dy_amax, float* dw_tcc, hipStream_t st, int* rc) {
+  const int mode = df_split_mode();
+  if (mode == 0 || (mode == 2 && !(x_amax && dy_amax))) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
@@ -555,7 +699,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax};
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;
@@ -568,7 +712,8 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if (want > maxs) want = maxs;
   k.runs_per_block = (int)((k.runs_total + want - 1) / want);
   const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
-  conv3x3_wgrad_bf16x3_k<<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
+  if (mode == 2) conv3x3_wgrad_split_k<2><<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
+  else conv3x3_wgrad_split_k<3><<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;

@@ -51,14 +51,26 @@ def set_conv_profiler(fn):
     _CONV_PROFILER[0] = fn
 
 
-def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp):
+def absmax(t):
+    """Device scalar max|t| (range probe of the fp16x2 split kernels, csrc/conv3x3s.hip)."""
+    out = torch.empty(1, device=t.device, dtype=torch.float32)
+    check(lib().dfmir_absmax(_p(t), t.numel(), _p(out), _st()))
+    return out
+
+
+def _wants_amax(K, stride, dil, Di, Cin, Cout):
+    """Shapes the split 3x3 kernels take (the C side decides; this only avoids useless probes)."""
+    return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
+
+
+def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None):
     N, Cin, Di, Hi, Wi = x5.shape
     y = torch.empty((N, Cout) + tuple(out_sp), device=x5.device, dtype=torch.float32)
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, out_sp[0], out_sp[1], out_sp[2], K[0], K[1], K[2],
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
 
     def launch():
-        check(lib().dfmir_conv_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _st()))
+        check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax), _p(w_tcc), _p(bias), _p(y), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -72,7 +84,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     return y
 
 
-def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None):
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None):
     """dW in the tap-major packing; `out` (same packing) is accumulated into when given."""
     N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
@@ -81,7 +93,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None):
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
     def launch():
-        check(lib().dfmir_conv_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+        check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax), _p(dy5), _p(dy_amax), _p(dw), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -173,7 +185,9 @@ class ConvFn(Function):
         sp = x5.shape[2:]
         out_sp = tuple((sp[i] + 2 * p3[i] - K[i]) // stride + 1 for i in range(3))
         w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
-        y5 = conv_raw(x5, w_tcc, bias, weight.shape[0], K, stride, p3, 1, pad_mode, act, slope, out_sp)
+        x_amax = absmax(x5) if _wants_amax(K, stride, 1, x5.shape[2], x5.shape[1], weight.shape[0]) else None
+        y5 = conv_raw(x5, w_tcc, bias, weight.shape[0], K, stride, p3, 1, pad_mode, act, slope, out_sp, x_amax)
+        ctx.x_amax = x_amax
         ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
         ctx.save_for_backward(x5, weight, y5 if act else None)
         ctx.has_bias = bias is not None
@@ -191,6 +205,8 @@ class ConvFn(Function):
             dy5 = dpre
         dx = dw = db = None
         Cout, Cin = weight.shape[0], weight.shape[1]
+        # dY feeds the dgrad conv (as its input) and the wgrad: one range probe for both
+        dy_amax = absmax(dy5) if (_wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None) else None
         if ctx.needs_input_grad[0]:
             wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
             in_sp = tuple(x5.shape[2:])
@@ -198,7 +214,7 @@ class ConvFn(Function):
                 # full correlation onto the reflect-padded frame, then fold the halo back
                 padp = tuple(K[i] - 1 for i in range(3))
                 out_sp = tuple(in_sp[i] + 2 * p3[i] for i in range(3))
-                dxp = conv_raw(dy5, wd, None, Cin, K, 1, padp, 1, 0, 0, 0.0, out_sp)
+                dxp = conv_raw(dy5, wd, None, Cin, K, 1, padp, 1, 0, 0, 0.0, out_sp, dy_amax)
                 if p3[0] != 0 or p3[1] != p3[2]:
                     raise DfmirHipError("reflect padding is 2-D, symmetric only")
                 dx5 = torch.empty_like(x5)
@@ -206,7 +222,7 @@ class ConvFn(Function):
                                                     p3[1], _st()))
             else:
                 padp = tuple(K[i] - 1 - p3[i] for i in range(3))
-                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp)
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax)
             dx = dx5 if nd == 3 else dx5.squeeze(2)
         defer = (_DEFER["on"] and owner is not None and getattr(owner, "weight", None) is not None
                  and owner.weight.grad is not None and owner.weight.grad.is_contiguous())
@@ -214,9 +230,10 @@ class ConvFn(Function):
             if defer:
                 T = K[0] * K[1] * K[2]
                 conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode,
-                               out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device))
+                               out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device),
+                               x_amax=ctx.x_amax, dy_amax=dy_amax)
             else:
-                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode)
+                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax)
                 dw = weight_unpack(dwt, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]

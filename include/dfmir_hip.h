@@ -30,9 +30,9 @@ const char* dfmir_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Convolutions (implicit GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, and -- for the
- * 2-D 3x3 stride-1 layers with more than 64 output channels -- fp32 emulated exactly on
- * v_mfma_f32_32x32x16_bf16 by 3-way operand splitting, csrc/conv3x3s.hip; DFMIR_CONV_FP32=1 keeps the
- * fp32 instruction there too).
+ * 2-D 3x3 stride-1 layers with more than 32 output channels -- fp32 emulated on the 16-bit matrix pipe by
+ * operand splitting, csrc/conv3x3s.hip: scaled fp16x2 (default) or bf16x3 (DFMIR_CONV_SPLIT=bf16x3);
+ * DFMIR_CONV_FP32=1 keeps the fp32 instruction there too).
  * Replaces nn.Conv2d / nn.Conv3d (+ the ReflectionPad2d in front of it, + the LeakyReLU/Tanh
  * behind it) at: models/networks.py:982-983, 995, 1016-1023 (ResnetGenerator),
  * models/networks.py:1201,1214 (ResnetBlock), models/networks.py:587-595 (PatchSampleF MLP,
@@ -60,9 +60,20 @@ typedef struct DfConvGeom {
 /* y[N,Cout,Do,Ho,Wo] = act(conv(x[N,Cin,Di,Hi,Wi], w) + bias).  bias may be NULL. */
 int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
                    float* y, void* stream);
+/* The same with max|x| supplied (device scalar written by dfmir_absmax on the same stream).  The maximum
+ * lets the 2-D 3x3 stride-1 kernels take the scaled fp16x2 split form (csrc/conv3x3s.hip: 3 matrix products
+ * per fp32 product instead of bf16x3's 6); without it -- dfmir_conv_fwd -- those layers run bf16x3
+ * (DFMIR_CONV_SPLIT=bf16x3) or fp32 MFMA.  x_amax may be NULL. */
+int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+                          const float* bias, float* y, void* stream);
+/* out[0] = max_i |x[i]| (NaN counts as +inf).  Replaces nothing in the reference: it is the range probe of the
+ * fp16x2 split. */
+int dfmir_absmax(const float* x, long long n, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                      void* stream);
+int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
+                            const float* dy_amax, float* dw_tcc, void* stream);
 /* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
 int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
 /* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
