@@ -35,8 +35,8 @@ _SIGS = {
     "dfmir_tapstack_bwd": [P, P] + [c_int] * 7 + [P],
     "dfmir_tapsum_fwd": [P, P, P] + [c_int] * 10 + [c_float, P],
     "dfmir_tapsum_bwd": [P, P] + [c_int] * 9 + [P],
-    "dfmir_instnorm_fwd": [P, P, P, P, P, c_int, c_longlong, c_float, c_int, P],
-    "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P],
+    "dfmir_instnorm_fwd": [P, P, P, P, P, c_int, c_longlong, c_float, c_int, P, P],
+    "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P, P],
     "dfmir_act_bwd": [P, P, P, c_longlong, c_int, c_float, P],
     "dfmir_blur_down_fwd": [P, P, c_int, c_int, c_int, P],
     "dfmir_blur_down_bwd": [P, P, c_int, c_int, c_int, P],

@@ -456,7 +456,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
                                 const float* dy_amax, float* dw_tcc, hipStream_t st, int* rc);
 int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st);
-int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st);
+int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc);
 bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
@@ -493,7 +493,7 @@ extern "C" int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const 
 }
 extern "C" int dfmir_absmax(const float* x, long long n, float* out, void* stream) {
   DF_ARG_CHECK(x && out && n > 0);
-  const int rc = df_absmax_launch(x, n, out, (hipStream_t)stream);
+  const int rc = df_absmax_launch(x, n, out, (hipStream_t)stream, false);
   if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }

@@ -6,9 +6,10 @@
 //        bf16 has fp32's exponent range: no scaling, exact for any input.
 //   NSP = 2, "fp16x2":  a = (a0 + a1) / s  with  a0 = fp16(s*a), a1 = fp16(s*a - a0)   (11 + 11 bits, +-2^-23)
 //        a*b ~= a0b0 + a0b1 + a1b0                              3 MFMAs, dropped a1b1 <= 2^-22 |ab|
-//        fp16 has 5 exponent bits, so each tensor is scaled by a power of two s = 2^(13 - ilogb(max|a|))
-//        taken from a device-side max|a| (dfmir_absmax; weights: at pack time); elements more than 2^16
-//        below the tensor maximum keep a fixed absolute error of 2^-38 max|a| instead of a relative one.
+//        fp16 has 5 exponent bits, so each tensor is scaled by a power of two s = 2^(14 - ilogb(max|a|))
+//        taken from a device-side max|a| (dfmir_absmax; weights: at pack time).  Elements within 2^-17 of the
+//        tensor maximum keep 22 bits; smaller ones degrade gradually (fixed absolute error 2^-40 max|a|):
+//        18 bits at 1e-6 of the maximum, 11 bits at 4e-9.
 //        The result is rescaled by 2^-(ea+eb) in the epilogue.  Half the matrix-pipe work of bf16x3.
 //
 // Products are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.  Against an fp64 convolution both forms
@@ -76,16 +77,16 @@ template <int NSP> struct Prod;
 template <> struct Prod<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0}; };
 template <> struct Prod<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}; };
 
-// power-of-two scale exponent of a tensor whose max |.| is amax: |a| * 2^e < 2^14
+// power-of-two scale exponent of a tensor whose max |.| is amax: |a| * 2^e < 2^15 (fp16 max 65504)
 __device__ __forceinline__ int scale_exp(float amax) {
   const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
-  int e = (amax > 0.f) ? 13 - be : 0;
+  int e = (amax > 0.f) ? 14 - be : 0;
   e = e < -60 ? -60 : (e > 60 ? 60 : e);
   return e;
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
-// ---- max |x| of a tensor (device scalar, must be zeroed by the caller: dfmir_absmax does)
+// ---- max |x| of a tensor, folded into a device scalar: out = max(out, max|x|)
 __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
   __shared__ float red[8];
   float m = 0.f;
@@ -104,12 +105,15 @@ __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, lon
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     if (!(m == m)) m = __uint_as_float(0x7f800000u);   // NaN -> +inf so that it survives the integer max
-    atomicMax(out, __float_as_uint(m));                // non-negative floats order like their bit patterns
+    // non-negative floats order like their bit patterns; the plain read keeps the blocks off one atomic
+    if (__float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(out, __float_as_uint(m));
   }
 }
-int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
+int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first) {
+  if (zero_first) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
   long long blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
@@ -174,7 +178,7 @@ int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipS
   u32x4* sec = reinterpret_cast<u32x4*>(split_section(packed, K, M));
   float* tr = split_trailer(packed, K, M, mode);
   if (mode == 2) {
-    const int rc = df_absmax_launch(w_tcc, (long long)9 * K * M, tr, st);
+    const int rc = df_absmax_launch(w_tcc, (long long)9 * K * M, tr, st, true);
     if (rc) return rc;
     weight_split_k<2><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, K, M);
   } else {

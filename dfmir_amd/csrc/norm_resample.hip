@@ -81,7 +81,8 @@ template <int NT, int E>
 __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict__ x,
                                                          const float* __restrict__ res,
                                                          float* __restrict__ y, float* __restrict__ mean_o,
-                                                         float* __restrict__ rstd_o, float eps, int relu) {
+                                                         float* __restrict__ rstd_o, float eps, int relu,
+                                                         float* __restrict__ amax) {
   __shared__ float sm[17];
   constexpr long long S = (long long)NT * 4 * E;
   const long long base = (long long)blockIdx.x * S;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
   }
   const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
   float4* y4 = reinterpret_cast<float4*>(y + base);
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     float4 o;
@@ -121,14 +123,17 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     y4[threadIdx.x + NT * i] = o;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (amax) publish_absmax(am, sm, amax);   // range probe for the next conv's fp16x2 split
 }
 template <int NT, int E>
 __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict__ dy,
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i,
-                                                         float* __restrict__ dx, int relu) {
+                                                         float* __restrict__ dx, int relu,
+                                                         float* __restrict__ amax) {
   __shared__ float sm[17];
   constexpr long long S = (long long)NT * 4 * E;
   const long long base = (long long)blockIdx.x * S;
@@ -155,13 +160,16 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
   const float m1 = block_sum(s1, sm) / (float)S;
   const float m2 = block_sum(s2, sm) / (float)S;
   float4* d4 = reinterpret_cast<float4*>(dx + base);
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     float4 o;
     o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
     o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
     d4[threadIdx.x + NT * i] = o;
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (amax) publish_absmax(am, sm, amax);
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
@@ -506,27 +514,42 @@ __global__ void scale_k(const float* __restrict__ x, float* __restrict__ y, long
 }
 
 // ---------------------------------------------------------------------------------------------
+int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
+// y_amax / dx_amax (may be NULL): device scalar that receives max(old value, max |output|) -- the range probe the
+// fp16x2 conv kernels need for their next input, produced while the output is still in registers.
 extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
-                                  int planes, long long S, float eps, int relu, void* stream) {
+                                  int planes, long long S, float eps, int relu, float* y_amax, void* stream) {
   DF_ARG_CHECK(x && y && mean && rstd && planes > 0 && S > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (S == 4096) instnorm_fwd_reg_k<256, 4><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu);
-  else if (S == 16384) instnorm_fwd_reg_k<256, 16><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu);
-  else if (S == 65536) instnorm_fwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(x, res, y, mean, rstd, eps, relu);
-  else
-  instnorm_fwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(x, res, y, mean, rstd, S, eps, relu);
+  if (S == 4096) instnorm_fwd_reg_k<256, 4><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu, y_amax);
+  else if (S == 16384) instnorm_fwd_reg_k<256, 16><<<planes, 256, 0, st>>>(x, res, y, mean, rstd, eps, relu, y_amax);
+  else if (S == 65536) instnorm_fwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(x, res, y, mean, rstd, eps, relu, y_amax);
+  else {
+    instnorm_fwd_k<<<planes, 256, 0, st>>>(x, res, y, mean, rstd, S, eps, relu);
+    if (y_amax) {
+      DF_LAUNCH_CHECK();
+      const int rc = df_absmax_launch(y, (long long)planes * S, y_amax, st, false);
+      if (rc) return df_set_error(rc, __FILE__, __LINE__);
+    }
+  }
   DF_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                                  float* dx, int planes, long long S, int relu, void* stream) {
+                                  float* dx, int planes, long long S, int relu, float* dx_amax, void* stream) {
   DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu);
-  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu);
-  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu);
-  else
-  instnorm_bwd_k<<<planes, 256, 0, (hipStream_t)stream>>>(dy, x, mean, rstd, dx, S, relu);
+  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
+  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
+  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
+  else {
+    instnorm_bwd_k<<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, S, relu);
+    if (dx_amax) {
+      DF_LAUNCH_CHECK();
+      const int rc = df_absmax_launch(dx, (long long)planes * S, dx_amax, st, false);
+      if (rc) return df_set_error(rc, __FILE__, __LINE__);
+    }
+  }
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -51,11 +51,38 @@ def set_conv_profiler(fn):
     _CONV_PROFILER[0] = fn
 
 
+# Range probes (max |t|) of the fp16x2 split kernels (csrc/conv3x3s.hip).  Slots come zero-initialised from
+# a pool (one fill per 4096 probes).  A producer that computes the maximum as a by-product (InstanceNorm
+# forward / backward) tags its output tensor with it; `amax_of` reuses the tag while the tensor is unmodified.
+_AMAX_POOL = {"buf": None, "next": 0}
+
+
+def amax_slot(device):
+    pool = _AMAX_POOL
+    if pool["buf"] is None or pool["next"] >= pool["buf"].numel() or pool["buf"].device != device:
+        pool["buf"] = torch.zeros(4096, device=device, dtype=torch.float32)
+        pool["next"] = 0
+    i = pool["next"]
+    pool["next"] = i + 1
+    return pool["buf"][i:i + 1]
+
+
 def absmax(t):
-    """Device scalar max|t| (range probe of the fp16x2 split kernels, csrc/conv3x3s.hip)."""
-    out = torch.empty(1, device=t.device, dtype=torch.float32)
+    out = amax_slot(t.device)
     check(lib().dfmir_absmax(_p(t), t.numel(), _p(out), _st()))
     return out
+
+
+def tag_amax(t, slot):
+    t._df_amax = (slot, t._version, t.data_ptr())
+    return t
+
+
+def amax_of(t):
+    tag = getattr(t, "_df_amax", None)
+    if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr():
+        return tag[0]
+    return absmax(t)
 
 
 def _wants_amax(K, stride, dil, Di, Cin, Cout):
@@ -185,7 +212,9 @@ class ConvFn(Function):
         sp = x5.shape[2:]
         out_sp = tuple((sp[i] + 2 * p3[i] - K[i]) // stride + 1 for i in range(3))
         w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
-        x_amax = absmax(x5) if _wants_amax(K, stride, 1, x5.shape[2], x5.shape[1], weight.shape[0]) else None
+        x_amax = None
+        if _wants_amax(K, stride, 1, x5.shape[2], x5.shape[1], weight.shape[0]):
+            x_amax = amax_of(x) if x.is_contiguous() else absmax(x5)
         y5 = conv_raw(x5, w_tcc, bias, weight.shape[0], K, stride, p3, 1, pad_mode, act, slope, out_sp, x_amax)
         ctx.x_amax = x_amax
         ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
@@ -206,7 +235,9 @@ class ConvFn(Function):
         dx = dw = db = None
         Cout, Cin = weight.shape[0], weight.shape[1]
         # dY feeds the dgrad conv (as its input) and the wgrad: one range probe for both
-        dy_amax = absmax(dy5) if (_wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None) else None
+        dy_amax = None
+        if _wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None:
+            dy_amax = amax_of(dy) if dy.is_contiguous() else absmax(dy5)
         if ctx.needs_input_grad[0]:
             wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
             in_sp = tuple(x5.shape[2:])
@@ -337,8 +368,10 @@ class InstNormFn(Function):
         mean = torch.empty(planes, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         r = _c(res) if res is not None else None
+        slot = amax_slot(x.device)
         check(lib().dfmir_instnorm_fwd(_p(x), _p(r), _p(y), _p(mean), _p(rstd), planes, S, float(eps),
-                                       int(relu), _st()))
+                                       int(relu), _p(slot), _st()))
+        _LAST_AMAX[0] = slot
         ctx.save_for_backward(x, mean, rstd)
         ctx.relu = int(relu)
         ctx.has_res = res is not None
@@ -354,13 +387,20 @@ class InstNormFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu, _st()))
+            slot = amax_slot(x.device)
+            check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
+                                           _p(slot), _st()))
+            tag_amax(dx, slot)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
         return dx, dres, None, None
 
 
+_LAST_AMAX = [None]
+
+
 def instance_norm(x, res=None, relu=False, eps=1e-5):
-    return InstNormFn.apply(x, res, relu, eps)
+    y = InstNormFn.apply(x, res, relu, eps)
+    return tag_amax(y, _LAST_AMAX[0])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 1
+#define DFMIR_ABI_VERSION 2
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -66,8 +66,9 @@ int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, cons
  * (DFMIR_CONV_SPLIT=bf16x3) or fp32 MFMA.  x_amax may be NULL. */
 int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
                           const float* bias, float* y, void* stream);
-/* out[0] = max_i |x[i]| (NaN counts as +inf).  Replaces nothing in the reference: it is the range probe of the
- * fp16x2 split. */
+/* out[0] = max(out[0], max_i |x[i]|) (NaN counts as +inf; the caller zero-initialises out).  Replaces nothing in
+ * the reference: it is the range probe of the fp16x2 split.  dfmir_instnorm_fwd/bwd can produce the same value for
+ * their output as a by-product (y_amax / dx_amax). */
 int dfmir_absmax(const float* x, long long n, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
@@ -106,9 +107,9 @@ int dfmir_tapsum_bwd(const float* dy, float* dz, int N, int C, int Hz, int Wz, i
  * y = res + relu?((x-mean)*rstd) ; mean/rstd [planes] are saved for backward.
  * ---------------------------------------------------------------------------------------- */
 int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
-                       int planes, long long S, float eps, int relu, void* stream);
+                       int planes, long long S, float eps, int relu, float* y_amax, void* stream);
 int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                       float* dx, int planes, long long S, int relu, void* stream);
+                       float* dx, int planes, long long S, int relu, float* dx_amax, void* stream);
 
 /* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
 int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,

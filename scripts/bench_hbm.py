@@ -52,10 +52,10 @@ for name, shp in (("instnorm [32,128,256,256]", (32, 128, 256, 256)), ("instnorm
     y = torch.empty_like(x); mean = torch.empty(shp[0] * shp[1], device=dev); rstd = torch.empty_like(mean)
     from dfmir_amd._lib import lib, check
     S = shp[2] * shp[3]
-    ms = timeit(lambda: check(lib().dfmir_instnorm_fwd(ops._p(x), None, ops._p(y), ops._p(mean), ops._p(rstd), shp[0] * shp[1], S, 1e-5, 1, ops._st())), 10)
+    ms = timeit(lambda: check(lib().dfmir_instnorm_fwd(ops._p(x), None, ops._p(y), ops._p(mean), ops._p(rstd), shp[0] * shp[1], S, 1e-5, 1, None, ops._st())), 10)
     report(name + " fwd+relu", 8 * x.numel(), ms)
     dy = torch.randn_like(x); dx = torch.empty_like(x)
-    ms = timeit(lambda: check(lib().dfmir_instnorm_bwd(ops._p(dy), ops._p(x), ops._p(mean), ops._p(rstd), ops._p(dx), shp[0] * shp[1], S, 1, ops._st())), 10)
+    ms = timeit(lambda: check(lib().dfmir_instnorm_bwd(ops._p(dy), ops._p(x), ops._p(mean), ops._p(rstd), ops._p(dx), shp[0] * shp[1], S, 1, None, ops._st())), 10)
     report(name + " bwd", 12 * x.numel(), ms)
 # ---- blur / pad / adam
 x = torch.randn(32, 128, 256, 256, device=dev)
