@@ -532,8 +532,14 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     float* ys = y + (long long)n0 * (out_img / 4);
     const long long Ps = (long long)k.g.N * g->Do * g->Ho * g->Wo;
     if (g->Cout > 64) {
-      dim3 grid((unsigned)((Ps + 127) / 128), (unsigned)((g->Cout + 127) / 128));
-      conv_mfma_k<2, 2, 2, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      const long long big = ((Ps + 127) / 128) * ((g->Cout + 127) / 128);
+      if (big < 256) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
+        dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));
+        conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      } else {
+        dim3 grid((unsigned)((Ps + 127) / 128), (unsigned)((g->Cout + 127) / 128));
+        conv_mfma_k<2, 2, 2, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      }
     } else if (g->Cout > 32) {
       dim3 grid((unsigned)((Ps + 255) / 256), 1);
       conv_mfma_k<1, 4, 2, 2><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);

@@ -532,18 +532,21 @@ struct WS3P {
   const float* dy_amax;
 };
 
-template <int NSP>
+// BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
+// BC = 64 : 8 waves = 2 ci tiles x 2 co tiles x 2 k-steps (the two k-step waves of a tile both add their
+//           partial sums atomically, like the split-K workgroups do).
+template <int NSP, int BC>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __restrict__ x,
                                                                 const float* __restrict__ dy,
                                                                 float* __restrict__ dwt, WS3P k) {
   using P = Prod<NSP>;
-  constexpr int CT = 64, BC = 128;
+  constexpr int CT = 64, NWC = BC / 32, KS = 4 / NWC, NSTEP = 18 / KS;
   constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
   __shared__ __attribute__((aligned(16))) u32x4 Xc[NSP * 3 * 4 * XSLAB];
   __shared__ __attribute__((aligned(16))) u32x4 Dy[NSP * 2 * 2 * BC];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wi = wid >> 2, wc = wid & 3;
+  const int wc = wid % NWC, wi = (wid / NWC) & 1, kh = wid / (2 * NWC);   // kh: this wave's k-step when KS == 2
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HW = k.H * k.W;
   const int ci0 = blockIdx.y * CT, co0 = blockIdx.z * BC;
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   // loader roles (512 threads): X group (patch row xr 0..3, half xu 0..1, channel xc 0..63) and
   // dY group (k-step dk, half du, channel dc 0..127)
   const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
-  const int dc = tid & 127, du = (tid >> 7) & 1, dk = tid >> 8;
+  const int dc = tid % BC, du = (tid / BC) & 1, dk = (tid / (2 * BC)) & 1;
+  const bool dload = tid < 4 * BC;                   // BC = 64: 256 dY groups for 512 threads
   const unsigned hw4 = (unsigned)HW * 4u;
   constexpr unsigned OOB = 0x80000000u;
 
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
     rxl = __builtin_amdgcn_raw_buffer_load_b32(bx_, (ol_ < 0 || !cok_) ? OOB : cb_ + (unsigned)ol_ * 4u, 0, 0); \
     rxr = __builtin_amdgcn_raw_buffer_load_b32(bx_, (or_ < 0 || !cok_) ? OOB : cb_ + (unsigned)or_ * 4u, 0, 0); \
-    const unsigned db_ = (co0 + dc >= k.Cout) ? OOB                                              \
+    const unsigned db_ = (co0 + dc >= k.Cout || !dload) ? OOB                                    \
         : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + dk) * k.W + 16 * xs_ + 8 * du) * 4u;    \
     rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
     rdb = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_ == OOB ? OOB : db_ + 16u, 0, 0);        \
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] *= dscale; }              \
     u32x4 sp[NSP];                                                                               \
     split8<NSP>(v, sp);                                                                          \
-    _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
+    if (dload) { _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; } \
   }
 
   if (run_beg < run_end) {
@@ -631,8 +635,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   __syncthreads();
 
   // operand unit indices of this lane: A = Xc[((s*3 + dx)*4 + row)*2 + lhi][ci], B = Dy[(s*2 + ks)*2 + lhi][co]
-  const int abase = lhi * CT + wi * 32 + l31;
-  const int bbase = lhi * BC + wc * 32 + l31;
+  const int abase = lhi * CT + wi * 32 + l31 + (KS == 2 ? kh * XSLAB : 0);
+  const int bbase = lhi * BC + wc * 32 + l31 + (KS == 2 ? kh * 2 * BC : 0);
   for (int run = run_beg; run < run_end; ++run) {
     const bool more = (run + 1) < run_end;
     if (more) WS_GLOAD(run + 1);
@@ -640,15 +644,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 #define WS_LOADA(set_, step_)                                                                    \
   _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                                \
     a[set_][s] = Xc[((s * 3 + ((step_) % 3)) * 4 + (step_) / 9 + ((step_) % 9) / 3) * XSLAB + abase];
-    // 18 steps = (k-step ks, tap): step = ks*9 + ty*3 + dx; operands of step+1 are read during step
+    // NSTEP steps = (k-step ks, tap): step = ks*9 + ty*3 + dx (KS == 2: this wave's k-step sits in abase /
+    // bbase and step = tap); operands of step+1 are read during step
     WS_LOADA(0, 0)
 #pragma unroll
-    for (int step = 0; step < 18; ++step) {
+    for (int step = 0; step < NSTEP; ++step) {
       if (step % 9 == 0) {
 #pragma unroll
         for (int s = 0; s < NSP; ++s) b[s] = Dy[(s * 2 + step / 9) * 2 * BC + bbase];
       }
-      if (step + 1 < 18) WS_LOADA((step + 1) & 1, step + 1)
+      if (step + 1 < NSTEP) WS_LOADA((step + 1) & 1, step + 1)
 #pragma unroll
       for (int q = 0; q < P::N; ++q)
         acc[step % 9] = mma16<NSP>(a[step & 1][P::A[q]], b[P::B[q]], acc[step % 9]);
@@ -657,8 +662,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 #pragma unroll
     for (int i = 0; i < 2 * NSP; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int step = 0; step < 18; ++step) {
-      const int nr = (step + 1 < 18 ? NSP : 0) + ((step + 1) % 9 == 0 && step + 1 < 18 ? NSP : 0);
+    for (int step = 0; step < NSTEP; ++step) {
+      const int nr = (step + 1 < NSTEP ? NSP : 0) + ((step + 1) % 9 == 0 && step + 1 < NSTEP ? NSP : 0);
 #pragma unroll
       for (int i = 0; i < P::N; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -699,7 +704,8 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
-  if (g->Cout < 128 || g->Cin < 64) return false;
+  if (g->Cout < 64 || g->Cin < 64) return false;
+  const bool wide = g->Cout > 64;
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
@@ -708,7 +714,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;
   k.runs_total = (int)total;
-  const unsigned ny = (g->Cin + 63) / 64, nz = (g->Cout + 127) / 128;
+  const unsigned ny = (g->Cin + 63) / 64, nz = wide ? (g->Cout + 127) / 128 : 1;
   long long want = 256 / ((long long)ny * nz);    // one resident round: 1 workgroup per CU
   if (want < 1) want = 1;
   long long maxs = (k.runs_total + 7) / 8;        // >= 8 runs per block
@@ -716,8 +722,14 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if (want > maxs) want = maxs;
   k.runs_per_block = (int)((k.runs_total + want - 1) / want);
   const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
-  if (mode == 2) conv3x3_wgrad_split_k<2><<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
-  else conv3x3_wgrad_split_k<3><<<dim3(nx, ny, nz), 512, 0, st>>>(x, dy, dw_tcc, k);
+  const dim3 grid(nx, ny, nz);
+  if (mode == 2) {
+    if (wide) conv3x3_wgrad_split_k<2, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+    else conv3x3_wgrad_split_k<2, 64><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+  } else {
+    if (wide) conv3x3_wgrad_split_k<3, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+    else conv3x3_wgrad_split_k<3, 64><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+  }
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;
