@@ -81,7 +81,7 @@ template <> struct Prod<2> { static constexpr int N = 3; static constexpr int A[
 __device__ __forceinline__ int scale_exp(float amax) {
   const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
   int e = (amax > 0.f) ? 14 - be : 0;
-  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);   // 2^e and 2^-e stay normal fp32 numbers
   return e;
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
@@ -302,12 +302,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
   u32x4* __restrict__ Xg = Xs[grp];
 
   // scales (NSP = 2): input scaled by 2^ex when it is split, result rescaled by 2^-(ex+ew)
-  float xscale = 1.f, oscale = 1.f;
+  float xscale = 1.f, oscale = 1.f, oscale2 = 1.f;   // two factors: 2^-(ex+ew) alone can leave fp32's range
   if (NSP == 2) {
     const int ex = scale_exp(sc.x_amax[0]);
     const int ew = (int)sc.w_trailer[1];
     xscale = pow2f(ex);
-    oscale = pow2f(-(ex + ew));
+    oscale = pow2f(-ex);
+    oscale2 = pow2f(-ew);
   }
 
   constexpr unsigned OOB = 0x80000000u;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
         const int cc = cl + (r & 3) + 8 * (r >> 2);
         const int co = m0 + cc;
         if (co < k.Cout) {
-          float v = (NSP == 2 ? acc[i][j][r] * oscale : acc[i][j][r]) + bs[cc];
+          float v = (NSP == 2 ? acc[i][j][r] * oscale * oscale2 : acc[i][j][r]) + bs[cc];
           if (k.act == 1) v = v > 0.f ? v : v * k.slope;
           else if (k.act == 2) v = tanhf(v);
           yb[(long long)co * HWo + q] = v;
@@ -554,10 +555,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   int run_end = run_beg + k.runs_per_block;
   if (run_end > k.runs_total) run_end = k.runs_total;
 
-  float xscale = 1.f, dscale = 1.f, oscale = 1.f;
+  float xscale = 1.f, dscale = 1.f, oscale = 1.f, oscale2 = 1.f;
   if (NSP == 2) {
     const int ex = scale_exp(k.x_amax[0]), ed = scale_exp(k.dy_amax[0]);
-    xscale = pow2f(ex); dscale = pow2f(ed); oscale = pow2f(-(ex + ed));
+    xscale = pow2f(ex); dscale = pow2f(ed); oscale = pow2f(-ex); oscale2 = pow2f(-ed);
   }
 
   // loader roles (512 threads): X group (patch row xr 0..3, half xu 0..1, channel xc 0..63) and
@@ -691,7 +692,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
         if (ci < k.Cin)
-          atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], NSP == 2 ? acc[t][r] * oscale : acc[t][r]);
+          atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co],
+                    NSP == 2 ? acc[t][r] * oscale * oscale2 : acc[t][r]);
       }
     }
   }

@@ -101,6 +101,44 @@ def test_conv2d(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
 
 
+@pytest.mark.parametrize("xs,ws,gs", [(1e-12, 1.0, 1e-14), (3e9, 1e-6, 7e5), (1.0, 40.0, 1e-30), (0.0, 1.0, 1.0)],
+                         ids=["tiny", "huge", "denormal_grads", "zero_input"])
+def test_conv3x3_split_dynamic_range(ops, xs, ws, gs):
+    """The fp16x2 split rescales every tensor by a power of two taken from its own maximum: inputs, weights and
+    gradients of any magnitude (down to denormal gradients, all-zero inputs) must come out at fp32 accuracy --
+    checked against an fp64 convolution, relative to each result's own scale."""
+    Cin, Cout, N, H, W = 64, 128, 2, 16, 32
+    x = (C.randn(71, N, Cin, H, W) * xs).to(DEV).requires_grad_()
+    w = (C.randn(72, Cout, Cin, 3, 3) * ws / 24.0).to(DEV).requires_grad_()
+    cot = (C.randn(73, N, Cout, H, W) * gs).to(DEV)
+    y = ops.conv(x, w, None, None, 1, 1, 1, 0, 0.0)
+    (y * cot).sum().backward()
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    yd = F.conv2d(F.pad(xd, (1, 1, 1, 1), mode="reflect"), wd)
+    (yd * cot.double()).sum().backward()
+    for got, ref, what in ((y, yd, "y"), (x.grad, xd.grad, "dx"), (w.grad, wd.grad, "dw")):
+        assert torch.isfinite(got).all(), what
+        scale = float(ref.abs().max())
+        err = float((got.double() - ref.detach()).abs().max())
+        assert err <= 2e-5 * scale + 0.0 * scale, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def test_conv3x3_split_channel_magnitude_spread(ops):
+    """Per-tensor scaling with output-gradient channels 1e6 apart: every channel's weight gradient must still be
+    accurate relative to ITS OWN scale (the small channels sit 2^-20 below the tensor maximum)."""
+    Cin, Cout, N, H, W = 64, 128, 2, 16, 32
+    x = C.randn(81, N, Cin, H, W).to(DEV)
+    mag = torch.logspace(0, -6, Cout).view(1, Cout, 1, 1)
+    dy = (C.randn(82, N, Cout, H, W) * mag).to(DEV)
+    dwt = ops.conv_wgrad_raw(x.unsqueeze(2), dy.unsqueeze(2), (1, 3, 3), 1, (0, 1, 1), 0,
+                             x_amax=ops.absmax(x), dy_amax=ops.absmax(dy))
+    dw = ops.weight_unpack(dwt, (Cout, Cin, 3, 3)).double()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+    per_ch_err = (dw - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+    assert float(per_ch_err.max()) < 2e-4, per_ch_err.max()
+    assert float(per_ch_err[:64].max()) < 2e-6, per_ch_err[:64].max()   # channels within 1e-3 of the maximum
+
+
 @pytest.mark.parametrize("cfg", [(1, 64, 7, 3, True, 0, 2, 20, 24), (64, 1, 7, 3, True, 2, 2, 20, 24),
                                  (1, 8, 5, 2, False, 1, 1, 9, 11), (6, 2, 5, 2, True, 0, 1, 12, 10)],
                          ids=["1to64_k7_refl", "64to1_k7_refl_tanh", "1to8_k5_zero_leaky", "6to2_k5_refl"])
