@@ -391,6 +391,133 @@ __global__ void blur_up_bwd_k(const float* __restrict__ dy, float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 4-outputs-per-thread forms of the four resampling kernels (W % 8 == 0 / W % 4 == 0, even H): 16-B loads
+// and stores, each loaded value reused by up to 4 outputs, 32-bit index math, one grid row per plane.
+// Same arithmetic (and summation order) as the scalar kernels above, which remain the general fallback.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blur_down_fwd_v4_k(const float* __restrict__ x, float* __restrict__ y,
+                                                          int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1, G = Wo >> 2;          // G groups of 4 outputs per row
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Ho * G) return;
+  const int oy = i / G, ox = (i - oy * G) << 2;
+  const float* xp = x + (long long)blockIdx.y * H * W;
+  float h[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int iy = refl1(2 * oy + a - 1, H);
+    const float* row = xp + iy * W + 2 * ox;
+    const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 4);
+    const float l = ox ? row[-1] : row[1];                  // reflect: column -1 -> column 1
+    const float v[9] = {l, v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float rs = 0.f;
+      rs += 0.25f * v[2 * j]; rs += 0.5f * v[2 * j + 1]; rs += 0.25f * v[2 * j + 2];
+      h[a][j] = rs;
+    }
+  }
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = 0.f;
+    t += 0.25f * h[0][j]; t += 0.5f * h[1][j]; t += 0.25f * h[2][j];
+    o[j] = t;
+  }
+  *reinterpret_cast<float4*>(y + ((long long)blockIdx.y * Ho + oy) * Wo + ox) = make_float4(o[0], o[1], o[2], o[3]);
+}
+// adjoint of the above (even H, W): per axis, input i gets g[i/2]/2 (i even) or (g[(i-1)/2] + g[(i+1)/2])/4
+// (i odd; the second term only while (i+1)/2 < n/2), plus g[0]/4 at i == 1 (the reflected column -1)
+__global__ __launch_bounds__(256) void blur_down_bwd_v4_k(const float* __restrict__ dy, float* __restrict__ dx,
+                                                          int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1, G = W >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * G) return;
+  const int iy = i / G, ix = (i - iy * G) << 2;
+  const float* gp = dy + (long long)blockIdx.y * Ho * Wo;
+  int oy[3]; float wy[3];
+  blur_down_adj(iy, H, Ho, oy, wy);
+  const int c = ix >> 1;                                     // dy columns c, c+1, c+2 serve inputs ix..ix+3
+  const bool c2 = c + 2 < Wo;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (wy[a] == 0.f) continue;
+    const float* row = gp + oy[a] * Wo + c;
+    const float g0 = row[0], g1 = row[1], g2 = c2 ? row[2] : 0.f;
+    const float r0 = 0.5f * g0;
+    const float r1 = 0.25f * g0 + 0.25f * g1 + (ix == 0 ? 0.25f * g0 : 0.f);   // column 1 also gets the reflected -1
+    const float r2 = 0.5f * g1;
+    const float r3 = 0.25f * g1 + 0.25f * g2;
+    s[0] += wy[a] * r0; s[1] += wy[a] * r1; s[2] += wy[a] * r2; s[3] += wy[a] * r3;
+  }
+  *reinterpret_cast<float4*>(dx + ((long long)blockIdx.y * H + iy) * W + ix) = make_float4(s[0], s[1], s[2], s[3]);
+}
+__global__ __launch_bounds__(256) void blur_up_fwd_v4_k(const float* __restrict__ x, float* __restrict__ y,
+                                                        int H, int W) {
+  const int G = W >> 2, Wo = 2 * W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * G) return;
+  const int iy = i / G, ix = (i - iy * G) << 2;
+  const float* xp = x + (long long)blockIdx.y * H * W;
+  float v[3][6];                                             // rows iy-1, iy, iy+1 (clamped); columns ix-1 .. ix+4 (clamped)
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int r = iy + a - 1;
+    r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+    const float* row = xp + r * W + ix;
+    const float4 q = *reinterpret_cast<const float4*>(row);
+    v[a][0] = ix ? row[-1] : q.x;
+    v[a][1] = q.x; v[a][2] = q.y; v[a][3] = q.z; v[a][4] = q.w;
+    v[a][5] = (ix + 4 < W) ? row[4] : q.w;
+  }
+  float* yp = y + ((long long)blockIdx.y * 2 * H + 2 * iy) * Wo + 2 * ix;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {                              // output rows 2iy (neighbour iy-1) and 2iy+1 (neighbour iy+1)
+    const int nb = p ? 2 : 0;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                          // output columns 2(ix+j) (neighbour -1) and +1 (neighbour +1)
+        const int xn = q ? j + 2 : j;
+        const float r0 = 0.75f * v[1][j + 1] + 0.25f * v[1][xn];
+        const float r1 = 0.75f * v[nb][j + 1] + 0.25f * v[nb][xn];
+        o[2 * j + q] = 0.75f * r0 + 0.25f * r1;
+      }
+    }
+    *reinterpret_cast<float4*>(yp + p * Wo) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(yp + p * Wo + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+// adjoint: per axis the 4-tap filter (1/4, 3/4, 3/4, 1/4) over dy[2m-1 .. 2m+2] with clamped indices
+__global__ __launch_bounds__(256) void blur_up_bwd_v4_k(const float* __restrict__ dy, float* __restrict__ dx,
+                                                        int H, int W) {
+  const int G = W >> 2, Wo = 2 * W, Ho = 2 * H;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * G) return;
+  const int iy = i / G, ix = (i - iy * G) << 2;
+  const float* gp = dy + (long long)blockIdx.y * Ho * Wo;
+  const float w4[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int r = 2 * iy - 1 + a;
+    r = r < 0 ? 0 : (r > Ho - 1 ? Ho - 1 : r);
+    const float* row = gp + r * Wo + 2 * ix;
+    const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
+    const float l = ix ? row[-1] : q0.x, rr = (2 * ix + 8 < Wo) ? row[8] : q1.w;
+    const float v[10] = {l, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, rr};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float hs = 0.25f * v[2 * j] + 0.75f * v[2 * j + 1] + 0.75f * v[2 * j + 2] + 0.25f * v[2 * j + 3];
+      s[j] += w4[a] * hs;
+    }
+  }
+  *reinterpret_cast<float4*>(dx + ((long long)blockIdx.y * H + iy) * W + ix) = make_float4(s[0], s[1], s[2], s[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void reflect_pad2d_fwd_k(const float* __restrict__ x, float* __restrict__ y, int planes,
                                     int H, int W, int p) {
   const int Ho = H + 2 * p, Wo = W + 2 * p;
@@ -563,6 +690,12 @@ extern "C" int dfmir_act_bwd(const float* dy, const float* y, float* dx, long lo
 extern "C" int dfmir_blur_down_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
   DF_ARG_CHECK(x && y && planes > 0 && H > 1 && W > 1);
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if ((H & 1) == 0 && (W & 7) == 0 && planes <= 65535 && (long long)H * W < (1LL << 30)) {
+    blur_down_fwd_v4_k<<<dim3((unsigned)(((H / 2) * (W / 8) + 255) / 256), (unsigned)planes), 256, 0,
+                         (hipStream_t)stream>>>(x, y, H, W);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   blur_down_fwd_k<<<df_grid((long long)planes * Ho * Wo, 256, 8192), 256, 0, (hipStream_t)stream>>>(
       x, y, planes, H, W, Ho, Wo);
   DF_LAUNCH_CHECK();
@@ -571,6 +704,12 @@ extern "C" int dfmir_blur_down_fwd(const float* x, float* y, int planes, int H, 
 extern "C" int dfmir_blur_down_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream) {
   DF_ARG_CHECK(dy && dx && planes > 0 && H > 1 && W > 1);
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if ((H & 1) == 0 && (W & 3) == 0 && H >= 4 && W >= 4 && planes <= 65535 && (long long)H * W < (1LL << 30)) {
+    blur_down_bwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
+                         (hipStream_t)stream>>>(dy, dx, H, W);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   blur_down_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
       dy, dx, planes, H, W, Ho, Wo);
   DF_LAUNCH_CHECK();
@@ -578,6 +717,12 @@ extern "C" int dfmir_blur_down_bwd(const float* dy, float* dx, int planes, int H
 }
 extern "C" int dfmir_blur_up_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
   DF_ARG_CHECK(x && y && planes > 0 && H > 0 && W > 0);
+  if ((W & 3) == 0 && planes <= 65535 && (long long)H * W < (1LL << 28)) {
+    blur_up_fwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
+                       (hipStream_t)stream>>>(x, y, H, W);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   blur_up_fwd_k<<<df_grid((long long)planes * H * W * 4, 256, 8192), 256, 0, (hipStream_t)stream>>>(
       x, y, planes, H, W);
   DF_LAUNCH_CHECK();
@@ -585,6 +730,12 @@ extern "C" int dfmir_blur_up_fwd(const float* x, float* y, int planes, int H, in
 }
 extern "C" int dfmir_blur_up_bwd(const float* dy, float* dx, int planes, int H, int W, void* stream) {
   DF_ARG_CHECK(dy && dx && planes > 0 && H > 0 && W > 0);
+  if ((W & 3) == 0 && planes <= 65535 && (long long)H * W < (1LL << 28)) {
+    blur_up_bwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
+                       (hipStream_t)stream>>>(dy, dx, H, W);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   blur_up_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
       dy, dx, planes, H, W);
   DF_LAUNCH_CHECK();

@@ -227,6 +227,24 @@ def test_instnorm(ops, shape, relu, res):
         close(rg.grad, rr.grad, what="dres")
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 2, 64, 64), (1, 1, 8, 8), (1, 2, 4, 8), (1, 2, 6, 12)])
+def test_blur_vectorised_vs_oracle(ops, shape):
+    """Shapes that take the 4-outputs-per-thread resampling kernels (norm_resample.hip *_v4_k), against the
+    oracle's Downsample / Upsample restatement, values and input gradients."""
+    from oracle import dfmir_oracle as O
+    for name, mod, fn in (("down", O.BlurDown(shape[1]), ops.blur_down), ("up", O.BlurUp(shape[1]), ops.blur_up)):
+        x = C.randn(91, *shape)
+        xr = x.clone().requires_grad_()
+        yr = mod(xr)
+        cot = C.randn(92, *yr.shape)
+        (yr * cot).sum().backward()
+        xg = x.clone().to(DEV).requires_grad_()
+        yg = fn(xg)
+        (yg * cot.to(DEV)).sum().backward()
+        close(yg, yr.detach(), what=name)
+        close(xg.grad, xr.grad, what="d" + name)
+
+
 def test_blur_reflect_golden(ops, golden):
     g = golden("blur.npz")
     x = C.randn(31, 2, 8, 12, 12).to(DEV).requires_grad_()
