@@ -66,11 +66,11 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
   __syncthreads();
   return sm[16];
 }
-// fold a workgroup's max |.| into a device scalar (non-negative floats order like their bit patterns; the
-// plain read first keeps thousands of workgroups from serialising on one atomic)
-__device__ __forceinline__ void publish_absmax(float m, float* sm, float* out) {
-  float t = block_max(m, sm);
-  if (threadIdx.x == 0) {
+// fold every wave's max |.| into a device scalar (non-negative floats order like their bit patterns; the
+// plain read first keeps thousands of waves from serialising on one atomic; no workgroup barrier)
+__device__ __forceinline__ void publish_absmax(float m, float* out) {
+  float t = wave_max(m);
+  if ((threadIdx.x & 63) == 0) {
     if (!(t == t)) t = __uint_as_float(0x7f800000u);
     if (__float_as_uint(t) > __float_as_uint(*reinterpret_cast<volatile float*>(out)))
       atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(t));

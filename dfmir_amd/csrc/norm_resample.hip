@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
     y4[threadIdx.x + NT * i] = o;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
-  if (amax) publish_absmax(am, sm, amax);   // range probe for the next conv's fp16x2 split
+  if (amax) publish_absmax(am, amax);   // range probe for the next conv's fp16x2 split
 }
 template <int NT, int E>
 __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict__ dy,
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
     d4[threadIdx.x + NT * i] = o;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
-  if (amax) publish_absmax(am, sm, amax);
+  if (amax) publish_absmax(am, amax);
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
