@@ -590,14 +590,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
         const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, (unsigned)(k.Cout * HW) * 4u, 0x00020000); \
     const bool cok_ = ci0 + xc < k.Cin;                                                          \
     const unsigned cb_ = (unsigned)(ci0 + xc) * hw4;                                             \
-    const int o1_ = halo_offset(y0_ - 1 + xr, x0_, k.H, k.W, k.pad_mode);                        \
-    const int ol_ = halo_offset(y0_ - 1 + xr, x0_ - 1, k.H, k.W, k.pad_mode);                    \
-    const int or_ = halo_offset(y0_ - 1 + xr, x0_ + 8, k.H, k.W, k.pad_mode);                    \
-    const unsigned xb_ = (o1_ < 0 || !cok_) ? OOB : cb_ + (unsigned)o1_ * 4u;                    \
+    /* patch row -> image row (reflected, or outside = zeros); the group itself is always inside the row, */ \
+    /* only its left / right neighbour can be padding */                                         \
+    int ry_ = y0_ - 1 + xr;                                                                      \
+    bool rok_ = (unsigned)ry_ < (unsigned)k.H;                                                   \
+    if (k.pad_mode == 1) { ry_ = ry_ < 0 ? -ry_ : (ry_ >= k.H ? 2 * (k.H - 1) - ry_ : ry_); rok_ = true; } \
+    const int rb_ = ry_ * k.W;                                                                   \
+    const bool lin_ = x0_ > 0, rin_ = x0_ + 8 < k.W;                                             \
+    const int ol_ = rb_ + (lin_ ? x0_ - 1 : 1), or_ = rb_ + (rin_ ? x0_ + 8 : k.W - 2);          \
+    const bool lok_ = rok_ && cok_ && (lin_ || k.pad_mode == 1), rrok_ = rok_ && cok_ && (rin_ || k.pad_mode == 1); \
+    const unsigned xb_ = (rok_ && cok_) ? cb_ + (unsigned)(rb_ + x0_) * 4u : OOB;                \
     rxa = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_, 0, 0);                                 \
     rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
-    rxl = __builtin_amdgcn_raw_buffer_load_b32(bx_, (ol_ < 0 || !cok_) ? OOB : cb_ + (unsigned)ol_ * 4u, 0, 0); \
-    rxr = __builtin_amdgcn_raw_buffer_load_b32(bx_, (or_ < 0 || !cok_) ? OOB : cb_ + (unsigned)or_ * 4u, 0, 0); \
+    rxl = __builtin_amdgcn_raw_buffer_load_b32(bx_, lok_ ? cb_ + (unsigned)ol_ * 4u : OOB, 0, 0); \
+    rxr = __builtin_amdgcn_raw_buffer_load_b32(bx_, rrok_ ? cb_ + (unsigned)or_ * 4u : OOB, 0, 0); \
     const unsigned db_ = (co0 + dc >= k.Cout || !dload) ? OOB                                    \
         : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + dk) * k.W + 16 * xs_ + 8 * du) * 4u;    \
     rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
