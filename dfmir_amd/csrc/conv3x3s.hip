@@ -474,6 +474,244 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16x2 forward/dgrad, second form: 2-D pixel tiles, 16-channel chunks, wave groups split by OUTPUT CHANNEL.
+//
+// The kernel above spends half of every half-step outside the MFMAs (profiles/r01_conv3x3s_pmc.md): the
+// ninth tap's padded k-step, the patch split (done once per wave group because each group has its own
+// pixels) and a barrier per 8 channels.  Here both groups of the 512-thread workgroup work on the SAME
+// 8 x 32 pixel tile and each owns 64 of the 128 output channels:
+//   * the halo patch (10 x 34 positions) is shared: each group converts one 8-channel half of a 16-channel
+//     chunk, so the split VALU work per MFMA halves;
+//   * K = 16 of an MFMA = one tap x 16 channels (lanes 0-31: channels 0-7, lanes 32-63: 8-15): 9 k-steps,
+//     no padded tap;
+//   * one barrier per 16 channels per group.
+// LDS: W_g[split][tap][half][64 couts] per group, single-buffered (a group rewrites its weights in its own
+// store half-step); X[buf][split][half][352] double-buffered (both groups read chunk c, one after the
+// other, while chunk c+1 is being written).  Schedule (c = h >> 1):
+//   A (couts 0-63)  : computes chunk c at h = 2c (prefetching W_A(c+1), X-half-0(c+1)), stores them at 2c+1;
+//   B (couts 64-127): stores W_B(c), X-half-1(c+1) at h = 2c, computes chunk c at 2c+1 (prefetching
+//                     W_B(c+1), X-half-1(c+2)).
+//   X(c+1) is complete at the end of h = 2c+1; its buffer was last read (chunk c-1) at h = 2c-1.
+constexpr int CS_TH = 8, CS_TW = 32, CS_PW = CS_TW + 2, CS_XP = 352;   // 10 x 34 = 340 patch positions
+
+template <int NV>
+__device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb, int abase,
+                                             const int (&pb)[2], f32x16 (&acc)[2][2]) {
+  constexpr int SA = 9 * 2 * 64, SX = 2 * CS_XP;          // units per split in W_g / X
+  using P = Prod<2>;
+  u32x4 a[2][2][2], b[2][2][2];                           // [set][tile][split]
+#define CS_LOAD(set_, t_)                                                                        \
+  {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) a[set_][i][s] = Ab[s * SA + (t_) * 128 + abase + i * 32]; \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) b[set_][j][s] = Xb[s * SX + pb[j] + ((t_) / 3) * CS_PW + (t_) % 3]; \
+  }
+  CS_LOAD(0, 0)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t < 8) CS_LOAD((t + 1) & 1, t + 1)
+#pragma unroll
+    for (int q = 0; q < P::N; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = mma16<2>(a[t & 1][i][P::A[q]], b[t & 1][j][P::B[q]], acc[i][j]);
+  }
+#undef CS_LOAD
+  constexpr int VP = (NV + 7) / 8 < 4 ? (NV + 7) / 8 : 4;  // prefetch loads riding behind MFMAs, per tap
+#pragma unroll
+  for (int i = 0; i < 8; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 12 - 8 - VP; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+}
+
+struct ConvCsP {
+  int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;
+  float slope;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __restrict__ x, const u32x4* __restrict__ ws,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             ConvCsP k, SplitScale sc) {
+  constexpr int NSP = 2, XP = CS_XP, NPOS = (CS_TH + 2) * CS_PW;
+  constexpr int WUG = NSP * 9 * 2 * 64;                   // 16-B units of one group's weight chunk (16 channels)
+  constexpr int NW = WUG / 256;                           // 9 per thread
+  constexpr int NS = (NPOS + 255) / 256;                  // 2 patch positions per thread
+  __shared__ __attribute__((aligned(16))) u32x4 Wg[2][WUG];
+  __shared__ __attribute__((aligned(16))) u32x4 Xs[2][NSP * 2 * XP];
+  __shared__ float bs[128];
+
+  // wave-uniform by construction; readfirstlane tells the compiler so (otherwise every buffer load whose
+  // descriptor depends on the group is wrapped in a waterfall loop)
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
+  int bt = blockIdx.x;
+  const int tx = bt % k.tiles_x; bt /= k.tiles_x;
+  const int ty = bt % k.tiles_y;
+  const int n = bt / k.tiles_y;
+  const int oy0 = ty * CS_TH, ox0 = tx * CS_TW;
+  const int m0 = blockIdx.y * 128, m0g = m0 + 64 * grp;
+
+  const int ex = scale_exp(sc.x_amax[0]);
+  const int ew = (int)sc.w_trailer[1];
+  const float xscale = pow2f(ex), oscale = pow2f(-ex), oscale2 = pow2f(-ew);
+
+  constexpr unsigned OOB = 0x80000000u;
+  // this thread's patch positions: byte offset of channel ch of its 8-channel half, within a 16-channel slab
+  unsigned gvo[NS][8];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pos = tid + 256 * s;
+    int off = -1;
+    if (pos < NPOS) {
+      const int r = pos / CS_PW, c = pos - r * CS_PW;
+      off = halo_offset(oy0 - k.pad + r, ox0 - k.pad + c, k.Hi, k.Wi, k.pad_mode);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gvo[s][c] = off < 0 ? OOB : (unsigned)(off + (8 * grp + c) * HWi) * 4u;
+  }
+  if (threadIdx.x < 128) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
+
+  // MFMA operand indices: wave w of a group owns tile rows 2w, 2w+1 (32 pixels each)
+  int pb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) pb[j] = lhi * XP + (2 * wid + j) * CS_PW + l31;
+  const int abase = lhi * 64 + l31;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* xn = x + (long long)n * k.Cin * HWi;
+  const int chunks8 = (k.Cin + 7) / 8, chunks = (k.Cin + 15) / 16;
+  // weight unit idx = r*64 + co with r = (split*9 + tap)*2 + half; global unit ((2c + half)*NSP*9 + split*9 + tap)*Cout + cout
+  unsigned wb[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int idx = tid + 256 * j;
+    const int co = m0g + (idx & 63), r = idx >> 6;
+    const int half = r & 1, st = r >> 1;
+    wb[j] = co < k.Cout ? (unsigned)((half * NSP * 9 + st) * k.Cout + co) * 16u : OOB;
+  }
+  const int wunits8 = NSP * 9 * k.Cout;                   // units of one 8-channel chunk in the packed weights
+
+  u32x4 rw[NW];
+  unsigned rx[NS][8];
+#define CS_GLOADW(c_)                                                                            \
+  {                                                                                              \
+    const int q_ = 2 * (c_);                                                                     \
+    const int left_ = chunks8 - q_;                                                              \
+    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<u32x4*>(ws + (long long)q_ * wunits8), 0,                                     \
+        left_ > 0 ? (unsigned)((left_ < 2 ? left_ : 2) * wunits8) * 16u : 0u, 0x00020000);       \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) rw[j] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wb[j], 0, 0); \
+  }
+#define CS_GLOADX(c_)                                                                            \
+  {                                                                                              \
+    const int c0_ = 16 * (c_);                                                                   \
+    const int left_ = k.Cin - c0_;                                                               \
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(xn + (long long)c0_ * HWi), 0,                                        \
+        left_ > 0 ? (unsigned)((left_ < 16 ? left_ : 16) * HWi) * 4u : 0u, 0x00020000);          \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s)                                               \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                              \
+        rx[s][c] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[s][c], 0, 0);                   \
+  }
+#define CS_LSTOREW()                                                                             \
+  { _Pragma("unroll") for (int j = 0; j < NW; ++j) Wg[grp][tid + 256 * j] = rw[j]; }
+#define CS_LSTOREX(buf_)                                                                         \
+  {                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
+      const int pos = tid + 256 * s;                                                             \
+      if (pos < NPOS) {                                                                          \
+        float v[8];                                                                              \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rx[s][c]) * xscale; \
+        u32x4 sp[NSP];                                                                           \
+        split8<NSP>(v, sp);                                                                      \
+        _Pragma("unroll") for (int q = 0; q < NSP; ++q) Xs[buf_][(q * 2 + grp) * XP + pos] = sp[q]; \
+      }                                                                                          \
+    }                                                                                            \
+  }
+
+  // prologue: X(0) (each group its channel half) and W_A(0) in place; B holds W_B(0), X-half-1(1) in registers
+  CS_GLOADX(0);
+  if (grp == 0) CS_GLOADW(0);
+  CS_LSTOREX(0);
+  if (grp == 0) CS_LSTOREW();
+  if (grp == 1) { CS_GLOADW(0); CS_GLOADX(1); }
+  __syncthreads();
+
+  for (int h = 0; h < 2 * chunks; ++h) {
+    const int c = h >> 1;
+    if ((h & 1) == grp) {
+      // compute chunk c; the prefetch (chunks past the end read zeros) rides behind the MFMAs
+      CS_GLOADW(c + 1);
+      CS_GLOADX(c + 1 + grp);
+      cs_mma_chunk<NW + NS * 8>(Wg[grp], Xs[c & 1], abase, pb, acc);
+    } else {
+      // store what this group prefetched during its last compute half-step (B at h = 0: the prologue's)
+      if (grp == 0) {
+        if (c + 1 < chunks) { CS_LSTOREW(); CS_LSTOREX((c + 1) & 1); }
+      } else {
+        CS_LSTOREW();
+        if (c + 1 < chunks) CS_LSTOREX((c + 1) & 1);
+      }
+    }
+    __syncthreads();
+  }
+#undef CS_GLOADW
+#undef CS_GLOADX
+#undef CS_LSTOREW
+#undef CS_LSTOREX
+
+  float* yb = y + (long long)n * k.Cout * HWo;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int oy = oy0 + 2 * wid + j, ox = ox0 + l31;
+    if (oy >= k.Ho || ox >= k.Wo) continue;
+    const int q = oy * k.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = 64 * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+        const int co = m0 + cc;
+        if (co < k.Cout) {
+          float v = acc[i][j][r] * oscale * oscale2 + bs[cc];
+          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+          else if (k.act == 2) v = tanhf(v);
+          yb[(long long)co * HWo + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_packed,
                               const float* bias, float* y, hipStream_t st, int* rc) {
   const int mode = df_split_mode();
@@ -491,6 +729,22 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
   const SplitScale sc{x_amax, split_trailer(w_packed, g->Cin, g->Cout, mode)};
+  static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
+  if (mode == 2 && g->Cout > 64 && use_cs) {
+    ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope,
+               (g->Wo + CS_TW - 1) / CS_TW, (g->Ho + CS_TH - 1) / CS_TH};
+    const long long nb = (long long)g->N * kc.tiles_x * kc.tiles_y;
+    // 8 x 32 tiles fit the forward shapes exactly but waste 37 % on the 66 x 66 padded frames the dgrad of a
+    // reflect-padded conv produces: those stay on the flat-run kernel below
+    const double fill = (double)HWo / ((double)kc.tiles_x * CS_TW * kc.tiles_y * CS_TH);
+    if (nb < (1LL << 31) && fill >= 0.85) {
+      dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
+      conv3x3_split_cs_k<<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      hipError_t e = hipGetLastError();
+      *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+      return true;
+    }
+  }
   k.tiles_per_img = (int)((HWo + 255) / 256);
   const bool big = g->Cout > 64;
   dim3 grid((unsigned)(g->N * k.tiles_per_img), big ? (unsigned)((g->Cout + 127) / 128) : 1u);
