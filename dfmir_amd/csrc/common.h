@@ -66,15 +66,22 @@ __device__ __forceinline__ float block_max(float v, float* sm) {
   __syncthreads();
   return sm[16];
 }
-// fold every wave's max |.| into a device scalar (non-negative floats order like their bit patterns; the
-// plain read first keeps thousands of waves from serialising on one atomic; no workgroup barrier)
-__device__ __forceinline__ void publish_absmax(float m, float* out) {
-  float t = wave_max(m);
-  if ((threadIdx.x & 63) == 0) {
-    if (!(t == t)) t = __uint_as_float(0x7f800000u);
-    if (__float_as_uint(t) > __float_as_uint(*reinterpret_cast<volatile float*>(out)))
-      atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(t));
-  }
+// Range probes (max |.|) travel as arrays of partial maxima: a producer writes one value per workgroup
+// (plain stores, no global atomics), the consumer reduces the array in its prologue.
+//   producer: smax zeroed before a barrier; at the end every wave folds its maximum into smax (LDS atomic on
+//   the bit pattern: non-negative floats order like unsigned integers), one barrier, thread 0 stores.
+__device__ __forceinline__ void publish_block_absmax(float m, unsigned* smax, float* out_block) {
+  const float t = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(smax, __float_as_uint(t == t ? t : __uint_as_float(0x7f800000u)));
+  __syncthreads();
+  if (threadIdx.x == 0) *out_block = __uint_as_float(*smax);
+}
+//   consumer: sm = >= 17 floats of LDS scratch
+__device__ __forceinline__ float reduce_absmax(const float* __restrict__ a, int n, float* sm) {
+  if (n <= 1) return a[0];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, a[i]);
+  return block_max(m, sm);
 }
 
 // Input coordinate of output index o / tap t along one axis.

@@ -451,10 +451,10 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
                         float* y, hipStream_t st, int* rc);
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
-bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_packed,
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
                               const float* bias, float* y, hipStream_t st, int* rc);
-bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                                const float* dy_amax, float* dw_tcc, hipStream_t st, int* rc);
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
+                                const float* dy_amax, int dy_n, float* dw_tcc, hipStream_t st, int* rc);
 int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st);
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
@@ -481,15 +481,15 @@ static int check_geom(const DfConvGeom* g) {
   return 0;
 }
 
-static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_tcc,
                          const float* bias, float* y, void* stream);
 extern "C" int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc,
                               const float* bias, float* y, void* stream) {
-  return conv_fwd_impl(g, x, nullptr, w_tcc, bias, y, stream);
+  return conv_fwd_impl(g, x, nullptr, 0, w_tcc, bias, y, stream);
 }
-extern "C" int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
-                                     const float* bias, float* y, void* stream) {
-  return conv_fwd_impl(g, x, x_amax, w_tcc, bias, y, stream);
+extern "C" int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                     const float* w_tcc, const float* bias, float* y, void* stream) {
+  return conv_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, bias, y, stream);
 }
 extern "C" int dfmir_absmax(const float* x, long long n, float* out, void* stream) {
   DF_ARG_CHECK(x && out && n > 0);
@@ -497,14 +497,14 @@ extern "C" int dfmir_absmax(const float* x, long long n, float* out, void* strea
   if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }
-static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
+static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_tcc,
                          const float* bias, float* y, void* stream) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && w_tcc && y);
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_fwd_try(g, x, x_amax, w_tcc, bias, y, st, &rc)) return rc;
+    if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
@@ -552,24 +552,25 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
   return 0;
 }
 
-static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                           const float* dy_amax, float* dw_tcc, void* stream);
+static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
+                           const float* dy_amax, int dy_n, float* dw_tcc, void* stream);
 extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                                 void* stream) {
-  return conv_wgrad_impl(g, x, nullptr, dy, nullptr, dw_tcc, stream);
+  return conv_wgrad_impl(g, x, nullptr, 0, dy, nullptr, 0, dw_tcc, stream);
 }
-extern "C" int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                                       const float* dy_amax, float* dw_tcc, void* stream) {
-  return conv_wgrad_impl(g, x, x_amax, dy, dy_amax, dw_tcc, stream);
+extern "C" int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                       const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
+                                       void* stream) {
+  return conv_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, stream);
 }
-static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                           const float* dy_amax, float* dw_tcc, void* stream) {
+static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
+                           const float* dy_amax, int dy_n, float* dw_tcc, void* stream) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
   DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_wgrad_try(g, x, x_amax, dy, dy_amax, dw_tcc, st, &rc)) return rc;
+    if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, st, &rc)) return rc;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }

@@ -263,7 +263,8 @@ __device__ __forceinline__ void split_mma_chunk(const u32x4* __restrict__ Ab, co
 //   W(c+1) is therefore complete at the end of h = 2c+1, and its buffer was last read (chunk c-1) at
 //   h = 2c-1: every hand-over is ordered by the per-half-step barrier.
 struct SplitScale {
-  const float* x_amax;    // device: max |x| of the input tensor (NSP = 2 only)
+  const float* x_amax;    // device: x_n partial maxima of |x| over the input tensor (NSP = 2 only)
+  int x_n;
   const float* w_trailer; // device: [1] = weight scale exponent (NSP = 2 only)
 };
 
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
   // scales (NSP = 2): input scaled by 2^ex when it is split, result rescaled by 2^-(ex+ew)
   float xscale = 1.f, oscale = 1.f, oscale2 = 1.f;   // two factors: 2^-(ex+ew) alone can leave fp32's range
   if (NSP == 2) {
-    const int ex = scale_exp(sc.x_amax[0]);
+    const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, bs));   // bs: scratch here, bias below
+    __syncthreads();
     const int ew = (int)sc.w_trailer[1];
     xscale = pow2f(ex);
     oscale = pow2f(-ex);
@@ -572,7 +574,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   const int oy0 = ty * CS_TH, ox0 = tx * CS_TW;
   const int m0 = blockIdx.y * 128, m0g = m0 + 64 * grp;
 
-  const int ex = scale_exp(sc.x_amax[0]);
+  const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, bs));     // bs: scratch here, bias below
+  __syncthreads();
   const int ew = (int)sc.w_trailer[1];
   const float xscale = pow2f(ex), oscale = pow2f(-ex), oscale2 = pow2f(-ew);
 
@@ -712,10 +715,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_packed,
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
                               const float* bias, float* y, hipStream_t st, int* rc) {
   const int mode = df_split_mode();
-  if (mode == 0 || (mode == 2 && !x_amax)) return false;
+  if (mode == 0 || (mode == 2 && !(x_amax && x_n > 0))) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->Cout <= 32 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
@@ -728,7 +731,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   if (worst_npos(g->Wo, (int)HWo, 128) > 399) return false;
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
-  const SplitScale sc{x_amax, split_trailer(w_packed, g->Cin, g->Cout, mode)};
+  const SplitScale sc{x_amax, x_n, split_trailer(w_packed, g->Cin, g->Cout, mode)};
   static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
   if (mode == 2 && g->Cout > 64 && use_cs) {
     ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope,
@@ -783,8 +786,9 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
 struct WS3P {
   int N, Cin, Cout, H, W, pad_mode;
   int runs_per_row, runs_per_img, runs_total, runs_per_block;
-  const float* x_amax;    // NSP = 2: device max |x|, max |dy|
+  const float* x_amax;    // NSP = 2: partial maxima of |x| (x_n of them) and |dy| (dy_n)
   const float* dy_amax;
+  int x_n, dy_n;
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -811,7 +815,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 
   float xscale = 1.f, dscale = 1.f, oscale = 1.f, oscale2 = 1.f;
   if (NSP == 2) {
-    const int ex = scale_exp(k.x_amax[0]), ed = scale_exp(k.dy_amax[0]);
+    __shared__ float red[17];
+    const int ex = scale_exp(reduce_absmax(k.x_amax, k.x_n, red));
+    __syncthreads();
+    const int ed = scale_exp(reduce_absmax(k.dy_amax, k.dy_n, red));
     xscale = pow2f(ex); dscale = pow2f(ed); oscale = pow2f(-ex); oscale2 = pow2f(-ed);
   }
 
@@ -959,10 +966,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   }
 }
 
-bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                                const float* dy_amax, float* dw_tcc, hipStream_t st, int* rc) {
+bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
+                                const float* dy_amax, int dy_n, float* dw_tcc, hipStream_t st, int* rc) {
   const int mode = df_split_mode();
-  if (mode == 0 || (mode == 2 && !(x_amax && dy_amax))) return false;
+  if (mode == 0 || (mode == 2 && !(x_amax && dy_amax && x_n > 0 && dy_n > 0))) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
@@ -971,7 +978,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n};
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;

@@ -57,14 +57,15 @@ def set_conv_profiler(fn):
 _AMAX_POOL = {"buf": None, "next": 0}
 
 
-def amax_slot(device):
+def amax_slot(device, n=1):
+    """n floats of zero-initialised device memory (a probe = n partial maxima)."""
     pool = _AMAX_POOL
-    if pool["buf"] is None or pool["next"] >= pool["buf"].numel() or pool["buf"].device != device:
-        pool["buf"] = torch.zeros(4096, device=device, dtype=torch.float32)
+    if pool["buf"] is None or pool["next"] + n > pool["buf"].numel() or pool["buf"].device != device:
+        pool["buf"] = torch.zeros(max(1 << 18, n), device=device, dtype=torch.float32)
         pool["next"] = 0
     i = pool["next"]
-    pool["next"] = i + 1
-    return pool["buf"][i:i + 1]
+    pool["next"] = i + n
+    return pool["buf"][i:i + n]
 
 
 def absmax(t):
@@ -97,7 +98,8 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
 
     def launch():
-        check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax), _p(w_tcc), _p(bias), _p(y), _st()))
+        check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax), 0 if x_amax is None else x_amax.numel(),
+                                          _p(w_tcc), _p(bias), _p(y), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -120,7 +122,9 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
     def launch():
-        check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax), _p(dy5), _p(dy_amax), _p(dw), _st()))
+        check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
+                                            0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
+                                            0 if dy_amax is None else dy_amax.numel(), _p(dw), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -368,7 +372,7 @@ class InstNormFn(Function):
         mean = torch.empty(planes, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         r = _c(res) if res is not None else None
-        slot = amax_slot(x.device)
+        slot = amax_slot(x.device, planes)
         check(lib().dfmir_instnorm_fwd(_p(x), _p(r), _p(y), _p(mean), _p(rstd), planes, S, float(eps),
                                        int(relu), _p(slot), _st()))
         _LAST_AMAX[0] = slot
@@ -387,7 +391,7 @@ class InstNormFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            slot = amax_slot(x.device)
+            slot = amax_slot(x.device, planes)
             check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
                                            _p(slot), _st()))
             tag_amax(dx, slot)

@@ -60,21 +60,22 @@ typedef struct DfConvGeom {
 /* y[N,Cout,Do,Ho,Wo] = act(conv(x[N,Cin,Di,Hi,Wi], w) + bias).  bias may be NULL. */
 int dfmir_conv_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias,
                    float* y, void* stream);
-/* The same with max|x| supplied (device scalar written by dfmir_absmax on the same stream).  The maximum
- * lets the 2-D 3x3 stride-1 kernels take the scaled fp16x2 split form (csrc/conv3x3s.hip: 3 matrix products
- * per fp32 product instead of bf16x3's 6); without it -- dfmir_conv_fwd -- those layers run bf16x3
- * (DFMIR_CONV_SPLIT=bf16x3) or fp32 MFMA.  x_amax may be NULL. */
-int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* w_tcc,
-                          const float* bias, float* y, void* stream);
+/* The same with a range probe of x supplied: x_amax[0..x_amax_n) are partial maxima whose maximum is max|x|
+ * (one value from dfmir_absmax, or the per-plane values dfmir_instnorm_fwd/bwd leave behind; written on the same
+ * stream).  The probe lets the 2-D 3x3 stride-1 kernels take the scaled fp16x2 split form (csrc/conv3x3s.hip:
+ * 3 matrix products per fp32 product instead of bf16x3's 6); without it -- dfmir_conv_fwd -- those layers run
+ * bf16x3 (DFMIR_CONV_SPLIT=bf16x3) or fp32 MFMA.  x_amax may be NULL. */
+int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                          const float* w_tcc, const float* bias, float* y, void* stream);
 /* out[0] = max(out[0], max_i |x[i]|) (NaN counts as +inf; the caller zero-initialises out).  Replaces nothing in
- * the reference: it is the range probe of the fp16x2 split.  dfmir_instnorm_fwd/bwd can produce the same value for
- * their output as a by-product (y_amax / dx_amax). */
+ * the reference: it is the range probe of the fp16x2 split.  dfmir_instnorm_fwd/bwd produce a probe of their output
+ * as a by-product: y_amax / dx_amax = array of `planes` per-plane maxima (NULL to skip). */
 int dfmir_absmax(const float* x, long long n, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                      void* stream);
-int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, const float* dy,
-                            const float* dy_amax, float* dw_tcc, void* stream);
+int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                            const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);
 /* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
 int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
 /* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
