@@ -244,7 +244,13 @@ def main():
                                    "VoxelMorph + bilinear warps, fwd+bwd+Adam), BASELINE configs[1]" % (S, S, B, args.ngf),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                         # HBM-side bytes of ONE launch of the dominant shape (256->256 3x3 @64^2, n = 32: 154.6 GFLOP,
+                         # 272 MB algorithmic), rocprofv3 PMC passes of scripts/prof_conv.sh (profiles/r01_conv3x3s_pmc.md):
+                         # FETCH_SIZE 346.3 MB (dword gathers: no x2 correction) + WRITE_SIZE 134.2 MB
+                         "traffic": 480.5e6 if split and nprod == 3.0 else None,
+                         "traffic_note": "bytes per launch of the 154.6-GFLOP shape, PMC (FETCH_SIZE + WRITE_SIZE); "
+                                         "algorithmic 272 MB; MFMA-bound: 480 MB in 0.43 ms is 1.1 TB/s",
                          "kernel": ("conv3x3_split_pp_k (fp32 operands split into 16-bit terms, %s on "
                                     "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; 128 couts x 2x128 pixels, "
                                     "ping-pong wave groups)" % form if split else
