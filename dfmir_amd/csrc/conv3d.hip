@@ -376,7 +376,7 @@ static bool is_3x3x3_s1_p1(const DfConvGeom* g) {
 
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc) {
-  if (!is_3x3x3_s1_p1(g) || g->Cout <= 4) return false;
+  if (!is_3x3x3_s1_p1(g) || (g->Cout <= 4 && g->Cin < 8)) return false;   // 16->3 flow conv: one 16-row tile, 19 % used, still 3x the direct kernel
   const long long S = (long long)g->Di * g->Hi * g->Wi;
   if ((long long)g->Cin * S * 4 >= 0x7FFFFFFFLL || (long long)g->Cout * S * 4 >= 0x7FFFFFFFLL) return false;
   C3dP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 1) / 2, (g->Hi + 7) / 8, (g->Wi + 15) / 16};
