@@ -409,8 +409,14 @@ __global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db
   if (threadIdx.x == 0 && beg < S) atomicAdd(&db[c], s);
 }
 
-__global__ void weight_pack_k(const float* __restrict__ w, float* __restrict__ o, int Cout, int Cin,
-                              int T, int mode) {
+// part (may be NULL): part[blockIdx.x] <- this block's max |w| -- the range probe of the fp16x2 split, taken
+// while the weights pass through anyway (weight_split_k reduces the gridDim.x partials)
+__global__ __launch_bounds__(256) void weight_pack_k(const float* __restrict__ w, float* __restrict__ o, int Cout,
+                                                     int Cin, int T, int mode, float* __restrict__ part) {
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
+  __syncthreads();
+  float am = 0.f;
   const long long total = (long long)Cout * Cin * T;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -421,14 +427,17 @@ __global__ void weight_pack_k(const float* __restrict__ w, float* __restrict__ o
       const int ci = (int)(r % Cin);
       const int t = (int)(r / Cin);
       o[i] = w[((long long)co * Cin + ci) * T + t];
+      am = fmaxf(am, fabsf(o[i]));
     } else {  // o[t][co][ci] = w[co][ci][T-1-t]
       const int ci = (int)(i % Cin);
       long long r = i / Cin;
       const int co = (int)(r % Cout);
       const int t = (int)(r / Cout);
       o[i] = w[((long long)co * Cin + ci) * T + (T - 1 - t)];
+      am = fmaxf(am, fabsf(o[i]));
     }
   }
+  if (part) publish_block_absmax(am, &smax, part + blockIdx.x);
 }
 __global__ void weight_unpack_k(const float* __restrict__ gt, float* __restrict__ g, int Cout, int Cin,
                                 int T) {
@@ -455,7 +464,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
                               const float* bias, float* y, hipStream_t st, int* rc);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, hipStream_t st, int* rc);
-int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st);
+int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int npart, hipStream_t st);
+float* df_weight_probe_slots(float* packed, int K, int M);
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
 bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                        hipStream_t st, int* rc);
@@ -634,11 +644,13 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
                                  void* stream) {
   DF_ARG_CHECK(w && w_tcc && Cout > 0 && Cin > 0 && T > 0 && (mode == 0 || mode == 1));
   const long long total = (long long)Cout * Cin * T;
-  weight_pack_k<<<df_grid(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(w, w_tcc, Cout, Cin, T, mode);
+  const unsigned nblk = df_grid(total, 256, 2048);
+  const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;   // K = reduction, M = produced channels
+  float* part = (T == 9) ? df_weight_probe_slots(w_tcc, K, M) : nullptr;
+  weight_pack_k<<<nblk, 256, 0, (hipStream_t)stream>>>(w, w_tcc, Cout, Cin, T, mode, part);
   DF_LAUNCH_CHECK();
-  if (T == 9) {   // split-bf16 section for the 3x3 kernels (conv3x3s.hip); K = reduction, M = produced channels
-    const int K = mode ? Cout : Cin, M = mode ? Cin : Cout;
-    const int rc = df_weight_split_launch(w_tcc, w_tcc, K, M, (hipStream_t)stream);
+  if (T == 9) {   // split section for the 3x3 kernels (conv3x3s.hip)
+    const int rc = df_weight_split_launch(w_tcc, w_tcc, K, M, (int)nblk, (hipStream_t)stream);
     if (rc) return df_set_error(rc, __FILE__, __LINE__);
   }
   return 0;
@@ -647,7 +659,7 @@ extern "C" long long dfmir_weight_pack_floats(int Cout, int Cin, int T) {
   if (Cout <= 0 || Cin <= 0 || T <= 0) return -1;
   // [T][K][M] fp32 (rounded up to 16 B) + the split section when T == 9; one size for both packings
   const long long s0 = df_pack_split_floats(Cin, Cout, T), s1 = df_pack_split_floats(Cout, Cin, T);
-  return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1) + (T == 9 ? 4 : 0);   // + scale trailer
+  return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1) + (T == 9 ? 4 + 2048 : 0);   // + scale trailer, probe slots
 }
 extern "C" int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T,
                                    void* stream) {

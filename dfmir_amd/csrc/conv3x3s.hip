@@ -122,15 +122,17 @@ int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bo
 }
 
 // ---- weight splitting: w_tcc [9][K][M] fp32 -> [ceil(K/8)][NSP][9][M] x 16 B.
-// NSP = 2: trailer[0] = max|w| (from absmax_k), trailer[1] <- the scale exponent used (as a float)
+// NSP = 2: trailer[4 .. 4+npart) = partial maxima of |w| left by weight_pack_k; trailer[1] <- the scale exponent
+// used (as a float), read by the conv kernels
 template <int NSP>
 __global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ w_tcc, u32x4* __restrict__ out,
-                                                      float* __restrict__ trailer, int K, int M) {
+                                                      float* __restrict__ trailer, int npart, int K, int M) {
+  __shared__ float red[17];
   const int chunks = (K + 7) >> 3;
   const long long total = (long long)chunks * 9 * M;
   int e = 0;
   if (NSP == 2) {
-    e = scale_exp(trailer[0]);
+    e = scale_exp(reduce_absmax(trailer + 4, npart, red));
     if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = (float)e;
   }
   const float sc = pow2f(e);
@@ -171,19 +173,19 @@ static inline float* split_trailer(const float* packed, int K, int M, int nsp) {
   return split_section(packed, K, M) + (long long)((K + 7) / 8) * 9 * nsp * M * 4;
 }
 
-int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, hipStream_t st) {
+// where weight_pack_k leaves its partial maxima (after the 4-float trailer of the active split form)
+float* df_weight_probe_slots(float* packed, int K, int M) {
+  const int mode = df_split_mode();
+  return mode == 2 ? split_trailer(packed, K, M, mode) + 4 : nullptr;
+}
+int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int npart, hipStream_t st) {
   const int mode = df_split_mode();
   if (mode == 0) return 0;
   const long long total = (long long)((K + 7) / 8) * 9 * M;
   u32x4* sec = reinterpret_cast<u32x4*>(split_section(packed, K, M));
   float* tr = split_trailer(packed, K, M, mode);
-  if (mode == 2) {
-    const int rc = df_absmax_launch(w_tcc, (long long)9 * K * M, tr, st, true);
-    if (rc) return rc;
-    weight_split_k<2><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, K, M);
-  } else {
-    weight_split_k<3><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, K, M);
-  }
+  if (mode == 2) weight_split_k<2><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, npart, K, M);
+  else weight_split_k<3><<<df_grid(total, 256, 2048), 256, 0, st>>>(w_tcc, sec, tr, npart, K, M);
   return (int)hipGetLastError();
 }
 
