@@ -498,9 +498,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
 //   X(c+1) is complete at the end of h = 2c+1; its buffer was last read (chunk c-1) at h = 2c-1.
 constexpr int CS_TH = 8, CS_TW = 32, CS_PW = CS_TW + 2, CS_XP = 352;   // 10 x 34 = 340 patch positions
 
-template <int NV>
+// One compute half-step: 9 taps x 12 MFMAs.  Per tap, in one fenced scheduling region: the ds_reads of the next
+// tap's operands, a slice of the caller's prefetch (the 9 weight + 16 patch loads of the chunk this group stores
+// next), and the MFMAs, interleaved by sched_group_barrier.  Without the fences the scheduler hoisted all 25
+// buffer loads in front of the first MFMA and the half-step paid their issue time (16 % of the kernel).
 __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb, int abase,
-                                             const int (&pb)[2], f32x16 (&acc)[2][2]) {
+                                             const int (&pb)[2], f32x16 (&acc)[2][2],
+                                             const __amdgpu_buffer_rsrc_t rw_, const unsigned (&wb)[9], u32x4 (&rw)[9],
+                                             const __amdgpu_buffer_rsrc_t rx_, const unsigned (&gvo)[2][8],
+                                             unsigned (&rx)[2][8]) {
   constexpr int SA = 9 * 2 * 64, SX = 2 * CS_XP;          // units per split in W_g / X
   using P = Prod<2>;
   u32x4 a[2][2][2], b[2][2][2];                           // [set][tile][split]
@@ -512,9 +518,17 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
       _Pragma("unroll") for (int s = 0; s < 2; ++s) b[set_][j][s] = Xb[s * SX + pb[j] + ((t_) / 3) * CS_PW + (t_) % 3]; \
   }
   CS_LOAD(0, 0)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     if (t < 8) CS_LOAD((t + 1) & 1, t + 1)
+    // prefetch slice: loads 3t .. 3t+2 of the flattened list [9 weight units | 2 x 8 patch channels]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int L = 3 * t + q;
+      if (L < 9) rw[L] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wb[L], 0, 0);
+      else if (L < 25) rx[(L - 9) >> 3][(L - 9) & 7] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[(L - 9) >> 3][(L - 9) & 7], 0, 0);
+    }
 #pragma unroll
     for (int q = 0; q < P::N; ++q)
 #pragma unroll
@@ -522,28 +536,16 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = mma16<2>(a[t & 1][i][P::A[q]], b[t & 1][j][P::B[q]], acc[i][j]);
+    const int nds = t < 8 ? 8 : 0, nvm = (3 * t + 3 <= 25) ? 3 : (25 - 3 * t > 0 ? 25 - 3 * t : 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if (i - nds < nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #undef CS_LOAD
-  constexpr int VP = (NV + 7) / 8 < 4 ? (NV + 7) / 8 : 4;  // prefetch loads riding behind MFMAs, per tap
-#pragma unroll
-  for (int i = 0; i < 8; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < VP; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 12 - 8 - VP; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < 12; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 }
 
 struct ConvCsP {
@@ -674,9 +676,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
     const int c = h >> 1;
     if ((h & 1) == grp) {
       // compute chunk c; the prefetch (chunks past the end read zeros) rides behind the MFMAs
-      CS_GLOADW(c + 1);
-      CS_GLOADX(c + 1 + grp);
-      cs_mma_chunk<NW + NS * 8>(Wg[grp], Xs[c & 1], abase, pb, acc);
+      const int qw_ = 2 * (c + 1), lw_ = chunks8 - qw_;
+      const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<u32x4*>(ws + (long long)qw_ * wunits8), 0,
+          lw_ > 0 ? (unsigned)((lw_ < 2 ? lw_ : 2) * wunits8) * 16u : 0u, 0x00020000);
+      const int cx_ = 16 * (c + 1 + grp), lx_ = k.Cin - cx_;
+      const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(xn + (long long)cx_ * HWi), 0,
+          lx_ > 0 ? (unsigned)((lx_ < 16 ? lx_ : 16) * HWi) * 4u : 0u, 0x00020000);
+      cs_mma_chunk(Wg[grp], Xs[c & 1], abase, pb, acc, rwd, wb, rw, rxd, gvo, rx);
     } else {
       // store what this group prefetched during its last compute half-step (B at h = 0: the prologue's)
       if (grp == 0) {
