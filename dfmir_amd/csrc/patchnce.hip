@@ -241,6 +241,143 @@ __global__ __launch_bounds__(256) void patchnce_bwd_k(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Matrix-core forms for the training configuration (R = 256 rows per group, C = 256 channels).  The scalar
+// kernels above are latency chains (256 dependent global loads per thread, 96 workgroup barriers in the
+// forward): 122 / 126 us per call.  Here the 16 x 256 logits of a workgroup are one small GEMM on
+// v_mfma_f32_16x16x4_f32 staged through LDS, and the softmax runs on 16-lane row groups with shuffles only.
+// ---------------------------------------------------------------------------------------------
+typedef float nce_f4 __attribute__((ext_vector_type(4)));
+#define NCE_KP 272   // LDS row stride (== 16 mod 32: the two k-groups of a half-wave hit disjoint banks)
+
+__global__ __launch_bounds__(256) void patchnce_fwd_mfma_k(const float* __restrict__ q, const float* __restrict__ k,
+                                                           float* __restrict__ loss, float* __restrict__ probs,
+                                                           long long rows, int C, float invT) {
+  constexpr int R = 256;
+  __shared__ float qs[256 * NCE_TI];        // [c][16 rows]
+  __shared__ float Ks[32 * NCE_KP];         // [c in chunk][256 keys]
+  __shared__ float sS[NCE_TI * 260];        // logits [16][256] (+pad)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const long long r0 = (long long)blockIdx.x * NCE_TI;
+  const long long g0 = (r0 / R) * R;
+  const int i0 = (int)(r0 - g0);
+  for (int idx = tid; idx < C * NCE_TI; idx += 256) {
+    const int ii = idx % NCE_TI, c = idx / NCE_TI;
+    qs[c * NCE_TI + ii] = q[(long long)c * rows + r0 + ii];
+  }
+  nce_f4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = nce_f4{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    __syncthreads();                        // qs visible (first pass) / previous chunk consumed
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) Ks[c * NCE_KP + tid] = k[(long long)(c0 + c) * rows + g0 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float a = qs[(c0 + ks * 4 + lk) * NCE_TI + l15];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float b = Ks[(ks * 4 + lk) * NCE_KP + (wid * 4 + t) * 16 + l15];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sS[(lk * 4 + r) * 260 + (wid * 4 + t) * 16 + l15] = acc[t][r];
+  __syncthreads();
+  // row ii = tid >> 4 is handled by 16 consecutive lanes; lane `sub` takes columns sub, sub+16, ...
+  const int ii = tid >> 4, sub = tid & 15;
+  const long long ld = (long long)R + 1;
+  float v[16];
+  float lp = 0.f, m = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int j = sub + 16 * u;
+    float x = sS[ii * 260 + j];
+    if (j == i0 + ii) { lp = x * invT; x = -10.0f; }
+    x *= invT;
+    v[u] = x;
+    m = fmaxf(m, x);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lp += __shfl_xor(lp, o); }
+  m = fmaxf(m, lp);                         // lp: exactly one lane of the row held the diagonal, the others 0
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { v[u] = expf(v[u] - m); sum += v[u]; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float e0 = expf(lp - m);
+  sum += e0;
+  const float inv = 1.f / sum;
+  float* pr = probs + (r0 + ii) * ld;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) pr[1 + sub + 16 * u] = v[u] * inv;
+  if (sub == 0) {
+    pr[0] = e0 / sum;
+    loss[r0 + ii] = logf(sum) + m - lp;
+  }
+}
+
+// dq[c][r] = (g_r/T) * ( sum_{j != i} probs[r][1+j] k[c][j] + (probs[r][0]-1) k[c][r] ): M = c, N = 16 rows, K = j
+__global__ __launch_bounds__(256) void patchnce_bwd_mfma_k(const float* __restrict__ dloss,
+                                                           const float* __restrict__ probs,
+                                                           const float* __restrict__ k, float* __restrict__ dq,
+                                                           long long rows, int C, float invT) {
+  constexpr int R = 256, JT = 32;
+  __shared__ float ks[JT * NCE_KP];         // [j in chunk][c]
+  __shared__ float dls[JT * NCE_TI];        // [j in chunk][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const long long r0 = (long long)blockIdx.x * NCE_TI;
+  const long long g0 = (r0 / R) * R;
+  const int i0 = (int)(r0 - g0);
+  const long long ld = (long long)R + 1;
+  const int ntile = C / 16;                 // 16-channel tiles; wave w owns tiles 4w .. 4w+3
+  nce_f4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = nce_f4{0.f, 0.f, 0.f, 0.f};
+  for (int jb = 0; jb < R; jb += JT) {
+    __syncthreads();
+    for (int idx = tid; idx < JT * C; idx += 256) {
+      const int jj = idx % JT, c = idx / JT;
+      ks[jj * NCE_KP + c] = k[(long long)c * rows + g0 + jb + jj];
+    }
+    for (int idx = tid; idx < NCE_TI * JT; idx += 256) {
+      const int jj = idx % JT, ii = idx / JT;
+      const int j = jb + jj;
+      dls[jj * NCE_TI + ii] = (j != i0 + ii) ? probs[(r0 + ii) * ld + 1 + j] * dloss[r0 + ii] * invT : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < JT / 4; ++s) {
+      const float b = dls[(s * 4 + lk) * NCE_TI + l15];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ct = wid * 4 + t;
+        const float a = ct < ntile ? ks[(s * 4 + lk) * NCE_KP + ct * 16 + l15] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  const long long r = r0 + l15;             // D layout: column = row of the workgroup, rows = channels
+  const float dpos = (probs[r * ld] - 1.f) * dloss[r] * invT;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ct = wid * 4 + t;
+    if (ct >= ntile) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long off = (long long)(ct * 16 + lk * 4 + e) * rows + r;
+      dq[off] = acc[t][e] + dpos * k[off];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 extern "C" int dfmir_patch_gather_fwd(const float* feat, const long long* ids, float* out, int B, int C,
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(feat && ids && out && B > 0 && C > 0 && S > 0 && P > 0);
@@ -277,6 +414,11 @@ extern "C" int dfmir_patchnce_fwd(const float* q, const float* k, float* loss, f
   DF_ARG_CHECK(rows % G == 0);
   const int R = (int)(rows / G);
   DF_ARG_CHECK(R % NCE_TI == 0);
+  if (R == 256 && C <= 256 && (C & 31) == 0) {
+    patchnce_fwd_mfma_k<<<(unsigned)(rows / NCE_TI), 256, 0, (hipStream_t)stream>>>(q, k, loss, probs, rows, C, 1.f / T);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t sh = ((size_t)C * NCE_TI + 32 + 3 * NCE_TI) * sizeof(float);
   DF_ARG_CHECK(sh <= 64 * 1024);
   patchnce_fwd_k<<<(unsigned)(rows / NCE_TI), 256, sh, (hipStream_t)stream>>>(q, k, loss, probs, rows, C, R,
@@ -290,6 +432,11 @@ extern "C" int dfmir_patchnce_bwd(const float* dloss, const float* probs, const 
   DF_ARG_CHECK(rows % G == 0);
   const int R = (int)(rows / G);
   DF_ARG_CHECK(R % NCE_TI == 0 && C <= 1024);
+  if (R == 256 && C <= 256 && (C & 15) == 0) {
+    patchnce_bwd_mfma_k<<<(unsigned)(rows / NCE_TI), 256, 0, (hipStream_t)stream>>>(dloss, probs, k, dq, rows, C, 1.f / T);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t sh = ((size_t)NCE_JT * (C + 1) + NCE_TI * NCE_JT + (size_t)C * NCE_TI) * sizeof(float);
   DF_ARG_CHECK(sh <= 64 * 1024);
   patchnce_bwd_k<<<(unsigned)(rows / NCE_TI), 256, sh, (hipStream_t)stream>>>(dloss, probs, k, dq, rows, C, R,

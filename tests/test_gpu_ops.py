@@ -416,6 +416,24 @@ def test_patch_gather_l2norm_nce(ops):
     close(m, lr_.mean(), what="mean")
 
 
+@pytest.mark.parametrize("Cc", [256, 128, 32])
+def test_patchnce_matrix_core_form(ops, Cc):
+    """R = 256 rows per image and C a multiple of 32 take the MFMA forms of the PatchNCE kernels
+    (patchnce.hip *_mfma_k): loss and d(loss)/dq against the oracle's bmm + cross-entropy."""
+    from oracle import dfmir_oracle as O
+    B, P = 3, 256
+    q = O.l2_normalize(C.randn(65, B * P, Cc)).requires_grad_()
+    k = O.l2_normalize(C.randn(66, B * P, Cc))
+    lr_ = O.patchnce_loss(q, k, B, 0.07)
+    cot = C.rand(67, B * P) + 0.5
+    (lr_ * cot).sum().backward()
+    qg = q.detach().t().contiguous().to(DEV).requires_grad_()                       # [C, B*P]
+    lg = ops.patchnce_rows(qg, k.t().contiguous().to(DEV), B, 0.07)
+    close(lg, lr_.detach(), what="nce loss")
+    (lg * cot.to(DEV)).sum().backward()
+    close(qg.grad.t(), q.grad, rtol=3e-4, what="dq")
+
+
 # ------------------------------------------------------------------------------------------ losses
 def test_losses_golden(ops, golden):
     g = golden("losses.npz")
