@@ -28,7 +28,7 @@ _SIGS = {
     "dfmir_weight_pack": [P, P, c_int, c_int, c_int, c_int, P],
     "dfmir_weight_pack_floats": [c_int, c_int, c_int],
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
-    "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P],
+    "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],
     "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],
     "dfmir_tapstack_fwd": [P, P] + [c_int] * 7 + [P],

@@ -463,7 +463,7 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
                               const float* bias, float* y, hipStream_t st, int* rc);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                                const float* dy_amax, int dy_n, float* dw_tcc, hipStream_t st, int* rc);
+                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc);
 int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int npart, hipStream_t st);
 float* df_weight_probe_slots(float* packed, int K, int M);
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
@@ -563,24 +563,32 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
 }
 
 static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                           const float* dy_amax, int dy_n, float* dw_tcc, void* stream);
+                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream);
 extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                                 void* stream) {
-  return conv_wgrad_impl(g, x, nullptr, 0, dy, nullptr, 0, dw_tcc, stream);
+  return conv_wgrad_impl(g, x, nullptr, 0, dy, nullptr, 0, dw_tcc, nullptr, stream);
 }
 extern "C" int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                        const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
-                                       void* stream) {
-  return conv_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, stream);
+                                       float* db, void* stream) {
+  return conv_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream);
 }
+static int bias_grad_launch(const float* dy, float* db, int N, int C, long long S, hipStream_t st);
 static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                           const float* dy_amax, int dy_n, float* dw_tcc, void* stream) {
+                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
   DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, st, &rc)) return rc;
+    if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, db, st, &rc)) return rc;   // db fused
+  }
+  if (db) {   // every other kernel: the bias gradient is its own pass over dY
+    const int rcb = bias_grad_launch(dy, db, g->N, g->Cout, (long long)g->Do * g->Ho * g->Wo, st);
+    if (rcb) return rcb;
+  }
+  if (!use_generic_only()) {
+    int rc = 0;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }
@@ -629,15 +637,18 @@ static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_a
   return 0;
 }
 
-extern "C" int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream) {
-  DF_ARG_CHECK(dy && db && N > 0 && C > 0 && S > 0);
+static int bias_grad_launch(const float* dy, float* db, int N, int C, long long S, hipStream_t st) {
   int nsplit = (int)((S + 65535) / 65536);      // planes larger than 64K elements are split further
   if (nsplit > 64) nsplit = 64;
   if (nsplit < 1) nsplit = 1;
   DF_ARG_CHECK(N <= 65535);
-  bias_grad_k<<<dim3(C, N, nsplit), S >= 4096 ? 256 : 64, 0, (hipStream_t)stream>>>(dy, db, N, C, S, nsplit);
+  bias_grad_k<<<dim3(C, N, nsplit), S >= 4096 ? 256 : 64, 0, st>>>(dy, db, N, C, S, nsplit);
   DF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream) {
+  DF_ARG_CHECK(dy && db && N > 0 && C > 0 && S > 0);
+  return bias_grad_launch(dy, db, N, C, S, (hipStream_t)stream);
 }
 
 extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, int mode,

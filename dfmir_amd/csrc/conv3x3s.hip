@@ -799,6 +799,7 @@ struct WS3P {
   const float* x_amax;    // NSP = 2: partial maxima of |x| (x_n of them) and |dy| (dy_n)
   const float* dy_amax;
   int x_n, dy_n;
+  float* db;              // optional: bias gradient db[co] += sum_{n,p} dY, taken from the dY units as they pass
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -813,8 +814,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
   __shared__ __attribute__((aligned(16))) u32x4 Xc[NSP * 3 * 4 * XSLAB];
   __shared__ __attribute__((aligned(16))) u32x4 Dy[NSP * 2 * 2 * BC];
+  __shared__ float bsum[BC];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool want_db = k.db != nullptr && blockIdx.y == 0;   // one ci-tile column of workgroups sees every dY once
+  if (tid < BC) bsum[tid] = 0.f;
   const int wc = wid % NWC, wi = (wid / NWC) & 1, kh = wid / (2 * NWC);   // kh: this wave's k-step when KS == 2
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HW = k.H * k.W;
@@ -900,6 +904,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     }                                                                                            \
     float v[8];                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
+    if (want_db && dload) atomicAdd(&bsum[dc], ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))); \
     if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] *= dscale; }              \
     u32x4 sp[NSP];                                                                               \
     split8<NSP>(v, sp);                                                                          \
@@ -961,6 +966,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 #undef WS_GLOAD
 #undef WS_LSTORE
 
+  if (want_db) {
+    __syncthreads();
+    if (tid < BC && co0 + tid < k.Cout) atomicAdd(&k.db[co0 + tid], bsum[tid]);
+  }
   const int co = co0 + wc * 32 + l31;
   if (co < k.Cout) {
 #pragma unroll
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 }
 
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                                const float* dy_amax, int dy_n, float* dw_tcc, hipStream_t st, int* rc) {
+                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc) {
   const int mode = df_split_mode();
   if (mode == 0 || (mode == 2 && !(x_amax && dy_amax && x_n > 0 && dy_n > 0))) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
@@ -988,7 +997,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db};
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;

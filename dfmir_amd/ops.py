@@ -113,7 +113,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     return y
 
 
-def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None):
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None):
     """dW in the tap-major packing; `out` (same packing) is accumulated into when given."""
     N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
@@ -124,7 +124,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
     def launch():
         check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
                                             0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
-                                            0 if dy_amax is None else dy_amax.numel(), _p(dw), _st()))
+                                            0 if dy_amax is None else dy_amax.numel(), _p(dw), _p(db), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -261,23 +261,27 @@ class ConvFn(Function):
             dx = dx5 if nd == 3 else dx5.squeeze(2)
         defer = (_DEFER["on"] and owner is not None and getattr(owner, "weight", None) is not None
                  and owner.weight.grad is not None and owner.weight.grad.is_contiguous())
+        # bias gradient target: straight into bias.grad when deferring, else a fresh buffer (returned to autograd);
+        # it rides along with the wgrad call (which reads dY anyway) when there is one
+        db_buf = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            bg = getattr(owner, "bias", None).grad if defer and getattr(owner, "bias", None) is not None else None
+            if bg is not None and bg.is_contiguous():
+                db_buf = bg
+            else:
+                db = db_buf = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
         if ctx.needs_input_grad[1]:
             if defer:
                 T = K[0] * K[1] * K[2]
                 conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode,
                                out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device),
-                               x_amax=ctx.x_amax, dy_amax=dy_amax)
+                               x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf)
             else:
-                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax)
+                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf)
                 dw = weight_unpack(dwt, tuple(weight.shape))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif db_buf is not None:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
-            bg = getattr(owner, "bias", None).grad if defer and getattr(owner, "bias", None) is not None else None
-            if bg is not None and bg.is_contiguous():
-                check(lib().dfmir_bias_grad(_p(dy5), _p(bg), dy5.shape[0], Cout, S, _st()))   # accumulates
-            else:
-                db = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
-                check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, S, _st()))
+            check(lib().dfmir_bias_grad(_p(dy5), _p(db_buf), dy5.shape[0], Cout, S, _st()))   # accumulates
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -74,8 +74,11 @@ int dfmir_absmax(const float* x, long long n, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                      void* stream);
+/* db (may be NULL): the bias gradient db[Cout] += sum_{n,o} dy of the same layer, accumulated by this call -- inside
+ * the wgrad kernel where it reads dY anyway (split 3x3 kernels), otherwise by a dfmir_bias_grad pass. */
 int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
-                            const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);
+                            const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
+                            void* stream);
 /* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
 int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
 /* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
