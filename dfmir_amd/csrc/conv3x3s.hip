@@ -819,6 +819,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool want_db = k.db != nullptr && blockIdx.y == 0;   // one ci-tile column of workgroups sees every dY once
   if (tid < BC) bsum[tid] = 0.f;
+  float bacc = 0.f;
   const int wc = wid % NWC, wi = (wid / NWC) & 1, kh = wid / (2 * NWC);   // kh: this wave's k-step when KS == 2
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HW = k.H * k.W;
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     }                                                                                            \
     float v[8];                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
-    if (want_db && dload) atomicAdd(&bsum[dc], ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))); \
+    bacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));   /* this thread's dY channel is fixed */ \
     if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] *= dscale; }              \
     u32x4 sp[NSP];                                                                               \
     split8<NSP>(v, sp);                                                                          \
@@ -967,6 +968,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 #undef WS_LSTORE
 
   if (want_db) {
+    if (dload) atomicAdd(&bsum[dc], bacc);
     __syncthreads();
     if (tid < BC && co0 + tid < k.Cout) atomicAdd(&k.db[co0 + tid], bsum[tid]);
   }
