@@ -314,3 +314,56 @@ def test_registration3d_step_vs_oracle(O, shape, plugin):
                 close(ph.grad, po.grad, rtol=3e-3, atol=1e-9, what="grad " + k)
         for k in ("ncc", "grad"):
             assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-7), (it, k, got[k], ref[k])
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+@pytest.mark.parametrize("cfg", [(256, 256, 64, 32, True), (64, 128, 256, 16, False), (128, 64, 256, 16, False),
+                                 (256, 128, 128, 16, False)],
+                         ids=["res256@64x32", "64to128@256x16", "128to64@256x16", "256to128@128x16"])
+def test_full_size_conv_adjoint_and_linearity(cfg):
+    """BASELINE configs[1] layer shapes at the bench's batch: the kernels must satisfy the identities a convolution
+    satisfies at any size --  <conv(x,w), g> = <x, dgrad(g)> = <w, wgrad(x,g)>  and linearity in w -- to fp32
+    round-off of the (fp64-accumulated) inner products.  Exercises the split fp16x2 forward, dgrad and wgrad
+    kernels on the exact launch geometries of the measured step."""
+    from dfmir_amd import ops
+    Cin, Cout, H, N, reflect = cfg
+    x = C.randn(101, 1, Cin, H, H).to(DEV).expand(N, -1, -1, -1).contiguous()
+    x = (x * torch.linspace(0.5, 1.5, N, device=DEV).view(N, 1, 1, 1)).requires_grad_()
+    w = (C.randn(102, Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV).requires_grad_()
+    g = C.randn(103, 1, Cout, H, H).to(DEV).expand(N, -1, -1, -1).contiguous()
+    y = ops.conv(x, w, None, None, 1, 1, 1 if reflect else 0, 0, 0.0)
+    (y * g).sum().backward()
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    yg, xdx, wdw = dot(y, g), dot(x, x.grad), dot(w, w.grad)
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(yg - xdx) <= 2e-6 * scale, (yg, xdx, scale)
+    assert abs(yg - wdw) <= 2e-6 * scale, (yg, wdw, scale)
+    with torch.no_grad():
+        w2 = (C.randn(104, Cout, Cin, 3, 3) / (Cin * 9) ** 0.5).to(DEV)
+        y2 = ops.conv(x, w2, None, None, 1, 1, 1 if reflect else 0, 0, 0.0)
+        y12 = ops.conv(x, w.detach() + w2, None, None, 1, 1, 1 if reflect else 0, 0, 0.0)
+        err = float((y12 - (y + y2)).abs().max())
+        assert err <= 2e-5 * float(y12.abs().max()), err
+
+
+def test_full_size_warp_properties():
+    """160x192x224 (BASELINE configs[4] geometry): zero displacement is the identity, an integer shift moves
+    voxels exactly, and the warp is linear in src with d(src) as its adjoint."""
+    from dfmir_amd import ops
+    shp = (1, 1, 160, 192, 224)
+    src = C.randn(111, 1, 1, 40, 48, 56).to(DEV)
+    src = torch.nn.functional.interpolate(src, size=shp[2:], mode="trilinear", align_corners=True).requires_grad_()
+    zero = torch.zeros(1, 3, *shp[2:], device=DEV)
+    assert torch.equal(ops.warp(src.detach(), zero), src.detach())
+    shift = zero.clone(); shift[:, 2] = 3.0
+    ys = ops.warp(src.detach(), shift)
+    assert torch.equal(ys[..., :-3], src.detach()[..., 3:]) and float(ys[..., -3:].abs().max()) == 0.0
+    coarse = C.randn(112, 1, 3, 5, 6, 7).to(DEV)
+    flow = torch.nn.functional.interpolate(coarse, size=shp[2:], mode="trilinear", align_corners=True)
+    g = C.randn(113, 1, 1, 40, 48, 56).to(DEV)
+    g = torch.nn.functional.interpolate(g, size=shp[2:], mode="nearest")
+    y = ops.warp(src, flow)
+    (y * g).sum().backward()
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs, rhs = dot(y, g), dot(src, src.grad)
+    assert abs(lhs - rhs) <= 2e-6 * float(y.double().norm() * g.double().norm()), (lhs, rhs)
