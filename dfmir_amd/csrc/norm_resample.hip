@@ -564,6 +564,34 @@ __global__ void reflect_pad2d_bwd_k(const float* __restrict__ dy, float* __restr
   }
 }
 
+// pad 1, W % 4 == 0, H, W >= 8: 4 outputs per thread (one 16-B load of the padded row + the two halo columns
+// at the row ends), rows 1 and H-2 also take the halo rows 0 and H+1
+__global__ __launch_bounds__(256) void reflect_pad1_bwd_v4_k(const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int H, int W) {
+  typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
+  const int G = W >> 2, Wo = W + 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * G) return;
+  const int y = i / G, x0 = (i - y * G) << 2;
+  const float* gp = dy + (long long)blockIdx.y * (H + 2) * Wo;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0,
+                                                                      (unsigned)((H + 2) * Wo) * 4u, 0x00020000);
+  int rows[2] = {y + 1, y + 1};
+  int nr = 1;
+  if (y == 1) { rows[1] = 0; nr = 2; }
+  else if (y == H - 2) { rows[1] = H + 1; nr = 2; }
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < nr; ++a) {
+    const int rb = rows[a] * Wo;
+    const rp_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(rb + x0 + 1) * 4u, 0, 0);
+    s[0] += __uint_as_float(v[0]); s[1] += __uint_as_float(v[1]);
+    s[2] += __uint_as_float(v[2]); s[3] += __uint_as_float(v[3]);
+    if (x0 == 0) s[1] += gp[rb];                  // output column 1 <- padded column 0
+    if (x0 == W - 4) s[2] += gp[rb + W + 1];      // output column W-2 <- padded column W+1
+  }
+  *reinterpret_cast<float4*>(dx + ((long long)blockIdx.y * H + y) * W + x0) = make_float4(s[0], s[1], s[2], s[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // y[n][c] = c < Ca ? a[n][c][z/sd][y/2][x/2] : b[n][c-Ca][z][y][x]
 // ---------------------------------------------------------------------------------------------
@@ -759,6 +787,12 @@ extern "C" int dfmir_reflect_pad2d_fwd(const float* x, float* y, int planes, int
 extern "C" int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p,
                                        void* stream) {
   DF_ARG_CHECK(dy && dx && planes > 0 && p >= 0 && p < H && p < W);
+  if (p == 1 && (W & 3) == 0 && H >= 8 && W >= 8 && planes <= 65535 && (long long)(H + 2) * (W + 2) < (1LL << 29)) {
+    reflect_pad1_bwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
+                            (hipStream_t)stream>>>(dy, dx, H, W);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   reflect_pad2d_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
       dy, dx, planes, H, W, p);
   DF_LAUNCH_CHECK();

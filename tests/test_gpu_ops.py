@@ -259,7 +259,7 @@ def test_blur_reflect_golden(ops, golden):
     yo = ops.blur_down(xo)
     (yo * C.randn(36, *yo.shape).to(DEV)).sum().backward()
     close(yo, g["down_odd"], what="down odd"); close(xo.grad, g["ddown_odd"], what="ddown odd")
-    for p, shp in ((3, (2, 1, 9, 12)), (1, (1, 4, 5, 6)), (2, (1, 2, 3, 3))):
+    for p, shp in ((3, (2, 1, 9, 12)), (1, (1, 4, 5, 6)), (2, (1, 2, 3, 3)), (1, (2, 3, 8, 8)), (1, (1, 2, 10, 24)), (1, (1, 1, 64, 64))):
         x = C.randn(37, *shp)
         xr = x.clone().requires_grad_()
         yr = F.pad(xr, (p, p, p, p), mode='reflect')
