@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfmir_hip.so")
+# DFMIR_HIP_LIB: an alternative build of the same C ABI (A/B experiments); default = the in-tree library
+LIB_PATH = os.environ.get("DFMIR_HIP_LIB") or os.path.join(_HERE, "libdfmir_hip.so")
 
 
 class DfConvGeom(Structure):

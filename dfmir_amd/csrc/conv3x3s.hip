@@ -27,6 +27,18 @@
 //     reads differ by the tap's patch shift).  The ninth tap pairs with a zero operand (10 % idle).
 #include "conv3x3_common.h"
 
+// Wave priorities of the ping-pong kernels (s_setprio): the computing group above the converting one.  With equal
+// priorities the SIMD arbiter favours the lower wave slots, so group A's convert/store instructions displaced group
+// B's MFMAs and B's compute half-steps ran 20 % longer than A's (per-half-step s_memtime trace, -DCS_TRACE).
+#ifndef PP_COMPUTE_PRIO
+#define PP_COMPUTE_PRIO 1
+#endif
+#ifndef CS_COMPUTE_PRIO
+#define CS_COMPUTE_PRIO 1
+#endif
+#ifndef CS_STORE_PRIO
+#define CS_STORE_PRIO 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -52,6 +64,34 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&p)[NSP
     const f32x2 r = v - __builtin_convertvector(h, f32x2);        // exact
     p[0] = __builtin_bit_cast(unsigned, h);
     p[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  }
+}
+// The scaled fp16x2 split of a pair in 4 instructions: v_fma_mix{lo,hi}_f16 multiply by the (power-of-two) scale,
+// subtract the leading term read straight from its fp16 half, and round to fp16 once -- the same values as
+// cvt(x*s), cvt(x*s - float(h)) (x*s and the difference are exact), without the 2 multiplies, 2 conversions back
+// and 2 subtractions.  Every VALU instruction of the converting wave costs the computing wave matrix-pipe time.
+__device__ __forceinline__ void split_pair_scaled(float x0, float x1, float s, unsigned (&p)[2]) {
+  unsigned h, r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+  p[0] = h; p[1] = r;
+}
+template <int NSP>
+__device__ __forceinline__ void split_pair_s(float x0, float x1, float s, unsigned (&p)[NSP]) {
+  if constexpr (NSP == 2) split_pair_scaled(x0, x1, s, p);
+  else split_pair<NSP>(x0, x1, p);                               // bf16x3 is unscaled
+}
+// 8 fp32 (times the scale s in the fp16x2 form) -> NSP 16-B vectors of 8 halves
+template <int NSP>
+__device__ __forceinline__ void split8_s(const float v[8], float s, u32x4 (&out)[NSP]) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned p[NSP];
+    split_pair_s<NSP>(v[2 * w], v[2 * w + 1], s, p);
+#pragma unroll
+    for (int q = 0; q < NSP; ++q) out[q][w] = p[q];
   }
 }
 // 8 fp32 -> NSP 16-B vectors of 8 halves
@@ -412,9 +452,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
       if (pos < npos) {                                                                          \
         float v[8];                                                                              \
         _Pragma("unroll") for (int c = 0; c < CK; ++c)                                           \
-          v[c] = (NSP == 2) ? __uint_as_float(rx[s][c]) * xscale : __uint_as_float(rx[s][c]);    \
+          v[c] = __uint_as_float(rx[s][c]);                                                      \
         u32x4 sp[NSP];                                                                           \
-        split8<NSP>(v, sp);                                                                      \
+        split8_s<NSP>(v, xscale, sp);                                                                      \
         _Pragma("unroll") for (int q = 0; q < NSP; ++q) Xg[q * XP + pos] = sp[q];                \
       }                                                                                          \
     }                                                                                            \
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
     if ((h & 1) == grp) {
       // ---- compute half-step: the MFMAs of chunk c with the prefetch loads interleaved.  Chunks past
       // the end lie beyond the buffer descriptors and read 0, so the loads need no guard.
+      __builtin_amdgcn_s_setprio(PP_COMPUTE_PRIO);      // the converting group must fit in, not win (see cs kernel)
       if (gvalid) {
         P3_GLOADX(c + 1);
         P3_GLOADW(c + 1 + grp);
@@ -442,6 +483,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_pp_k(const float* __rest
       }
     } else {
       // ---- store half-step: what this group prefetched during its last compute half-step
+      __builtin_amdgcn_s_setprio(0);
       const int cx = c + 1 - grp;               // A: X(c+1);  B: X(c)  (B's X(0) is already in place)
       if (cx < chunks && h > 0) P3_LSTOREX();
       if (c + 1 < chunks) P3_LSTOREW((c + 1) & 1);
@@ -503,7 +545,7 @@ constexpr int CS_TH = 8, CS_TW = 32, CS_PW = CS_TW + 2, CS_XP = 352;   // 10 x 3
 // next), and the MFMAs, interleaved by sched_group_barrier.  Without the fences the scheduler hoisted all 25
 // buffer loads in front of the first MFMA and the half-step paid their issue time (16 % of the kernel).
 __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb, int abase,
-                                             const int (&pb)[2], f32x16 (&acc)[2][2],
+                                             const int (&pb)[2], f32x16 (&acc)[4],
                                              const __amdgpu_buffer_rsrc_t rw_, const unsigned (&wb)[9], u32x4 (&rw)[9],
                                              const __amdgpu_buffer_rsrc_t rx_, const unsigned (&gvo)[2][8],
                                              unsigned (&rx)[2][8]) {
@@ -535,7 +577,7 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = mma16<2>(a[t & 1][i][P::A[q]], b[t & 1][j][P::B[q]], acc[i][j]);
+          acc[2 * i + j] = mma16<2>(a[t & 1][i][P::A[q]], b[t & 1][j][P::B[q]], acc[2 * i + j]);
     const int nds = t < 8 ? 8 : 0, nvm = (3 * t + 3 <= 25) ? 3 : (25 - 3 * t > 0 ? 25 - 3 * t : 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -548,12 +590,95 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
 #undef CS_LOAD
 }
 
+// Row-reuse form of the same half-step.  A wave owns 32 output channels x 4 tile rows instead of 64 x 2: the X
+// operand of tap (ky, kx) for tile row r is the operand of tap (ky+1, kx) for row r-1, so per kx the wave reads 6
+// patch rows once (instead of 3 taps x 4 rows) and one weight block per tap: 54 ds_read_b128 per 108 MFMAs
+// instead of 72 -- the LDS operand traffic is what bounds this kernel (profiles/r01_conv3x3s_pmc.md).
+// Stage order: kx outer, ky inner; the reads of stage s+1 (row ky+4 and the next weight block, or the next kx's
+// first four rows) and a slice of the prefetch ride between the MFMAs of stage s.
+__device__ __forceinline__ void cs_mma_chunk_rr(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb, int abase,
+                                                int xb, f32x16 (&acc)[4],
+                                                const __amdgpu_buffer_rsrc_t rw_, const unsigned (&wb)[9], u32x4 (&rw)[9],
+                                                const __amdgpu_buffer_rsrc_t rx_, const unsigned (&gvo)[2][8],
+                                                unsigned (&rx)[2][8]) {
+  constexpr int SA = 9 * 2 * 64, SX = 2 * CS_XP;          // units per split in W_g / X
+  using P = Prod<2>;
+  u32x4 a[9][2], xr[3][6][2];                             // [stage][split], [kx][patch row][split]
+#define CS_LDA(st_, s_) a[st_][s_] = Ab[(s_) * SA + (((st_) % 3) * 3 + (st_) / 3) * 128 + abase];
+#define CS_LDX(kx_, r_, s_) xr[kx_][r_][s_] = Xb[(s_) * SX + xb + (r_) * CS_PW + (kx_)];
+  // operand reads of stage n (N(n)): stage kx*3: weights + rows 0-3 (10 reads), kx*3+1: weights + row 4, kx*3+2:
+  // weights + row 5 (4 each); first-needed first (product 0 = A term 1 x B term 0)
+#define CS_NEED(n_)                                                                              \
+  {                                                                                              \
+    constexpr int kx_ = (n_) / 3, ky_ = (n_) % 3;                                                \
+    CS_LDA(n_, 1)                                                                                \
+    if (ky_ == 0) { _Pragma("unroll") for (int r = 0; r < 4; ++r) CS_LDX(kx_, r, 0) }            \
+    else CS_LDX(kx_, ky_ + 3, 0)                                                                 \
+    CS_LDA(n_, 0)                                                                                \
+    if (ky_ == 0) { _Pragma("unroll") for (int r = 0; r < 4; ++r) CS_LDX(kx_, r, 1) }            \
+    else CS_LDX(kx_, ky_ + 3, 1)                                                                 \
+  }
+  // Issue plan (reads ride between the MFMAs of the stage named first; the LDS needs ~2 stages of lead when the
+  // four computing waves of the CU read in lockstep -- with one stage of lead the MFMAs and the reads serialised):
+  //   after the barrier: N0 | stage 0: N1 N2 | 1: N3 | 2: N4 | 3: N5 | 4: N6 | 5: N7 | 6: N8 | 7, 8: none
+  CS_NEED(0)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int st = 0; st < 9; ++st) {
+    const int kx = st / 3, ky = st % 3;
+    int nds = 0;
+    if (st == 0) { CS_NEED(1) CS_NEED(2) nds = 8; }
+    else if (st == 1) { CS_NEED(3) nds = 10; }
+    else if (st == 2) { CS_NEED(4) nds = 4; }
+    else if (st == 3) { CS_NEED(5) nds = 4; }
+    else if (st == 4) { CS_NEED(6) nds = 10; }
+    else if (st == 5) { CS_NEED(7) nds = 4; }
+    else if (st == 6) { CS_NEED(8) nds = 4; }
+    // prefetch slices per stage: 4 2 4 4 2 4 4 1 0 = 25
+    const int L0 = st == 0 ? 0 : st == 1 ? 4 : st == 2 ? 6 : st == 3 ? 10 : st == 4 ? 14 : st == 5 ? 16 : st == 6 ? 20 : 24;
+    const int nvm = (st == 1 || st == 4) ? 2 : (st == 7 ? 1 : (st == 8 ? 0 : 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int L = L0 + q;
+      if (q < nvm) {
+        if (L < 9) rw[L] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wb[L], 0, 0);
+        else if (L < 25) rx[(L - 9) >> 3][(L - 9) & 7] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[(L - 9) >> 3][(L - 9) & 7], 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < P::N; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = mma16<2>(a[st][P::A[q]], xr[kx][ky + j][P::B[q]], acc[j]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i >= 12 - nvm) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef CS_NEED
+#undef CS_LDA
+#undef CS_LDX
+}
+
 struct ConvCsP {
   int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;
   float slope;
   int tiles_x, tiles_y;
 };
 
+#ifdef CS_TRACE
+__device__ unsigned g_cs_trace[8 * 32 * 8 + 8];
+extern "C" int dfmir_cs_trace_dump(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(unsigned) * (8 * 32 * 8 + 8));
+}
+#define TRC(slot_) { if (trace_blk && lane == 0) trc[((grp * 4 + wid) * 32 + (h & 31)) * 8 + (slot_)] = (unsigned)__builtin_readcyclecounter(); }
+#else
+#define TRC(slot_)
+#endif
+template <bool RR>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __restrict__ x, const u32x4* __restrict__ ws,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              ConvCsP k, SplitScale sc) {
@@ -564,6 +689,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   __shared__ __attribute__((aligned(16))) u32x4 Wg[2][WUG];
   __shared__ __attribute__((aligned(16))) u32x4 Xs[2][NSP * 2 * XP];
   __shared__ float bs[128];
+#ifdef CS_TRACE
+  __shared__ unsigned trc[8 * 32 * 8];
+  const bool trace_blk = blockIdx.x == 300 && blockIdx.y == 0;
+  const unsigned long long trc_t0 = __builtin_readcyclecounter(), trc_r0 = wall_clock64();
+#endif
 
   // wave-uniform by construction; readfirstlane tells the compiler so (otherwise every buffer load whose
   // descriptor depends on the group is wrapped in a waterfall loop)
@@ -599,19 +729,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   }
   if (threadIdx.x < 128) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
 
-  // MFMA operand indices: wave w of a group owns tile rows 2w, 2w+1 (32 pixels each)
+  // MFMA operand indices.  Plain form: wave w of a group owns 64 couts x tile rows 2w, 2w+1 (32 pixels each);
+  // row-reuse form: 32 couts (w & 1) x tile rows 4(w >> 1) .. +3
   int pb[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) pb[j] = lhi * XP + (2 * wid + j) * CS_PW + l31;
-  const int abase = lhi * 64 + l31;
+  const int xb = lhi * XP + 4 * (wid >> 1) * CS_PW + l31;
+  const int abase = lhi * 64 + l31 + (RR ? 32 * (wid & 1) : 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];                                          // plain: [cout block i][row j] at 2i + j; row-reuse: [row]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const float* xn = x + (long long)n * k.Cin * HWi;
   const int chunks8 = (k.Cin + 7) / 8, chunks = (k.Cin + 15) / 16;
@@ -656,9 +786,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       const int pos = tid + 256 * s;                                                             \
       if (pos < NPOS) {                                                                          \
         float v[8];                                                                              \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rx[s][c]) * xscale; \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rx[s][c]);          \
         u32x4 sp[NSP];                                                                           \
-        split8<NSP>(v, sp);                                                                      \
+        split8_s<NSP>(v, xscale, sp);                                                                      \
         _Pragma("unroll") for (int q = 0; q < NSP; ++q) Xs[buf_][(q * 2 + grp) * XP + pos] = sp[q]; \
       }                                                                                          \
     }                                                                                            \
@@ -674,8 +804,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 
   for (int h = 0; h < 2 * chunks; ++h) {
     const int c = h >> 1;
+    TRC(0)
     if ((h & 1) == grp) {
       // compute chunk c; the prefetch (chunks past the end read zeros) rides behind the MFMAs
+      __builtin_amdgcn_s_setprio(CS_COMPUTE_PRIO);
       const int qw_ = 2 * (c + 1), lw_ = chunks8 - qw_;
       const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<u32x4*>(ws + (long long)qw_ * wunits8), 0,
@@ -684,18 +816,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(xn + (long long)cx_ * HWi), 0,
           lx_ > 0 ? (unsigned)((lx_ < 16 ? lx_ : 16) * HWi) * 4u : 0u, 0x00020000);
-      cs_mma_chunk(Wg[grp], Xs[c & 1], abase, pb, acc, rwd, wb, rw, rxd, gvo, rx);
+      if constexpr (RR) cs_mma_chunk_rr(Wg[grp], Xs[c & 1], abase, xb, acc, rwd, wb, rw, rxd, gvo, rx);
+      else cs_mma_chunk(Wg[grp], Xs[c & 1], abase, pb, acc, rwd, wb, rw, rxd, gvo, rx);
     } else {
       // store what this group prefetched during its last compute half-step (B at h = 0: the prologue's)
+      __builtin_amdgcn_s_setprio(CS_STORE_PRIO);
+      {
+#ifdef CS_TRACE
+      __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0): separates the load wait from the convert + store
+      TRC(3)
+#endif
+#ifdef CS_TRACE
+      CS_LSTOREW();
+      TRC(4)
+      if (c + 1 < chunks) CS_LSTOREX((c + 1) & 1);
+#else
       if (grp == 0) {
         if (c + 1 < chunks) { CS_LSTOREW(); CS_LSTOREX((c + 1) & 1); }
       } else {
         CS_LSTOREW();
         if (c + 1 < chunks) CS_LSTOREX((c + 1) & 1);
       }
+#endif
+      }
     }
+    TRC(1)
     __syncthreads();
+    TRC(2)
   }
+#ifdef CS_TRACE
+  if (trace_blk) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 32 * 8; i += 512) g_cs_trace[i] = trc[i];
+    if (threadIdx.x == 0) {
+      const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+      g_cs_trace[2048] = (unsigned)trc_t0; g_cs_trace[2049] = (unsigned)t1;
+      g_cs_trace[2050] = (unsigned)trc_r0; g_cs_trace[2051] = (unsigned)r1;
+    }
+  }
+#endif
 #undef CS_GLOADW
 #undef CS_GLOADX
 #undef CS_LSTOREW
@@ -703,22 +862,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 
   float* yb = y + (long long)n * k.Cout * HWo;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int oy = oy0 + 2 * wid + j, ox = ox0 + l31;
+  for (int b = 0; b < 4; ++b) {
+    const int i = RR ? (wid & 1) : (b >> 1);              // 32-cout block of the group's 64
+    const int row = RR ? 4 * (wid >> 1) + b : 2 * wid + (b & 1);
+    const int oy = oy0 + row, ox = ox0 + l31;
     if (oy >= k.Ho || ox >= k.Wo) continue;
     const int q = oy * k.Wo + ox;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = 64 * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-        const int co = m0 + cc;
-        if (co < k.Cout) {
-          float v = acc[i][j][r] * oscale * oscale2 + bs[cc];
-          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
-          else if (k.act == 2) v = tanhf(v);
-          yb[(long long)co * HWo + q] = v;
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int cc = 64 * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+      const int co = m0 + cc;
+      if (co < k.Cout) {
+        float v = acc[b][r] * oscale * oscale2 + bs[cc];
+        if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+        else if (k.act == 2) v = tanhf(v);
+        yb[(long long)co * HWo + q] = v;
       }
     }
   }
@@ -752,7 +910,9 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
     const double fill = (double)HWo / ((double)kc.tiles_x * CS_TW * kc.tiles_y * CS_TH);
     if (nb < (1LL << 31) && fill >= 0.85) {
       dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
-      conv3x3_split_cs_k<<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
+      if (rr) conv3x3_split_cs_k<true><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      else conv3x3_split_cs_k<false><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
       hipError_t e = hipGetLastError();
       *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
       return true;
@@ -893,10 +1053,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     float r[10];                                                                                 \
     r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
-    if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 10; ++e) r[e] *= xscale; }             \
     unsigned pa[5][NSP], pb[4][NSP];                                                             \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair<NSP>(r[2 * i], r[2 * i + 1], pa[i]); \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) split_pair<NSP>(r[2 * i + 1], r[2 * i + 2], pb[i]); \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_s<NSP>(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
+    if (NSP == 2) {            /* the odd pairing is the even one shifted by a half: v_alignbit */ \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+        _Pragma("unroll") for (int s = 0; s < NSP; ++s) pb[i][s] = __builtin_amdgcn_alignbit(pa[i + 1][s], pa[i][s], 16); \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) split_pair<NSP>(r[2 * i + 1], r[2 * i + 2], pb[i]); \
+    }                                                                                            \
     _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
       u32x4* dst = Xc + ((s * 3 * 4 + xr) * 2 + xu) * CT + xc;                                   \
       dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
@@ -906,9 +1070,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
     float v[8];                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
     bacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));   /* this thread's dY channel is fixed */ \
-    if (NSP == 2) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] *= dscale; }              \
     u32x4 sp[NSP];                                                                               \
-    split8<NSP>(v, sp);                                                                          \
+    split8_s<NSP>(v, dscale, sp);                                                                \
     if (dload) { _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; } \
   }
 

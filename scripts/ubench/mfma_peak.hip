@@ -54,6 +54,62 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   out[blockIdx.x * 256 + t] = s;
 }
 
+
+// Software-pipelined operand reads (the conv kernels' real pattern): the 12 ds_read_b128 of iteration i+1 are issued
+// between the 24 MFMAs of iteration i.  SPACING 1: one read after each of the first 12 MFMAs (bunched);
+// SPACING 2: one read after every second MFMA (even).  NRD reads per 24 MFMAs.
+template <int SPACING, int NRD>
+__global__ __launch_bounds__(256) void kp(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2048];
+  const int t = threadIdx.x;
+  for (int i = t; i < 2048; i += 256) lds[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  __syncthreads();
+  f32x16 acc[4];
+  for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  u32x4 v[2][16];
+  for (int i = 0; i < 16; ++i) v[0][i] = lds[(t + 64 * i) & 2047];
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) v[half ^ 1][i] = lds[(t + 64 * i + it + half) & 2047];
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v[half][(p * 2) % NRD]),
+                                                           __builtin_bit_cast(bf16x8, v[half][(p * 2 + a + 1) % NRD]), acc[a], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (SPACING == 1) { if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        else if (SPACING == 2) { if ((i & 1) == 1 && (i >> 1) < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        else { if (i < 24 && (i * NRD) / 24 != ((i + 1) * NRD) / 24) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+  for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  out[blockIdx.x * 256 + t] = s;
+}
+template <int SPACING, int NRD>
+void runp(const char* name, int waves_per_simd) {
+  float* out; hipMalloc(&out, 1 << 24);
+  const int blocks = 256 * waves_per_simd, iters = 4000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  kp<SPACING, NRD><<<blocks, 256>>>(out, 200);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  kp<SPACING, NRD><<<blocks, 256>>>(out, iters);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double mf = (double)blocks * 4 * iters * 24;
+  printf("%-44s %d wave/SIMD  %8.3f ms  %8.1f TFLOP/s  (%.2f ns per MFMA per SIMD)\n", name, waves_per_simd, ms,
+         mf * 32768.0 / ms / 1e9, ms * 1e6 / ((double)iters * 24 * waves_per_simd));
+  hipFree(out);
+}
+
 template <int MODE>
 void run(const char* name, double flop_per_mfma, int waves_per_simd) {
   float* out; hipMalloc(&out, 1 << 24);
@@ -79,6 +135,11 @@ int main() {
     run<3>("bf16 32x32x16 + 2 VALU per MFMA", 32768.0, w);
     run<4>("bf16 32x32x16 + 4 VALU per MFMA", 32768.0, w);
     run<5>("bf16 32x32x16, ONE accumulator chain", 32768.0, w);
+    runp<1, 12>("pipelined 12 reads / 24, bunched 1:1", w);
+    runp<2, 12>("pipelined 12 reads / 24, every 2nd MFMA", w);
+    runp<1, 16>("pipelined 16 reads / 24, bunched 1:1", w);
+    runp<3, 16>("pipelined 16 reads / 24, spread", w);
+    runp<3, 8>("pipelined 8 reads / 24, spread", w);
   }
   return 0;
 }
