@@ -1,5 +1,7 @@
+"""Run one split conv shape back to back for 6 s while sampling rocm-smi clocks/power (profiles/r01_power_clock.md).
+args: randn | relu | zero (input data)"""
 import os, sys, time, subprocess, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dfmir_amd import ops
 Cin = Cout = 256; H = 64; n = 32
