@@ -257,6 +257,8 @@ def main():
                                     % form if split else
                                     "conv3x3_mfma_k<2,2,2,2,400> (v_mfma_f32_32x32x2_f32; 128 couts x 128 pixels)") +
                                    ": forward + dgrad of every 3x3 conv with Cout > 64",
+                         "clock_note": "these kernels hold the package at its 1400 W cap: sclk 1.75 GHz sustained "
+                                       "(profiles/r01_power_clock.md), i.e. a 1.84 PFLOP/s 16-bit roof at that clock",
                          "peak_note": "peak = dense fp32 MFMA (dtype f32); achieved = algorithmic fp32 FLOP/s" +
                                       (", above it because the products run on the 16-bit matrix pipe" if split else ""),
                          "issued_mfma_tflops": issued, "issued_mfma_peak": 2500.0 if split else FP32_MFMA_PEAK_TFLOPS,
