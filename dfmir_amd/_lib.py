@@ -45,6 +45,7 @@ _SIGS = {
     "dfmir_blur_up_bwd": [P, P, c_int, c_int, c_int, P],
     "dfmir_reflect_pad2d_fwd": [P, P, c_int, c_int, c_int, c_int, P],
     "dfmir_reflect_pad2d_bwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "dfmir_reflect_pad2d_bwd_add": [P, P, P, c_int, c_int, c_int, c_int, P],
     "dfmir_upcat_fwd": [P, P, P] + [c_int] * 7 + [P],
     "dfmir_upcat_bwd": [P, P, P] + [c_int] * 7 + [P],
     "dfmir_cat_channels_fwd": [P, P, P, c_longlong, c_longlong, c_longlong, P],

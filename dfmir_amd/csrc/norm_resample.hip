@@ -543,8 +543,8 @@ __device__ __forceinline__ int reflect_adj(int i, int n, int p, int* qq) {
   if (i <= n - 2 && i >= n - 1 - p) qq[cnt++] = p + 2 * (n - 1) - i;
   return cnt;
 }
-__global__ void reflect_pad2d_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int planes,
-                                    int H, int W, int p) {
+__global__ void reflect_pad2d_bwd_k(const float* __restrict__ dy, const float* __restrict__ add,
+                                    float* __restrict__ dx, int planes, int H, int W, int p) {
   const int Ho = H + 2 * p, Wo = W + 2 * p;
   const long long total = (long long)planes * H * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -560,14 +560,15 @@ __global__ void reflect_pad2d_bwd_k(const float* __restrict__ dy, float* __restr
     float s = 0.f;
     for (int a = 0; a < ny; ++a)
       for (int b = 0; b < nx; ++b) s += gp[(long long)qy[a] * Wo + qx[b]];
-    dx[i] = s;
+    dx[i] = add ? s + add[i] : s;
   }
 }
 
 // pad 1, W % 4 == 0, H, W >= 8: 4 outputs per thread (one 16-B load of the padded row + the two halo columns
-// at the row ends), rows 1 and H-2 also take the halo rows 0 and H+1
-__global__ __launch_bounds__(256) void reflect_pad1_bwd_v4_k(const float* __restrict__ dy, float* __restrict__ dx,
-                                                             int H, int W) {
+// at the row ends), rows 1 and H-2 also take the halo rows 0 and H+1.  `add` (optional): a second gradient of the
+// same tensor -- the residual branch of a ResnetBlock -- summed in the same pass instead of by a separate kernel
+__global__ __launch_bounds__(256) void reflect_pad1_bwd_v4_k(const float* __restrict__ dy, const float* __restrict__ add,
+                                                             float* __restrict__ dx, int H, int W) {
   typedef unsigned rp_u32x4 __attribute__((ext_vector_type(4)));
   const int G = W >> 2, Wo = W + 2;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -589,7 +590,12 @@ __global__ __launch_bounds__(256) void reflect_pad1_bwd_v4_k(const float* __rest
     if (x0 == 0) s[1] += gp[rb];                  // output column 1 <- padded column 0
     if (x0 == W - 4) s[2] += gp[rb + W + 1];      // output column W-2 <- padded column W+1
   }
-  *reinterpret_cast<float4*>(dx + ((long long)blockIdx.y * H + y) * W + x0) = make_float4(s[0], s[1], s[2], s[3]);
+  const long long o = ((long long)blockIdx.y * H + y) * W + x0;
+  if (add) {
+    const float4 r = *reinterpret_cast<const float4*>(add + o);
+    s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w;
+  }
+  *reinterpret_cast<float4*>(dx + o) = make_float4(s[0], s[1], s[2], s[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -784,19 +790,28 @@ extern "C" int dfmir_reflect_pad2d_fwd(const float* x, float* y, int planes, int
   DF_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p,
-                                       void* stream) {
+static int reflect_pad2d_bwd_impl(const float* dy, const float* add, float* dx, int planes, int H, int W, int p,
+                                  void* stream) {
   DF_ARG_CHECK(dy && dx && planes > 0 && p >= 0 && p < H && p < W);
   if (p == 1 && (W & 3) == 0 && H >= 8 && W >= 8 && planes <= 65535 && (long long)(H + 2) * (W + 2) < (1LL << 29)) {
     reflect_pad1_bwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
-                            (hipStream_t)stream>>>(dy, dx, H, W);
+                            (hipStream_t)stream>>>(dy, add, dx, H, W);
     DF_LAUNCH_CHECK();
     return 0;
   }
   reflect_pad2d_bwd_k<<<df_grid((long long)planes * H * W, 256, 8192), 256, 0, (hipStream_t)stream>>>(
-      dy, dx, planes, H, W, p);
+      dy, add, dx, planes, H, W, p);
   DF_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p,
+                                       void* stream) {
+  return reflect_pad2d_bwd_impl(dy, nullptr, dx, planes, H, W, p, stream);
+}
+extern "C" int dfmir_reflect_pad2d_bwd_add(const float* dy, const float* add, float* dx, int planes, int H, int W,
+                                           int p, void* stream) {
+  DF_ARG_CHECK(add != nullptr);
+  return reflect_pad2d_bwd_impl(dy, add, dx, planes, H, W, p, stream);
 }
 extern "C" int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, int Ca, int Cb, int Da,
                                int Ha, int Wa, int sd, void* stream) {

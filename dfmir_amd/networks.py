@@ -9,6 +9,7 @@ x + conv_block(x)) are executed as fused launches by the sequential walker in
 `ResnetGenerator.forward`.
 """
 import functools
+import os
 import math
 
 import numpy as np
@@ -228,6 +229,9 @@ def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[], debug=False, i
 # ------------------------------------------------------------------------------------------------
 # generator
 # ------------------------------------------------------------------------------------------------
+_NO_SKIP_FOLD = bool(os.environ.get("DFMIR_NO_SKIP_FOLD"))   # A/B switch: skip gradient summed by autograd's add
+
+
 class ResnetBlock(nn.Module):
     """x + [pad,conv,IN,ReLU,pad,conv,IN](x) (models/networks.py:1164-1221) as 4 fused launches."""
 
@@ -241,10 +245,15 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):
         cb = self.conv_block
-        h = _reflect_conv(cb[0], cb[1], x)
+        if torch.is_grad_enabled() and x.requires_grad and x.is_contiguous() and not _NO_SKIP_FOLD:
+            # the skip branch leaves through the first conv's autograd node, whose backward sums its gradient
+            # inside the halo-fold kernel (one pass instead of fold + add)
+            h, xs = ops.conv(x, cb[1].weight, cb[1].bias, cb[1], cb[1].stride, cb[0].padding, 1, 0, 0.0, skip=True)
+        else:
+            h, xs = _reflect_conv(cb[0], cb[1], x), x
         h = cb[2](h, relu=True)
         h = _reflect_conv(cb[4], cb[5], h)
-        return cb[6](h, relu=False, res=x)
+        return cb[6](h, relu=False, res=xs)
 
 
 def _reflect_conv(pad, conv, x, act=0):

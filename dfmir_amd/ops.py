@@ -207,7 +207,10 @@ class ConvFn(Function):
     """y = act(conv(x, w) + b).  `owner` supplies cached packed weights (owner.packed(mode))."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, owner, stride, pad, pad_mode, act, slope):
+    def forward(ctx, x, weight, bias, owner, stride, pad, pad_mode, act, slope, skip=False):
+        # skip=True (reflect-padded stride-1 convs): also return x itself as a second output for a residual
+        # branch, so that backward receives that branch's gradient and sums it inside the halo-fold kernel
+        # (ResnetBlock: out = x + conv_block(x), models/networks.py:1219-1221) instead of autograd's add kernel.
         _need(x, weight, bias)
         nd = x.dim() - 2
         x5 = _c(x) if nd == 3 else _c(x).unsqueeze(2)
@@ -224,12 +227,21 @@ class ConvFn(Function):
         ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
         ctx.save_for_backward(x5, weight, y5 if act else None)
         ctx.has_bias = bias is not None
-        return y5 if nd == 3 else y5.squeeze(2)
+        ctx.skip = bool(skip)
+        y = y5 if nd == 3 else y5.squeeze(2)
+        if skip:
+            if not (stride == 1 and pad_mode == 1 and x.is_contiguous()):
+                raise DfmirHipError("conv(skip=True) is the reflect-padded stride-1 case on a contiguous input")
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
+        return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         nd, K, stride, p3, pad_mode, act, slope, owner = ctx.cfg
+        if dy is None:              # only the skip output was used downstream
+            return (dskip,) + (None,) * 9
         x5, weight, y5 = ctx.saved_tensors
         dy5 = _c(dy) if nd == 3 else _c(dy).unsqueeze(2)
         if act:
@@ -253,12 +265,19 @@ class ConvFn(Function):
                 if p3[0] != 0 or p3[1] != p3[2]:
                     raise DfmirHipError("reflect padding is 2-D, symmetric only")
                 dx5 = torch.empty_like(x5)
-                check(lib().dfmir_reflect_pad2d_bwd(_p(dxp), _p(dx5), x5.shape[0] * Cin, in_sp[1], in_sp[2],
-                                                    p3[1], _st()))
+                if dskip is not None:
+                    check(lib().dfmir_reflect_pad2d_bwd_add(_p(dxp), _p(_c(dskip)), _p(dx5), x5.shape[0] * Cin,
+                                                            in_sp[1], in_sp[2], p3[1], _st()))
+                    dskip = None
+                else:
+                    check(lib().dfmir_reflect_pad2d_bwd(_p(dxp), _p(dx5), x5.shape[0] * Cin, in_sp[1], in_sp[2],
+                                                        p3[1], _st()))
             else:
                 padp = tuple(K[i] - 1 - p3[i] for i in range(3))
                 dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax)
             dx = dx5 if nd == 3 else dx5.squeeze(2)
+        if dskip is not None:       # not folded in above (x needs no conv-path gradient, or non-reflect dgrad)
+            dx = dskip if dx is None else dx + dskip
         defer = (_DEFER["on"] and owner is not None and getattr(owner, "weight", None) is not None
                  and owner.weight.grad is not None and owner.weight.grad.is_contiguous())
         # bias gradient target: straight into bias.grad when deferring, else a fresh buffer (returned to autograd);
@@ -282,11 +301,11 @@ class ConvFn(Function):
         elif db_buf is not None:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
             check(lib().dfmir_bias_grad(_p(dy5), _p(db_buf), dy5.shape[0], Cout, S, _st()))   # accumulates
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0):
-    return ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope)
+def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0, skip=False):
+    return ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope, skip)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -131,6 +131,11 @@ int dfmir_blur_up_bwd(const float* dy, float* dx, int planes, int H, int W, void
 /* nn.ReflectionPad2d(p) -- models/networks.py:982,1022 (materialised only for NCE layer 0). */
 int dfmir_reflect_pad2d_fwd(const float* x, float* y, int planes, int H, int W, int p, void* stream);
 int dfmir_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int p, void* stream);
+/* dx = fold(dy) + add: the adjoint of ReflectionPad2d summed with a second gradient of the same tensor in one pass --
+ * ResnetBlock's `out = x + self.conv_block(x)` (models/networks.py:1219-1221): x feeds the padded conv AND the skip,
+ * so its gradient is fold(d conv path) + d out.  add[planes][H][W]. */
+int dfmir_reflect_pad2d_bwd_add(const float* dy, const float* add, float* dx, int planes, int H, int W, int p,
+                                void* stream);
 
 /* nn.Upsample(scale 2, nearest) + torch.cat([up(a), b], 1) -- torchvoxelmorph/networks.py:64,97-100.
  * a[N,Ca,Da,Ha,Wa] -> factor sd (1 for 2-D, 2 for 3-D) in D and 2 in H,W; b[N,Cb,Da*sd,2Ha,2Wa]. */

@@ -269,6 +269,13 @@ def test_blur_reflect_golden(ops, golden):
         yg = ops.reflect_pad2d(xg, p)
         (yg * cot.to(DEV)).sum().backward()
         close(yg, yr, what="pad"); close(xg.grad, xr.grad, what="dpad")
+        # the fold with a second gradient summed in the same pass (ResnetBlock's skip branch)
+        from dfmir_amd._lib import lib, check
+        add = C.randn(39, *shp).to(DEV)
+        cg, out = cot.to(DEV).contiguous(), torch.empty(*shp, device=DEV)
+        check(lib().dfmir_reflect_pad2d_bwd_add(cg.data_ptr(), add.data_ptr(), out.data_ptr(), shp[0] * shp[1],
+                                                shp[2], shp[3], p, torch.cuda.current_stream().cuda_stream))
+        close(out, xr.grad + add.cpu(), what="dpad + skip")
 
 
 @pytest.mark.parametrize("nd", [2, 3])
