@@ -265,8 +265,8 @@ def main():
                          "issued_mfma_tflops": issued, "issued_mfma_peak": 2500.0 if split else FP32_MFMA_PEAK_TFLOPS,
                          "issued_mfma_frac": issued / (2500.0 if split else FP32_MFMA_PEAK_TFLOPS),
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-                         "wgrad_kernel": ("conv3x3_wgrad_split_k (same split; 64 ci x 128 co x 9 taps per workgroup, "
-                                          "runs of 2 rows x 16 px)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
+                         "wgrad_kernel": ("conv3x3_wgrad_split2_k (same split; 64 ci x 128 co x 9 taps per workgroup, runs of "
+                                          "2 rows x 16 px, double-buffered LDS, staggered wave groups)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
                          "wgrad_kernel_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
                          "wgrad_issued_mfma_frac": (wg_tf * nprod / 2500.0) if split else wg_tf / FP32_MFMA_PEAK_TFLOPS,
                          "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},

@@ -1150,6 +1150,220 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16x2, 128 output channels: the same tiling as conv3x3_wgrad_split_k<2,128> with the three things its knock-out
+// timings asked for (profiles/r01_conv3x3s_pmc.md: the non-matrix work alone was 70 % of that kernel):
+//   * LDS tiles double-buffered, ONE barrier per run: the conversion + LDS stores of run r+1 happen during the MFMA
+//     phase of run r, and the two wave groups are staggered -- waves 0-3 convert first and then compute, waves 4-7
+//     compute first and then convert -- so each SIMD always has one wave on the matrix pipe (a wave of each group);
+//   * an operand unit Xc[dx][row] serves both k-steps (row = ks + ty): 12 distinct units per run instead of 18
+//     reads, i.e. 28 ds_read_b128 per 54 MFMAs instead of 40;
+//   * operands are read one unit (3 or 6 MFMAs) ahead; two or three units ahead measured the same.
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ dwt, WS3P k) {
+  constexpr int NSP = 2, BC = 128, CT = 64;
+  using P = Prod<2>;
+  constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
+  constexpr int XCU = NSP * 3 * 4 * XSLAB, DYU = NSP * 2 * 2 * BC;
+  __shared__ __attribute__((aligned(16))) u32x4 Xc[2 * XCU];
+  __shared__ __attribute__((aligned(16))) u32x4 Dy[2 * DYU];
+  __shared__ float bsum[BC];
+  __shared__ float red[17];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool want_db = k.db != nullptr && blockIdx.y == 0;
+  if (tid < BC) bsum[tid] = 0.f;
+  float bacc = 0.f;
+  const int wc = wid & 3, wi = wid >> 2;             // wi is also the stagger group
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int HW = k.H * k.W;
+  const int ci0 = blockIdx.y * CT, co0 = blockIdx.z * BC;
+  const int run_beg = blockIdx.x * k.runs_per_block;
+  int run_end = run_beg + k.runs_per_block;
+  if (run_end > k.runs_total) run_end = k.runs_total;
+
+  const int ex = scale_exp(reduce_absmax(k.x_amax, k.x_n, red));
+  __syncthreads();
+  const int ed = scale_exp(reduce_absmax(k.dy_amax, k.dy_n, red));
+  const float xscale = pow2f(ex), dscale = pow2f(ed), oscale = pow2f(-ex), oscale2 = pow2f(-ed);
+
+  // loader roles: X group (patch row xr 0..3, half xu, channel xc 0..63), dY group (k-step dk, half du, channel dc)
+  const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
+  const int dc = tid & (BC - 1), du = (tid >> 7) & 1, dk = tid >> 8;
+  const unsigned hw4 = (unsigned)HW * 4u;
+  constexpr unsigned OOB = 0x80000000u;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  u32x4 rxa, rxb, rda, rdb;   // 8 px of X, 8 px of dY
+  unsigned rxl, rxr;          // the pixel left / right of the X group
+
+  // past the last run of this workgroup the descriptors are empty (loads return zeros, stores are harmless)
+#define W2_GLOAD(run_)                                                                           \
+  {                                                                                              \
+    const bool live_ = (run_) < run_end;                                                         \
+    const int n_ = live_ ? (run_) / k.runs_per_img : 0;                                          \
+    const int q_ = live_ ? (run_) - n_ * k.runs_per_img : 0;                                     \
+    const int yp_ = q_ / k.runs_per_row, xs_ = q_ - yp_ * k.runs_per_row;                        \
+    const int y0_ = 2 * yp_, x0_ = 16 * xs_ + 8 * xu;                                            \
+    const __amdgpu_buffer_rsrc_t bx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(x + (long long)n_ * k.Cin * HW), 0, live_ ? (unsigned)(k.Cin * HW) * 4u : 0u, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t bd_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, live_ ? (unsigned)(k.Cout * HW) * 4u : 0u, 0x00020000); \
+    const bool cok_ = ci0 + xc < k.Cin;                                                          \
+    const unsigned cb_ = (unsigned)(ci0 + xc) * hw4;                                             \
+    int ry_ = y0_ - 1 + xr;                                                                      \
+    bool rok_ = (unsigned)ry_ < (unsigned)k.H;                                                   \
+    if (k.pad_mode == 1) { ry_ = ry_ < 0 ? -ry_ : (ry_ >= k.H ? 2 * (k.H - 1) - ry_ : ry_); rok_ = true; } \
+    const int rb_ = ry_ * k.W;                                                                   \
+    const bool lin_ = x0_ > 0, rin_ = x0_ + 8 < k.W;                                             \
+    const int ol_ = rb_ + (lin_ ? x0_ - 1 : 1), or_ = rb_ + (rin_ ? x0_ + 8 : k.W - 2);          \
+    const bool lok_ = rok_ && cok_ && (lin_ || k.pad_mode == 1), rrok_ = rok_ && cok_ && (rin_ || k.pad_mode == 1); \
+    const unsigned xb_ = (rok_ && cok_) ? cb_ + (unsigned)(rb_ + x0_) * 4u : OOB;                \
+    rxa = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_, 0, 0);                                 \
+    rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
+    rxl = __builtin_amdgcn_raw_buffer_load_b32(bx_, lok_ ? cb_ + (unsigned)ol_ * 4u : OOB, 0, 0); \
+    rxr = __builtin_amdgcn_raw_buffer_load_b32(bx_, rrok_ ? cb_ + (unsigned)or_ * 4u : OOB, 0, 0); \
+    const unsigned db_ = (co0 + dc >= k.Cout) ? OOB                                              \
+        : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + dk) * k.W + 16 * xs_ + 8 * du) * 4u;    \
+    rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
+    rdb = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_ == OOB ? OOB : db_ + 16u, 0, 0);        \
+  }
+  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour; pairs (0,1)..(8,9) make the units
+  // dx=0 (cols -1..6) and dx=2 (cols 1..8), the odd pairing dx=1 is the even one shifted by a half
+#define W2_LSTORE(buf_)                                                                          \
+  {                                                                                              \
+    float r[10];                                                                                 \
+    r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
+    unsigned pa[5][NSP], pb[4][NSP];                                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s) pb[i][s] = __builtin_amdgcn_alignbit(pa[i + 1][s], pa[i][s], 16); \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
+      u32x4* dst = Xc + (buf_) * XCU + ((s * 3 * 4 + xr) * 2 + xu) * CT + xc;                    \
+      dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
+      dst[4 * XSLAB] = u32x4{pb[0][s], pb[1][s], pb[2][s], pb[3][s]};                            \
+      dst[8 * XSLAB] = u32x4{pa[1][s], pa[2][s], pa[3][s], pa[4][s]};                            \
+    }                                                                                            \
+    float v[8];                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
+    bacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));                   \
+    u32x4 sp[NSP];                                                                               \
+    split8_s<NSP>(v, dscale, sp);                                                                \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[(buf_) * DYU + ((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
+  }
+
+  // operand unit indices of this lane: A = Xc[((s*3 + dx)*4 + row)*2 + lhi][ci], B = Dy[(s*2 + ks)*2 + lhi][co]
+  const int abase = lhi * CT + wi * 32 + l31;
+  const int bbase = lhi * BC + wc * 32 + l31;
+  // the 12 operand units of a run in an order that never puts two 3-MFMA units (rows 0, 3) next to each other
+  //   unit u -> (dx, row);  MFMAs of a unit: k-steps ks with 0 <= row - ks <= 2, tap = (row - ks)*3 + dx
+#ifndef W2_LEAD
+#define W2_LEAD 1      // operand units read ahead (1-3 measured equal; 1 needs the fewest registers)
+#endif
+#ifdef W2_NOPRIO
+#define W2_PRIO(p_)
+#else
+#define W2_PRIO(p_) __builtin_amdgcn_s_setprio(p_)
+#endif
+#define W2_UDX(u_) ((u_) / 4)
+#define W2_UROW(u_) ((u_) < 4 ? (u_) : ((u_) % 4 == 0 ? 1 : ((u_) % 4 == 1 ? 0 : (u_) % 4)))
+#define W2_LOADA(set_, u_)                                                                       \
+  _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                                \
+    a[set_][s] = Xb[((s * 3 + W2_UDX(u_)) * 4 + W2_UROW(u_)) * XSLAB + abase];
+#define W2_MMA_PHASE(buf_)                                                                       \
+  {                                                                                              \
+    const u32x4* Xb = Xc + (buf_) * XCU;                                                         \
+    const u32x4* Db = Dy + (buf_) * DYU;                                                         \
+    u32x4 b[2][NSP], a[W2_LEAD + 1][NSP];                                                        \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) b[0][s] = Db[(s * 2 + 0) * 2 * BC + bbase];  \
+    W2_LOADA(0, 0)                                                                               \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) b[1][s] = Db[(s * 2 + 1) * 2 * BC + bbase];  \
+    if (W2_LEAD > 1) W2_LOADA(1, 1)                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    _Pragma("unroll") for (int u = 0; u < 12; ++u) {                                             \
+      if (u + W2_LEAD < 12) W2_LOADA((u + W2_LEAD) % (W2_LEAD + 1), u + W2_LEAD)                 \
+      const int dx_ = W2_UDX(u), row_ = W2_UROW(u);                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                         \
+        const int ty_ = row_ - ks;                                                               \
+        if (ty_ >= 0 && ty_ <= 2) {                                                              \
+          _Pragma("unroll") for (int q = 0; q < P::N; ++q)                                       \
+            acc[ty_ * 3 + dx_] = mma16<NSP>(a[u % (W2_LEAD + 1)][P::A[q]], b[ks][P::B[q]], acc[ty_ * 3 + dx_]); \
+        }                                                                                        \
+      }                                                                                          \
+      const int nm_ = (row_ == 0 || row_ == 3) ? 3 : 6;                                          \
+      _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                            \
+        if (i < nm_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+        if (i < NSP && u + W2_LEAD < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+      }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  }
+
+  if (run_beg < run_end) {
+    W2_GLOAD(run_beg);
+    W2_LSTORE(0);
+    W2_GLOAD(run_beg + 1);
+  }
+  __syncthreads();
+
+  // two copies of the run loop rather than a branch inside one: each group's loop gets its own register allocation
+  // (a branch in the body spilled 270 registers); both execute the same number of barriers
+  if (wi == 0) {
+    for (int run = run_beg; run < run_end; ++run) {
+      const int buf = (run - run_beg) & 1;
+      W2_PRIO(0);
+      W2_LSTORE(buf ^ 1);
+      W2_GLOAD(run + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      W2_PRIO(1);
+      W2_MMA_PHASE(buf);
+      __syncthreads();
+    }
+  } else {
+    for (int run = run_beg; run < run_end; ++run) {
+      const int buf = (run - run_beg) & 1;
+      W2_PRIO(1);
+      W2_MMA_PHASE(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      W2_PRIO(0);
+      W2_LSTORE(buf ^ 1);
+      W2_GLOAD(run + 2);
+      __syncthreads();
+    }
+  }
+#undef W2_GLOAD
+#undef W2_LSTORE
+#undef W2_LOADA
+#undef W2_MMA_PHASE
+#undef W2_UDX
+#undef W2_UROW
+
+  if (want_db) {
+    atomicAdd(&bsum[dc], bacc);
+    __syncthreads();
+    if (tid < BC && co0 + tid < k.Cout) atomicAdd(&k.db[co0 + tid], bsum[tid]);
+  }
+  const int co = co0 + wc * 32 + l31;
+  if (co < k.Cout) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r] * oscale * oscale2);
+      }
+    }
+  }
+}
+
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc) {
   const int mode = df_split_mode();
@@ -1177,7 +1391,9 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
   const dim3 grid(nx, ny, nz);
   if (mode == 2) {
-    if (wide) conv3x3_wgrad_split_k<2, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+    static const bool v1 = getenv("DFMIR_WGRAD_V1") != nullptr;      // A/B: the single-buffered kernel
+    if (wide && !v1) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+    else if (wide) conv3x3_wgrad_split_k<2, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
     else conv3x3_wgrad_split_k<2, 64><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
   } else {
     if (wide) conv3x3_wgrad_split_k<3, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
