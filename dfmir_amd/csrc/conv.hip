@@ -453,6 +453,23 @@ __global__ void weight_unpack_k(const float* __restrict__ gt, float* __restrict_
   }
 }
 
+// All deferred weight gradients of a step in one launch: job j (blockIdx.y) adds its tap-major accumulator into the
+// reference-layout gradient, g[co][ci][t] += gt[t][ci][co], and clears the accumulator for the next step.
+__global__ __launch_bounds__(256) void weight_unpack_add_batch_k(const DfUnpackJob* __restrict__ jobs) {
+  const DfUnpackJob jb = jobs[blockIdx.y];
+  const long long total = (long long)jb.Cout * jb.Cin * jb.T;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % jb.T);
+    long long r = i / jb.T;
+    const int ci = (int)(r % jb.Cin);
+    const int co = (int)(r / jb.Cin);
+    const long long j = ((long long)t * jb.Cin + ci) * jb.Cout + co;
+    jb.dst[i] += jb.src[j];
+    jb.src[j] = 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -671,6 +688,15 @@ extern "C" long long dfmir_weight_pack_floats(int Cout, int Cin, int T) {
   // [T][K][M] fp32 (rounded up to 16 B) + the split section when T == 9; one size for both packings
   const long long s0 = df_pack_split_floats(Cin, Cout, T), s1 = df_pack_split_floats(Cout, Cin, T);
   return df_pack_tcc_floats(Cin, Cout, T) + (s0 > s1 ? s0 : s1) + (T == 9 ? 4 + 2048 : 0);   // + scale trailer, probe slots
+}
+extern "C" int dfmir_weight_unpack_add_batch(const DfUnpackJob* jobs_dev, int njobs, long long max_total,
+                                             void* stream) {
+  DF_ARG_CHECK(jobs_dev && njobs > 0 && njobs <= 65535 && max_total > 0);
+  long long bx = (max_total + 255) / 256;
+  if (bx > 64) bx = 64;
+  weight_unpack_add_batch_k<<<dim3((unsigned)bx, (unsigned)njobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  DF_LAUNCH_CHECK();
+  return 0;
 }
 extern "C" int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T,
                                    void* stream) {

@@ -178,13 +178,32 @@ class deferred_weight_grads:
     def __exit__(self, *exc):
         _DEFER["on"] = False
         pending, _DEFER["pending"] = _DEFER["pending"], {}
-        if exc[0] is None:
-            with torch.no_grad():
-                for owner, buf, shape in pending.values():
-                    g = owner.weight.grad
-                    g.add_(weight_unpack(buf, shape).view_as(g))
-                    buf.zero_()
+        if exc[0] is None and pending:
+            _flush_deferred(list(pending.values()))
         return False
+
+
+_JOBS = {"key": None, "dev": None, "max": 0}
+
+
+def _flush_deferred(items):
+    """grad += unpack(accumulator); accumulator = 0 for every deferred conv, one launch (the job table is uploaded
+    once and reused while the same buffers come back, i.e. every step after the first)."""
+    import numpy as np
+    key = tuple((buf.data_ptr(), owner.weight.grad.data_ptr(), tuple(shape)) for owner, buf, shape in items)
+    if _JOBS["key"] != key:
+        tab = np.zeros((len(items), 4), dtype=np.int64)            # struct DfUnpackJob = 2 pointers + 4 ints
+        mx = 0
+        for i, (owner, buf, shape) in enumerate(items):
+            Cout, Cin = int(shape[0]), int(shape[1])
+            T = buf.numel() // (Cout * Cin)
+            tab[i, 0], tab[i, 1] = buf.data_ptr(), owner.weight.grad.data_ptr()
+            tab[i, 2] = Cout | (Cin << 32)
+            tab[i, 3] = T
+            mx = max(mx, Cout * Cin * T)
+        _JOBS["dev"] = torch.from_numpy(tab).to(items[0][1].device)
+        _JOBS["key"], _JOBS["max"] = key, mx
+    check(lib().dfmir_weight_unpack_add_batch(_p(_JOBS["dev"]), len(items), _JOBS["max"], _st()))
 
 
 def _deferred_buffer(owner, T, Cin, Cout, shape, device):

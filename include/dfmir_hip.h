@@ -90,6 +90,16 @@ long long dfmir_weight_pack_floats(int Cout, int Cin, int T);
 int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin, int T, int mode, void* stream);
 /* g[co][ci][t] = g_tcc[t][ci][co]  (gradient back to the reference's parameter layout). */
 int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, void* stream);
+/* The deferred form of the same step for every conv of a backward pass at once (one launch per train step instead
+ * of unpack + add + clear per layer): job j adds its tap-major accumulator src[T][Cin][Cout] into the gradient in the
+ * reference layout, dst[Cout][Cin][T] += src (torch accumulates p.grad the same way, autograd/functions/
+ * accumulate_grad.h), and zeroes src.  `jobs` is DEVICE memory; max_total = max_j Cout*Cin*T. */
+typedef struct DfUnpackJob {
+  float* src;
+  float* dst;
+  int Cout, Cin, T, reserved;
+} DfUnpackJob;
+int dfmir_weight_unpack_add_batch(const DfUnpackJob* jobs, int njobs, long long max_total, void* stream);
 
 /* 7x7 convs of the generator as 1x1 GEMMs (models/networks.py:982-983 Conv2d(1,64,7) and :1022-1024
  * Conv2d(64,1,7)+Tanh, both behind ReflectionPad2d(3)):

@@ -483,3 +483,36 @@ def test_adam_matches_torch(ops):
         o_ref.step(); o_got.step()
     for r, q in zip(ref, got):
         close(q, r, rtol=1e-6, what="adam params")
+
+
+def test_deferred_weight_grads_batch_flush(ops):
+    """Weight gradients accumulated in tap-major buffers and flushed by ONE batched launch at the end of backward
+    (ops.deferred_weight_grads) equal the per-layer path, accumulate into existing .grad, and leave the accumulators
+    cleared for the next step."""
+    from dfmir_amd import networks as N
+    torch.manual_seed(5)
+    convs = [N.Conv2d(6, 10, 3, padding=1).to(DEV), N.Conv2d(10, 4, 1).to(DEV), N.Conv2d(4, 7, 3, padding=1).to(DEV)]
+    x = C.randn(71, 2, 6, 9, 12).to(DEV)
+    cot = C.randn(72, 2, 7, 9, 12).to(DEV)
+
+    def run(deferred, steps):
+        for c in convs:
+            c.weight.grad = torch.full_like(c.weight, 0.25)     # existing gradient: the flush must add to it
+            c.bias.grad = torch.zeros_like(c.bias)
+        for _ in range(steps):
+            h = x
+            for c in convs:
+                h = c(h)
+            if deferred:
+                with ops.deferred_weight_grads():
+                    (h * cot).sum().backward()
+            else:
+                (h * cot).sum().backward()
+        return [c.weight.grad.clone() for c in convs]
+
+    ref = run(False, 2)
+    got = run(True, 2)
+    for g, r in zip(got, ref):
+        close(g, r, rtol=1e-5, what="deferred dW")
+    for c in convs:
+        assert float(c._dw_tcc.abs().max()) == 0.0
