@@ -229,6 +229,7 @@ def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[], debug=False, i
 # ------------------------------------------------------------------------------------------------
 # generator
 # ------------------------------------------------------------------------------------------------
+_NO_SHARE_TAP = bool(os.environ.get("DFMIR_NO_SHARE_TAP"))   # A/B switch: dense gradients of the sampled features
 _NO_SKIP_FOLD = bool(os.environ.get("DFMIR_NO_SKIP_FOLD"))   # A/B switch: skip gradient summed by autograd's add
 
 
@@ -308,16 +309,20 @@ class ResnetGenerator(nn.Module):
         feat = x
         i = 0
 
-        def emit(idx, t):
+        def emit(idx, t, shared=True):
+            nonlocal feat
+            stop = encode_only and idx == last
             if idx in want:
+                if shared and not stop and not _NO_SHARE_TAP and t is feat:
+                    feat, t = ops.fork_tap(t)     # t also feeds the next layer: see ops.TapForkFn
                 feats.append(t)
-            return encode_only and idx == last
+            return stop
 
         while i < n:
             m = mods[i]
             if isinstance(m, ReflectionPad2d) and i + 1 < n and isinstance(mods[i + 1], Conv2d):
                 if i in want:
-                    if emit(i, m(feat)):
+                    if emit(i, m(feat), shared=False):
                         return feat, feats, True
                 conv = mods[i + 1]
                 tanh = i + 2 < n and isinstance(mods[i + 2], Tanh) and (i + 1) not in want

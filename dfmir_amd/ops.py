@@ -737,12 +737,61 @@ def resize_linear(x, out_sp, mult=1.0):
 # ------------------------------------------------------------------------------------------------
 # PatchNCE
 # ------------------------------------------------------------------------------------------------
+class TapForkFn(Function):
+    """feat -> (main, tap): two aliases of a feature map that is tapped for PatchNCE sampling AND feeds the next
+    layer.  The sampled rows' gradient is a scatter of a few hundred positions per plane; returned densely
+    (zeros + scatter) autograd would then sum two full-size tensors.  `patch_gather` on `tap` instead parks
+    (d rows, ids) in `stash` and returns no gradient; this node's backward scatters them into the next layer's
+    gradient in place (or into zeros if `main` received none)."""
+
+    @staticmethod
+    def forward(ctx, feat, stash):
+        ctx.stash = stash
+        ctx.shape = tuple(feat.shape)
+        ctx.set_materialize_grads(False)
+        return feat.view_as(feat), feat.view_as(feat)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_main, g_tap):
+        stash = ctx.stash
+        g = g_main
+        if stash:
+            if g is None:
+                g = torch.zeros(ctx.shape, device=stash[0][0].device, dtype=torch.float32)
+            elif not g.is_contiguous():
+                g = g.contiguous()
+            for dout, ids, (shape, B, C, S, Pn) in stash:
+                check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(g), B, C, S, Pn, _st()))
+            del stash[:]
+            if hasattr(g, "_df_amax"):
+                del g._df_amax                   # modified through the raw pointer: a range tag would be stale
+        if g_tap is not None:                    # a dense gradient on the tap (some other use of it)
+            g = g_tap if g is None else g + g_tap
+        return g, None
+
+
+def fork_tap(feat):
+    """(main, tap) for a tapped feature that also feeds the next layer; see TapForkFn.  Without grad: (feat, feat)."""
+    if not (torch.is_grad_enabled() and feat.requires_grad and feat.is_contiguous()):
+        return feat, feat
+    stash = []
+    main, tap = TapForkFn.apply(feat, stash)
+    tap._df_tap_stash = stash
+    tag = getattr(feat, "_df_amax", None)
+    if tag is not None and tag[1] == feat._version and tag[2] == feat.data_ptr():
+        tag_amax(main, tag[0])
+        tag_amax(tap, tag[0])
+    return main, tap
+
+
 class PatchGatherFn(Function):
     """feat [B,C,*sp], ids int64 [P] -> channel-major rows [C, B*P]."""
 
     @staticmethod
     def forward(ctx, feat, ids):
         _need(feat, ids)
+        ctx.stash = getattr(feat, "_df_tap_stash", None) if feat.is_contiguous() else None
         feat = _c(feat)
         ids = _c(ids.to(torch.int64))
         B, C = feat.shape[0], feat.shape[1]
@@ -760,6 +809,9 @@ class PatchGatherFn(Function):
         (ids,) = ctx.saved_tensors
         shape, B, C, S, Pn = ctx.meta
         dout = _c(dout)
+        if ctx.stash is not None:                # collected by TapForkFn.backward, which runs after this node
+            ctx.stash.append((dout, ids, ctx.meta))
+            return None, None
         dfeat = torch.zeros(shape, device=dout.device, dtype=torch.float32)
         check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, _st()))
         return dfeat, None

@@ -516,3 +516,30 @@ def test_deferred_weight_grads_batch_flush(ops):
         close(g, r, rtol=1e-5, what="deferred dW")
     for c in convs:
         assert float(c._dw_tcc.abs().max()) == 0.0
+
+
+def test_shared_tap_sparse_gradient(ops):
+    """A tapped feature that also feeds the next layer (ops.fork_tap): the sampled rows' gradient is scattered into
+    the other consumer's gradient in place instead of being returned densely and summed by autograd; same result,
+    also when the other consumer yields no gradient or the rows are unused."""
+    x0 = C.randn(81, 2, 6, 8, 8).to(DEV)
+    ids = torch.tensor([3, 17, 40, 63, 5], device=DEV)
+    w = C.randn(82, 2, 6, 8, 8).to(DEV)
+    cot = C.randn(83, 6, 2 * 5).to(DEV)
+
+    def run(shared, use_main, use_rows):
+        x = x0.clone().requires_grad_()
+        t = x * 2.0                                   # the "feature": non-leaf
+        main, tap = ops.fork_tap(t) if shared else (t, t)
+        rows = ops.patch_gather(tap, ids)
+        loss = (x * 0.0).sum()
+        if use_main:
+            loss = loss + (main * w).sum()
+        if use_rows:
+            loss = loss + (rows * cot).sum()
+        loss.backward()
+        return x.grad
+
+    for use_main, use_rows in ((True, True), (False, True), (True, False)):
+        close(run(True, use_main, use_rows), run(False, use_main, use_rows), rtol=1e-6,
+              what="fork_tap grad main=%s rows=%s" % (use_main, use_rows))
