@@ -28,6 +28,7 @@ _SIGS = {
     "dfmir_bias_grad": [P, P, c_int, c_int, c_longlong, P],
     "dfmir_weight_pack": [P, P, c_int, c_int, c_int, c_int, P],
     "dfmir_weight_pack_floats": [c_int, c_int, c_int],
+    "dfmir_weight_pack_batch": [P, c_int, P, c_int, P],
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
     "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],

@@ -13,6 +13,7 @@
 // 64 cycles per 32x32x2 so the per-element gather arithmetic hides under the matrix pipe.
 #include "conv3x3_common.h"
 #include <stdlib.h>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -453,6 +454,37 @@ __global__ void weight_unpack_k(const float* __restrict__ gt, float* __restrict_
   }
 }
 
+// Every weight packing of a step in one launch (job = blockIdx.y): same arithmetic as weight_pack_k
+__global__ __launch_bounds__(256) void weight_pack_batch_k(const DfPackJobDev* __restrict__ jobs) {
+  const DfPackJobDev jb = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= jb.nblk) return;
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
+  __syncthreads();
+  float am = 0.f;
+  const int Cout = jb.Cout, Cin = jb.Cin, T = jb.T;
+  const long long total = (long long)Cout * Cin * T;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)jb.nblk * 256) {
+    float v;
+    if (jb.mode == 0) {  // o[t][ci][co]
+      const int co = (int)(i % Cout);
+      long long r = i / Cout;
+      const int ci = (int)(r % Cin);
+      const int t = (int)(r / Cin);
+      v = jb.w[((long long)co * Cin + ci) * T + t];
+    } else {             // o[t][co][ci] = w[co][ci][T-1-t]
+      const int ci = (int)(i % Cin);
+      long long r = i / Cin;
+      const int co = (int)(r % Cout);
+      const int t = (int)(r / Cout);
+      v = jb.w[((long long)co * Cin + ci) * T + (T - 1 - t)];
+    }
+    jb.o[i] = v;
+    am = fmaxf(am, fabsf(v));
+  }
+  if (jb.part) publish_block_absmax(am, &smax, jb.part + blockIdx.x);
+}
+
 // All deferred weight gradients of a step in one launch: job j (blockIdx.y) adds its tap-major accumulator into the
 // reference-layout gradient, g[co][ci][t] += gt[t][ci][co], and clears the accumulator for the next step.
 __global__ __launch_bounds__(256) void weight_unpack_add_batch_k(const DfUnpackJob* __restrict__ jobs) {
@@ -681,6 +713,35 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
     const int rc = df_weight_split_launch(w_tcc, w_tcc, K, M, (int)nblk, (hipStream_t)stream);
     if (rc) return df_set_error(rc, __FILE__, __LINE__);
   }
+  return 0;
+}
+extern "C" int dfmir_weight_pack_batch(const DfPackJob* jobs_host, int njobs, void* table_dev, int upload,
+                                       void* stream) {
+  DF_ARG_CHECK(jobs_host && table_dev && njobs > 0 && njobs <= 65535);
+  static_assert(sizeof(DfPackJobDev) == 64, "job table stride");
+  hipStream_t st = (hipStream_t)stream;
+  int max_nblk = 0, max_nsplit = 0;
+  std::vector<DfPackJobDev> tab((size_t)njobs);
+  for (int i = 0; i < njobs; ++i) {
+    const DfPackJob& h = jobs_host[i];
+    DF_ARG_CHECK(h.w && h.packed && h.Cout > 0 && h.Cin > 0 && h.T > 0 && (h.mode == 0 || h.mode == 1));
+    DfPackJobDev& d = tab[(size_t)i];
+    d.w = h.w; d.o = h.packed; d.Cout = h.Cout; d.Cin = h.Cin; d.T = h.T; d.mode = h.mode;
+    d.nblk = (int)df_grid((long long)h.Cout * h.Cin * h.T, 256, 2048);
+    df_weight_split_fill(&d);
+    max_nblk = d.nblk > max_nblk ? d.nblk : max_nblk;
+    max_nsplit = d.nsplit > max_nsplit ? d.nsplit : max_nsplit;
+  }
+  if (upload) {
+    // pageable source: the runtime stages it before returning, so `tab` may go out of scope
+    hipError_t e = hipMemcpyAsync(table_dev, tab.data(), sizeof(DfPackJobDev) * (size_t)njobs, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
+  }
+  weight_pack_batch_k<<<dim3((unsigned)max_nblk, (unsigned)njobs), 256, 0, st>>>(
+      reinterpret_cast<const DfPackJobDev*>(table_dev));
+  DF_LAUNCH_CHECK();
+  const int rc = df_weight_split_batch_launch(reinterpret_cast<const DfPackJobDev*>(table_dev), njobs, max_nsplit, st);
+  if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }
 extern "C" long long dfmir_weight_pack_floats(int Cout, int Cin, int T) {

@@ -42,3 +42,18 @@ static inline long long df_pack_tcc_floats(long long K, long long M, int T) { re
 static inline long long df_pack_split_floats(long long K, long long M, int T) {
   return T == 9 ? ((K + 7) / 8) * 27 * M * 4 : 0;
 }
+
+// One job of the batched weight packing (dfmir_weight_pack_batch): device-side view with the derived pointers.
+struct DfPackJobDev {
+  const float* w;      // [Cout][Cin][T]
+  float* o;            // packed buffer: [T][K][M] fp32 first
+  float* part;         // probe slots (partial maxima of |w|) or NULL
+  float* sec;          // split section (16-B units) or NULL
+  float* trailer;      // split trailer or NULL
+  int Cout, Cin, T, mode;
+  int nblk;            // workgroups of the pack pass = number of partial maxima
+  int nsplit;          // workgroups of the split pass (0: no split section)
+};
+int df_weight_split_batch_launch(const DfPackJobDev* jobs_dev, int njobs, int max_nsplit, hipStream_t st);
+void df_weight_split_fill(DfPackJobDev* j);   // fills part / sec / trailer / nsplit for a T == 9 job
+

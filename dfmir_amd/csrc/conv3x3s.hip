@@ -229,6 +229,58 @@ int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int 
   return (int)hipGetLastError();
 }
 
+// ---- batched form: every packed weight of a step in one launch (job = blockIdx.y)
+template <int NSP>
+__global__ __launch_bounds__(256) void weight_split_batch_k(const DfPackJobDev* __restrict__ jobs) {
+  const DfPackJobDev jb = jobs[blockIdx.y];
+  if ((int)blockIdx.x >= jb.nsplit) return;
+  __shared__ float red[17];
+  const int K = jb.mode ? jb.Cout : jb.Cin, M = jb.mode ? jb.Cin : jb.Cout;
+  const int chunks = (K + 7) >> 3;
+  const long long total = (long long)chunks * 9 * M;
+  int e = 0;
+  if (NSP == 2) {
+    e = scale_exp(reduce_absmax(jb.trailer + 4, jb.nblk, red));
+    if (blockIdx.x == 0 && threadIdx.x == 0) jb.trailer[1] = (float)e;
+  }
+  const float sc = pow2f(e);
+  u32x4* out = reinterpret_cast<u32x4*>(jb.sec);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)jb.nsplit * 256) {
+    const int m = (int)(i % M);
+    const int tap = (int)((i / M) % 9);
+    const int ch = (int)(i / ((long long)9 * M));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = ch * 8 + j;
+      v[j] = kk < K ? jb.o[((long long)tap * K + kk) * M + m] * sc : 0.f;
+    }
+    u32x4 sp[NSP];
+    split8<NSP>(v, sp);
+    const long long base = (long long)ch * 9 * NSP * M + (long long)tap * M + m;
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) out[base + (long long)s * 9 * M] = sp[s];
+  }
+}
+void df_weight_split_fill(DfPackJobDev* j) {
+  const int mode = df_split_mode();
+  j->part = nullptr; j->sec = nullptr; j->trailer = nullptr; j->nsplit = 0;
+  if (j->T != 9 || mode == 0) return;
+  const int K = j->mode ? j->Cout : j->Cin, M = j->mode ? j->Cin : j->Cout;
+  j->sec = split_section(j->o, K, M);
+  j->trailer = split_trailer(j->o, K, M, mode);
+  j->part = mode == 2 ? j->trailer + 4 : nullptr;
+  j->nsplit = (int)df_grid((long long)((K + 7) / 8) * 9 * M, 256, 2048);
+}
+int df_weight_split_batch_launch(const DfPackJobDev* jobs_dev, int njobs, int max_nsplit, hipStream_t st) {
+  const int mode = df_split_mode();
+  if (mode == 0 || max_nsplit <= 0) return 0;
+  const dim3 grid((unsigned)max_nsplit, (unsigned)njobs);
+  if (mode == 2) weight_split_batch_k<2><<<grid, 256, 0, st>>>(jobs_dev);
+  else weight_split_batch_k<3><<<grid, 256, 0, st>>>(jobs_dev);
+  return (int)hipGetLastError();
+}
+
 // ---- the MFMA phase of one 8-channel chunk for a wave tile of TM x TN 32x32 blocks.
 // Ab: weight chunk [split][tap][BM] (16-B units), Xb: halo patch [split][XP]; aoff[pr] / bidx[pr][j] are
 // this lane's unit indices for tap pair pr.  Operands of pair pr+1 are read from LDS while the matrix pipe

@@ -47,13 +47,7 @@ class _ConvNd(nn.Module):
             init.uniform_(self.bias, -bound, bound)
 
     def packed(self, mode):
-        w = self.weight
-        ver = (w.data_ptr(), w._version, ops.weights_epoch())
-        ent = self._packs.get(mode)
-        if ent is None or ent[0] != ver:
-            ent = (ver, ops.weight_pack(w.detach(), mode))
-            self._packs[mode] = ent
-        return ent[1]
+        return ops.packed_weight(self, self.weight.detach(), mode)
 
     def forward(self, x, act=0, slope=0.0, reflect=False):
         return ops.conv(x, self.weight, self.bias, self, self.stride, self.padding,
@@ -88,13 +82,7 @@ class Linear(nn.Module):
         init.uniform_(self.bias, -bound, bound)
 
     def packed(self, mode):
-        w = self.weight
-        ver = (w.data_ptr(), w._version, ops.weights_epoch())
-        ent = self._packs.get(mode)
-        if ent is None or ent[0] != ver:
-            ent = (ver, ops.weight_pack(w.detach().view(self.out_features, self.in_features, 1), mode))
-            self._packs[mode] = ent
-        return ent[1]
+        return ops.packed_weight(self, self.weight.detach().view(self.out_features, self.in_features, 1), mode)
 
     def forward(self, x_cr, relu=False):
         """x_cr: [in_features, rows] -> [out_features, rows]."""

@@ -94,6 +94,16 @@ int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, 
  * of unpack + add + clear per layer): job j adds its tap-major accumulator src[T][Cin][Cout] into the gradient in the
  * reference layout, dst[Cout][Cin][T] += src (torch accumulates p.grad the same way, autograd/functions/
  * accumulate_grad.h), and zeroes src.  `jobs` is DEVICE memory; max_total = max_j Cout*Cin*T. */
+/* Every packing of a train step at once (the weights of all layers change together, at the optimizer step): the same
+ * result as njobs dfmir_weight_pack calls, in two launches.  `jobs` is HOST memory; `table_dev` is njobs * 64 bytes of
+ * device scratch owned by the caller, (re)written when upload != 0 -- pass 0 while the same jobs come back. */
+typedef struct DfPackJob {
+  const float* w;      /* [Cout][Cin][T] */
+  float* packed;       /* dfmir_weight_pack_floats(Cout, Cin, T) floats */
+  int Cout, Cin, T, mode;
+} DfPackJob;
+int dfmir_weight_pack_batch(const DfPackJob* jobs, int njobs, void* table_dev, int upload, void* stream);
+
 typedef struct DfUnpackJob {
   float* src;
   float* dst;
