@@ -486,19 +486,51 @@ __global__ __launch_bounds__(256) void weight_pack_batch_k(const DfPackJobDev* _
 }
 
 // All deferred weight gradients of a step in one launch: job j (blockIdx.y) adds its tap-major accumulator into the
-// reference-layout gradient, g[co][ci][t] += gt[t][ci][co], and clears the accumulator for the next step.
+// reference-layout gradient, g[co][ci][t] += gt[t][ci][co], and clears the accumulator for the next step.  T <= 9:
+// 32 co x 32 ci tiles through LDS, so that both the accumulator rows (co contiguous) and the gradient rows
+// ((ci, t) contiguous) move as full cache lines; larger T (the 7x7 ends, a few KB): element-wise.
 __global__ __launch_bounds__(256) void weight_unpack_add_batch_k(const DfUnpackJob* __restrict__ jobs) {
   const DfUnpackJob jb = jobs[blockIdx.y];
-  const long long total = (long long)jb.Cout * jb.Cin * jb.T;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % jb.T);
-    long long r = i / jb.T;
-    const int ci = (int)(r % jb.Cin);
-    const int co = (int)(r / jb.Cin);
-    const long long j = ((long long)t * jb.Cin + ci) * jb.Cout + co;
-    jb.dst[i] += jb.src[j];
-    jb.src[j] = 0.f;
+  const int Cout = jb.Cout, Cin = jb.Cin, T = jb.T;
+  if (T > 9) {
+    const long long total = (long long)Cout * Cin * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+      const int t = (int)(i % T);
+      long long r = i / T;
+      const int ci = (int)(r % Cin);
+      const int co = (int)(r / Cin);
+      const long long j = ((long long)t * Cin + ci) * Cout + co;
+      jb.dst[i] += jb.src[j];
+      jb.src[j] = 0.f;
+    }
+    return;
+  }
+  __shared__ float tile[32][32 * 9 + 1];
+  const int tco = (Cout + 31) >> 5, tci = (Cin + 31) >> 5;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;          // 32 x 8
+  for (int tl = blockIdx.x; tl < tco * tci; tl += gridDim.x) {
+    const int co0 = (tl % tco) << 5, ci0 = (tl / tco) << 5;
+    // rows (t, ci) of the accumulator: 32 consecutive co each
+    for (int r = ly; r < T * 32; r += 8) {
+      const int t = r >> 5, ci = ci0 + (r & 31), co = co0 + lx;
+      float v = 0.f;
+      if (ci < Cin && co < Cout) {
+        const long long j = ((long long)t * Cin + ci) * Cout + co;
+        v = jb.src[j];
+        jb.src[j] = 0.f;
+      }
+      tile[lx][(r & 31) * T + t] = v;
+    }
+    __syncthreads();
+    // rows co of the gradient: (ci0 .. ci0+31, t) = 32 T consecutive floats
+    const int ncol = 32 * T;
+    for (int e = threadIdx.x; e < 32 * ncol; e += 256) {
+      const int c = e / ncol, q = e - c * ncol;
+      const int co = co0 + c, ci = ci0 + q / T;
+      if (co < Cout && ci < Cin) jb.dst[((long long)co * Cin + ci0) * T + q] += tile[c][q];
+    }
+    __syncthreads();
   }
 }
 
