@@ -648,15 +648,19 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
 // instead of 72 -- the LDS operand traffic is what bounds this kernel (profiles/r01_conv3x3s_pmc.md).
 // Stage order: kx outer, ky inner; the reads of stage s+1 (row ky+4 and the next weight block, or the next kx's
 // first four rows) and a slice of the prefetch ride between the MFMAs of stage s.
+// CPG = output channels per wave group (64: tile 8 x 32, 32: tile 16 x 32), XP = patch positions (padded),
+// NW / NS = weight units / patch positions a thread prefetches per chunk.
+template <int CPG, int XP, int NW, int NS>
 __device__ __forceinline__ void cs_mma_chunk_rr(const u32x4* __restrict__ Ab, const u32x4* __restrict__ Xb, int abase,
                                                 int xb, f32x16 (&acc)[4],
-                                                const __amdgpu_buffer_rsrc_t rw_, const unsigned (&wb)[9], u32x4 (&rw)[9],
-                                                const __amdgpu_buffer_rsrc_t rx_, const unsigned (&gvo)[2][8],
-                                                unsigned (&rx)[2][8]) {
-  constexpr int SA = 9 * 2 * 64, SX = 2 * CS_XP;          // units per split in W_g / X
+                                                const __amdgpu_buffer_rsrc_t rw_, const unsigned (&wb)[NW], u32x4 (&rw)[NW],
+                                                const __amdgpu_buffer_rsrc_t rx_, const unsigned (&gvo)[NS][8],
+                                                unsigned (&rx)[NS][8]) {
+  constexpr int SA = 9 * 2 * CPG, SX = 2 * XP;            // units per split in W_g / X
+  constexpr int NL = NW + 8 * NS;                         // prefetch loads of a chunk
   using P = Prod<2>;
   u32x4 a[9][2], xr[3][6][2];                             // [stage][split], [kx][patch row][split]
-#define CS_LDA(st_, s_) a[st_][s_] = Ab[(s_) * SA + (((st_) % 3) * 3 + (st_) / 3) * 128 + abase];
+#define CS_LDA(st_, s_) a[st_][s_] = Ab[(s_) * SA + (((st_) % 3) * 3 + (st_) / 3) * (2 * CPG) + abase];
 #define CS_LDX(kx_, r_, s_) xr[kx_][r_][s_] = Xb[(s_) * SX + xb + (r_) * CS_PW + (kx_)];
   // operand reads of stage n (N(n)): stage kx*3: weights + rows 0-3 (10 reads), kx*3+1: weights + row 4, kx*3+2:
   // weights + row 5 (4 each); first-needed first (product 0 = A term 1 x B term 0)
@@ -686,15 +690,22 @@ __device__ __forceinline__ void cs_mma_chunk_rr(const u32x4* __restrict__ Ab, co
     else if (st == 4) { CS_NEED(6) nds = 10; }
     else if (st == 5) { CS_NEED(7) nds = 4; }
     else if (st == 6) { CS_NEED(8) nds = 4; }
-    // prefetch slices per stage: 4 2 4 4 2 4 4 1 0 = 25
-    const int L0 = st == 0 ? 0 : st == 1 ? 4 : st == 2 ? 6 : st == 3 ? 10 : st == 4 ? 14 : st == 5 ? 16 : st == 6 ? 20 : 24;
-    const int nvm = (st == 1 || st == 4) ? 2 : (st == 7 ? 1 : (st == 8 ? 0 : 4));
+    // prefetch slices per stage.  25 loads: 4 2 4 4 2 4 4 1 0; otherwise spread evenly over stages 0-7
+    int L0, nvm;
+    if (NL == 25) {
+      L0 = st == 0 ? 0 : st == 1 ? 4 : st == 2 ? 6 : st == 3 ? 10 : st == 4 ? 14 : st == 5 ? 16 : st == 6 ? 20 : 24;
+      nvm = (st == 1 || st == 4) ? 2 : (st == 7 ? 1 : (st == 8 ? 0 : 4));
+    } else {
+      const int lo = NL / 8, ex = NL % 8;
+      L0 = st * lo + (st < ex ? st : ex);
+      nvm = st < 8 ? lo + (st < ex ? 1 : 0) : 0;
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (NL + 7) / 8; ++q) {
       const int L = L0 + q;
       if (q < nvm) {
-        if (L < 9) rw[L] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wb[L], 0, 0);
-        else if (L < 25) rx[(L - 9) >> 3][(L - 9) & 7] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[(L - 9) >> 3][(L - 9) & 7], 0, 0);
+        if (L < NW) rw[L] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wb[L], 0, 0);
+        else if (L < NL) rx[(L - NW) >> 3][(L - NW) & 7] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[(L - NW) >> 3][(L - NW) & 7], 0, 0);
       }
     }
 #pragma unroll
@@ -730,17 +741,22 @@ extern "C" int dfmir_cs_trace_dump(unsigned* out) {
 #else
 #define TRC(slot_)
 #endif
-template <bool RR>
+// <RR, CPG, TH>: <*, 64, 8> = 128 output channels per workgroup on an 8 x 32 tile (RR: row-reuse compute phase);
+// <true, 32, 16> = 64 output channels on a 16 x 32 tile (the 128->64 / 64<-128 layers at 256^2): a wave still owns
+// 32 couts x 4 tile rows, a group its 32 couts over all 16 rows.
+template <bool RR, int CPG, int TH>
 __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __restrict__ x, const u32x4* __restrict__ ws,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              ConvCsP k, SplitScale sc) {
-  constexpr int NSP = 2, XP = CS_XP, NPOS = (CS_TH + 2) * CS_PW;
-  constexpr int WUG = NSP * 9 * 2 * 64;                   // 16-B units of one group's weight chunk (16 channels)
-  constexpr int NW = WUG / 256;                           // 9 per thread
-  constexpr int NS = (NPOS + 255) / 256;                  // 2 patch positions per thread
+  static_assert((CPG == 64 && TH == 8) || (RR && CPG == 32 && TH == 16), "tile forms");
+  constexpr int CS_TH = TH;
+  constexpr int NSP = 2, XP = (TH == 8 ? CS_XP : 640), NPOS = (CS_TH + 2) * CS_PW;
+  constexpr int WUG = NSP * 9 * 2 * CPG;                  // 16-B units of one group's weight chunk (16 channels)
+  constexpr int NW = (WUG + 255) / 256;                   // 9 (CPG 64) / 5 (CPG 32, the last one half used) per thread
+  constexpr int NS = (NPOS + 255) / 256;                  // 2 / 3 patch positions per thread
   __shared__ __attribute__((aligned(16))) u32x4 Wg[2][WUG];
   __shared__ __attribute__((aligned(16))) u32x4 Xs[2][NSP * 2 * XP];
-  __shared__ float bs[128];
+  __shared__ float bs[2 * CPG];
 #ifdef CS_TRACE
   __shared__ unsigned trc[8 * 32 * 8];
   const bool trace_blk = blockIdx.x == 300 && blockIdx.y == 0;
@@ -758,7 +774,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   const int ty = bt % k.tiles_y;
   const int n = bt / k.tiles_y;
   const int oy0 = ty * CS_TH, ox0 = tx * CS_TW;
-  const int m0 = blockIdx.y * 128, m0g = m0 + 64 * grp;
+  const int m0 = blockIdx.y * (2 * CPG), m0g = m0 + CPG * grp;
 
   const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, bs));     // bs: scratch here, bias below
   __syncthreads();
@@ -779,15 +795,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 #pragma unroll
     for (int c = 0; c < 8; ++c) gvo[s][c] = off < 0 ? OOB : (unsigned)(off + (8 * grp + c) * HWi) * 4u;
   }
-  if (threadIdx.x < 128) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
+  if (threadIdx.x < 2 * CPG) bs[threadIdx.x] = (bias && (m0 + (int)threadIdx.x) < k.Cout) ? bias[m0 + threadIdx.x] : 0.f;
 
   // MFMA operand indices.  Plain form: wave w of a group owns 64 couts x tile rows 2w, 2w+1 (32 pixels each);
   // row-reuse form: 32 couts (w & 1) x tile rows 4(w >> 1) .. +3
   int pb[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) pb[j] = lhi * XP + (2 * wid + j) * CS_PW + l31;
-  const int xb = lhi * XP + 4 * (wid >> 1) * CS_PW + l31;
-  const int abase = lhi * 64 + l31 + (RR ? 32 * (wid & 1) : 0);
+  const int rowgrp = CPG == 64 ? (wid >> 1) : wid;        // this wave's 4 tile rows
+  const int xb = lhi * XP + 4 * rowgrp * CS_PW + l31;
+  const int abase = lhi * CPG + l31 + ((RR && CPG == 64) ? 32 * (wid & 1) : 0);
 
   f32x16 acc[4];                                          // plain: [cout block i][row j] at 2i + j; row-reuse: [row]
 #pragma unroll
@@ -802,9 +819,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int idx = tid + 256 * j;
-    const int co = m0g + (idx & 63), r = idx >> 6;
+    const int co = m0g + (idx % CPG), r = idx / CPG;
     const int half = r & 1, st = r >> 1;
-    wb[j] = co < k.Cout ? (unsigned)((half * NSP * 9 + st) * k.Cout + co) * 16u : OOB;
+    wb[j] = (idx < WUG && co < k.Cout) ? (unsigned)((half * NSP * 9 + st) * k.Cout + co) * 16u : OOB;
   }
   const int wunits8 = NSP * 9 * k.Cout;                   // units of one 8-channel chunk in the packed weights
 
@@ -831,7 +848,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
         rx[s][c] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[s][c], 0, 0);                   \
   }
 #define CS_LSTOREW()                                                                             \
-  { _Pragma("unroll") for (int j = 0; j < NW; ++j) Wg[grp][tid + 256 * j] = rw[j]; }
+  { _Pragma("unroll") for (int j = 0; j < NW; ++j) if (WUG % 256 == 0 || tid + 256 * j < WUG) Wg[grp][tid + 256 * j] = rw[j]; }
 #define CS_LSTOREX(buf_)                                                                         \
   {                                                                                              \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                             \
@@ -868,8 +885,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(xn + (long long)cx_ * HWi), 0,
           lx_ > 0 ? (unsigned)((lx_ < 16 ? lx_ : 16) * HWi) * 4u : 0u, 0x00020000);
-      if constexpr (RR) cs_mma_chunk_rr(Wg[grp], Xs[c & 1], abase, xb, acc, rwd, wb, rw, rxd, gvo, rx);
-      else cs_mma_chunk(Wg[grp], Xs[c & 1], abase, pb, acc, rwd, wb, rw, rxd, gvo, rx);
+      if constexpr (RR) cs_mma_chunk_rr<CPG, XP, NW, NS>(Wg[grp], Xs[c & 1], abase, xb, acc, rwd, wb, rw, rxd, gvo, rx);
+      else if constexpr (CPG == 64) cs_mma_chunk(Wg[grp], Xs[c & 1], abase, pb, acc, rwd, wb, rw, rxd, gvo, rx);
     } else {
       // store what this group prefetched during its last compute half-step (B at h = 0: the prologue's)
       __builtin_amdgcn_s_setprio(CS_STORE_PRIO);
@@ -915,14 +932,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   float* yb = y + (long long)n * k.Cout * HWo;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    const int i = RR ? (wid & 1) : (b >> 1);              // 32-cout block of the group's 64
-    const int row = RR ? 4 * (wid >> 1) + b : 2 * wid + (b & 1);
+    const int i = CPG == 32 ? 0 : (RR ? (wid & 1) : (b >> 1));   // 32-cout block of the group's couts
+    const int row = RR ? 4 * rowgrp + b : 2 * wid + (b & 1);
     const int oy = oy0 + row, ox = ox0 + l31;
     if (oy >= k.Ho || ox >= k.Wo) continue;
     const int q = oy * k.Wo + ox;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int cc = 64 * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+      const int cc = CPG * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
       const int co = m0 + cc;
       if (co < k.Cout) {
         float v = acc[b][r] * oscale * oscale2 + bs[cc];
@@ -953,18 +970,24 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
   const SplitScale sc{x_amax, x_n, split_trailer(w_packed, g->Cin, g->Cout, mode)};
   static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
-  if (mode == 2 && g->Cout > 64 && use_cs) {
+  static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
+  if (mode == 2 && use_cs && (g->Cout > 64 || rr)) {
+    // 8 x 32 tiles (128 couts per workgroup) or 16 x 32 tiles (64 couts).  They fit the forward shapes exactly but
+    // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces: those stay on the
+    // flat-run kernel below
+    const int th = g->Cout > 64 ? 8 : 16;
     ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope,
-               (g->Wo + CS_TW - 1) / CS_TW, (g->Ho + CS_TH - 1) / CS_TH};
+               (g->Wo + CS_TW - 1) / CS_TW, (g->Ho + th - 1) / th};
     const long long nb = (long long)g->N * kc.tiles_x * kc.tiles_y;
-    // 8 x 32 tiles fit the forward shapes exactly but waste 37 % on the 66 x 66 padded frames the dgrad of a
-    // reflect-padded conv produces: those stay on the flat-run kernel below
-    const double fill = (double)HWo / ((double)kc.tiles_x * CS_TW * kc.tiles_y * CS_TH);
+    const double fill = (double)HWo / ((double)kc.tiles_x * CS_TW * kc.tiles_y * th);
     if (nb < (1LL << 31) && fill >= 0.85) {
-      dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
-      static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
-      if (rr) conv3x3_split_cs_k<true><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
-      else conv3x3_split_cs_k<false><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      if (g->Cout > 64) {
+        dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
+        if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+        else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      } else {
+        conv3x3_split_cs_k<true, 32, 16><<<dim3((unsigned)nb, 1u), 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      }
       hipError_t e = hipGetLastError();
       *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
       return true;

@@ -64,6 +64,10 @@ CONV2D = [
     (72, 136, 3, 1, 1, True, 1, 2, 10, 48),
     (64, 160, 3, 1, 1, False, 0, 1, 6, 16),
     (200, 129, 3, 1, 1, True, 0, 1, 18, 32),
+    # 64-cout form of the shared-tile kernel (16 x 32 tiles): reflect halo + activation + 3 channel chunks;
+    # ragged everything (Cin 20, 40 of 64 couts, last tile row 14 of 16 rows, 60 of 64 columns)
+    (48, 64, 3, 1, 1, True, 1, 2, 32, 64),
+    (20, 40, 3, 1, 1, False, 0, 1, 30, 60),
 ]
 
 
