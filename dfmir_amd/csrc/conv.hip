@@ -542,7 +542,8 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
-                              const float* bias, float* y, hipStream_t st, int* rc);
+                              const float* bias, const float* res, float* y, hipStream_t st, int* rc);
+int df_conv3x3_split_res_ok(const DfConvGeom* g);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc);
 int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int npart, hipStream_t st);
@@ -582,6 +583,19 @@ extern "C" int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const 
                                      const float* w_tcc, const float* bias, float* y, void* stream) {
   return conv_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, bias, y, stream);
 }
+extern "C" int dfmir_conv3x3_res_ok(const DfConvGeom* g) {
+  return (g && check_geom(g) == 0 && !use_generic_only()) ? df_conv3x3_split_res_ok(g) : 0;
+}
+extern "C" int dfmir_conv3x3_fwd_scaled_res(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                            const float* w_tcc, const float* bias, const float* res, float* y,
+                                            void* stream) {
+  DF_ARG_CHECK(g && check_geom(g) == 0 && x && x_amax && x_amax_n > 0 && w_tcc && res && y);
+  DF_ARG_CHECK(!use_generic_only() && df_conv3x3_split_res_ok(g));
+  int rc = 0;
+  if (!df_conv3x3_split_fwd_try(g, x, x_amax, x_amax_n, w_tcc, bias, res, y, (hipStream_t)stream, &rc))
+    return df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__);
+  return rc;
+}
 extern "C" int dfmir_absmax(const float* x, long long n, float* out, void* stream) {
   DF_ARG_CHECK(x && out && n > 0);
   const int rc = df_absmax_launch(x, n, out, (hipStream_t)stream, false);
@@ -595,7 +609,7 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, y, st, &rc)) return rc;
+    if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, nullptr, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
@@ -745,6 +759,20 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
     const int rc = df_weight_split_launch(w_tcc, w_tcc, K, M, (int)nblk, (hipStream_t)stream);
     if (rc) return df_set_error(rc, __FILE__, __LINE__);
   }
+  return 0;
+}
+int df_conv3x3_reflect_ring_ok(const DfConvGeom* g);
+int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
+                                   const float* wd_packed, float* dx, hipStream_t st);
+extern "C" int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
+  return (g && check_geom(g) == 0) ? df_conv3x3_reflect_ring_ok(g) : 0;
+}
+extern "C" int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
+                                          const float* wd_packed, float* dx, void* stream) {
+  DF_ARG_CHECK(g && check_geom(g) == 0 && dy && dy_amax && dy_amax_n > 0 && wd_packed && dx);
+  DF_ARG_CHECK(df_conv3x3_reflect_ring_ok(g));
+  const int rc = df_conv3x3_reflect_ring_launch(g, dy, dy_amax, dy_amax_n, wd_packed, dx, (hipStream_t)stream);
+  if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }
 extern "C" int dfmir_weight_pack_batch(const DfPackJob* jobs_host, int njobs, void* table_dev, int upload,

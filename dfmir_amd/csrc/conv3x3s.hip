@@ -730,6 +730,7 @@ struct ConvCsP {
   int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;
   float slope;
   int tiles_x, tiles_y;
+  const float* res;       // optional [N][Cout][Ho][Wo]: y = act(conv + bias) + res (a second gradient / residual)
 };
 
 #ifdef CS_TRACE
@@ -937,6 +938,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
     const int oy = oy0 + row, ox = ox0 + l31;
     if (oy >= k.Ho || ox >= k.Wo) continue;
     const int q = oy * k.Wo + ox;
+    float rv[16];                                            // residual: all 16 loads in flight before the first use
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    if (k.res) {
+      const float* rb = k.res + (long long)n * k.Cout * HWo + q;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + CPG * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+        if (co < k.Cout) rv[r] = rb[(long long)co * HWo];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cc = CPG * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
@@ -945,6 +957,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
         float v = acc[b][r] * oscale * oscale2 + bs[cc];
         if (k.act == 1) v = v > 0.f ? v : v * k.slope;
         else if (k.act == 2) v = tanhf(v);
+        v += rv[r];
         yb[(long long)co * HWo + q] = v;
       }
     }
@@ -952,10 +965,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
-                              const float* bias, float* y, hipStream_t st, int* rc) {
-  const int mode = df_split_mode();
-  if (mode == 0 || (mode == 2 && !(x_amax && x_n > 0))) return false;
+// res != NULL (y = act(conv + bias) + res): only the shared-tile kernel has that epilogue -- df_conv3x3_split_res_ok(g)
+// tells whether this geometry takes it; otherwise *rc is an error
+static bool cs_plan(const DfConvGeom* g, int* th_out, int* tx_out, int* ty_out) {
+  static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
+  static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
+  if (!(df_split_mode() == 2 && use_cs && (g->Cout > 64 || rr))) return false;
+  const int th = g->Cout > 64 ? 8 : 16;
+  const int tx = (g->Wo + CS_TW - 1) / CS_TW, ty = (g->Ho + th - 1) / th;
+  const double fill = (double)g->Ho * g->Wo / ((double)tx * CS_TW * ty * th);
+  if (!((long long)g->N * tx * ty < (1LL << 31) && fill >= 0.85)) return false;
+  *th_out = th; *tx_out = tx; *ty_out = ty;
+  return true;
+}
+static bool split_fwd_geom_ok(const DfConvGeom* g) {
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;
   if (g->Cout <= 32 || g->Cin < 16 || g->ph != g->pw || g->pd != 0) return false;
@@ -966,33 +989,42 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   if (HWo >= (1LL << 30) || (long long)g->Hi * g->Wi >= (1LL << 30)) return false;
   if ((long long)((g->Cin + 7) / 8) * 27 * g->Cout * 16 >= (1LL << 31)) return false;
   if (worst_npos(g->Wo, (int)HWo, 128) > 399) return false;
+  return true;
+}
+int df_conv3x3_split_res_ok(const DfConvGeom* g) {
+  int th, tx, ty;
+  return (df_split_mode() == 2 && split_fwd_geom_ok(g) && cs_plan(g, &th, &tx, &ty)) ? 1 : 0;
+}
+bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
+                              const float* bias, const float* res, float* y, hipStream_t st, int* rc) {
+  const int mode = df_split_mode();
+  if (mode == 0 || (mode == 2 && !(x_amax && x_n > 0))) return false;
+  if (!split_fwd_geom_ok(g)) return false;
+  const int p = g->ph;
+  const long long HWo = (long long)g->Ho * g->Wo;
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
   const SplitScale sc{x_amax, x_n, split_trailer(w_packed, g->Cin, g->Cout, mode)};
-  static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
   static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
-  if (mode == 2 && use_cs && (g->Cout > 64 || rr)) {
+  int th = 0, tlx = 0, tly = 0;
+  if (mode == 2 && cs_plan(g, &th, &tlx, &tly)) {
     // 8 x 32 tiles (128 couts per workgroup) or 16 x 32 tiles (64 couts).  They fit the forward shapes exactly but
-    // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces: those stay on the
-    // flat-run kernel below
-    const int th = g->Cout > 64 ? 8 : 16;
-    ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope,
-               (g->Wo + CS_TW - 1) / CS_TW, (g->Ho + th - 1) / th};
-    const long long nb = (long long)g->N * kc.tiles_x * kc.tiles_y;
-    const double fill = (double)HWo / ((double)kc.tiles_x * CS_TW * kc.tiles_y * th);
-    if (nb < (1LL << 31) && fill >= 0.85) {
-      if (g->Cout > 64) {
-        dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
-        if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
-        else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
-      } else {
-        conv3x3_split_cs_k<true, 32, 16><<<dim3((unsigned)nb, 1u), 512, 0, st>>>(x, ws, bias, y, kc, sc);
-      }
-      hipError_t e = hipGetLastError();
-      *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
-      return true;
+    // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces (those go through the
+    // zero-padded form + ring kernel instead; what still arrives here unfilled stays on the flat-run kernel below)
+    ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, tlx, tly, res};
+    const long long nb = (long long)g->N * tlx * tly;
+    if (g->Cout > 64) {
+      dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
+      if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+      else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
+    } else {
+      conv3x3_split_cs_k<true, 32, 16><<<dim3((unsigned)nb, 1u), 512, 0, st>>>(x, ws, bias, y, kc, sc);
     }
+    hipError_t e = hipGetLastError();
+    *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+    return true;
   }
+  if (res) { *rc = df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__); return true; }
   k.tiles_per_img = (int)((HWo + 255) / 256);
   const bool big = g->Cout > 64;
   dim3 grid((unsigned)(g->N * k.tiles_per_img), big ? (unsigned)((g->Cout + 127) / 128) : 1u);
@@ -1223,6 +1255,135 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input gradient of conv3x3(reflection_pad1(x)): the ring.
+// dX = fold(G), G = the full correlation of dY with the flipped weights on the (H+2) x (W+2) padded frame.  The
+// interior of G folds onto itself: that part is the ordinary zero-padded dgrad ("same" size), which the shared-tile
+// kernel computes at 100 % tile fill (on the 66 x 66 frame it fills 63 %, and the flat-run kernel used instead is
+// 20 % slower per pixel).  What remains is the one-pixel ring of G -- frame rows 0 and H+1, columns 0 and W+1 --
+// which reflection folds onto rows 1 / H-2 and columns 1 / W-2.  On the ring only one tap row (or column) meets
+// non-zero dY, so each of the four strips is a 3-tap 1-D convolution of ONE line of dY:
+//     G[0][c]   = sum_j Wd[(2, j)] dY[row 0  ][c + j - 2]      G[r][0]   = sum_j Wd[(j, 2)] dY[col 0  ][r + j - 2]
+//     G[H+1][c] = sum_j Wd[(0, j)] dY[row H-1][c + j - 2]      G[r][W+1] = sum_j Wd[(j, 0)] dY[col W-1][r + j - 2]
+// (Wd = dgrad packing, taps already flipped; c over 0..W+1, r over 1..H: the corners belong to the row strips.)
+// 2 % of the interior's FLOPs.  Workgroup = (strip, image, 128 produced channels): the line [K][L] is split into
+// LDS once, 8 waves = 4 channel blocks x 2 K-halves, weights straight from the packed split section (L2-resident),
+// results added atomically into dX (corners receive a row-strip and a column-strip term).
+struct RingP {
+  int N, K, M, H, W;          // K = reduction channels (the conv's Cout), M = produced channels (its Cin)
+};
+constexpr int RING_P = 100, RING_KG = 32;            // line positions (2 zeros + <= 94 + zeros), 8-channel groups
+
+__global__ __launch_bounds__(512, 1) void conv3x3_reflect_ring_k(const float* __restrict__ dy, const u32x4* __restrict__ ws,
+                                                                 float* __restrict__ dx, RingP k, SplitScale sc) {
+  constexpr int NSP = 2;
+  using P = Prod<2>;
+  __shared__ __attribute__((aligned(16))) u32x4 Ls[NSP * RING_KG * RING_P];
+  __shared__ float red[17];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int strip = blockIdx.x & 3, n = blockIdx.x >> 2;
+  const int m0 = blockIdx.y * 128;
+  const bool rowstrip = strip < 2;
+  const int L = rowstrip ? k.W : k.H;                    // line length
+  const int HW = k.H * k.W;
+  // the line of dY: element i of channel kk at dyl[kk * HW + i * istr]
+  const float* dyl = dy + (long long)n * k.K * HW +
+                     (strip == 0 ? 0 : strip == 1 ? (k.H - 1) * k.W : strip == 2 ? 0 : k.W - 1);
+  const int istr = rowstrip ? 1 : k.W;
+
+  const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, red));
+  const int ew = (int)sc.w_trailer[1];
+  const float xscale = pow2f(ex), oscale = pow2f(-ex), oscale2 = pow2f(-ew);
+
+  const int kg_n = (k.K + 7) >> 3;                       // 8-channel groups of the reduction
+  for (int i = tid; i < NSP * RING_KG * RING_P; i += 512) Ls[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  for (int it = tid; it < kg_n * L; it += 512) {
+    const int i = it % L, kg = it / L;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kk = kg * 8 + e;
+      v[e] = kk < k.K ? dyl[(long long)kk * HW + (long long)i * istr] : 0.f;
+    }
+    u32x4 sp[NSP];
+    split8_s<NSP>(v, xscale, sp);
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) Ls[(s * RING_KG + kg) * RING_P + i + 2] = sp[s];
+  }
+  __syncthreads();
+
+  const int mb = wid & 3, kh = wid >> 2;
+  const int m = m0 + mb * 32 + l31;                      // this lane's weight column
+  const int nb_n = (L + 2 + 31) >> 5;                    // 32-pixel blocks of the strip (<= 3)
+  f32x16 acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int chunks = (k.K + 15) >> 4;
+  for (int c = kh; c < chunks; c += 2) {
+    const int kg = 2 * c + lhi;                          // this half-wave's 8-channel group
+    const bool kok = kg < kg_n && m < k.M;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tap = strip == 0 ? 6 + j : strip == 1 ? j : strip == 2 ? 3 * j + 2 : 3 * j;
+      u32x4 a[NSP];
+#pragma unroll
+      for (int s = 0; s < NSP; ++s)
+        a[s] = kok ? ws[((long long)kg * NSP * 9 + s * 9 + tap) * k.M + m] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        if (b < nb_n) {
+          u32x4 x2[NSP];
+#pragma unroll
+          for (int s = 0; s < NSP; ++s) x2[s] = Ls[(s * RING_KG + (kg < RING_KG ? kg : 0)) * RING_P + b * 32 + l31 + j];
+#pragma unroll
+          for (int q = 0; q < P::N; ++q) acc[b] = mma16<NSP>(a[P::A[q]], x2[P::B[q]], acc[b]);
+        }
+      }
+    }
+  }
+
+  // fold: frame position -> the reflected source pixel; corners only from the row strips
+  float* dxn = dx + (long long)n * k.M * HW;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    if (b >= nb_n) continue;
+    const int c = b * 32 + l31;                          // position along the strip, frame coordinates
+    if (c > L + 1 || (!rowstrip && (c == 0 || c == L + 1))) continue;
+    const int along = c == 0 ? 1 : (c == L + 1 ? L - 2 : c - 1);
+    const int row = strip == 0 ? 1 : strip == 1 ? k.H - 2 : along;
+    const int col = strip == 2 ? 1 : strip == 3 ? k.W - 2 : along;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = m0 + mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+      if (mm < k.M) atomicAdd(&dxn[(long long)mm * HW + row * k.W + col], acc[b][r] * oscale * oscale2);
+    }
+  }
+}
+
+// 1 if the ring kernel takes this (forward) geometry: fp16x2 mode, 3x3 stride 1 reflect pad 1
+int df_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
+  if (df_split_mode() != 2) return 0;
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1)) return 0;
+  if (g->pad_mode != 1 || g->ph != 1 || g->pw != 1 || g->pd != 0) return 0;
+  if (g->Ho != g->Hi || g->Wo != g->Wi || g->Hi < 4 || g->Wi < 4 || g->Hi > 94 || g->Wi > 94) return 0;
+  if (g->Cout > 8 * RING_KG || g->Cout < 16 || g->Cin <= 32) return 0;   // K in LDS; M > 32: the split dgrad kernels' range
+  return 1;
+}
+int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
+                                   const float* wd_packed, float* dx, hipStream_t st) {
+  // wd_packed: the dgrad packing (K = Cout reduction, M = Cin produced)
+  const RingP k{g->N, g->Cout, g->Cin, g->Hi, g->Wi};
+  const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(wd_packed, g->Cout, g->Cin));
+  const SplitScale sc{dy_amax, dy_n, split_trailer(wd_packed, g->Cout, g->Cin, 2)};
+  conv3x3_reflect_ring_k<<<dim3((unsigned)(4 * g->N), (unsigned)((g->Cin + 127) / 128)), 512, 0, st>>>(dy, ws, dx, k, sc);
+  return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

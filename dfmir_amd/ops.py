@@ -91,15 +91,25 @@ def _wants_amax(K, stride, dil, Di, Cin, Cout):
     return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
 
 
-def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None):
+def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None):
+    """res (optional, shape of the output): y = act(conv + bias) + res, inside the kernel's epilogue where the
+    library has one (dfmir_conv3x3_res_ok), else by a separate add."""
     N, Cin, Di, Hi, Wi = x5.shape
     y = torch.empty((N, Cout) + tuple(out_sp), device=x5.device, dtype=torch.float32)
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, out_sp[0], out_sp[1], out_sp[2], K[0], K[1], K[2],
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
+    fuse_res = (res is not None and not _NO_RES and x_amax is not None and res.is_contiguous() and tuple(res.shape) == tuple(y.shape)
+                and lib().dfmir_conv3x3_res_ok(ctypes.byref(g)))
 
     def launch():
-        check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax), 0 if x_amax is None else x_amax.numel(),
-                                          _p(w_tcc), _p(bias), _p(y), _st()))
+        if fuse_res:
+            check(lib().dfmir_conv3x3_fwd_scaled_res(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc),
+                                                     _p(bias), _p(res), _p(y), _st()))
+        else:
+            check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
+                                              0 if x_amax is None else x_amax.numel(), _p(w_tcc), _p(bias), _p(y), _st()))
+            if res is not None:
+                y.add_(res.reshape(y.shape))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -231,6 +241,8 @@ def bump_weights_epoch():
 # wgrad kernels of all those passes accumulate into ONE persistent tap-major buffer per module and the
 # bias gradients straight into `bias.grad`; the buffers are unpacked into `weight.grad` once, on exit.
 # Without it every pass pays a zero-fill, an unpack and an autograd `add` per parameter (~900 tiny launches).
+_NO_RES = bool(os.environ.get("DFMIR_NO_RES"))       # A/B switch: residual added by a separate kernel
+_NO_RING = bool(os.environ.get("DFMIR_NO_RING"))     # A/B switch: reflect dgrad as padded-frame conv + fold
 _DEFER = {"on": False, "pending": {}}
 
 
@@ -340,7 +352,23 @@ class ConvFn(Function):
         if ctx.needs_input_grad[0]:
             wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
             in_sp = tuple(x5.shape[2:])
-            if stride == 1 and pad_mode == 1:
+            gf = None
+            if stride == 1 and pad_mode == 1 and dy_amax is not None and not _NO_RING:
+                gf = DfConvGeom(x5.shape[0], Cin, Cout, 1, in_sp[1], in_sp[2], 1, in_sp[1], in_sp[2], K[0], K[1], K[2],
+                                1, 1, p3[0], p3[1], p3[2], 1, 0, 0.0)
+                if not lib().dfmir_conv3x3_reflect_ring_ok(ctypes.byref(gf)):
+                    gf = None
+            if gf is not None:
+                # interior of the padded frame = the zero-padded "same" dgrad (full tiles); the one-pixel ring of the
+                # frame, folded by the reflection, is added by the ring kernel (csrc/conv3x3s.hip)
+                res5 = None
+                if dskip is not None:
+                    res5 = _c(dskip) if nd == 3 else _c(dskip).unsqueeze(2)
+                    dskip = None
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, p3, 1, 0, 0, 0.0, in_sp, dy_amax, res=res5)
+                check(lib().dfmir_conv3x3_reflect_ring(ctypes.byref(gf), _p(dy5), _p(dy_amax), dy_amax.numel(),
+                                                       _p(wd), _p(dx5), _st()))
+            elif stride == 1 and pad_mode == 1:
                 # full correlation onto the reflect-padded frame, then fold the halo back
                 padp = tuple(K[i] - 1 for i in range(3))
                 out_sp = tuple(in_sp[i] + 2 * p3[i] for i in range(3))

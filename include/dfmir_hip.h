@@ -94,6 +94,22 @@ int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, 
  * of unpack + add + clear per layer): job j adds its tap-major accumulator src[T][Cin][Cout] into the gradient in the
  * reference layout, dst[Cout][Cin][T] += src (torch accumulates p.grad the same way, autograd/functions/
  * accumulate_grad.h), and zeroes src.  `jobs` is DEVICE memory; max_total = max_j Cout*Cin*T. */
+/* dfmir_conv_fwd_scaled with a residual epilogue, y = act(conv(x) + bias) + res (res[N][Cout][Ho][Wo]), for the
+ * geometries dfmir_conv3x3_res_ok(g) accepts (the shared-tile split 3x3 kernel).  Used for the input gradient of a
+ * ResnetBlock's first conv, whose input also feeds the skip: dx = dgrad(dy) + d out (models/networks.py:1219-1221). */
+int dfmir_conv3x3_res_ok(const DfConvGeom* g);
+int dfmir_conv3x3_fwd_scaled_res(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                 const float* w_tcc, const float* bias, const float* res, float* y, void* stream);
+
+/* Input gradient of conv3x3(ReflectionPad2d(1)(x)) (ResnetBlock, models/networks.py:1190-1214) in two parts: the
+ * zero-padded "same" dgrad (dfmir_conv_fwd_scaled with the dgrad packing, pad 1) and this ring term, which ADDS to dx
+ * the fold of the one-pixel border of the full correlation (four 3-tap 1-D convolutions of the border lines of dy).
+ * g = the FORWARD geometry; wd_packed = dfmir_weight_pack(mode 1); dy_amax as for dfmir_conv_fwd_scaled.
+ * dfmir_conv3x3_reflect_ring_ok(g) != 0 iff this library build takes the geometry. */
+int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g);
+int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
+                               const float* wd_packed, float* dx, void* stream);
+
 /* Every packing of a train step at once (the weights of all layers change together, at the optimizer step): the same
  * result as njobs dfmir_weight_pack calls, in two launches.  `jobs` is HOST memory; `table_dev` is njobs * 64 bytes of
  * device scratch owned by the caller, (re)written when upload != 0 -- pass 0 while the same jobs come back. */

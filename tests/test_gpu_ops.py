@@ -547,3 +547,25 @@ def test_shared_tap_sparse_gradient(ops):
     for use_main, use_rows in ((True, True), (False, True), (True, False)):
         close(run(True, use_main, use_rows), run(False, use_main, use_rows), rtol=1e-6,
               what="fork_tap grad main=%s rows=%s" % (use_main, use_rows))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (1, 72, 12, 40), (1, 40, 8, 16)])
+def test_reflect_conv_skip_gradient(ops, shape):
+    """conv(reflection_pad(x)) whose input also leaves through the skip output (ResnetBlock): dx = dgrad + d skip.
+    64 / 72 channels take the zero-padded dgrad with the residual in its epilogue + the ring kernel; 40 x (8 x 16) the
+    ring with a separate add (tiles under-filled); all against torch."""
+    N, Cch, H, W = shape
+    x = C.randn(91, *shape)
+    w = C.randn(92, Cch, Cch, 3, 3) * 0.05
+    b = C.randn(93, Cch) * 0.1
+    c1, c2 = C.randn(94, *shape), C.randn(95, *shape)
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode='reflect'), wr, b)
+    ((yr * c1).sum() + (xr * c2).sum()).backward()
+    xg = x.clone().to(DEV).requires_grad_()
+    wg = w.clone().to(DEV).requires_grad_()
+    yg, xs = ops.conv(xg, wg, b.to(DEV), None, 1, 1, 1, 0, 0.0, skip=True)
+    ((yg * c1.to(DEV)).sum() + (xs * c2.to(DEV)).sum()).backward()
+    close(yg, yr, what="y"); close(xg.grad, xr.grad, rtol=2e-4, what="dx with skip")
+    close(wg.grad, wr.grad, rtol=1e-3, what="dw")
