@@ -30,8 +30,9 @@ _SIGS = {
     "dfmir_weight_pack_floats": [c_int, c_int, c_int],
     "dfmir_weight_pack_batch": [P, c_int, P, c_int, P],
     "dfmir_conv3x3_res_ok": [_GP],
-    "dfmir_conv3x3_fwd_scaled_res": [_GP, P, P, c_int, P, P, P, P, P],
+    "dfmir_conv3x3_fwd_scaled_res": [_GP, P, P, c_int, P, P, P, P, c_int, P, P],
     "dfmir_conv3x3_reflect_ring_ok": [_GP],
+    "dfmir_conv3x3_reflect_ring_len": [_GP],
     "dfmir_conv3x3_reflect_ring": [_GP, P, P, c_int, P, P, P],
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
     "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],

@@ -542,7 +542,8 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
-                              const float* bias, const float* res, float* y, hipStream_t st, int* rc);
+                              const float* bias, const float* res, const float* ring, int ring_rl, float* y,
+                              hipStream_t st, int* rc);
 int df_conv3x3_split_res_ok(const DfConvGeom* g);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc);
@@ -587,12 +588,13 @@ extern "C" int dfmir_conv3x3_res_ok(const DfConvGeom* g) {
   return (g && check_geom(g) == 0 && !use_generic_only()) ? df_conv3x3_split_res_ok(g) : 0;
 }
 extern "C" int dfmir_conv3x3_fwd_scaled_res(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
-                                            const float* w_tcc, const float* bias, const float* res, float* y,
-                                            void* stream) {
-  DF_ARG_CHECK(g && check_geom(g) == 0 && x && x_amax && x_amax_n > 0 && w_tcc && res && y);
+                                            const float* w_tcc, const float* bias, const float* res,
+                                            const float* ring, int ring_len, float* y, void* stream) {
+  DF_ARG_CHECK(g && check_geom(g) == 0 && x && x_amax && x_amax_n > 0 && w_tcc && (res || ring) && y);
   DF_ARG_CHECK(!use_generic_only() && df_conv3x3_split_res_ok(g));
+  DF_ARG_CHECK(!ring || (ring_len >= (g->Ho > g->Wo ? g->Ho : g->Wo) + 2 && g->Ho >= 4 && g->Wo >= 4));
   int rc = 0;
-  if (!df_conv3x3_split_fwd_try(g, x, x_amax, x_amax_n, w_tcc, bias, res, y, (hipStream_t)stream, &rc))
+  if (!df_conv3x3_split_fwd_try(g, x, x_amax, x_amax_n, w_tcc, bias, res, ring, ring_len, y, (hipStream_t)stream, &rc))
     return df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__);
   return rc;
 }
@@ -609,7 +611,7 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, nullptr, y, st, &rc)) return rc;
+    if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, nullptr, nullptr, 0, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
     if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
@@ -763,15 +765,19 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
 }
 int df_conv3x3_reflect_ring_ok(const DfConvGeom* g);
 int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
-                                   const float* wd_packed, float* dx, hipStream_t st);
+                                   const float* wd_packed, float* ring, hipStream_t st);
+int df_conv3x3_reflect_ring_len(const DfConvGeom* g);
 extern "C" int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
   return (g && check_geom(g) == 0) ? df_conv3x3_reflect_ring_ok(g) : 0;
 }
+extern "C" int dfmir_conv3x3_reflect_ring_len(const DfConvGeom* g) {
+  return (g && check_geom(g) == 0 && df_conv3x3_reflect_ring_ok(g)) ? df_conv3x3_reflect_ring_len(g) : 0;
+}
 extern "C" int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
-                                          const float* wd_packed, float* dx, void* stream) {
-  DF_ARG_CHECK(g && check_geom(g) == 0 && dy && dy_amax && dy_amax_n > 0 && wd_packed && dx);
+                                          const float* wd_packed, float* ring, void* stream) {
+  DF_ARG_CHECK(g && check_geom(g) == 0 && dy && dy_amax && dy_amax_n > 0 && wd_packed && ring);
   DF_ARG_CHECK(df_conv3x3_reflect_ring_ok(g));
-  const int rc = df_conv3x3_reflect_ring_launch(g, dy, dy_amax, dy_amax_n, wd_packed, dx, (hipStream_t)stream);
+  const int rc = df_conv3x3_reflect_ring_launch(g, dy, dy_amax, dy_amax_n, wd_packed, ring, (hipStream_t)stream);
   if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }

@@ -731,6 +731,8 @@ struct ConvCsP {
   float slope;
   int tiles_x, tiles_y;
   const float* res;       // optional [N][Cout][Ho][Wo]: y = act(conv + bias) + res (a second gradient / residual)
+  const float* ring;      // optional [N][4][Cout][ring_rl]: the reflect ring of a dgrad (conv3x3_reflect_ring_k)
+  int ring_rl;
 };
 
 #ifdef CS_TRACE
@@ -938,6 +940,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
     const int oy = oy0 + row, ox = ox0 + l31;
     if (oy >= k.Ho || ox >= k.Wo) continue;
     const int q = oy * k.Wo + ox;
+    const bool on_ring = k.ring != nullptr && (oy == 1 || oy == k.Ho - 2 || ox == 1 || ox == k.Wo - 2);
     float rv[16];                                            // residual: all 16 loads in flight before the first use
 #pragma unroll
     for (int r = 0; r < 16; ++r) rv[r] = 0.f;
@@ -958,6 +961,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
         if (k.act == 1) v = v > 0.f ? v : v * k.slope;
         else if (k.act == 2) v = tanhf(v);
         v += rv[r];
+        if (on_ring) {                                       // the reflection folds frame positions onto this pixel
+          const float* rg = k.ring + ((long long)n * 4 * k.Cout + co) * k.ring_rl;
+          const long long ss = (long long)k.Cout * k.ring_rl;      // strip stride: top, bottom, left, right
+          if (oy == 1) v += rg[ox + 1] + (ox == 1 ? rg[0] : 0.f) + (ox == k.Wo - 2 ? rg[k.Wo + 1] : 0.f);
+          if (oy == k.Ho - 2) v += rg[ss + ox + 1] + (ox == 1 ? rg[ss] : 0.f) + (ox == k.Wo - 2 ? rg[ss + k.Wo + 1] : 0.f);
+          if (ox == 1) v += rg[2 * ss + oy + 1];
+          if (ox == k.Wo - 2) v += rg[3 * ss + oy + 1];
+        }
         yb[(long long)co * HWo + q] = v;
       }
     }
@@ -996,7 +1007,8 @@ int df_conv3x3_split_res_ok(const DfConvGeom* g) {
   return (df_split_mode() == 2 && split_fwd_geom_ok(g) && cs_plan(g, &th, &tx, &ty)) ? 1 : 0;
 }
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
-                              const float* bias, const float* res, float* y, hipStream_t st, int* rc) {
+                              const float* bias, const float* res, const float* ring, int ring_rl, float* y,
+                              hipStream_t st, int* rc) {
   const int mode = df_split_mode();
   if (mode == 0 || (mode == 2 && !(x_amax && x_n > 0))) return false;
   if (!split_fwd_geom_ok(g)) return false;
@@ -1011,7 +1023,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
     // 8 x 32 tiles (128 couts per workgroup) or 16 x 32 tiles (64 couts).  They fit the forward shapes exactly but
     // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces (those go through the
     // zero-padded form + ring kernel instead; what still arrives here unfilled stays on the flat-run kernel below)
-    ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, tlx, tly, res};
+    ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, tlx, tly, res,
+               ring, ring_rl};
     const long long nb = (long long)g->N * tlx * tly;
     if (g->Cout > 64) {
       dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
@@ -1024,7 +1037,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
     *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
     return true;
   }
-  if (res) { *rc = df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__); return true; }
+  if (res || ring) { *rc = df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__); return true; }
   k.tiles_per_img = (int)((HWo + 255) / 256);
   const bool big = g->Cout > 64;
   dim3 grid((unsigned)(g->N * k.tiles_per_img), big ? (unsigned)((g->Cout + 127) / 128) : 1u);
@@ -1270,17 +1283,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 // (Wd = dgrad packing, taps already flipped; c over 0..W+1, r over 1..H: the corners belong to the row strips.)
 // 2 % of the interior's FLOPs.  Workgroup = (strip, image, 128 produced channels): the line [K][L] is split into
 // LDS once, 8 waves = 4 channel blocks x 2 K-halves, weights straight from the packed split section (L2-resident),
-// results added atomically into dX (corners receive a row-strip and a column-strip term).
+// results to a compact buffer ring[n][strip][m][RL]; the interior kernel's epilogue adds ring[.][c] to the pixels the
+// reflection folds frame position c onto (rows 1 / H-2, columns 1 / W-2; the frame's corners through the row strips).
 struct RingP {
   int N, K, M, H, W;          // K = reduction channels (the conv's Cout), M = produced channels (its Cin)
+  int RL;                     // row length of the ring buffer (>= max(H, W) + 2)
 };
-constexpr int RING_P = 100, RING_KG = 32;            // line positions (2 zeros + <= 94 + zeros), 8-channel groups
+constexpr int RING_KG = 32;                          // 8-channel groups of the reduction held in LDS (K <= 256)
 
-__global__ __launch_bounds__(512, 1) void conv3x3_reflect_ring_k(const float* __restrict__ dy, const u32x4* __restrict__ ws,
-                                                                 float* __restrict__ dx, RingP k, SplitScale sc) {
+// RP = line positions in LDS: 2 zeros + the line + zeros (72: lines up to 64 -> two workgroups per CU; 100: up to 94)
+template <int RP>
+__global__ __launch_bounds__(512) void conv3x3_reflect_ring_k(const float* __restrict__ dy, const u32x4* __restrict__ ws,
+                                                              float* __restrict__ ring, RingP k, SplitScale sc) {
   constexpr int NSP = 2;
   using P = Prod<2>;
-  __shared__ __attribute__((aligned(16))) u32x4 Ls[NSP * RING_KG * RING_P];
+  __shared__ __attribute__((aligned(16))) u32x4 Ls[NSP * RING_KG * RP];
   __shared__ float red[17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1300,8 +1317,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reflect_ring_k(const float* __
   const float xscale = pow2f(ex), oscale = pow2f(-ex), oscale2 = pow2f(-ew);
 
   const int kg_n = (k.K + 7) >> 3;                       // 8-channel groups of the reduction
-  for (int i = tid; i < NSP * RING_KG * RING_P; i += 512) Ls[i] = u32x4{0u, 0u, 0u, 0u};
-  __syncthreads();
+  // zero padding positions (0, 1 and L+2 ..) of every group; groups past K entirely
+  {
+    const int npad = RP - L;
+    for (int it = tid; it < NSP * RING_KG * npad; it += 512) {
+      const int q = it % npad, g = it / npad;
+      Ls[g * RP + (q < 2 ? q : L + q)] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const int kz = RING_KG - kg_n;
+    for (int it = tid; it < NSP * kz * L; it += 512) {
+      const int i = it % L, g = it / L, s2 = g / kz, kg = kg_n + g % kz;
+      Ls[(s2 * RING_KG + kg) * RP + i + 2] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
   for (int it = tid; it < kg_n * L; it += 512) {
     const int i = it % L, kg = it / L;
     float v[8];
@@ -1313,7 +1341,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reflect_ring_k(const float* __
     u32x4 sp[NSP];
     split8_s<NSP>(v, xscale, sp);
 #pragma unroll
-    for (int s = 0; s < NSP; ++s) Ls[(s * RING_KG + kg) * RING_P + i + 2] = sp[s];
+    for (int s = 0; s < NSP; ++s) Ls[(s * RING_KG + kg) * RP + i + 2] = sp[s];
   }
   __syncthreads();
 
@@ -1326,43 +1354,68 @@ __global__ __launch_bounds__(512, 1) void conv3x3_reflect_ring_k(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   const int chunks = (k.K + 15) >> 4;
+  const int tap0 = strip == 0 ? 6 : strip == 1 ? 0 : strip == 2 ? 2 : 0, tapd = rowstrip ? 1 : 3;
+  // weights of a chunk: 3 taps x 2 split terms, straight from the packed split section; two chunks ahead (a chunk's
+  // 27 MFMAs are shorter than an L2 round trip)
+  u32x4 a[3][NSP], an[3][NSP], an2[3][NSP];
+#define RING_LOADA(dst_, c_)                                                                     \
+  {                                                                                              \
+    const int kg_ = 2 * (c_) + lhi;                                                              \
+    const bool ok_ = (c_) < chunks && kg_ < kg_n && m < k.M;                                     \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                            \
+        dst_[j][s] = ok_ ? ws[((long long)kg_ * NSP * 9 + s * 9 + tap0 + j * tapd) * k.M + m] : u32x4{0u, 0u, 0u, 0u}; \
+  }
+  RING_LOADA(a, kh)
+  RING_LOADA(an, kh + 2)
   for (int c = kh; c < chunks; c += 2) {
-    const int kg = 2 * c + lhi;                          // this half-wave's 8-channel group
-    const bool kok = kg < kg_n && m < k.M;
+    RING_LOADA(an2, c + 4)
+    const int kg = 2 * c + lhi;                          // this half-wave's 8-channel group (< RING_KG)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int tap = strip == 0 ? 6 + j : strip == 1 ? j : strip == 2 ? 3 * j + 2 : 3 * j;
-      u32x4 a[NSP];
-#pragma unroll
-      for (int s = 0; s < NSP; ++s)
-        a[s] = kok ? ws[((long long)kg * NSP * 9 + s * 9 + tap) * k.M + m] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         if (b < nb_n) {
+          int pos = b * 32 + l31 + j;
+          pos = pos < RP ? pos : RP - 1;                 // lanes past the strip: any zero unit
           u32x4 x2[NSP];
 #pragma unroll
-          for (int s = 0; s < NSP; ++s) x2[s] = Ls[(s * RING_KG + (kg < RING_KG ? kg : 0)) * RING_P + b * 32 + l31 + j];
+          for (int s = 0; s < NSP; ++s) x2[s] = Ls[(s * RING_KG + kg) * RP + pos];
 #pragma unroll
-          for (int q = 0; q < P::N; ++q) acc[b] = mma16<NSP>(a[P::A[q]], x2[P::B[q]], acc[b]);
+          for (int q = 0; q < P::N; ++q) acc[b] = mma16<NSP>(a[j][P::A[q]], x2[P::B[q]], acc[b]);
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < NSP; ++s) { a[j][s] = an[j][s]; an[j][s] = an2[j][s]; }
   }
+#undef RING_LOADA
 
-  // fold: frame position -> the reflected source pixel; corners only from the row strips
-  float* dxn = dx + (long long)n * k.M * HW;
+  // the two K halves meet in LDS (the line is no longer needed); the strip goes to the compact ring buffer
+  // ring[n][strip][m][RL] (index = frame coordinate along the strip), which the interior kernel's epilogue folds in
+  __syncthreads();
+  float* xch = reinterpret_cast<float*>(Ls);             // [mb][b][r][64 lanes]
+  if (kh == 1) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[((mb * 3 + b) * 16 + r) * 64 + lane] = acc[b][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  float* rg = ring + ((long long)(n * 4 + strip) * k.M) * k.RL;
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     if (b >= nb_n) continue;
     const int c = b * 32 + l31;                          // position along the strip, frame coordinates
-    if (c > L + 1 || (!rowstrip && (c == 0 || c == L + 1))) continue;
-    const int along = c == 0 ? 1 : (c == L + 1 ? L - 2 : c - 1);
-    const int row = strip == 0 ? 1 : strip == 1 ? k.H - 2 : along;
-    const int col = strip == 2 ? 1 : strip == 3 ? k.W - 2 : along;
+    if (c > L + 1) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mm = m0 + mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-      if (mm < k.M) atomicAdd(&dxn[(long long)mm * HW + row * k.W + col], acc[b][r] * oscale * oscale2);
+      if (mm < k.M)
+        rg[(long long)mm * k.RL + c] = (acc[b][r] + xch[((mb * 3 + b) * 16 + r) * 64 + lane]) * oscale * oscale2;
     }
   }
 }
@@ -1376,13 +1429,16 @@ int df_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
   if (g->Cout > 8 * RING_KG || g->Cout < 16 || g->Cin <= 32) return 0;   // K in LDS; M > 32: the split dgrad kernels' range
   return 1;
 }
+int df_conv3x3_reflect_ring_len(const DfConvGeom* g) { return ((g->Hi > g->Wi ? g->Hi : g->Wi) + 2 + 3) & ~3; }
 int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
-                                   const float* wd_packed, float* dx, hipStream_t st) {
+                                   const float* wd_packed, float* ring, hipStream_t st) {
   // wd_packed: the dgrad packing (K = Cout reduction, M = Cin produced)
-  const RingP k{g->N, g->Cout, g->Cin, g->Hi, g->Wi};
+  const RingP k{g->N, g->Cout, g->Cin, g->Hi, g->Wi, df_conv3x3_reflect_ring_len(g)};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(wd_packed, g->Cout, g->Cin));
   const SplitScale sc{dy_amax, dy_n, split_trailer(wd_packed, g->Cout, g->Cin, 2)};
-  conv3x3_reflect_ring_k<<<dim3((unsigned)(4 * g->N), (unsigned)((g->Cin + 127) / 128)), 512, 0, st>>>(dy, ws, dx, k, sc);
+  const dim3 grid((unsigned)(4 * g->N), (unsigned)((g->Cin + 127) / 128));
+  if (g->Hi <= 64 && g->Wi <= 64) conv3x3_reflect_ring_k<72><<<grid, 512, 0, st>>>(dy, ws, ring, k, sc);
+  else conv3x3_reflect_ring_k<100><<<grid, 512, 0, st>>>(dy, ws, ring, k, sc);
   return (int)hipGetLastError();
 }
 

@@ -91,9 +91,10 @@ def _wants_amax(K, stride, dil, Di, Cin, Cout):
     return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
 
 
-def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None):
+def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None, ring=None):
     """res (optional, shape of the output): y = act(conv + bias) + res, inside the kernel's epilogue where the
-    library has one (dfmir_conv3x3_res_ok), else by a separate add."""
+    library has one (dfmir_conv3x3_res_ok), else by a separate add.  ring = (buffer, row length) of
+    dfmir_conv3x3_reflect_ring: folded in by the same epilogue (the caller checked dfmir_conv3x3_res_ok)."""
     N, Cin, Di, Hi, Wi = x5.shape
     y = torch.empty((N, Cout) + tuple(out_sp), device=x5.device, dtype=torch.float32)
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, out_sp[0], out_sp[1], out_sp[2], K[0], K[1], K[2],
@@ -102,9 +103,13 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                 and lib().dfmir_conv3x3_res_ok(ctypes.byref(g)))
 
     def launch():
-        if fuse_res:
+        if fuse_res or ring is not None:
             check(lib().dfmir_conv3x3_fwd_scaled_res(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc),
-                                                     _p(bias), _p(res), _p(y), _st()))
+                                                     _p(bias), _p(res) if fuse_res else None,
+                                                     _p(ring[0]) if ring is not None else None,
+                                                     ring[1] if ring is not None else 0, _p(y), _st()))
+            if res is not None and not fuse_res:
+                y.add_(res.reshape(y.shape))
         else:
             check(lib().dfmir_conv_fwd_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
                                               0 if x_amax is None else x_amax.numel(), _p(w_tcc), _p(bias), _p(y), _st()))
@@ -356,18 +361,24 @@ class ConvFn(Function):
             if stride == 1 and pad_mode == 1 and dy_amax is not None and not _NO_RING:
                 gf = DfConvGeom(x5.shape[0], Cin, Cout, 1, in_sp[1], in_sp[2], 1, in_sp[1], in_sp[2], K[0], K[1], K[2],
                                 1, 1, p3[0], p3[1], p3[2], 1, 0, 0.0)
-                if not lib().dfmir_conv3x3_reflect_ring_ok(ctypes.byref(gf)):
+                gd = DfConvGeom(x5.shape[0], Cout, Cin, 1, in_sp[1], in_sp[2], 1, in_sp[1], in_sp[2], K[0], K[1], K[2],
+                                1, 1, p3[0], p3[1], p3[2], 0, 0, 0.0)      # the zero-padded dgrad as a conv
+                if not (lib().dfmir_conv3x3_reflect_ring_ok(ctypes.byref(gf))
+                        and lib().dfmir_conv3x3_res_ok(ctypes.byref(gd))):
                     gf = None
             if gf is not None:
-                # interior of the padded frame = the zero-padded "same" dgrad (full tiles); the one-pixel ring of the
-                # frame, folded by the reflection, is added by the ring kernel (csrc/conv3x3s.hip)
+                # the one-pixel ring of the padded frame first (four 1-D convolutions of dY's border lines, into a
+                # compact buffer), then the frame's interior = the zero-padded "same" dgrad on full tiles, whose
+                # epilogue folds the ring (and the skip branch's gradient) in   (csrc/conv3x3s.hip)
+                rl = lib().dfmir_conv3x3_reflect_ring_len(ctypes.byref(gf))
+                ringbuf = torch.empty(x5.shape[0] * 4 * Cin * rl, device=dy5.device, dtype=torch.float32)
+                check(lib().dfmir_conv3x3_reflect_ring(ctypes.byref(gf), _p(dy5), _p(dy_amax), dy_amax.numel(),
+                                                       _p(wd), _p(ringbuf), _st()))
                 res5 = None
                 if dskip is not None:
                     res5 = _c(dskip) if nd == 3 else _c(dskip).unsqueeze(2)
                     dskip = None
-                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, p3, 1, 0, 0, 0.0, in_sp, dy_amax, res=res5)
-                check(lib().dfmir_conv3x3_reflect_ring(ctypes.byref(gf), _p(dy5), _p(dy_amax), dy_amax.numel(),
-                                                       _p(wd), _p(dx5), _st()))
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, p3, 1, 0, 0, 0.0, in_sp, dy_amax, res=res5, ring=(ringbuf, rl))
             elif stride == 1 and pad_mode == 1:
                 # full correlation onto the reflect-padded frame, then fold the halo back
                 padp = tuple(K[i] - 1 for i in range(3))

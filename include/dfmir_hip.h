@@ -94,21 +94,27 @@ int dfmir_weight_unpack(const float* g_tcc, float* g, int Cout, int Cin, int T, 
  * of unpack + add + clear per layer): job j adds its tap-major accumulator src[T][Cin][Cout] into the gradient in the
  * reference layout, dst[Cout][Cin][T] += src (torch accumulates p.grad the same way, autograd/functions/
  * accumulate_grad.h), and zeroes src.  `jobs` is DEVICE memory; max_total = max_j Cout*Cin*T. */
-/* dfmir_conv_fwd_scaled with a residual epilogue, y = act(conv(x) + bias) + res (res[N][Cout][Ho][Wo]), for the
- * geometries dfmir_conv3x3_res_ok(g) accepts (the shared-tile split 3x3 kernel).  Used for the input gradient of a
- * ResnetBlock's first conv, whose input also feeds the skip: dx = dgrad(dy) + d out (models/networks.py:1219-1221). */
+/* dfmir_conv_fwd_scaled with an epilogue y = act(conv(x) + bias) + res + fold(ring), for the geometries
+ * dfmir_conv3x3_res_ok(g) accepts (the shared-tile split 3x3 kernel).  res[N][Cout][Ho][Wo] (optional): a second
+ * gradient of the same tensor -- the skip branch of a ResnetBlock, dx = dgrad(dy) + d out (models/networks.py:1219-1221).
+ * ring (optional): see dfmir_conv3x3_reflect_ring. */
 int dfmir_conv3x3_res_ok(const DfConvGeom* g);
 int dfmir_conv3x3_fwd_scaled_res(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
-                                 const float* w_tcc, const float* bias, const float* res, float* y, void* stream);
+                                 const float* w_tcc, const float* bias, const float* res, const float* ring,
+                                 int ring_len, float* y, void* stream);
 
-/* Input gradient of conv3x3(ReflectionPad2d(1)(x)) (ResnetBlock, models/networks.py:1190-1214) in two parts: the
- * zero-padded "same" dgrad (dfmir_conv_fwd_scaled with the dgrad packing, pad 1) and this ring term, which ADDS to dx
- * the fold of the one-pixel border of the full correlation (four 3-tap 1-D convolutions of the border lines of dy).
- * g = the FORWARD geometry; wd_packed = dfmir_weight_pack(mode 1); dy_amax as for dfmir_conv_fwd_scaled.
- * dfmir_conv3x3_reflect_ring_ok(g) != 0 iff this library build takes the geometry. */
+/* Input gradient of conv3x3(ReflectionPad2d(1)(x)) (ResnetBlock, models/networks.py:1190-1214) in two parts.  The
+ * gradient is the fold of the full correlation of dy on the (H+2) x (W+2) padded frame; the frame's interior is the
+ * zero-padded "same" dgrad (dfmir_conv3x3_fwd_scaled_res with the dgrad packing, pad 1), and its one-pixel ring is
+ * four 3-tap 1-D convolutions of the border lines of dy, computed here into ring[N][4][Cin][ring_len] (strips: top,
+ * bottom, left, right; index = frame coordinate along the strip), which the interior call folds in through its
+ * `ring` argument.  g = the FORWARD geometry; wd_packed = dfmir_weight_pack(mode 1); dy_amax as for
+ * dfmir_conv_fwd_scaled.  dfmir_conv3x3_reflect_ring_ok(g) != 0 iff this library build takes the geometry;
+ * dfmir_conv3x3_reflect_ring_len(g) = ring_len. */
 int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g);
+int dfmir_conv3x3_reflect_ring_len(const DfConvGeom* g);
 int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
-                               const float* wd_packed, float* dx, void* stream);
+                               const float* wd_packed, float* ring, void* stream);
 
 /* Every packing of a train step at once (the weights of all layers change together, at the optimizer step): the same
  * result as njobs dfmir_weight_pack calls, in two launches.  `jobs` is HOST memory; `table_dev` is njobs * 64 bytes of
