@@ -33,7 +33,7 @@ _SIGS = {
     "dfmir_conv3x3_fwd_scaled_res": [_GP, P, P, c_int, P, P, P, P, c_int, P, P],
     "dfmir_conv3x3_reflect_ring_ok": [_GP],
     "dfmir_conv3x3_reflect_ring_len": [_GP],
-    "dfmir_conv3x3_reflect_ring": [_GP, P, P, c_int, P, P, P],
+    "dfmir_conv3x3_reflect_ring": [_GP, P, P, P, c_int, P, P, P],
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
     "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],
@@ -45,6 +45,8 @@ _SIGS = {
     "dfmir_tapsum_bwd": [P, P] + [c_int] * 9 + [P],
     "dfmir_instnorm_fwd": [P, P, P, P, P, c_int, c_longlong, c_float, c_int, P, P],
     "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P, P],
+    "dfmir_instnorm_bwd_cols_ok": [c_longlong, c_int],
+    "dfmir_instnorm_bwd_cols": [P, P, P, P, P, c_int, c_longlong, c_int, P, P, c_int, P],
     "dfmir_act_bwd": [P, P, P, c_longlong, c_int, c_float, P],
     "dfmir_blur_down_fwd": [P, P, c_int, c_int, c_int, P],
     "dfmir_blur_down_bwd": [P, P, c_int, c_int, c_int, P],

@@ -764,8 +764,8 @@ extern "C" int dfmir_weight_pack(const float* w, float* w_tcc, int Cout, int Cin
   return 0;
 }
 int df_conv3x3_reflect_ring_ok(const DfConvGeom* g);
-int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
-                                   const float* wd_packed, float* ring, hipStream_t st);
+int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_cols, const float* dy_amax,
+                                   int dy_n, const float* wd_packed, float* ring, hipStream_t st);
 int df_conv3x3_reflect_ring_len(const DfConvGeom* g);
 extern "C" int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
   return (g && check_geom(g) == 0) ? df_conv3x3_reflect_ring_ok(g) : 0;
@@ -773,11 +773,12 @@ extern "C" int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
 extern "C" int dfmir_conv3x3_reflect_ring_len(const DfConvGeom* g) {
   return (g && check_geom(g) == 0 && df_conv3x3_reflect_ring_ok(g)) ? df_conv3x3_reflect_ring_len(g) : 0;
 }
-extern "C" int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
-                                          const float* wd_packed, float* ring, void* stream) {
+extern "C" int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_cols,
+                                          const float* dy_amax, int dy_amax_n, const float* wd_packed, float* ring,
+                                          void* stream) {
   DF_ARG_CHECK(g && check_geom(g) == 0 && dy && dy_amax && dy_amax_n > 0 && wd_packed && ring);
   DF_ARG_CHECK(df_conv3x3_reflect_ring_ok(g));
-  const int rc = df_conv3x3_reflect_ring_launch(g, dy, dy_amax, dy_amax_n, wd_packed, ring, (hipStream_t)stream);
+  const int rc = df_conv3x3_reflect_ring_launch(g, dy, dy_cols, dy_amax, dy_amax_n, wd_packed, ring, (hipStream_t)stream);
   if (rc) return df_set_error(rc, __FILE__, __LINE__);
   return 0;
 }

@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
 struct RingP {
   int N, K, M, H, W;          // K = reduction channels (the conv's Cout), M = produced channels (its Cin)
   int RL;                     // row length of the ring buffer (>= max(H, W) + 2)
+  const float* cols;          // optional [N*K][2][H]: first / last column of dY, left by its producer (instnorm_bwd)
 };
 constexpr int RING_KG = 32;                          // 8-channel groups of the reduction held in LDS (K <= 256)
 
@@ -1336,7 +1337,8 @@ __global__ __launch_bounds__(512) void conv3x3_reflect_ring_k(const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int kk = kg * 8 + e;
-      v[e] = kk < k.K ? dyl[(long long)kk * HW + (long long)i * istr] : 0.f;
+      if (!rowstrip && k.cols) v[e] = kk < k.K ? k.cols[(((long long)n * k.K + kk) * 2 + (strip - 2)) * k.H + i] : 0.f;
+      else v[e] = kk < k.K ? dyl[(long long)kk * HW + (long long)i * istr] : 0.f;
     }
     u32x4 sp[NSP];
     split8_s<NSP>(v, xscale, sp);
@@ -1430,10 +1432,10 @@ int df_conv3x3_reflect_ring_ok(const DfConvGeom* g) {
   return 1;
 }
 int df_conv3x3_reflect_ring_len(const DfConvGeom* g) { return ((g->Hi > g->Wi ? g->Hi : g->Wi) + 2 + 3) & ~3; }
-int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_n,
-                                   const float* wd_packed, float* ring, hipStream_t st) {
+int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const float* dy_cols, const float* dy_amax,
+                                   int dy_n, const float* wd_packed, float* ring, hipStream_t st) {
   // wd_packed: the dgrad packing (K = Cout reduction, M = Cin produced)
-  const RingP k{g->N, g->Cout, g->Cin, g->Hi, g->Wi, df_conv3x3_reflect_ring_len(g)};
+  const RingP k{g->N, g->Cout, g->Cin, g->Hi, g->Wi, df_conv3x3_reflect_ring_len(g), dy_cols};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(wd_packed, g->Cout, g->Cin));
   const SplitScale sc{dy_amax, dy_n, split_trailer(wd_packed, g->Cout, g->Cin, 2)};
   const dim3 grid((unsigned)(4 * g->N), (unsigned)((g->Cin + 127) / 128));

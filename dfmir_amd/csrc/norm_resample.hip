@@ -135,7 +135,9 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
                                                          const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i,
                                                          float* __restrict__ dx, int relu,
-                                                         float* __restrict__ amax) {
+                                                         float* __restrict__ amax, float* __restrict__ cols, int W) {
+  // cols (optional, W % 4 == 0): cols[plane][2][H] <- the first and last column of dx, for the ring kernel of a
+  // reflect-padded conv's dgrad (a column of an NCHW tensor is one cache line per element to read back)
   __shared__ float sm[17];
   __shared__ unsigned smax;
   if (threadIdx.x == 0) smax = 0u;
@@ -172,6 +174,12 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
     o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
     d4[threadIdx.x + NT * i] = o;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    if (cols) {
+      const int e0 = 4 * (threadIdx.x + NT * i), H = (int)(S / W);
+      float* cp = cols + (long long)blockIdx.x * 2 * H;
+      if (e0 % W == 0) cp[e0 / W] = o.x;
+      if ((e0 + 3) % W == W - 1) cp[H + (e0 + 3) / W] = o.w;
+    }
   }
   if (amax) publish_block_absmax(am, &smax, amax + blockIdx.x);
 }
@@ -702,13 +710,28 @@ extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, fl
   DF_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int dfmir_instnorm_bwd_cols_ok(long long S, int W) {
+  return ((S == 4096 || S == 16384 || S == 65536) && W >= 4 && (W & 3) == 0 && S % W == 0) ? 1 : 0;
+}
+static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
+                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream);
 extern "C" int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                   float* dx, int planes, long long S, int relu, float* dx_amax, void* stream) {
+  return instnorm_bwd_impl(dy, x, mean, rstd, dx, planes, S, relu, dx_amax, nullptr, 0, stream);
+}
+extern "C" int dfmir_instnorm_bwd_cols(const float* dy, const float* x, const float* mean, const float* rstd,
+                                       float* dx, int planes, long long S, int relu, float* dx_amax, float* dx_cols,
+                                       int W, void* stream) {
+  DF_ARG_CHECK(dx_cols && dfmir_instnorm_bwd_cols_ok(S, W));
+  return instnorm_bwd_impl(dy, x, mean, rstd, dx, planes, S, relu, dx_amax, dx_cols, W, stream);
+}
+static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
+                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream) {
   DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
-  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
-  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax);
+  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
+  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
+  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
   else {
     instnorm_bwd_k<<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, S, relu);
     if (dx_amax) {

@@ -372,7 +372,10 @@ class ConvFn(Function):
                 # epilogue folds the ring (and the skip branch's gradient) in   (csrc/conv3x3s.hip)
                 rl = lib().dfmir_conv3x3_reflect_ring_len(ctypes.byref(gf))
                 ringbuf = torch.empty(x5.shape[0] * 4 * Cin * rl, device=dy5.device, dtype=torch.float32)
-                check(lib().dfmir_conv3x3_reflect_ring(ctypes.byref(gf), _p(dy5), _p(dy_amax), dy_amax.numel(),
+                ctag = getattr(dy, "_df_cols", None)
+                cols = ctag[0] if (ctag is not None and ctag[1] == dy._version and ctag[2] == dy.data_ptr()
+                                   and dy.is_contiguous() and not act) else None
+                check(lib().dfmir_conv3x3_reflect_ring(ctypes.byref(gf), _p(dy5), _p(cols), _p(dy_amax), dy_amax.numel(),
                                                        _p(wd), _p(ringbuf), _st()))
                 res5 = None
                 if dskip is not None:
@@ -537,8 +540,16 @@ class InstNormFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             slot = amax_slot(x.device, planes)
-            check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
-                                           _p(slot), _st()))
+            W = x.shape[-1]
+            if x.dim() == 4 and W <= 94 and S // W <= 94 and lib().dfmir_instnorm_bwd_cols_ok(S, W):   # ring-kernel sizes
+                # first / last column of dx on the side: the dgrad of a reflect-padded conv reads them (ring kernel)
+                cols = torch.empty(planes * 2 * (S // W), device=x.device, dtype=torch.float32)
+                check(lib().dfmir_instnorm_bwd_cols(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
+                                                    _p(slot), _p(cols), W, _st()))
+                dx._df_cols = (cols, dx._version, dx.data_ptr())
+            else:
+                check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
+                                               _p(slot), _st()))
             tag_amax(dx, slot)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
         return dx, dres, None, None
@@ -867,8 +878,9 @@ class TapForkFn(Function):
             for dout, ids, (shape, B, C, S, Pn) in stash:
                 check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(g), B, C, S, Pn, _st()))
             del stash[:]
-            if hasattr(g, "_df_amax"):
-                del g._df_amax                   # modified through the raw pointer: a range tag would be stale
+            for tag in ("_df_amax", "_df_cols"):      # modified through the raw pointer: these tags would be stale
+                if hasattr(g, tag):
+                    delattr(g, tag)
         if g_tap is not None:                    # a dense gradient on the tap (some other use of it)
             g = g_tap if g is None else g + g_tap
         return g, None

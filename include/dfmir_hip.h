@@ -113,8 +113,9 @@ int dfmir_conv3x3_fwd_scaled_res(const DfConvGeom* g, const float* x, const floa
  * dfmir_conv3x3_reflect_ring_len(g) = ring_len. */
 int dfmir_conv3x3_reflect_ring_ok(const DfConvGeom* g);
 int dfmir_conv3x3_reflect_ring_len(const DfConvGeom* g);
-int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_amax, int dy_amax_n,
-                               const float* wd_packed, float* ring, void* stream);
+int dfmir_conv3x3_reflect_ring(const DfConvGeom* g, const float* dy, const float* dy_cols, const float* dy_amax,
+                               int dy_amax_n, const float* wd_packed, float* ring, void* stream);
+/* dy_cols (optional): [N*Cout][2][H], the first and last column of dy as left by dfmir_instnorm_bwd_cols. */
 
 /* Every packing of a train step at once (the weights of all layers change together, at the optimizer step): the same
  * result as njobs dfmir_weight_pack calls, in two launches.  `jobs` is HOST memory; `table_dev` is njobs * 64 bytes of
@@ -156,6 +157,11 @@ int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, 
                        int planes, long long S, float eps, int relu, float* y_amax, void* stream);
 int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                        float* dx, int planes, long long S, int relu, float* dx_amax, void* stream);
+/* The same, also writing dx's first and last column compactly, dx_cols[planes][2][H] (S = H*W; supported iff
+ * dfmir_instnorm_bwd_cols_ok(S, W)): the reflect ring of the next conv's dgrad reads them from there. */
+int dfmir_instnorm_bwd_cols_ok(long long S, int W);
+int dfmir_instnorm_bwd_cols(const float* dy, const float* x, const float* mean, const float* rstd, float* dx, int planes,
+                            long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream);
 
 /* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
 int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,
