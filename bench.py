@@ -252,10 +252,10 @@ def main():
                          "traffic": 480.5e6 if split and nprod == 3.0 else None,
                          "traffic_note": "bytes per launch of the 154.6-GFLOP shape, PMC (FETCH_SIZE + WRITE_SIZE); "
                                          "algorithmic 272 MB; MFMA-bound: 480 MB in 0.43 ms is 1.1 TB/s",
-                         "kernel": ("conv3x3_split_cs_k + conv3x3_split_pp_k (fp32 operands split into 16-bit terms, %s on "
-                                    "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; cs: 128 couts x 8x32-pixel tile "
-                                    "shared by two wave groups, pp: 128 couts x 2x128-pixel runs, both ping-pong)"
-                                    % form if split else
+                         "kernel": ("conv3x3_split_cs_k<true,64,8> (fp32 operands split into 16-bit terms, %s on "
+                                    "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; 128 couts x 8x32-pixel tile shared by "
+                                    "two ping-pong wave groups; reflect dgrads = zero-padded form + ring kernel; "
+                                    "conv3x3_split_pp_k for tiles filled < 85 %%)" % form if split else
                                     "conv3x3_mfma_k<2,2,2,2,400> (v_mfma_f32_32x32x2_f32; 128 couts x 128 pixels)") +
                                    ": forward + dgrad of every 3x3 conv with Cout > 64",
                          "clock_note": "these kernels hold the package at its 1400 W cap: sclk 1.75 GHz sustained "
