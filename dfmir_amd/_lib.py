@@ -39,6 +39,8 @@ _SIGS = {
     "dfmir_absmax": [P, c_longlong, P, P],
     "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],
     "dfmir_weight_unpack_add_batch": [P, c_int, c_longlong, P],
+    "dfmir_conv7x7_c1_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "dfmir_conv7x7_c1_wgrad": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "dfmir_tapstack_fwd": [P, P] + [c_int] * 7 + [P],
     "dfmir_tapstack_bwd": [P, P] + [c_int] * 7 + [P],
     "dfmir_tapsum_fwd": [P, P, P] + [c_int] * 10 + [c_float, P],

@@ -181,3 +181,199 @@ extern "C" int dfmir_tapsum_bwd(const float* dy, float* dz, int N, int C, int Hz
   DF_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Direct forms of the Cin == 1 stem (7x7, 1 -> Cout <= 64): the tap-stack + 1x1 GEMM above moves 49 planes per
+// pixel through HBM (411 MB for 32 images at 256^2, against 8 MB of input); here the 49 taps are the MFMA's K and
+// the operand is gathered from an LDS patch of the single input channel.
+//   forward : Y[co][p] = b[co] + sum_t W[co][t] xp[p + t]       v_mfma_f32_32x32x2_f32, A = W (regs), B = patch gather
+//   wgrad   : dW[co][t] += sum_p dY[co][p] xp[p + t],  db[co] += sum_p dY[co][p]     (K = pixels)
+// Bound: the 64-plane output (forward) / dY (wgrad) stream and, equally, the fp32 matrix pipe (13 GFLOP per 32 images).
+// ---------------------------------------------------------------------------------------------
+typedef float st_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int S7_K = 7, S7_T = 49, S7_TH = 8, S7_TW = 32, S7_PW = S7_TW + 6, S7_PH = S7_TH + 6, S7_RW = S7_TH / 2;
+
+__device__ __forceinline__ int s7_src(int iy, int ix, int H, int W, int pad_mode) {
+  if (pad_mode == 1) {
+    if (iy < 0) iy = -iy;
+    if (iy >= H) iy = 2 * (H - 1) - iy;
+    if (ix < 0) ix = -ix;
+    if (ix >= W) ix = 2 * (W - 1) - ix;
+    iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+    return iy * W + ix;
+  }
+  return ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? iy * W + ix : -1;
+}
+
+// tile = 8 rows x 32 px, 256 threads = 4 waves: wave w -> cout block (w & 1), rows 4 (w >> 1) .. +3  (64 accumulator
+// registers per wave: several workgroups per CU overlap their patch loads, MFMAs and stores)
+__global__ __launch_bounds__(256, 2) void conv7x7_c1_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int H, int W, int Cout, int pad_mode, int tiles_x) {
+  __shared__ float patch[S7_PH * S7_PW];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * S7_TH, tx0 = (blockIdx.x % tiles_x) * S7_TW;
+  const float* xn = x + (long long)n * H * W;
+  for (int i = tid; i < S7_PH * S7_PW; i += 256) {
+    const int r = i / S7_PW, c = i - r * S7_PW;
+    const int o = s7_src(ty0 + r - 3, tx0 + c - 3, H, W, pad_mode);
+    patch[i] = o >= 0 ? xn[o] : 0.f;
+  }
+  const int mb = wid & 1, rg = wid >> 1;
+  const int co = mb * 32 + l31;
+  // A operand: this lane's weights for k-step s (tap 2s + lhi), kept in registers
+  float a[25];
+#pragma unroll
+  for (int s2 = 0; s2 < 25; ++s2) {
+    const int t = 2 * s2 + lhi;
+    a[s2] = (t < S7_T && co < Cout) ? w[co * S7_T + t] : 0.f;
+  }
+  __syncthreads();
+  st_f32x16 acc[S7_RW];
+#pragma unroll
+  for (int j = 0; j < S7_RW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < 25; ++s2) {
+    const int t = 2 * s2 + lhi < S7_T ? 2 * s2 + lhi : S7_T - 1;     // tap 49 has a zero weight
+    const int off = (t / S7_K) * S7_PW + (t % S7_K) + l31;
+#pragma unroll
+    for (int j = 0; j < S7_RW; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], patch[(rg * S7_RW + j) * S7_PW + off], acc[j], 0, 0, 0);
+  }
+  float* yn = y + (long long)n * Cout * H * W;
+  float bz[16];                                            // this lane's 16 output channels' biases
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+    bz[r] = (bias && c < Cout) ? bias[c] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < S7_RW; ++j) {
+    const int oy = ty0 + rg * S7_RW + j, ox = tx0 + l31;
+    if (oy >= H || ox >= W) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+      if (c < Cout) yn[((long long)c * H + oy) * W + ox] = acc[j][r] + bz[r];
+    }
+  }
+}
+
+// persistent workgroups over 8 x 32 pixel tiles; wave w -> (cout block w & 1, tap block w >> 1), one accumulator;
+// K = the tile's 256 pixels, two per MFMA.  dY tile and input patch in LDS.
+constexpr int S7W_TH = 8, S7W_PH = S7W_TH + 6;
+__global__ __launch_bounds__(256) void conv7x7_c1_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, float* __restrict__ db,
+                                                          int N, int H, int W, int Cout, int pad_mode,
+                                                          int tiles_x, int tiles_y) {
+  __shared__ float patch[S7W_PH * S7_PW];
+  __shared__ float dyt[64 * (S7W_TH * S7_TW + 1)];        // [co][px], row stride 257: conflict-free column reads
+  constexpr int DS = S7W_TH * S7_TW + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int mb = wid & 1, tb = wid >> 1;
+  const int t = tb * 32 + l31;                             // this lane's tap (B operand column)
+  const int tc = t < S7_T ? t : S7_T - 1;
+  const int toff = (tc / S7_K) * S7_PW + (tc % S7_K);
+  st_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // db rides in the padded tap column 49: its B operand is the constant 1, so acc[.][49] = sum_p dY[co][p]
+  const long long HW = (long long)H * W;
+  const int ntile = N * tiles_y * tiles_x;
+  for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+    const int n = tl / (tiles_y * tiles_x), q = tl - n * tiles_y * tiles_x;
+    const int ty0 = (q / tiles_x) * S7W_TH, tx0 = (q % tiles_x) * S7_TW;
+    const float* xn = x + (long long)n * HW;
+    const float* dyn = dy + (long long)n * Cout * HW;
+    __syncthreads();
+    for (int i = tid; i < S7W_PH * S7_PW; i += 256) {
+      const int r = i / S7_PW, c = i - r * S7_PW;
+      const int o = s7_src(ty0 + r - 3, tx0 + c - 3, H, W, pad_mode);
+      patch[i] = o >= 0 ? xn[o] : 0.f;
+    }
+    {
+      // 64 channels x 256 pixels as 16 float4 per thread, all loads issued before the first LDS store
+      float4 ld[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const int i4 = tid + 256 * q4, c = i4 >> 6, r4 = i4 & 63;
+        const int oy = ty0 + (r4 >> 3), ox = tx0 + ((r4 & 7) << 2);
+        const float* src = dyn + ((long long)c * H + oy) * W + ox;
+        if (c < Cout && oy < H && ox + 3 < W && (W & 3) == 0) ld[q4] = *reinterpret_cast<const float4*>(src);
+        else {
+          ld[q4].x = (c < Cout && oy < H && ox < W) ? src[0] : 0.f;
+          ld[q4].y = (c < Cout && oy < H && ox + 1 < W) ? src[1] : 0.f;
+          ld[q4].z = (c < Cout && oy < H && ox + 2 < W) ? src[2] : 0.f;
+          ld[q4].w = (c < Cout && oy < H && ox + 3 < W) ? src[3] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const int i4 = tid + 256 * q4, c = i4 >> 6, px = (i4 & 63) << 2;
+        float* d = dyt + c * DS + px;
+        d[0] = ld[q4].x; d[1] = ld[q4].y; d[2] = ld[q4].z; d[3] = ld[q4].w;
+      }
+    }
+    __syncthreads();
+    // 16 pixel pairs per group: the operands of group g+1 are read from LDS while the MFMAs of group g run
+    constexpr int G = 16, NG = S7W_TH * S7_TW / (2 * G);
+    float av[2][G], bv[2][G];
+    const float* arow = dyt + (mb * 32 + l31) * DS + lhi;
+#define S7W_LOAD(set_, g_)                                                                       \
+    _Pragma("unroll") for (int e = 0; e < G; ++e) {                                              \
+      const int px = 2 * ((g_) * G + e) + lhi;                                                   \
+      av[set_][e] = arow[2 * ((g_) * G + e)];                                                    \
+      bv[set_][e] = t == S7_T ? 1.f : patch[(px >> 5) * S7_PW + (px & 31) + toff];               \
+    }
+    S7W_LOAD(0, 0)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) S7W_LOAD((g + 1) & 1, g + 1)
+#pragma unroll
+      for (int e = 0; e < G; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][e], bv[g & 1][e], acc, 0, 0, 0);
+    }
+#undef S7W_LOAD
+  }
+  if (t <= S7_T) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+      if (c < Cout) {
+        if (t < S7_T) atomicAdd(&dw[c * S7_T + t], acc[r]);
+        else if (db) atomicAdd(&db[c], acc[r]);
+      }
+    }
+  }
+}
+
+extern "C" int dfmir_conv7x7_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
+                                    int Cout, int pad_mode, void* stream) {
+  DF_ARG_CHECK(x && w && y && N > 0 && N <= 65535 && H >= 4 && W >= 4 && Cout > 0 && Cout <= 64);
+  DF_ARG_CHECK(pad_mode == 0 || pad_mode == 1);
+  const int tx = (W + S7_TW - 1) / S7_TW, ty = (H + S7_TH - 1) / S7_TH;
+  conv7x7_c1_fwd_k<<<dim3((unsigned)(tx * ty), (unsigned)N), 256, 0, (hipStream_t)stream>>>(x, w, bias, y, H, W, Cout,
+                                                                                           pad_mode, tx);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_conv7x7_c1_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W,
+                                      int Cout, int pad_mode, void* stream) {
+  DF_ARG_CHECK(x && dy && dw && N > 0 && H >= 4 && W >= 4 && Cout > 0 && Cout <= 64);
+  DF_ARG_CHECK(pad_mode == 0 || pad_mode == 1);
+  const int tx = (W + S7_TW - 1) / S7_TW, ty = (H + S7W_TH - 1) / S7W_TH;
+  const long long ntile = (long long)N * tx * ty;
+  DF_ARG_CHECK(ntile < (1LL << 31));
+  // persistent workgroups, two per CU (68 KB of LDS each); every one ends with 3 200 atomic adds onto the same
+  // gradient, so more workgroups than that only add contention (1024: +70 us)
+  const unsigned grid = (unsigned)(ntile < 512 ? ntile : 512);
+  conv7x7_c1_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, N, H, W, Cout, pad_mode, tx, ty);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

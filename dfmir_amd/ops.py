@@ -494,10 +494,55 @@ class TapSumFn(Function):
         return dz, db, None, None, None, None, None, None
 
 
+class Stem7Fn(Function):
+    """7x7 conv of a single-channel image (Cout <= 64, pad 3) straight from the image (csrc/taps.hip), not through
+    the 49-plane tap stack.  Backward: dW, db by the direct kernel; dx (only when the image needs a gradient) through
+    the tap-stack adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad_mode):
+        _need(x, weight, bias)
+        x = _c(x)
+        N, _, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32)
+        check(lib().dfmir_conv7x7_c1_fwd(_p(x), _p(_c(weight)), _p(bias), _p(y), N, H, W, Cout, pad_mode, _st()))
+        ctx.save_for_backward(x, weight)
+        ctx.pad_mode = pad_mode
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        N, _, H, W = x.shape
+        Cout = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dwb = torch.zeros(Cout * 49 + Cout, device=dy.device, dtype=torch.float32)
+            dbp = dwb[Cout * 49:] if ctx.has_bias else None
+            check(lib().dfmir_conv7x7_c1_wgrad(_p(x), _p(dy), _p(dwb), _p(dbp), N, H, W, Cout, ctx.pad_mode, _st()))
+            dw = dwb[:Cout * 49].view(Cout, 1, 7, 7)
+            db = dbp if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.needs_input_grad[0]:
+            wd = weight_pack(weight.detach().view(Cout, 49, 1), 1)
+            ds = conv_raw(dy.unsqueeze(2), wd, None, 49, (1, 1, 1), 1, (0, 0, 0), 1, 0, 0, 0.0, (1, H, W))
+            dx = torch.empty_like(x)
+            check(lib().dfmir_tapstack_bwd(_p(ds), _p(dx), N, 1, H, W, 7, 3, ctx.pad_mode, _st()))
+        return dx, dw, db, None
+
+
+_NO_STEM7 = bool(os.environ.get("DFMIR_NO_STEM7"))    # A/B switch: the stem through tap stack + 1x1 GEMM
+
+
 def conv_taps(x, weight, bias, pad, pad_mode, act=0, slope=0.0):
     """KxK conv with Cin == 1 or Cout <= 4 as a 1x1 GEMM over K*K tap planes (see csrc/taps.hip)."""
     Cout, Cin, K = weight.shape[0], weight.shape[1], weight.shape[2]
     T = K * K
+    if Cin == 1 and K == 7 and pad == 3 and Cout <= 64 and act == 0 and x.dim() == 4 and not _NO_STEM7:
+        return Stem7Fn.apply(x, weight, bias, pad_mode)
     if Cin == 1:
         s = TapStackFn.apply(x, K, pad, pad_mode)
         return conv(s, weight.view(Cout, T, 1, 1), bias, None, 1, 0, 0, act, slope)

@@ -134,6 +134,15 @@ typedef struct DfUnpackJob {
 } DfUnpackJob;
 int dfmir_weight_unpack_add_batch(const DfUnpackJob* jobs, int njobs, long long max_total, void* stream);
 
+/* The Cin == 1 stem directly: nn.ReflectionPad2d(3) + nn.Conv2d(1, ngf, 7) (models/networks.py:982-983).
+ * x[N][1][H][W], w[Cout][1][7][7] (reference layout), Cout <= 64; pad 3, pad_mode 0 zero / 1 reflect.
+ * fwd: y = conv + bias.  wgrad: dw[Cout][49] += sum dy (x) x_padded-shifted, db[Cout] += sum dy (db optional); both
+ * ACCUMULATE (zero the buffers first). */
+int dfmir_conv7x7_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
+                         int pad_mode, void* stream);
+int dfmir_conv7x7_c1_wgrad(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, int Cout,
+                           int pad_mode, void* stream);
+
 /* 7x7 convs of the generator as 1x1 GEMMs (models/networks.py:982-983 Conv2d(1,64,7) and :1022-1024
  * Conv2d(64,1,7)+Tanh, both behind ReflectionPad2d(3)):
  *   tapstack: S[n][c*K*K+tap][p] = x[n][c][map(p + tap - pad)]            (then a 1x1 conv K*K -> Cout)

@@ -587,3 +587,25 @@ def test_instnorm_bwd_border_columns(ops):
         assert torch.equal(cols[:, 0], g.reshape(6, 64, 64)[:, :, 0])
         assert torch.equal(cols[:, 1], g.reshape(6, 64, 64)[:, :, 63])
     close(g if g is not None else dx, dx, rtol=0, atol=0, what="same dx")
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 20, 24, True), (1, 64, 33, 70, True), (3, 40, 16, 32, False), (1, 64, 256, 256, True)],
+                         ids=["small", "ragged", "zero_pad_40", "full"])
+def test_stem7_direct(ops, cfg):
+    """nn.ReflectionPad2d(3) + Conv2d(1, C, 7) through the direct kernels (forward, dW, db) and the tap-stack adjoint
+    (dx), against torch."""
+    N, Cout, H, W, reflect = cfg
+    x = C.randn(111, N, 1, H, W)
+    w = C.randn(112, Cout, 1, 7, 7) / 7.0
+    b = C.randn(113, Cout) * 0.1
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch_conv(xr, wr, br, 1, 3, reflect, 0, 2)
+    cot = C.randn(114, *yr.shape)
+    (yr * cot).sum().backward()
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+    yg = ops.conv_taps(xg, wg, bg, 3, 1 if reflect else 0)
+    (yg * cot.to(DEV)).sum().backward()
+    close(yg, yr, what="y")
+    close(xg.grad, xr.grad, rtol=3e-4, what="dx")
+    close(wg.grad, wr.grad, rtol=3e-4, atol=1e-4 * float(wr.grad.abs().max()), what="dw")
+    close(bg.grad, br.grad, rtol=3e-4, atol=1e-4 * float(br.grad.abs().max()), what="db")
