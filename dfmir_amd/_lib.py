@@ -70,6 +70,7 @@ _SIGS = {
     "dfmir_resize_bwd": [P, P] + [c_int] * 7 + [c_float, P],
     "dfmir_patch_gather_fwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
     "dfmir_patch_gather_bwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
+    "dfmir_patch_gather_bwd_amax": [P, P, P, c_int, c_int, c_longlong, c_int, P, P],
     "dfmir_l2norm_fwd": [P, P, P, c_int, c_longlong, c_float, P],
     "dfmir_l2norm_bwd": [P, P, P, P, c_int, c_longlong, c_float, P],
     "dfmir_patchnce_fwd": [P, P, P, P, c_longlong, c_int, c_int, c_float, P],

@@ -14,15 +14,24 @@ __global__ void patch_gather_fwd_k(const float* __restrict__ feat, const long lo
     out[c * ((long long)B * P) + b * P + p] = feat[bc * S + ids[p]];
   }
 }
+// amax (optional): per-plane range probe of dfeat (B*C floats, as left by the InstanceNorm kernels); kept valid by
+// raising amax[plane] to |new value| of every element this scatter touches (ids are distinct within a plane)
 __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long long* __restrict__ ids,
-                                   float* __restrict__ dfeat, int B, int C, long long S, int P) {
+                                   float* __restrict__ dfeat, int B, int C, long long S, int P,
+                                   unsigned* __restrict__ amax) {
   const long long total = (long long)B * C * P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int p = (int)(i % P);
     const long long bc = i / P;
     const long long b = bc / C, c = bc - b * C;
-    atomicAdd(&dfeat[bc * S + ids[p]], dout[c * ((long long)B * P) + b * P + p]);
+    const float v = dout[c * ((long long)B * P) + b * P + p];
+    const float old = atomicAdd(&dfeat[bc * S + ids[p]], v);
+    if (amax) {
+      float nv = fabsf(old + v);
+      if (!(nv == nv)) nv = __uint_as_float(0x7f800000u);
+      if (__float_as_uint(nv) > amax[bc]) atomicMax(&amax[bc], __float_as_uint(nv));
+    }
   }
 }
 
@@ -390,7 +399,15 @@ extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, f
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0);
   patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
-      dout, ids, dfeat, B, C, S, P);
+      dout, ids, dfeat, B, C, S, P, nullptr);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C,
+                                           long long S, int P, float* dfeat_amax, void* stream) {
+  DF_ARG_CHECK(dout && ids && dfeat && dfeat_amax && B > 0 && C > 0 && S > 0 && P > 0);
+  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      dout, ids, dfeat, B, C, S, P, reinterpret_cast<unsigned*>(dfeat_amax));
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -645,12 +645,21 @@ ReflectPadFn = _plane_op("dfmir_reflect_pad2d_fwd", "dfmir_reflect_pad2d_bwd",
                          lambda H, W, p: (H + 2 * p, W + 2 * p))
 
 
+def _bound_from(y, x):
+    """y is a convex combination of x's values (the [1,2,1] blurs: non-negative taps summing to 1 per output), so
+    max|x| bounds max|y|: x's range probe serves y's split conversion (no standalone absmax launch)."""
+    tag = getattr(x, "_df_amax", None)
+    if tag is not None and tag[1] == x._version and tag[2] == x.data_ptr():
+        tag_amax(y, tag[0])
+    return y
+
+
 def blur_down(x):
-    return BlurDownFn.apply(x)
+    return _bound_from(BlurDownFn.apply(x), x)
 
 
 def blur_up(x):
-    return BlurUpFn.apply(x)
+    return _bound_from(BlurUpFn.apply(x), x)
 
 
 def reflect_pad2d(x, p):
@@ -920,10 +929,19 @@ class TapForkFn(Function):
                 g = torch.zeros(ctx.shape, device=stash[0][0].device, dtype=torch.float32)
             elif not g.is_contiguous():
                 g = g.contiguous()
+            atag = getattr(g, "_df_amax", None)
+            if atag is not None and not (atag[1] == g._version and atag[2] == g.data_ptr()):
+                atag = None
             for dout, ids, (shape, B, C, S, Pn) in stash:
-                check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(g), B, C, S, Pn, _st()))
+                if atag is not None and atag[0].numel() == B * C:
+                    # keep g's per-plane range probe (from the InstanceNorm backward that produced it) valid
+                    check(lib().dfmir_patch_gather_bwd_amax(_p(dout), _p(ids), _p(g), B, C, S, Pn, _p(atag[0]), _st()))
+                else:
+                    check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(g), B, C, S, Pn, _st()))
+                    atag = None
             del stash[:]
-            for tag in ("_df_amax", "_df_cols"):      # modified through the raw pointer: these tags would be stale
+            # modified through the raw pointer: tags that were not maintained would be stale
+            for tag in (("_df_cols",) if atag is not None else ("_df_amax", "_df_cols")):
                 if hasattr(g, tag):
                     delattr(g, tag)
         if g_tap is not None:                    # a dense gradient on the tap (some other use of it)

@@ -247,7 +247,11 @@ int dfmir_resize_bwd(const float* dy, float* dx, int planes, int Di, int Hi, int
 int dfmir_patch_gather_fwd(const float* feat, const long long* ids, float* out, int B, int C,
                            long long S, int P, void* stream);
 int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
-                           long long S, int P, void* stream); /* accumulates */
+                           long long S, int P, void* stream);
+/* The same scatter into a gradient that already holds another consumer's contribution, keeping its per-plane range
+ * probe valid: dfeat_amax[B*C] (the dx_amax of dfmir_instnorm_bwd) is raised to |new value| where needed. */
+int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S,
+                                int P, float* dfeat_amax, void* stream); /* accumulates */
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
 int dfmir_l2norm_fwd(const float* x, float* y, float* norm, int C, long long rows, float eps, void* stream);
 int dfmir_l2norm_bwd(const float* dy, const float* x, const float* norm, float* dx, int C,
