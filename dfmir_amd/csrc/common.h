@@ -76,6 +76,18 @@ __device__ __forceinline__ void publish_block_absmax(float m, unsigned* smax, fl
   __syncthreads();
   if (threadIdx.x == 0) *out_block = __uint_as_float(*smax);
 }
+//   accumulating form: DF_PROBE_SLOTS floats per tensor, zero-initialised by the host; thread 0 of every producer
+//   workgroup folds its block's maximum into slot (blockIdx.x mod DF_PROBE_SLOTS) with a fire-and-forget atomic max
+//   (spread over 64 addresses: ~128 per address for 8192 planes; a single address serialised them, a read-before-
+//   atomic filter put an L2 round trip at the end of every short workgroup).  The consumers reduce 64 floats instead
+//   of one per plane (8192 per workgroup of the conv kernels used to cost them 2-4 %).
+#define DF_PROBE_SLOTS 64
+__device__ __forceinline__ void publish_block_absmax_acc(float m, unsigned* smax, float* out) {
+  const float t = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(smax, __float_as_uint(t == t ? t : __uint_as_float(0x7f800000u)));
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out) + (blockIdx.x & (DF_PROBE_SLOTS - 1)), *smax);
+}
 //   consumer: sm = >= 17 floats of LDS scratch
 __device__ __forceinline__ float reduce_absmax(const float* __restrict__ a, int n, float* sm) {
   if (n <= 1) return a[0];

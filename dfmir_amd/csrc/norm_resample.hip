@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
     y4[threadIdx.x + NT * i] = o;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
-  if (amax) publish_block_absmax(am, &smax, amax + blockIdx.x);   // range probe for the next conv's fp16x2 split
+  if (amax) publish_block_absmax_acc(am, &smax, amax);   // range probe for the next conv's fp16x2 split
 }
 template <int NT, int E>
 __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict__ dy,
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
       if ((e0 + 3) % W == W - 1) cp[H + (e0 + 3) / W] = o.w;
     }
   }
-  if (amax) publish_block_absmax(am, &smax, amax + blockIdx.x);
+  if (amax) publish_block_absmax_acc(am, &smax, amax);
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
@@ -688,9 +688,10 @@ __global__ void scale_k(const float* __restrict__ x, float* __restrict__ y, long
 
 // ---------------------------------------------------------------------------------------------
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
-// y_amax / dx_amax (may be NULL): array of `planes` floats that receives max |output| of every plane -- the range
-// probe the fp16x2 conv kernels need for their next input (they reduce the array in their prologue), produced
-// while the output is still in registers and without global atomics.
+// y_amax / dx_amax (may be NULL): DF_PROBE_SLOTS (64) floats, zero-initialised by the caller; their maximum is raised
+// to max |output| -- the range
+// probe the fp16x2 conv kernels need for their next input, produced while the output is still in registers (one
+// conditional atomic per workgroup, common.h publish_block_absmax_acc).
 extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
                                   int planes, long long S, float eps, int relu, float* y_amax, void* stream) {
   DF_ARG_CHECK(x && y && mean && rstd && planes > 0 && S > 0);
@@ -700,9 +701,8 @@ extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, fl
   else if (S == 65536) instnorm_fwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(x, res, y, mean, rstd, eps, relu, y_amax);
   else {
     instnorm_fwd_k<<<planes, 256, 0, st>>>(x, res, y, mean, rstd, S, eps, relu);
-    if (y_amax) {   // generic plane size: whole-tensor maximum in slot 0, zeros elsewhere
+    if (y_amax) {   // generic plane size: a pass over the output
       DF_LAUNCH_CHECK();
-      if (hipMemsetAsync(y_amax, 0, sizeof(float) * planes, st) != hipSuccess) return df_set_error(1, __FILE__, __LINE__);
       const int rc = df_absmax_launch(y, (long long)planes * S, y_amax, st, false);
       if (rc) return df_set_error(rc, __FILE__, __LINE__);
     }
@@ -736,7 +736,6 @@ static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean,
     instnorm_bwd_k<<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, S, relu);
     if (dx_amax) {
       DF_LAUNCH_CHECK();
-      if (hipMemsetAsync(dx_amax, 0, sizeof(float) * planes, st) != hipSuccess) return df_set_error(1, __FILE__, __LINE__);
       const int rc = df_absmax_launch(dx, (long long)planes * S, dx_amax, st, false);
       if (rc) return df_set_error(rc, __FILE__, __LINE__);
     }

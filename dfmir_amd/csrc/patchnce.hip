@@ -14,8 +14,8 @@ __global__ void patch_gather_fwd_k(const float* __restrict__ feat, const long lo
     out[c * ((long long)B * P) + b * P + p] = feat[bc * S + ids[p]];
   }
 }
-// amax (optional): per-plane range probe of dfeat (B*C floats, as left by the InstanceNorm kernels); kept valid by
-// raising amax[plane] to |new value| of every element this scatter touches (ids are distinct within a plane)
+// amax (optional): the range probe of dfeat (DF_PROBE_SLOTS floats, as left by the InstanceNorm kernels); kept valid
+// by raising a slot to |new value| of every element this scatter touches (ids are distinct within a plane)
 __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long long* __restrict__ ids,
                                    float* __restrict__ dfeat, int B, int C, long long S, int P,
                                    unsigned* __restrict__ amax) {
@@ -30,7 +30,8 @@ __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long lo
     if (amax) {
       float nv = fabsf(old + v);
       if (!(nv == nv)) nv = __uint_as_float(0x7f800000u);
-      if (__float_as_uint(nv) > amax[bc]) atomicMax(&amax[bc], __float_as_uint(nv));
+      unsigned* sl = amax + (bc & (DF_PROBE_SLOTS - 1));
+      if (__float_as_uint(nv) > *reinterpret_cast<volatile unsigned*>(sl)) atomicMax(sl, __float_as_uint(nv));
     }
   }
 }

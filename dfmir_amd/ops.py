@@ -54,6 +54,7 @@ def set_conv_profiler(fn):
 # Range probes (max |t|) of the fp16x2 split kernels (csrc/conv3x3s.hip).  Slots come zero-initialised from
 # a pool (one fill per 4096 probes).  A producer that computes the maximum as a by-product (InstanceNorm
 # forward / backward) tags its output tensor with it; `amax_of` reuses the tag while the tensor is unmodified.
+PROBE_SLOTS = 64          # DFMIR_PROBE_SLOTS: floats of an InstanceNorm by-product probe
 _AMAX_POOL = {"buf": None, "next": 0}
 
 
@@ -565,7 +566,7 @@ class InstNormFn(Function):
         mean = torch.empty(planes, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         r = _c(res) if res is not None else None
-        slot = amax_slot(x.device, planes)
+        slot = amax_slot(x.device, PROBE_SLOTS)
         check(lib().dfmir_instnorm_fwd(_p(x), _p(r), _p(y), _p(mean), _p(rstd), planes, S, float(eps),
                                        int(relu), _p(slot), _st()))
         _LAST_AMAX[0] = slot
@@ -584,7 +585,7 @@ class InstNormFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            slot = amax_slot(x.device, planes)
+            slot = amax_slot(x.device, PROBE_SLOTS)
             W = x.shape[-1]
             if x.dim() == 4 and W <= 94 and S // W <= 94 and lib().dfmir_instnorm_bwd_cols_ok(S, W):   # ring-kernel sizes
                 # first / last column of dx on the side: the dgrad of a reflect-padded conv reads them (ring kernel)
@@ -933,7 +934,7 @@ class TapForkFn(Function):
             if atag is not None and not (atag[1] == g._version and atag[2] == g.data_ptr()):
                 atag = None
             for dout, ids, (shape, B, C, S, Pn) in stash:
-                if atag is not None and atag[0].numel() == B * C:
+                if atag is not None and atag[0].numel() == PROBE_SLOTS:
                     # keep g's per-plane range probe (from the InstanceNorm backward that produced it) valid
                     check(lib().dfmir_patch_gather_bwd_amax(_p(dout), _p(ids), _p(g), B, C, S, Pn, _p(atag[0]), _st()))
                 else:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 2
+#define DFMIR_ABI_VERSION 3
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -69,7 +69,10 @@ int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_am
                           const float* w_tcc, const float* bias, float* y, void* stream);
 /* out[0] = max(out[0], max_i |x[i]|) (NaN counts as +inf; the caller zero-initialises out).  Replaces nothing in
  * the reference: it is the range probe of the fp16x2 split.  dfmir_instnorm_fwd/bwd produce a probe of their output
- * as a by-product: y_amax / dx_amax = array of `planes` per-plane maxima (NULL to skip). */
+ * as a by-product: y_amax / dx_amax = DFMIR_PROBE_SLOTS floats (caller zero-initialises; NULL to skip) whose maximum
+ * is max|output|.  x_amax_n of the conv entry points is the number of floats to reduce (1 after dfmir_absmax,
+ * DFMIR_PROBE_SLOTS after the InstanceNorm entry points). */
+#define DFMIR_PROBE_SLOTS 64
 int dfmir_absmax(const float* x, long long n, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
@@ -249,7 +252,7 @@ int dfmir_patch_gather_fwd(const float* feat, const long long* ids, float* out, 
 int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
                            long long S, int P, void* stream);
 /* The same scatter into a gradient that already holds another consumer's contribution, keeping its per-plane range
- * probe valid: dfeat_amax[B*C] (the dx_amax of dfmir_instnorm_bwd) is raised to |new value| where needed. */
+ * probe valid: dfeat_amax[DFMIR_PROBE_SLOTS] (the dx_amax of dfmir_instnorm_bwd) is raised to |new value| where needed. */
 int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S,
                                 int P, float* dfeat_amax, void* stream); /* accumulates */
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
