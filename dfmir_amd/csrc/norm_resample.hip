@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
   }
   if (amax) publish_block_absmax_acc(am, &smax, amax);   // range probe for the next conv's fp16x2 split
 }
-template <int NT, int E>
+template <int NT, int E, bool COLS>
 __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict__ dy,
                                                          const float* __restrict__ x,
                                                          const float* __restrict__ mean_i,
@@ -142,6 +142,9 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
   __shared__ unsigned smax;
   if (threadIdx.x == 0) smax = 0u;
   constexpr long long S = (long long)NT * 4 * E;
+  // (<1024,16>: 2 x 64 values per thread at the 128-register limit of a 1024-thread workgroup: 29 registers spill to
+  // scratch; parking part of g in LDS did not change that -- the pressure is in the load phase -- and the border-column
+  // code, 13 more, is compiled out for the plane sizes that never need it: COLS)
   const long long base = (long long)blockIdx.x * S;
   const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
   const float4* x4 = reinterpret_cast<const float4*>(x + base);
@@ -151,17 +154,18 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     const float4 xv = x4[threadIdx.x + NT * i];
-    g[i] = g4[threadIdx.x + NT * i];
+    float4 gi = g4[threadIdx.x + NT * i];
     xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
     xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
     if (relu) {
-      if (!(xh[i].x > 0.f)) g[i].x = 0.f;
-      if (!(xh[i].y > 0.f)) g[i].y = 0.f;
-      if (!(xh[i].z > 0.f)) g[i].z = 0.f;
-      if (!(xh[i].w > 0.f)) g[i].w = 0.f;
+      if (!(xh[i].x > 0.f)) gi.x = 0.f;
+      if (!(xh[i].y > 0.f)) gi.y = 0.f;
+      if (!(xh[i].z > 0.f)) gi.z = 0.f;
+      if (!(xh[i].w > 0.f)) gi.w = 0.f;
     }
-    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+    s1 += (gi.x + gi.y) + (gi.z + gi.w);
+    s2 += (gi.x * xh[i].x + gi.y * xh[i].y) + (gi.z * xh[i].z + gi.w * xh[i].w);
+    g[i] = gi;
   }
   const float m1 = block_sum(s1, sm) / (float)S;
   const float m2 = block_sum(s2, sm) / (float)S;
@@ -169,12 +173,13 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
   float am = 0.f;
 #pragma unroll
   for (int i = 0; i < E; ++i) {
+    const float4 gi = g[i];
     float4 o;
-    o.x = rstd * (g[i].x - m1 - xh[i].x * m2); o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
-    o.z = rstd * (g[i].z - m1 - xh[i].z * m2); o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+    o.x = rstd * (gi.x - m1 - xh[i].x * m2); o.y = rstd * (gi.y - m1 - xh[i].y * m2);
+    o.z = rstd * (gi.z - m1 - xh[i].z * m2); o.w = rstd * (gi.w - m1 - xh[i].w * m2);
     d4[threadIdx.x + NT * i] = o;
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-    if (cols) {
+    if (COLS && cols) {
       const int e0 = 4 * (threadIdx.x + NT * i), H = (int)(S / W);
       float* cp = cols + (long long)blockIdx.x * 2 * H;
       if (e0 % W == 0) cp[e0 / W] = o.x;
@@ -711,7 +716,7 @@ extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, fl
   return 0;
 }
 extern "C" int dfmir_instnorm_bwd_cols_ok(long long S, int W) {
-  return ((S == 4096 || S == 16384 || S == 65536) && W >= 4 && (W & 3) == 0 && S % W == 0) ? 1 : 0;
+  return ((S == 4096 || S == 16384) && W >= 4 && (W & 3) == 0 && S % W == 0) ? 1 : 0;
 }
 static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
                              int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream);
@@ -729,9 +734,12 @@ static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean,
                              int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream) {
   DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (S == 4096) instnorm_bwd_reg_k<256, 4><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
-  else if (S == 16384) instnorm_bwd_reg_k<256, 16><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
-  else if (S == 65536) instnorm_bwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
+  if (S == 4096 && dx_cols) instnorm_bwd_reg_k<256, 4, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
+  else if (S == 4096) instnorm_bwd_reg_k<256, 4, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
+  else if (S == 16384 && dx_cols) instnorm_bwd_reg_k<256, 16, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
+  else if (S == 16384) instnorm_bwd_reg_k<256, 16, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
+  else if (S == 65536 && dx_cols) return df_set_error(-1, __FILE__, __LINE__);     // dfmir_instnorm_bwd_cols_ok excludes it
+  else if (S == 65536) instnorm_bwd_reg_k<1024, 16, false><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
   else {
     instnorm_bwd_k<<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, S, relu);
     if (dx_amax) {
