@@ -71,6 +71,8 @@ _SIGS = {
     "dfmir_patch_gather_fwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
     "dfmir_patch_gather_bwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
     "dfmir_patch_gather_bwd_amax": [P, P, P, c_int, c_int, c_longlong, c_int, P, P],
+    "dfmir_patch_gather_fwd_g": [P, P, P, c_int, c_int, c_longlong, c_int, c_int, P],
+    "dfmir_patch_gather_bwd_g": [P, P, P, c_int, c_int, c_longlong, c_int, c_int, P, P],
     "dfmir_l2norm_fwd": [P, P, P, c_int, c_longlong, c_float, P],
     "dfmir_l2norm_bwd": [P, P, P, P, c_int, c_longlong, c_float, P],
     "dfmir_patchnce_fwd": [P, P, P, P, c_longlong, c_int, c_int, c_float, P],

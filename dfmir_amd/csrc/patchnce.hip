@@ -3,21 +3,23 @@
 // kernel, probabilities kept for backward).
 #include "common.h"
 
+// ids[G][P]: image b samples the positions of group b / (B / G)  (G = 1: one id set for the whole batch, as
+// PatchSampleF draws it; G > 1: several NCE terms' query images stacked along the batch, each with its term's ids)
 __global__ void patch_gather_fwd_k(const float* __restrict__ feat, const long long* __restrict__ ids,
-                                   float* __restrict__ out, int B, int C, long long S, int P) {
+                                   float* __restrict__ out, int B, int C, long long S, int P, int bpg) {
   const long long total = (long long)B * C * P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int p = (int)(i % P);
     const long long bc = i / P;
     const long long b = bc / C, c = bc - b * C;
-    out[c * ((long long)B * P) + b * P + p] = feat[bc * S + ids[p]];
+    out[c * ((long long)B * P) + b * P + p] = feat[bc * S + ids[(b / bpg) * P + p]];
   }
 }
 // amax (optional): the range probe of dfeat (DF_PROBE_SLOTS floats, as left by the InstanceNorm kernels); kept valid
 // by raising a slot to |new value| of every element this scatter touches (ids are distinct within a plane)
 __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long long* __restrict__ ids,
-                                   float* __restrict__ dfeat, int B, int C, long long S, int P,
+                                   float* __restrict__ dfeat, int B, int C, long long S, int P, int bpg,
                                    unsigned* __restrict__ amax) {
   const long long total = (long long)B * C * P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -26,7 +28,7 @@ __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long lo
     const long long bc = i / P;
     const long long b = bc / C, c = bc - b * C;
     const float v = dout[c * ((long long)B * P) + b * P + p];
-    const float old = atomicAdd(&dfeat[bc * S + ids[p]], v);
+    const float old = atomicAdd(&dfeat[bc * S + ids[(b / bpg) * P + p]], v);
     if (amax) {
       float nv = fabsf(old + v);
       if (!(nv == nv)) nv = __uint_as_float(0x7f800000u);
@@ -392,7 +394,23 @@ extern "C" int dfmir_patch_gather_fwd(const float* feat, const long long* ids, f
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(feat && ids && out && B > 0 && C > 0 && S > 0 && P > 0);
   patch_gather_fwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
-      feat, ids, out, B, C, S, P);
+      feat, ids, out, B, C, S, P, B);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_patch_gather_fwd_g(const float* feat, const long long* ids, float* out, int B, int C,
+                                        long long S, int P, int G, void* stream) {
+  DF_ARG_CHECK(feat && ids && out && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
+  patch_gather_fwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      feat, ids, out, B, C, S, P, B / G);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfeat, int B, int C,
+                                        long long S, int P, int G, float* dfeat_amax, void* stream) {
+  DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
+  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax));
   DF_LAUNCH_CHECK();
   return 0;
 }
@@ -400,7 +418,7 @@ extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, f
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0);
   patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
-      dout, ids, dfeat, B, C, S, P, nullptr);
+      dout, ids, dfeat, B, C, S, P, B, nullptr);
   DF_LAUNCH_CHECK();
   return 0;
 }
@@ -408,7 +426,7 @@ extern "C" int dfmir_patch_gather_bwd_amax(const float* dout, const long long* i
                                            long long S, int P, float* dfeat_amax, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && dfeat_amax && B > 0 && C > 0 && S > 0 && P > 0);
   patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
-      dout, ids, dfeat, B, C, S, P, reinterpret_cast<unsigned*>(dfeat_amax));
+      dout, ids, dfeat, B, C, S, P, B, reinterpret_cast<unsigned*>(dfeat_amax));
   DF_LAUNCH_CHECK();
   return 0;
 }

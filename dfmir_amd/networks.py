@@ -422,7 +422,10 @@ class PatchSampleF(nn.Module):
         init_net(self, self.init_type, self.init_gain, self.gpu_ids)
         self.mlp_init = True
 
-    def forward(self, feats, num_patches=64, patch_ids=None):
+    def forward(self, feats, num_patches=64, patch_ids=None, groups=1):
+        """groups > 1 (build-defined): `feats` stack the query images of `groups` NCE terms along the batch and
+        patch_ids[i] is [groups, P] -- each third of the batch is sampled at its own term's positions; the MLP then
+        runs once over all rows."""
         return_ids, return_feats = [], []
         if self.use_mlp and not self.mlp_init:
             self.create_mlp(feats)
@@ -435,7 +438,7 @@ class PatchSampleF(nn.Module):
             else:
                 patch_id = torch.randperm(S, device=feats[0].device)
                 patch_id = patch_id[:int(min(num_patches, patch_id.shape[0]))]
-            x = ops.patch_gather(feat, patch_id)              # [C, B*P]
+            x = ops.patch_gather(feat, patch_id, groups)      # [C, B*P]
             if self.use_mlp:
                 mlp = getattr(self, 'mlp_%d' % feat_id)
                 x = mlp[2](mlp[0](x, relu=True))

@@ -933,13 +933,12 @@ class TapForkFn(Function):
             atag = getattr(g, "_df_amax", None)
             if atag is not None and not (atag[1] == g._version and atag[2] == g.data_ptr()):
                 atag = None
-            for dout, ids, (shape, B, C, S, Pn) in stash:
-                if atag is not None and atag[0].numel() == PROBE_SLOTS:
-                    # keep g's per-plane range probe (from the InstanceNorm backward that produced it) valid
-                    check(lib().dfmir_patch_gather_bwd_amax(_p(dout), _p(ids), _p(g), B, C, S, Pn, _p(atag[0]), _st()))
-                else:
-                    check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(g), B, C, S, Pn, _st()))
+            for dout, ids, (shape, B, C, S, Pn, G) in stash:
+                if atag is not None and atag[0].numel() != PROBE_SLOTS:
                     atag = None
+                # with a probe: keep g's range probe (from the InstanceNorm backward that produced it) valid
+                check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(g), B, C, S, Pn, G,
+                                                     _p(atag[0]) if atag is not None else None, _st()))
             del stash[:]
             # modified through the raw pointer: tags that were not maintained would be stale
             for tag in (("_df_cols",) if atag is not None else ("_df_amax", "_df_cols")):
@@ -965,39 +964,42 @@ def fork_tap(feat):
 
 
 class PatchGatherFn(Function):
-    """feat [B,C,*sp], ids int64 [P] -> channel-major rows [C, B*P]."""
+    """feat [B,C,*sp], ids int64 [P] (or [G,P]: image b uses row b // (B/G)) -> channel-major rows [C, B*P]."""
 
     @staticmethod
-    def forward(ctx, feat, ids):
+    def forward(ctx, feat, ids, groups=1):
         _need(feat, ids)
         ctx.stash = getattr(feat, "_df_tap_stash", None) if feat.is_contiguous() else None
         feat = _c(feat)
         ids = _c(ids.to(torch.int64))
         B, C = feat.shape[0], feat.shape[1]
         S = feat.numel() // (B * C)
-        Pn = ids.numel()
+        G = int(groups)
+        if ids.numel() % G or B % G:
+            raise DfmirHipError("patch_gather: ids [G,P] with G dividing the batch")
+        Pn = ids.numel() // G
         out = torch.empty((C, B * Pn), device=feat.device, dtype=torch.float32)
-        check(lib().dfmir_patch_gather_fwd(_p(feat), _p(ids), _p(out), B, C, S, Pn, _st()))
+        check(lib().dfmir_patch_gather_fwd_g(_p(feat), _p(ids), _p(out), B, C, S, Pn, G, _st()))
         ctx.save_for_backward(ids)
-        ctx.meta = (feat.shape, B, C, S, Pn)
+        ctx.meta = (feat.shape, B, C, S, Pn, G)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        shape, B, C, S, Pn = ctx.meta
+        shape, B, C, S, Pn, G = ctx.meta
         dout = _c(dout)
         if ctx.stash is not None:                # collected by TapForkFn.backward, which runs after this node
             ctx.stash.append((dout, ids, ctx.meta))
-            return None, None
+            return None, None, None
         dfeat = torch.zeros(shape, device=dout.device, dtype=torch.float32)
-        check(lib().dfmir_patch_gather_bwd(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, _st()))
-        return dfeat, None
+        check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, G, None, _st()))
+        return dfeat, None, None
 
 
-def patch_gather(feat, ids):
-    return PatchGatherFn.apply(feat, ids)
+def patch_gather(feat, ids, groups=1):
+    return PatchGatherFn.apply(feat, ids, groups)
 
 
 class L2NormFn(Function):

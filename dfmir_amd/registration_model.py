@@ -156,11 +156,21 @@ class REGISTRATIONModel(BaseModel):
         if self.opt.netF == 'mlp_sample':
             self.optimizer_F.zero_grad()
 
+        self._nce_terms = None
+        if (getattr(self.opt, 'batch_query_passes', True) and self.opt.lambda_NCE > 0.0 and self.opt.nce_idt
+                and self.opt.lambda_GAN <= 0.0):
+            # The three NCE terms each run G's encoder on their own query batch (fake_B, idt_B, regA) with the same
+            # weights: one pass over the three stacked along the batch instead (per-sample kernels; same random
+            # draws in the same order -- only the key side draws).  Terms in the reference's order.
+            self._nce_terms = self.calculate_NCE_losses_stacked(
+                ((self.real_A, None), (self.real_B, None), (self.real_B, y_output[0])))
         self.loss_G = self.compute_G_loss()
 
         # masks (registration_model.py:160-161) are evaluated inside the fused masked-L1 kernel:
         # mask = (real_B > -0.95) | (registered > -0.95);  mask2 = (idt_B > -0.95) | (registered > -0.95)
-        self.loss_local = self.calculate_NCE_loss(self.real_B, y_output[0]) * 0.25
+        self.loss_local = (self._nce_terms[2] if self._nce_terms is not None
+                           else self.calculate_NCE_loss(self.real_B, y_output[0])) * 0.25
+        self._nce_terms = None
         self.loss_R = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold') * 1.0 \
             + self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold') * 1.0 + self.loss_local * 1.0
         self.loss_smooth = smooothing_loss(y_pred[1]) * 0.20
@@ -212,12 +222,13 @@ class REGISTRATIONModel(BaseModel):
         if self.opt.lambda_GAN > 0.0:
             raise NotImplementedError("the registration model is discriminator-free (lambda_GAN must be 0)")
         self.loss_G_GAN = 0.0
+        terms = getattr(self, '_nce_terms', None)
         if self.opt.lambda_NCE > 0.0:
-            self.loss_NCE = self.calculate_NCE_loss(self.real_A, self.fake_B)
+            self.loss_NCE = terms[0] if terms is not None else self.calculate_NCE_loss(self.real_A, self.fake_B)
         else:
             self.loss_NCE, self.loss_NCE_bd = 0.0, 0.0
         if self.opt.nce_idt and self.opt.lambda_NCE > 0.0:
-            self.loss_NCE_Y = self.calculate_NCE_loss(self.real_B, self.idt_B)
+            self.loss_NCE_Y = terms[1] if terms is not None else self.calculate_NCE_loss(self.real_B, self.idt_B)
             loss_NCE_both = (self.loss_NCE + self.loss_NCE_Y) * 0.5
         else:
             loss_NCE_both = self.loss_NCE
@@ -237,6 +248,32 @@ class REGISTRATIONModel(BaseModel):
             loss = crit(f_q, f_k)                      # [B*P], reduction='none'
             total_nce_loss += ops.mean(loss) * self.opt.lambda_NCE
         return total_nce_loss / n_layers
+
+    def calculate_NCE_losses_stacked(self, terms):
+        """calculate_NCE_loss(real_A, fake_B), (real_B, idt_B), (real_B, regA) with ONE query-side encoder pass over
+        cat(fake (= [fake_B; idt_B]), regA).  terms = ((src, tgt or None), ...): the first two targets are the halves
+        of self.fake."""
+        T = len(terms)
+        n_layers = len(self.nce_layers)
+        tgt = ops.cat_batch(self.fake, terms[2][1])
+        feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
+        pools_k, ids_t = [], []
+        with torch.no_grad():
+            for src, _ in terms:                          # the only random draws, in the reference's order
+                pool, ids = self.netF(self._encode_keys(src), self.opt.num_patches, None)
+                pools_k.append(pool)
+                ids_t.append(ids)
+        ids_stacked = [torch.stack([ids_t[t][l] for t in range(T)]) for l in range(n_layers)]
+        fq_pool, _ = self.netF(feat_q, self.opt.num_patches, ids_stacked, groups=T)
+        losses = []
+        for t in range(T):
+            total = 0.0
+            for l, crit in enumerate(self.criterionNCE):
+                f_q = fq_pool[l]
+                rows = f_q.shape[0] // T
+                total += ops.mean(crit(f_q[t * rows:(t + 1) * rows], pools_k[t][l])) * self.opt.lambda_NCE
+            losses.append(total / n_layers)
+        return losses
 
     # -- registration_model.py:255-263
     def calculate_L1_loss(self, src, tgt, mask):

@@ -254,7 +254,14 @@ int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat
 /* The same scatter into a gradient that already holds another consumer's contribution, keeping its per-plane range
  * probe valid: dfeat_amax[DFMIR_PROBE_SLOTS] (the dx_amax of dfmir_instnorm_bwd) is raised to |new value| where needed. */
 int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S,
-                                int P, float* dfeat_amax, void* stream); /* accumulates */
+                                int P, float* dfeat_amax, void* stream);
+/* Grouped forms: ids[G][P]; image b uses the ids of group b / (B / G) -- the query images of G NCE terms stacked along
+ * the batch, each sampled at its own term's positions (registration_model.py:237-253 called once per term in the
+ * reference).  bwd_g scatters (dfeat must hold zeros or another gradient); dfeat_amax optional as above. */
+int dfmir_patch_gather_fwd_g(const float* feat, const long long* ids, float* out, int B, int C, long long S, int P,
+                             int G, void* stream);
+int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
+                             int G, float* dfeat_amax, void* stream); /* accumulates */
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
 int dfmir_l2norm_fwd(const float* x, float* y, float* norm, int C, long long rows, float eps, void* stream);
 int dfmir_l2norm_bwd(const float* dy, const float* x, const float* norm, float* dx, int C,

@@ -151,11 +151,11 @@ def test_whole_step_golden(golden, O):
     call = [0]
     base_forward = model.netF.forward
 
-    def netF_forward(feats, num_patches=64, patch_ids=None):
+    def netF_forward(feats, num_patches=64, patch_ids=None, groups=1):
         if patch_ids is None:
             patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
             call[0] += 1
-        return base_forward(feats, num_patches, patch_ids)
+        return base_forward(feats, num_patches, patch_ids, groups)
 
     model.netF.forward = netF_forward
     A0, B0 = C.image_pair(93, B, size, size)
@@ -194,11 +194,11 @@ def test_key_feature_reuse_is_bit_identical(O):
         base_forward = model.netF.forward
         call = [0]
 
-        def netF_forward(feats, num_patches=64, patch_ids=None, base_forward=base_forward, call=call):
+        def netF_forward(feats, num_patches=64, patch_ids=None, groups=1, base_forward=base_forward, call=call):
             if patch_ids is None:
                 patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
                 call[0] += 1
-            return base_forward(feats, num_patches, patch_ids)
+            return base_forward(feats, num_patches, patch_ids, groups)
 
         model.netF.forward = netF_forward
         A0, B0 = C.image_pair(93, B, size, size)
@@ -226,6 +226,39 @@ def test_key_feature_reuse_is_bit_identical(O):
         assert float((a - b).norm()) <= 1e-5 * float(b.norm())
 
 
+def test_stacked_query_passes_match_sequential(O):
+    """The three NCE terms' query batches through ONE encoder pass (stacked along the batch, grouped patch ids) give
+    the losses and gradients of the reference's three passes (registration_model.py:213-253, 163)."""
+    from tests.test_oracle_golden import make_step
+    res = []
+    for stacked in (True, False):
+        st, size, B = make_step()
+        model, opt = _hip_model_from_oracle(st, size, B, 8)
+        opt.batch_query_passes = stacked
+        base_forward = model.netF.forward
+        call = [0]
+
+        def netF_forward(feats, num_patches=64, patch_ids=None, groups=1, base_forward=base_forward, call=call):
+            if patch_ids is None:
+                patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
+                call[0] += 1
+            return base_forward(feats, num_patches, patch_ids, groups)
+
+        model.netF.forward = netF_forward
+        A0, B0 = C.image_pair(93, B, size, size)
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+        _load(model.netF, st.netF)
+        model.setup(opt)
+        model.parallelize()
+        A_, B_ = C.image_pair(100, B, size, size)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        res.append(([v for v in model.get_current_losses().values()], [o_.flat_g.clone() for o_ in model.optimizers]))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm())
+
+
 def test_full_size_step_vs_oracle(O):
     """256x256, ngf=64 (BASELINE config 2 geometry at batch 1): one step of the HIP path against the
     oracle on identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""
@@ -246,11 +279,11 @@ def test_full_size_step_vs_oracle(O):
     call = [0]
     base_forward = model.netF.forward
 
-    def netF_forward(feats, num_patches=64, patch_ids=None):
+    def netF_forward(feats, num_patches=64, patch_ids=None, groups=1):
         if patch_ids is None:
             patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
             call[0] += 1
-        return base_forward(feats, num_patches, patch_ids)
+        return base_forward(feats, num_patches, patch_ids, groups)
 
     model.netF.forward = netF_forward
     model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""], "B_paths": [""]})
