@@ -157,7 +157,8 @@ class REGISTRATIONModel(BaseModel):
             self.optimizer_F.zero_grad()
 
         self._nce_terms = None
-        if (getattr(self.opt, 'batch_query_passes', True) and self.opt.lambda_NCE > 0.0 and self.opt.nce_idt
+        if (getattr(self.opt, 'batch_query_passes', True) and not os.environ.get('DFMIR_NO_STACKED_Q')
+                and self.opt.lambda_NCE > 0.0 and self.opt.nce_idt
                 and self.opt.lambda_GAN <= 0.0):
             # The three NCE terms each run G's encoder on their own query batch (fake_B, idt_B, regA) with the same
             # weights: one pass over the three stacked along the batch instead (per-sample kernels; same random
