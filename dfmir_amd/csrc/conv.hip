@@ -541,6 +541,8 @@ bool df_conv3x3_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc,
                         float* y, hipStream_t st, int* rc);
 bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                           hipStream_t st, int* rc);
+bool df_conv3x3_small_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
+                                int* rc);
 bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* w_packed,
                               const float* bias, const float* res, const float* ring, int ring_rl, float* y,
                               hipStream_t st, int* rc);
@@ -687,6 +689,7 @@ static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_a
   if (!use_generic_only()) {
     int rc = 0;
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
+    if (df_conv3x3_small_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
   }
   long long P = (long long)g->N * g->Do * g->Ho * g->Wo;

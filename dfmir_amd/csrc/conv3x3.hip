@@ -13,6 +13,7 @@
 //   wgrad's MFMA A operand is read straight out of the halo patch: one 32-row tile = 32 input
 //   channels of ONE tap, so the (tap, ci) "im2col" axis is never materialised.
 #include "conv3x3_common.h"
+#include <stdlib.h>
 
 template <int WM, int WN, int TM, int TN, int XP>
 __global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ x,
@@ -396,6 +397,141 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
   dim3 grid(nx, ny, nz);
   if (wide) conv3x3_wgrad_k<1, 4><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
   else conv3x3_wgrad_k<2, 2><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
+  hipError_t e = hipGetLastError();
+  *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
+  return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the small-channel 3x3 layers (VoxelMorph 2-D U-Net: Cin <= 48, Cout <= 32, stride 1, pad 1).
+// The generic implicit-GEMM wgrad gathers every input value once per tap from L2 and runs 32-wide tiles on 2-16
+// output channels (770 us for 34 -> 16 @256^2 x 16 images: 210 MB of tensors).  Here: v_mfma_f32_16x16x4_f32 with
+// M = (tap, ci) rows, N = output channels, K = pixels; a workgroup owns 8 x 32 pixel tiles (persistent), the input
+// patch of ALL channels (10 x 34 per channel) and the dY tile sit in LDS, wave w owns row blocks w, w+8, w+16, w+24.
+// ---------------------------------------------------------------------------------------------
+typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SW_TH = 8, SW_TW = 32, SW_PW = 36, SW_PP = (SW_TH + 2) * SW_PW, SW_DS = SW_TH * SW_TW + 1;
+constexpr int SW_CIN = 48, SW_COUT = 32;
+
+// the MFMA phase of one tile for a wave with NR row blocks: per group of 4 k-steps all operands are read first
+template <int NR, int NCT>
+__device__ __forceinline__ void sw_tile(const float* __restrict__ patch, const float* __restrict__ dyt,
+                                        const int (&aoff)[4], int l15, int lk, sw_f32x4 (&acc)[4][NCT]) {
+#pragma unroll 2
+  for (int k4 = 0; k4 < SW_TH * SW_TW / 16; ++k4) {
+    float a[4][NR], b[4][NCT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = 16 * k4 + 4 * u + lk;                     // this lane's pixel (K index) of k-step u
+      const int poff = (px >> 5) * SW_PW + (px & 31);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) b[u][c] = dyt[(c * 16 + l15) * SW_DS + px];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) a[u][r] = patch[aoff[r] + poff];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][r], b[u][c], acc[r][c], 0, 0, 0);
+  }
+}
+
+template <int NCT>   // 16-wide output-channel blocks (1: Cout <= 16, 2: Cout <= 32)
+__global__ __launch_bounds__(512, 1) void conv3x3_small_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ dwt, int N, int Cin, int Cout,
+                                                                int H, int W, int pad_mode, int tiles_x, int tiles_y) {
+  __shared__ float patch[SW_CIN * SW_PP];
+  __shared__ float dyt[16 * NCT * SW_DS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int J = 9 * Cin, nrb = (J + 15) >> 4;
+  const int nr = wid < nrb ? (nrb - wid + 7) / 8 : 0;          // row blocks of this wave (wave-uniform)
+  // A-operand offsets of this lane's row jj = rb*16 + l15 = tap*Cin + ci: patch[ci][ty][tx]
+  int aoff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int jj = (wid + 8 * r) * 16 + l15;
+    jj = jj < J ? jj : J - 1;
+    const int tap = jj / Cin, ci = jj - tap * Cin;
+    aoff[r] = ci * SW_PP + (tap / 3) * SW_PW + (tap % 3);
+  }
+  sw_f32x4 acc[4][NCT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r][c][e] = 0.f;
+  const long long HW = (long long)H * W;
+  const int ntile = N * tiles_y * tiles_x;
+  for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+    const int n = tl / (tiles_y * tiles_x), q = tl - n * tiles_y * tiles_x;
+    const int ty0 = (q / tiles_x) * SW_TH, tx0 = (q % tiles_x) * SW_TW;
+    const float* xn = x + (long long)n * Cin * HW;
+    const float* dyn = dy + (long long)n * Cout * HW;
+    __syncthreads();
+    // staging: threads 0..339 own one patch position each (halo offset decoded once, then one load per channel,
+    // eight in flight); the other 172 threads bring in the dY tile
+    constexpr int NPOS = (SW_TH + 2) * (SW_TW + 2);
+    if (tid < NPOS) {
+      const int rr = tid / (SW_TW + 2), c = tid - rr * (SW_TW + 2);
+      const int o = halo_offset(ty0 + rr - 1, tx0 + c - 1, H, W, pad_mode);
+      float* pd = patch + rr * SW_PW + c;
+      const float* src = xn + (o >= 0 ? o : 0);
+#pragma unroll 8
+      for (int ci = 0; ci < Cin; ++ci) pd[ci * SW_PP] = o >= 0 ? src[(long long)ci * HW] : 0.f;
+    } else {
+#pragma unroll 8
+      for (int i = tid - NPOS; i < 16 * NCT * SW_TH * SW_TW; i += 512 - NPOS) {
+        const int px = i & (SW_TH * SW_TW - 1), c = i >> 8;
+        const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
+        dyt[c * SW_DS + px] = (c < Cout && oy < H && ox < W) ? dyn[((long long)c * H + oy) * W + ox] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (nr == 4) sw_tile<4, NCT>(patch, dyt, aoff, l15, lk, acc);
+    else if (nr == 3) sw_tile<3, NCT>(patch, dyt, aoff, l15, lk, acc);
+    else if (nr == 2) sw_tile<2, NCT>(patch, dyt, aoff, l15, lk, acc);
+    else if (nr == 1) sw_tile<1, NCT>(patch, dyt, aoff, l15, lk, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= nr) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int jj = (wid + 8 * r) * 16 + lk * 4 + e;        // = tap*Cin + ci: the row index of dwt[tap][ci][co]
+      if (jj < J) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const int co = c * 16 + l15;
+          if (co < Cout) atomicAdd(&dwt[(long long)jj * Cout + co], acc[r][c][e]);
+        }
+      }
+    }
+  }
+}
+
+bool df_conv3x3_small_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
+                                int* rc) {
+  static const bool off = getenv("DFMIR_NO_SMALL_WGRAD") != nullptr;     // A/B switch
+  if (off) return false;
+  if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
+    return false;
+  if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
+  if (g->Cin > SW_CIN || g->Cout > SW_COUT || g->Hi < 2 || g->Wi < 2) return false;
+  const int tx = (g->Wi + SW_TW - 1) / SW_TW, ty = (g->Hi + SW_TH - 1) / SW_TH;
+  const long long ntile = (long long)g->N * tx * ty;
+  if (ntile >= (1LL << 31) || ntile < 32) return false;                  // tiny layers: the generic kernel is as good
+  const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);
+  if (g->Cout <= 16)
+    conv3x3_small_wgrad_k<1><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
+  else
+    conv3x3_small_wgrad_k<2><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;

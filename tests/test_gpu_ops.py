@@ -68,6 +68,11 @@ CONV2D = [
     # ragged everything (Cin 20, 40 of 64 couts, last tile row 14 of 16 rows, 60 of 64 columns)
     (48, 64, 3, 1, 1, True, 1, 2, 32, 64),
     (20, 40, 3, 1, 1, False, 0, 1, 30, 60),
+    # small-channel wgrad kernel (16x16x4 MFMA, all input channels' patch in LDS): ragged row blocks (34*9 = 306 rows),
+    # 2 output channels, two 16-channel column blocks with reflect padding, ragged tiles
+    (34, 16, 3, 1, 1, False, 0, 2, 64, 96),
+    (16, 2, 3, 1, 1, False, 0, 4, 40, 70),
+    (48, 32, 3, 1, 1, True, 1, 2, 64, 64),
 ]
 
 
