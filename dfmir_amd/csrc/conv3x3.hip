@@ -404,7 +404,7 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
 
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient of the small-channel 3x3 layers (VoxelMorph 2-D U-Net: Cin <= 48, Cout <= 32, stride 1, pad 1).
+// Weight gradient of the small-channel 3x3 layers (VoxelMorph 2-D U-Net: Cin <= 48, Cout <= 16, stride 1, pad 1).
 // The generic implicit-GEMM wgrad gathers every input value once per tap from L2 and runs 32-wide tiles on 2-16
 // output channels (770 us for 34 -> 16 @256^2 x 16 images: 210 MB of tensors).  Here: v_mfma_f32_16x16x4_f32 with
 // M = (tap, ci) rows, N = output channels, K = pixels; a workgroup owns 8 x 32 pixel tiles (persistent), the input
@@ -412,18 +412,19 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
 // ---------------------------------------------------------------------------------------------
 typedef float sw_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SW_TH = 8, SW_TW = 32, SW_PW = 36, SW_PP = (SW_TH + 2) * SW_PW, SW_DS = SW_TH * SW_TW + 1;
-constexpr int SW_CIN = 48, SW_COUT = 32;
+constexpr int SW_CIN = 48, SW_COUT = 16;   // (a two-column-block build for Cout <= 32 spilled 77 registers: not used)
 
 // the MFMA phase of one tile for a wave with NR row blocks: per group of 4 k-steps all operands are read first
 template <int NR, int NCT>
 __device__ __forceinline__ void sw_tile(const float* __restrict__ patch, const float* __restrict__ dyt,
                                         const int (&aoff)[4], int l15, int lk, sw_f32x4 (&acc)[4][NCT]) {
-#pragma unroll 2
-  for (int k4 = 0; k4 < SW_TH * SW_TW / 16; ++k4) {
-    float a[4][NR], b[4][NCT];
+  constexpr int KB = NCT == 1 ? 4 : 2;                        // k-steps per batch (register budget)
+#pragma unroll 1
+  for (int k4 = 0; k4 < SW_TH * SW_TW / (4 * KB); ++k4) {
+    float a[KB][NR], b[KB][NCT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int px = 16 * k4 + 4 * u + lk;                     // this lane's pixel (K index) of k-step u
+    for (int u = 0; u < KB; ++u) {
+      const int px = 4 * KB * k4 + 4 * u + lk;                 // this lane's pixel (K index) of k-step u
       const int poff = (px >> 5) * SW_PW + (px & 31);
 #pragma unroll
       for (int c = 0; c < NCT; ++c) b[u][c] = dyt[(c * 16 + l15) * SW_DS + px];
@@ -431,7 +432,7 @@ __device__ __forceinline__ void sw_tile(const float* __restrict__ patch, const f
       for (int r = 0; r < NR; ++r) a[u][r] = patch[aoff[r] + poff];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < KB; ++u)
 #pragma unroll
       for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -469,36 +470,68 @@ __global__ __launch_bounds__(512, 1) void conv3x3_small_wgrad_k(const float* __r
       for (int e = 0; e < 4; ++e) acc[r][c][e] = 0.f;
   const long long HW = (long long)H * W;
   const int ntile = N * tiles_y * tiles_x;
+  // staging through registers, one tile ahead: threads 0..339 own one patch position each (halo offset decoded once,
+  // one load per channel), the other 172 threads the dY tile; the loads of tile t+1 are in flight during the MFMAs of t
+  constexpr int NPOS = (SW_TH + 2) * (SW_TW + 2), NDY = 16 * NCT * SW_TH * SW_TW, DYT = 512 - NPOS;
+  constexpr int NPRE = (NDY + DYT - 1) / DYT > SW_CIN ? (NDY + DYT - 1) / DYT : SW_CIN;
+  float pre[NPRE];
+  const int prr = tid / (SW_TW + 2), pc = tid - prr * (SW_TW + 2);
+#define SW_FETCH(tl_)                                                                            \
+  {                                                                                              \
+    const int n_ = (tl_) / (tiles_y * tiles_x), q_ = (tl_) - n_ * tiles_y * tiles_x;             \
+    const int ty0_ = (q_ / tiles_x) * SW_TH, tx0_ = (q_ % tiles_x) * SW_TW;                      \
+    /* bounds-checked buffer loads: channel stride in the scalar offset (no per-load address registers); outside */ \
+    /* the image / past the last channel the load returns 0 */                                   \
+    if (tid < NPOS) {                                                                            \
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                      \
+          const_cast<float*>(x + (long long)n_ * Cin * HW), 0, (unsigned)(Cin * HW) * 4u, 0x00020000); \
+      const int o_ = halo_offset(ty0_ + prr - 1, tx0_ + pc - 1, H, W, pad_mode);                 \
+      const unsigned vo_ = o_ >= 0 ? (unsigned)o_ * 4u : 0x80000000u;                            \
+      _Pragma("unroll") for (int ci = 0; ci < SW_CIN; ++ci)                                      \
+        pre[ci] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_, vo_, (unsigned)(ci * (int)HW) * 4u, 0)); \
+    } else {                                                                                     \
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                      \
+          const_cast<float*>(dy + (long long)n_ * Cout * HW), 0, (unsigned)(Cout * HW) * 4u, 0x00020000); \
+      _Pragma("unroll") for (int e = 0; e < (NDY + DYT - 1) / DYT; ++e) {                        \
+        const int i_ = tid - NPOS + e * DYT;                                                     \
+        const int px_ = i_ & (SW_TH * SW_TW - 1), c_ = i_ >> 8;                                  \
+        const int oy_ = ty0_ + (px_ >> 5), ox_ = tx0_ + (px_ & 31);                              \
+        const bool ok_ = i_ < NDY && c_ < Cout && oy_ < H && ox_ < W;                            \
+        pre[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                           \
+            rs_, ok_ ? (unsigned)((c_ * H + oy_) * W + ox_) * 4u : 0x80000000u, 0, 0));          \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#define SW_STORE()                                                                               \
+  {                                                                                              \
+    if (tid < NPOS) {                                                                            \
+      float* pd_ = patch + prr * SW_PW + pc;                                                     \
+      _Pragma("unroll") for (int ci = 0; ci < SW_CIN; ++ci) if (ci < Cin) pd_[ci * SW_PP] = pre[ci]; \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int e = 0; e < (NDY + DYT - 1) / DYT; ++e) {                        \
+        const int i_ = tid - NPOS + e * DYT;                                                     \
+        if (i_ < NDY) dyt[(i_ >> 8) * SW_DS + (i_ & (SW_TH * SW_TW - 1))] = pre[e];              \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  if ((int)blockIdx.x < ntile) {
+    SW_FETCH((int)blockIdx.x)
+    SW_STORE()
+  }
+  __syncthreads();
   for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
-    const int n = tl / (tiles_y * tiles_x), q = tl - n * tiles_y * tiles_x;
-    const int ty0 = (q / tiles_x) * SW_TH, tx0 = (q % tiles_x) * SW_TW;
-    const float* xn = x + (long long)n * Cin * HW;
-    const float* dyn = dy + (long long)n * Cout * HW;
-    __syncthreads();
-    // staging: threads 0..339 own one patch position each (halo offset decoded once, then one load per channel,
-    // eight in flight); the other 172 threads bring in the dY tile
-    constexpr int NPOS = (SW_TH + 2) * (SW_TW + 2);
-    if (tid < NPOS) {
-      const int rr = tid / (SW_TW + 2), c = tid - rr * (SW_TW + 2);
-      const int o = halo_offset(ty0 + rr - 1, tx0 + c - 1, H, W, pad_mode);
-      float* pd = patch + rr * SW_PW + c;
-      const float* src = xn + (o >= 0 ? o : 0);
-#pragma unroll 8
-      for (int ci = 0; ci < Cin; ++ci) pd[ci * SW_PP] = o >= 0 ? src[(long long)ci * HW] : 0.f;
-    } else {
-#pragma unroll 8
-      for (int i = tid - NPOS; i < 16 * NCT * SW_TH * SW_TW; i += 512 - NPOS) {
-        const int px = i & (SW_TH * SW_TW - 1), c = i >> 8;
-        const int oy = ty0 + (px >> 5), ox = tx0 + (px & 31);
-        dyt[c * SW_DS + px] = (c < Cout && oy < H && ox < W) ? dyn[((long long)c * H + oy) * W + ox] : 0.f;
-      }
-    }
-    __syncthreads();
+    const bool more = tl + (int)gridDim.x < ntile;
+    if (more) SW_FETCH(tl + (int)gridDim.x)
     if (nr == 4) sw_tile<4, NCT>(patch, dyt, aoff, l15, lk, acc);
     else if (nr == 3) sw_tile<3, NCT>(patch, dyt, aoff, l15, lk, acc);
     else if (nr == 2) sw_tile<2, NCT>(patch, dyt, aoff, l15, lk, acc);
     else if (nr == 1) sw_tile<1, NCT>(patch, dyt, aoff, l15, lk, acc);
+    __syncthreads();
+    if (more) SW_STORE()
+    __syncthreads();
   }
+#undef SW_FETCH
+#undef SW_STORE
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (r >= nr) continue;
@@ -524,14 +557,12 @@ bool df_conv3x3_small_wgrad_try(const DfConvGeom* g, const float* x, const float
     return false;
   if (g->ph != 1 || g->pw != 1 || g->pd != 0 || g->Ho != g->Hi || g->Wo != g->Wi) return false;
   if (g->Cin > SW_CIN || g->Cout > SW_COUT || g->Hi < 2 || g->Wi < 2) return false;
+  if ((long long)g->Cin * g->Hi * g->Wi * 4 >= (1LL << 31) || (long long)g->Cout * g->Hi * g->Wi * 4 >= (1LL << 31)) return false;
   const int tx = (g->Wi + SW_TW - 1) / SW_TW, ty = (g->Hi + SW_TH - 1) / SW_TH;
   const long long ntile = (long long)g->N * tx * ty;
   if (ntile >= (1LL << 31) || ntile < 32) return false;                  // tiny layers: the generic kernel is as good
   const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);
-  if (g->Cout <= 16)
-    conv3x3_small_wgrad_k<1><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
-  else
-    conv3x3_small_wgrad_k<2><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
+  conv3x3_small_wgrad_k<1><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;

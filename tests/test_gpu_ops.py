@@ -69,10 +69,10 @@ CONV2D = [
     (48, 64, 3, 1, 1, True, 1, 2, 32, 64),
     (20, 40, 3, 1, 1, False, 0, 1, 30, 60),
     # small-channel wgrad kernel (16x16x4 MFMA, all input channels' patch in LDS): ragged row blocks (34*9 = 306 rows),
-    # 2 output channels, two 16-channel column blocks with reflect padding, ragged tiles
+    # 2 output channels, 48 input channels with reflect padding, ragged tiles
     (34, 16, 3, 1, 1, False, 0, 2, 64, 96),
     (16, 2, 3, 1, 1, False, 0, 4, 40, 70),
-    (48, 32, 3, 1, 1, True, 1, 2, 64, 64),
+    (48, 12, 3, 1, 1, True, 1, 2, 64, 64),
 ]
 
 
