@@ -1,8 +1,22 @@
-"""BaseModel with the reference's surface (models/base_model.py:8-258): the methods train.py /
-test.py call, in the same order and with the same side effects, minus DataParallel (replaced by
-one-process-per-GPU data parallelism, see dfmir_amd/distributed.py)."""
+"""Plugin base class: the surface `train.py` / `test.py` drive (reference
+models/base_model.py:70-258 fixes the method NAMES and their observable effects, not their bodies).
+
+What a driver may rely on:
+  construction      opt.gpu_ids / isTrain / checkpoints_dir / name  ->  self.device, self.save_dir
+  per-run           data_dependent_initialize(data) -> setup(opt) -> parallelize()
+  per-step          set_input(data) -> optimize_parameters()
+  read-outs         get_current_losses() -> {name: float} in loss_names order
+                    get_current_visuals() -> {name: tensor} in visual_names order
+                    get_image_paths(), compute_visuals()
+  persistence       save_networks(tag) / load_networks(tag): <save_dir>/<tag>_net_<X>.pth = state_dict of net<X>
+  schedule          update_learning_rate()
+  inference         eval(), test()
+
+Multi-GPU differs from the reference by design: one process per GPU (dfmir_amd.distributed), so `parallelize()`
+broadcasts rank 0's flat weight arenas instead of wrapping modules in nn.DataParallel, and `sync_gradients()`
+all-reduces each network's flat gradient arena once after backward.
+"""
 import os
-from abc import ABC, abstractmethod
 from collections import OrderedDict
 
 import torch
@@ -11,147 +25,131 @@ from . import distributed as dfdist
 from . import networks
 
 
-class BaseModel(ABC):
+class BaseModel(object):
     def __init__(self, opt):
         self.opt = opt
-        self.gpu_ids = opt.gpu_ids
         self.isTrain = opt.isTrain
-        self.device = torch.device('cuda:{}'.format(self.gpu_ids[0])) if self.gpu_ids else torch.device('cpu')
+        self.gpu_ids = opt.gpu_ids
+        self.device = torch.device('cuda', self.gpu_ids[0]) if len(self.gpu_ids) else torch.device('cpu')
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
-        self.loss_names = []
-        self.model_names = []
-        self.visual_names = []
-        self.optimizers = []
+        self.loss_names, self.model_names, self.visual_names = [], [], []
+        self.optimizers, self.schedulers = [], []
         self.image_paths = []
-        self.metric = 0
+        self.metric = 0          # what a 'plateau' schedule watches
+        self._ddp = False
 
+    # ---- hooks a plugin overrides ---------------------------------------------------------------
     @staticmethod
     def modify_commandline_options(parser, is_train):
         return parser
 
-    @abstractmethod
     def set_input(self, input):
-        pass
+        raise NotImplementedError
 
-    @abstractmethod
     def forward(self):
-        pass
+        raise NotImplementedError
 
-    @abstractmethod
     def optimize_parameters(self):
-        pass
+        raise NotImplementedError
 
+    def data_dependent_initialize(self, data):
+        return None
+
+    def compute_visuals(self):
+        return None
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _networks(self):
+        """(short name, module) for every entry of model_names."""
+        return [(n, getattr(self, 'net' + n)) for n in self.model_names if isinstance(n, str)]
+
+    def _arena_optimizers(self):
+        return [o for o in self.optimizers if hasattr(o, 'flat_p')]
+
+    def _checkpoint_path(self, tag, name, directory=None):
+        return os.path.join(directory or self.save_dir, '{}_net_{}.pth'.format(tag, name))
+
+    # ---- run set-up ---------------------------------------------------------------------------------
     def setup(self, opt):
-        """Create schedulers, optionally load networks (base_model.py:89-101)."""
+        """One LR scheduler per optimizer (training); weights from disk for inference / --continue_train."""
         if self.isTrain:
-            self.schedulers = [networks.get_scheduler(optimizer, opt) for optimizer in self.optimizers]
-        if not self.isTrain or opt.continue_train:
+            self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
+        if opt.continue_train or not self.isTrain:
             self.load_networks(opt.epoch)
         self.print_networks(opt.verbose)
 
     def parallelize(self):
-        """Reference: wrap nets in nn.DataParallel (base_model.py:103-107).  Here: when
-        torch.distributed is initialised, broadcast rank 0's weights once and switch the
-        optimisers to all-reduced, world-averaged gradients."""
+        """Called once, after data_dependent_initialize (netF exists only from then on)."""
         self._ddp = dfdist.is_distributed()
-        if self._ddp:
-            for opt_ in self.optimizers:
-                if hasattr(opt_, 'flat_p'):
-                    dfdist.broadcast_arena(opt_.flat_p, src=0)
-                    opt_.grad_scale = 1.0 / dfdist.world_size()
-            from . import ops
-            ops.bump_weights_epoch()
+        if not self._ddp:
+            return
+        for o in self._arena_optimizers():
+            dfdist.broadcast_arena(o.flat_p, src=0)
+            o.grad_scale = 1.0 / dfdist.world_size()      # the average is folded into the Adam kernel
+        from . import ops
+        ops.bump_weights_epoch()                          # packed-weight caches: rank 0's weights now
 
     def sync_gradients(self):
-        if getattr(self, '_ddp', False):
-            dfdist.allreduce_arenas([o.flat_g for o in self.optimizers if hasattr(o, 'flat_g')])
+        if self._ddp:
+            dfdist.allreduce_arenas([o.flat_g for o in self._arena_optimizers()])
 
-    def data_dependent_initialize(self, data):
-        pass
-
+    # ---- inference -----------------------------------------------------------------------------------
     def eval(self):
-        for name in self.model_names:
-            if isinstance(name, str):
-                getattr(self, 'net' + name).eval()
+        for _, net in self._networks():
+            net.eval()
 
     def test(self):
         with torch.no_grad():
             self.forward()
             self.compute_visuals()
 
-    def compute_visuals(self):
-        pass
-
     def get_image_paths(self):
         return self.image_paths
 
-    def update_learning_rate(self):
-        for scheduler in self.schedulers:
-            if self.opt.lr_policy == 'plateau':
-                scheduler.step(self.metric)
-            else:
-                scheduler.step()
-        lr = self.optimizers[0].param_groups[0]['lr']
-        print('learning rate = %.7f' % lr)
-
+    # ---- read-outs -------------------------------------------------------------------------------------
     def get_current_visuals(self):
-        visual_ret = OrderedDict()
-        for name in self.visual_names:
-            if isinstance(name, str):
-                visual_ret[name] = getattr(self, name)
-        return visual_ret
+        return OrderedDict((n, getattr(self, n)) for n in self.visual_names if isinstance(n, str))
 
     def get_current_losses(self):
-        errors_ret = OrderedDict()
-        for name in self.loss_names:
-            if isinstance(name, str):
-                v = getattr(self, 'loss_' + name)
-                errors_ret[name] = float(v.detach()) if torch.is_tensor(v) else float(v)
-        return errors_ret
+        """float() of every loss_<name> (a device->host sync, as in the reference)."""
+        out = OrderedDict()
+        for n in self.loss_names:
+            if isinstance(n, str):
+                v = getattr(self, 'loss_' + n)
+                out[n] = float(v.detach()) if torch.is_tensor(v) else float(v)
+        return out
 
+    def update_learning_rate(self):
+        plateau = self.opt.lr_policy == 'plateau'
+        for s in self.schedulers:
+            s.step(self.metric) if plateau else s.step()
+        print('learning rate = %.7f' % self.optimizers[0].param_groups[0]['lr'])
+
+    # ---- persistence -------------------------------------------------------------------------------------
     def save_networks(self, epoch):
-        """<save_dir>/<epoch>_net_<name>.pth = plain state_dict (base_model.py:164-180)."""
+        """Plain state_dicts on the host, key names as the reference's modules produce them (row N2)."""
         os.makedirs(self.save_dir, exist_ok=True)
-        for name in self.model_names:
-            if isinstance(name, str):
-                save_path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
-                net = getattr(self, 'net' + name)
-                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, save_path)
+        for name, net in self._networks():
+            host = OrderedDict((k, v.detach().to('cpu')) for k, v in net.state_dict().items())
+            torch.save(host, self._checkpoint_path(epoch, name))
 
     def load_networks(self, epoch):
-        for name in self.model_names:
-            if isinstance(name, str):
-                load_filename = '%s_net_%s.pth' % (epoch, name)
-                if self.opt.isTrain and getattr(self.opt, 'pretrained_name', None) is not None:
-                    load_dir = os.path.join(self.opt.checkpoints_dir, self.opt.pretrained_name)
-                else:
-                    load_dir = self.save_dir
-                load_path = os.path.join(load_dir, load_filename)
-                net = getattr(self, 'net' + name)
-                print('loading the model from %s' % load_path)
-                state_dict = torch.load(load_path, map_location=str(self.device))
-                if hasattr(state_dict, '_metadata'):
-                    del state_dict._metadata
-                net.load_state_dict(state_dict)
+        pretrained = getattr(self.opt, 'pretrained_name', None) if self.opt.isTrain else None
+        directory = os.path.join(self.opt.checkpoints_dir, pretrained) if pretrained is not None else self.save_dir
+        for name, net in self._networks():
+            path = self._checkpoint_path(epoch, name, directory)
+            print('loading the model from %s' % path)
+            state = torch.load(path, map_location=str(self.device))
+            state = OrderedDict(state.items())            # drops a pickled _metadata attribute, if any
+            net.load_state_dict(state)
+        from . import ops
+        ops.bump_weights_epoch()
 
     def print_networks(self, verbose):
         print('---------- Networks initialized -------------')
-        for name in self.model_names:
-            if isinstance(name, str):
-                net = getattr(self, 'net' + name)
-                num_params = sum(p.numel() for p in net.parameters())
-                if verbose:
-                    print(net)
-                print('[Network %s] Total number of parameters : %.3f M' % (name, num_params / 1e6))
+        for name, net in self._networks():
+            if verbose:
+                print(net)
+            count = sum(p.numel() for p in net.parameters())
+            print('[Network %s] Total number of parameters : %.3f M' % (name, count / 1e6))
         print('-----------------------------------------------')
-
-    def set_requires_grad(self, nets, requires_grad=False):
-        if not isinstance(nets, list):
-            nets = [nets]
-        for net in nets:
-            if net is not None:
-                for param in net.parameters():
-                    param.requires_grad = requires_grad
-
-    def generate_visuals_for_evaluation(self, data, mode):
-        return {}

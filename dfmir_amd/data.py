@@ -5,8 +5,10 @@ Mirrors the semantics of the reference's `data/unaligned_dataset.py:20-87` + `da
 (`--preprocess resize_and_crop`, grayscale): folders `<dataroot>/<phase>A`, `<phase>B`; sorted paths;
 B index = A index modulo |B|; joint random left-right flip of the pair in training; then per image
 Grayscale -> bicubic Resize(load_size) -> RandomCrop(crop_size) -> round to a multiple of 4 ->
-RandomHorizontalFlip (unless --no_flip) -> ToTensor -> Normalize(0.5, 0.5).  PIL + numpy only
-(the reference needs torchvision for the same PIL calls).
+RandomHorizontalFlip (unless --no_flip) -> ToTensor -> Normalize(0.5, 0.5).  PIL + numpy only; the two
+torchvision random transforms draw from the torch RNG in torchvision's order, the pair flip from `random`
+(data/unaligned_dataset.py:73-76).  Pinned by tests/golden/dataset.npz = the reference's own dataset class run
+over seeded image folders.
 """
 import os
 import random
@@ -45,14 +47,15 @@ def slice_transform(img, opt, load_size=None):
         cs = opt.crop_size
         if w < cs or h < cs:
             raise ValueError("crop_size %d larger than the %dx%d image" % (cs, w, h))
-        x = random.randint(0, w - cs)
-        y = random.randint(0, h - cs)
-        img = img.crop((x, y, x + cs, y + cs))
+        if (w, h) != (cs, cs):      # torchvision RandomCrop: top row, then left column, from the torch RNG
+            y = int(torch.randint(0, h - cs + 1, size=(1,)).item())
+            x = int(torch.randint(0, w - cs + 1, size=(1,)).item())
+            img = img.crop((x, y, x + cs, y + cs))
     ow, oh = img.size
     h4, w4 = int(round(oh / 4) * 4), int(round(ow / 4) * 4)
     if (h4, w4) != (oh, ow):
         img = img.resize((w4, h4), Image.BICUBIC)
-    if not getattr(opt, 'no_flip', False) and random.random() < 0.5:
+    if not getattr(opt, 'no_flip', False) and float(torch.rand(1)) < 0.5:   # torchvision RandomHorizontalFlip
         img = img.transpose(Image.FLIP_LEFT_RIGHT)
     a = np.asarray(img, dtype=np.float32) / 255.0
     return ((torch.from_numpy(a)[None] - 0.5) / 0.5).contiguous()

@@ -422,10 +422,10 @@ class PatchSampleF(nn.Module):
         init_net(self, self.init_type, self.init_gain, self.gpu_ids)
         self.mlp_init = True
 
-    def forward(self, feats, num_patches=64, patch_ids=None, groups=1):
-        """groups > 1 (build-defined): `feats` stack the query images of `groups` NCE terms along the batch and
-        patch_ids[i] is [groups, P] -- each third of the batch is sampled at its own term's positions; the MLP then
-        runs once over all rows."""
+    def forward(self, feats, num_patches=64, patch_ids=None):
+        """Reference signature (models/networks.py:602).  Build-defined extension carried by the ids themselves: a
+        2-D patch_ids[i] of shape [G, P] means `feats` stack the query images of G NCE terms along the batch and each
+        G-th of the batch is sampled at its own row of positions; the MLP then runs once over all rows."""
         return_ids, return_feats = [], []
         if self.use_mlp and not self.mlp_init:
             self.create_mlp(feats)
@@ -438,6 +438,7 @@ class PatchSampleF(nn.Module):
             else:
                 patch_id = torch.randperm(S, device=feats[0].device)
                 patch_id = patch_id[:int(min(num_patches, patch_id.shape[0]))]
+            groups = patch_id.shape[0] if patch_id.dim() == 2 else 1
             x = ops.patch_gather(feat, patch_id, groups)      # [C, B*P]
             if self.use_mlp:
                 mlp = getattr(self, 'mlp_%d' % feat_id)

@@ -262,6 +262,11 @@ class deferred_weight_grads:
         pending, _DEFER["pending"] = _DEFER["pending"], {}
         if exc[0] is None and pending:
             _flush_deferred(list(pending.values()))
+        elif pending:
+            # backward raised: the accumulators hold partial sums that only the flush kernel would clear; a caller
+            # that catches the error and goes on (skip-batch / OOM-retry loops) must not inherit them
+            for _, buf, _ in pending.values():
+                buf.zero_()
         return False
 
 

@@ -17,7 +17,8 @@ def default_options(**overrides):
         # registration_model.py (CUT defaults)
         CUT_mode='CUT', lambda_GAN=0.0, lambda_NCE=0.25, nce_idt=True, nce_layers='0,4,8,12,16',
         nce_includes_all_negatives_from_minibatch=False, netF='mlp_sample', netF_nc=256, nce_T=0.07,
-        num_patches=256, flip_equivariance=False, dvf_image=None,
+        num_patches=256, flip_equivariance=False,
+        dvf_image='synthetic',     # build-defined: None = ./deform256.jpg as in the reference (raises when absent)
         reuse_key_features=True,   # build-defined: tap NCE key features in forward() (exact, see registration_model.forward)
         batch_query_passes=True)   # build-defined: one encoder pass for the three NCE terms' query batches
     for k, v in overrides.items():

@@ -128,16 +128,31 @@ class REGISTRATIONModel(BaseModel):
                 self.optimizer_F = FlatAdam(self.netF.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, self.opt.beta2))
                 self.optimizers.append(self.optimizer_F)
 
+    def set_dvf_image(self, img):
+        """Install the test pattern `dvf` warps: a [1,C,H,W] tensor in [-1,1] at the model's crop size."""
+        if img.dim() != 4 or img.shape[0] != 1 or tuple(img.shape[2:]) != (self.opt.crop_size,) * 2:
+            raise ValueError("dvf image must be [1,C,%d,%d], got %s" % (self.opt.crop_size, self.opt.crop_size, tuple(img.shape)))
+        self._dvf_image = img.to(self.device, torch.float32).contiguous()
+
     def _checkerboard(self, batch):
-        """The visual-only test pattern warped into `dvf` (registration_model.py:148-149)."""
+        """The visual-only test pattern warped into `dvf` (registration_model.py:148-149): `./deform256.jpg` decoded
+        with CenterCrop(256) like the reference (for crop_size < 256: its top-left crop_size window), once.  A missing
+        file raises, as the reference does; `opt.dvf_image = 'synthetic'` asks for a generated checkerboard instead
+        (benchmarks / tests on a box without the asset), any other string is a path."""
         if self._dvf_image is None:
             size = self.opt.crop_size
-            path = getattr(self.opt, 'dvf_image', None) or "./deform256.jpg"
-            if os.path.exists(path) and size <= 256:
-                img = open_image_to_torch(path, size)
-            else:
+            choice = getattr(self.opt, 'dvf_image', None)
+            if choice == 'synthetic':
                 img = synthetic_checkerboard(size)
-            self._dvf_image = img.to(self.device)
+            else:
+                path = choice or "./deform256.jpg"
+                if not os.path.exists(path):
+                    raise FileNotFoundError("%s (the dvf test pattern, reference registration_model.py:148); "
+                                            "set opt.dvf_image to a path or to 'synthetic'" % path)
+                if size > 256:
+                    raise ValueError("the dvf test pattern is 256x256; crop_size %d needs opt.dvf_image='synthetic'" % size)
+                img = open_image_to_torch(path, 256)[:, :, :size, :size]
+            self.set_dvf_image(img)
         return self._dvf_image.expand(batch, -1, -1, -1).contiguous()
 
     # -- registration_model.py:138-171
@@ -265,7 +280,7 @@ class REGISTRATIONModel(BaseModel):
                 pools_k.append(pool)
                 ids_t.append(ids)
         ids_stacked = [torch.stack([ids_t[t][l] for t in range(T)]) for l in range(n_layers)]
-        fq_pool, _ = self.netF(feat_q, self.opt.num_patches, ids_stacked, groups=T)
+        fq_pool, _ = self.netF(feat_q, self.opt.num_patches, ids_stacked)   # [T,P] ids: grouped sampling
         losses = []
         for t in range(T):
             total = 0.0

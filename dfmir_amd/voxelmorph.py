@@ -1,12 +1,10 @@
 """Host-side mirror of the reference's VoxelMorph pieces on the hot path
 (models/voxelmorph/torchvoxelmorph/layers.py:6-97, networks.py:9-106, 1028-1165, 1506-1521,
-modelio.py:7-76): SpatialTransformer, VecInt, ResizeTransform, ConvBlock, Unet, VxmDense.
+modelio.py:7-35): SpatialTransformer, VecInt, ResizeTransform, ConvBlock, Unet, VxmDense.
 
 Same constructor signatures, forward semantics and state_dict keys; compute = libdfmir_hip.so.
 2-D and 3-D share every kernel (a 2-D tensor is the D == 1 case).
 """
-import inspect
-
 import torch
 import torch.nn as nn
 from torch.distributions.normal import Normal
@@ -68,48 +66,8 @@ class ResizeTransform(nn.Module):
         return ops.resize_linear(x, out_sp, self.factor * extra_mult)
 
 
-def store_config_args(func):
-    """modelio.py:7-35 (getargspec replaced by getfullargspec)."""
-    spec = inspect.getfullargspec(func)
-    attrs, defaults = spec.args, spec.defaults
-
-    def wrapper(self, *args, **kwargs):
-        self.config = {}
-        if defaults:
-            for attr, val in zip(reversed(attrs), reversed(defaults)):
-                self.config[attr] = val
-        for attr, val in zip(attrs[1:], args):
-            self.config[attr] = val
-        for attr, val in kwargs.items():
-            self.config[attr] = val
-        return func(self, *args, **kwargs)
-    wrapper.__wrapped__ = func
-    return wrapper
-
-
-class LoadableModel(nn.Module):
-    """modelio.py:38-76."""
-
-    def __init__(self, *args, **kwargs):
-        if not hasattr(self, 'config'):
-            raise RuntimeError('models that inherit from LoadableModel must decorate the constructor with @store_config_args')
-        super().__init__(*args, **kwargs)
-
-    def save(self, path):
-        sd = self.state_dict().copy()
-        for key in [k for k in sd.keys() if k.endswith('.grid')]:
-            sd.pop(key)
-        torch.save({'config': self.config, 'model_state': sd}, path)
-
-    @classmethod
-    def load(cls, path, device):
-        checkpoint = torch.load(path, map_location=torch.device(device))
-        model = cls(**checkpoint['config'])
-        model.load_state_dict(checkpoint['model_state'], strict=False)
-        return model
-
-
 def default_unet_features():
+    """Encoder / decoder widths of the stock VoxelMorph U-Net (networks.py:9-14)."""
     return [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
 
 
@@ -118,45 +76,52 @@ class ConvBlock(nn.Module):
 
     def __init__(self, ndims, in_channels, out_channels, stride=1):
         super().__init__()
-        Conv = {2: Conv2d, 3: Conv3d}[ndims]
-        self.main = Conv(in_channels, out_channels, 3, stride, 1)
+        self.main = (Conv2d, Conv3d)[ndims - 2](in_channels, out_channels, 3, stride, 1)
         self.activation = nn.LeakyReLU(0.2)  # parameter-free marker; fused into the conv epilogue
 
     def forward(self, x):
         return self.main(x, act=1, slope=0.2)
 
 
+def unet_channel_plan(enc_nf, dec_nf, in_channels=2):
+    """(cin, cout) of every conv of the U-Net, grouped as the state_dict groups them (networks.py:60-86):
+    `downarm` = one stride-2 conv per encoder width; `uparm` = the first len(enc) decoder widths, each but the first
+    fed with the previous decoder output concatenated with the mirrored encoder level; `extras` = the remaining
+    decoder widths at full resolution, the first of which also sees the `in_channels` input planes."""
+    down, c = [], in_channels
+    for nf in enc_nf:
+        down.append((c, nf))
+        c = nf
+    skips = enc_nf[::-1]                   # deepest level first; level i of the decoder meets skips[i]
+    up = []
+    for i, nf in enumerate(dec_nf[:len(enc_nf)]):
+        up.append((c + (skips[i] if i else 0), nf))
+        c = nf
+    extras, c = [], c + in_channels
+    for nf in dec_nf[len(enc_nf):]:
+        extras.append((c, nf))
+        c = nf
+    return down, up, extras
+
+
 class Unet(nn.Module):
-    """networks.py:16-106."""
+    """networks.py:16-106 for explicit feature lists (the only form the path passes)."""
 
     def __init__(self, inshape, nb_features=None, nb_levels=None, feat_mult=1):
         super().__init__()
-        ndims = len(inshape)
-        assert ndims in [2, 3], 'ndims should be 2 or 3 on this path. found: %d' % ndims
-        if nb_features is None:
-            nb_features = default_unet_features()
+        nd = len(inshape)
+        if nd not in (2, 3):
+            raise ValueError('ndims should be 2 or 3 on this path. found: %d' % nd)
         if isinstance(nb_features, int):
             raise NotImplementedError("integer nb_features is not on the path (lists are always passed)")
         if nb_levels is not None:
             raise ValueError('cannot use nb_levels if nb_features is not an integer')
-        self.enc_nf, self.dec_nf = nb_features
+        self.enc_nf, self.dec_nf = default_unet_features() if nb_features is None else nb_features
+        down, up, extras = unet_channel_plan(list(self.enc_nf), list(self.dec_nf))
         self.upsample = nn.Upsample(scale_factor=2, mode='nearest')  # marker; fused with the concat
-        prev_nf = 2
-        self.downarm = nn.ModuleList()
-        for nf in self.enc_nf:
-            self.downarm.append(ConvBlock(ndims, prev_nf, nf, stride=2))
-            prev_nf = nf
-        enc_history = list(reversed(self.enc_nf))
-        self.uparm = nn.ModuleList()
-        for i, nf in enumerate(self.dec_nf[:len(self.enc_nf)]):
-            channels = prev_nf + enc_history[i] if i > 0 else prev_nf
-            self.uparm.append(ConvBlock(ndims, channels, nf, stride=1))
-            prev_nf = nf
-        prev_nf += 2
-        self.extras = nn.ModuleList()
-        for nf in self.dec_nf[len(self.enc_nf):]:
-            self.extras.append(ConvBlock(ndims, prev_nf, nf, stride=1))
-            prev_nf = nf
+        self.downarm = nn.ModuleList(ConvBlock(nd, ci, co, stride=2) for ci, co in down)
+        self.uparm = nn.ModuleList(ConvBlock(nd, ci, co) for ci, co in up)
+        self.extras = nn.ModuleList(ConvBlock(nd, ci, co) for ci, co in extras)
 
     def forward(self, x):
         x_enc = [x]
@@ -171,31 +136,33 @@ class Unet(nn.Module):
         return x
 
 
-class VxmDense(LoadableModel):
+class VxmDense(nn.Module):
     """networks.py:1028-1145 (this fork returns the INTEGRATED full-resolution pos_flow when
-    bidir=True, networks.py:1143)."""
+    bidir=True, networks.py:1143).  `config` holds the constructor arguments, as the reference's
+    LoadableModel decorator records them (modelio.py:7-35)."""
 
-    @store_config_args
     def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1, int_steps=7,
                  int_downsize=2, bidir=False, use_probs=False):
         super().__init__()
-        self.training = True
-        ndims = len(inshape)
-        assert ndims in [2, 3], 'ndims should be 2 or 3 on this path. found: %d' % ndims
-        self.unet_model = Unet(inshape, nb_features=nb_unet_features, nb_levels=nb_unet_levels,
-                               feat_mult=unet_feat_mult)
-        Conv = {2: Conv2d, 3: Conv3d}[ndims]
-        self.flow = Conv(self.unet_model.dec_nf[-1], ndims, 3, padding=1)
-        self.flow.weight = nn.Parameter(Normal(0, 1e-5).sample(self.flow.weight.shape))
-        self.flow.bias = nn.Parameter(torch.zeros(self.flow.bias.shape))
+        self.config = dict(inshape=inshape, nb_unet_features=nb_unet_features, nb_unet_levels=nb_unet_levels,
+                           unet_feat_mult=unet_feat_mult, int_steps=int_steps, int_downsize=int_downsize,
+                           bidir=bidir, use_probs=use_probs)
         if use_probs:
             raise NotImplementedError('Flow variance has not been implemented in pytorch - set use_probs to False')
-        resize = int_steps > 0 and int_downsize > 1
-        self.resize = ResizeTransform(int_downsize, ndims) if resize else None
-        self.fullsize = ResizeTransform(1 / int_downsize, ndims) if resize else None
+        nd = len(inshape)
+        self.training = True
         self.bidir = bidir
-        down_shape = [int(dim / int_downsize) for dim in inshape]
-        self.integrate = VecInt(down_shape, int_steps) if int_steps > 0 else None
+        self.unet_model = Unet(inshape, nb_unet_features, nb_unet_levels, unet_feat_mult)
+        # flow head: N(0, 1e-5) weights, zero bias (networks.py:1077-1081)
+        self.flow = (Conv2d, Conv3d)[nd - 2](self.unet_model.dec_nf[-1], nd, 3, padding=1)
+        with torch.no_grad():
+            self.flow.weight.copy_(Normal(0, 1e-5).sample(self.flow.weight.shape))
+            self.flow.bias.zero_()
+        # integration happens at 1/int_downsize resolution
+        half = int_steps > 0 and int_downsize > 1
+        self.resize = ResizeTransform(int_downsize, nd) if half else None
+        self.fullsize = ResizeTransform(1 / int_downsize, nd) if half else None
+        self.integrate = VecInt([int(d / int_downsize) for d in inshape], int_steps) if int_steps > 0 else None
         self.transformer = SpatialTransformer(inshape)
 
     def forward(self, source, target, registration=False):

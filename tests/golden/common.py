@@ -51,3 +51,19 @@ def state_checksum(module):
 
 def multi_state_checksum(modules):
     return hashlib.sha256("".join(state_checksum(m) for m in modules).encode()).hexdigest()
+
+
+def write_slice_folders(root):
+    """Seeded synthetic image folders <root>/trainA (3 RGB PNGs, 40x36) and <root>/trainB (2 grayscale PNGs, 33x47)
+    for the data-pipeline fixture (row N3); PNG is lossless, so generator and test see the same pixels."""
+    import os
+    from PIL import Image
+    rs = np.random.RandomState(77)
+    for sub, n, shape in (("trainA", 3, (36, 40, 3)), ("trainB", 2, (47, 33))):
+        d = os.path.join(root, sub)
+        os.makedirs(d, exist_ok=True)
+        for i in range(n):
+            base = rs.randint(0, 256, size=(6, 5) + shape[2:]).astype(np.uint8)
+            img = Image.fromarray(base).resize((shape[1], shape[0]), Image.BILINEAR)   # smooth content
+            arr = np.asarray(img).astype(np.int32) + rs.randint(-20, 21, size=shape)
+            Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8)).save(os.path.join(d, "%s_%02d.png" % (sub, i)))

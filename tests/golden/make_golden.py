@@ -65,9 +65,57 @@ def install_shims():
         def __init__(self, *a, **k):
             pass
 
+    # The transforms data/base_dataset.py:82-131 composes, with torchvision's documented semantics on PIL images
+    # (torchvision itself is not installed): Grayscale = convert('L'); Resize((h, w), method) = PIL resize;
+    # RandomCrop draws the top row then the left column with torch.randint (none when the sizes already match);
+    # RandomHorizontalFlip flips when torch.rand(1) < p.
+    class Grayscale(object):
+        def __init__(self, num_output_channels=1):
+            assert num_output_channels == 1
+
+        def __call__(self, im):
+            return im.convert('L')
+
+    class Resize(object):
+        def __init__(self, size, interpolation=2):
+            self.size, self.method = size, interpolation
+
+        def __call__(self, im):
+            h, w = self.size
+            return im.resize((w, h), self.method)
+
+    class RandomCrop(object):
+        def __init__(self, size):
+            self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+        def __call__(self, im):
+            w, h = im.size
+            th, tw = self.size
+            if (w, h) == (tw, th):
+                return im
+            i = int(torch.randint(0, h - th + 1, size=(1,)).item())
+            j = int(torch.randint(0, w - tw + 1, size=(1,)).item())
+            return im.crop((j, i, j + tw, i + th))
+
+    class RandomHorizontalFlip(object):
+        def __init__(self, p=0.5):
+            self.p = p
+
+        def __call__(self, im):
+            from PIL import Image
+            return im.transpose(Image.FLIP_LEFT_RIGHT) if float(torch.rand(1)) < self.p else im
+
+    class Lambda(object):
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, im):
+            return self.fn(im)
+
     tr.Compose, tr.CenterCrop, tr.ToTensor, tr.Normalize = Compose, CenterCrop, ToTensor, Normalize
-    for n in ("Resize", "RandomCrop", "RandomHorizontalFlip", "Lambda", "Grayscale", "InterpolationMode"):
-        setattr(tr, n, _Named)
+    tr.Grayscale, tr.Resize, tr.RandomCrop, tr.RandomHorizontalFlip, tr.Lambda = \
+        Grayscale, Resize, RandomCrop, RandomHorizontalFlip, Lambda
+    tr.InterpolationMode = _Named
     tv.transforms = tr
     tv.models = types.ModuleType("torchvision.models")
     tv.utils = types.ModuleType("torchvision.utils")
@@ -331,12 +379,36 @@ def main():
         out["losses_%d" % it] = np.array([ls[k] for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y")], dtype=np.float64)
         if it == 0:
             out.update(fake_B=npy(model.fake_B), registered=npy(model.registered), regA=npy(model.regA),
-                       idt_B=npy(model.idt_B))
+                       idt_B=npy(model.idt_B),
+                       # row A12: the decoded test pattern the reference warped (input) and the visual it produced
+                       dvf_image=npy(RM.open_image_to_torch("./deform256.jpg", 256)[:1]), dvf=npy(model.dvf))
             for nm, net in (("G", model.netG), ("F", model.netF), ("R", model.netR)):
                 g2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters() if p.grad is not None)
                 out["gradnorm_" + nm] = np.array(g2 ** 0.5)
     save("step.npz", **out)
     RM.open_image_to_torch = orig_open
+
+    # ---- N3: the reference's own UnalignedDataset + get_transform (data/unaligned_dataset.py:20-87,
+    # data/base_dataset.py:82-131) over seeded synthetic image folders (C.write_slice_folders)
+    import random
+    from data.unaligned_dataset import UnalignedDataset as RefDataset
+    out = {}
+    for tag, flip in (("flip", False), ("noflip", True)):
+        root = tempfile.mkdtemp(prefix="dfmir_data_")
+        C.write_slice_folders(root)
+        dopt = ref_options(24, 1, 8)
+        dopt.dataroot, dopt.phase, dopt.load_size, dopt.crop_size = root, "train", 30, 24
+        dopt.preprocess, dopt.no_flip, dopt.serial_batches, dopt.max_dataset_size = "resize_and_crop", flip, False, float("inf")
+        ds = RefDataset(dopt)
+        out["len_" + tag] = np.array(len(ds))
+        for idx in range(4):
+            random.seed(500 + idx)
+            torch.manual_seed(700 + idx)
+            item = ds[idx]
+            out["A_%s_%d" % (tag, idx)] = npy(item["A"])
+            out["B_%s_%d" % (tag, idx)] = npy(item["B"])
+            out["names_%s_%d" % (tag, idx)] = np.array(os.path.basename(item["A_paths"]) + "|" + os.path.basename(item["B_paths"]))
+    save("dataset.npz", **out)
 
 
 if __name__ == "__main__":

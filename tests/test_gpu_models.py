@@ -151,13 +151,14 @@ def test_whole_step_golden(golden, O):
     call = [0]
     base_forward = model.netF.forward
 
-    def netF_forward(feats, num_patches=64, patch_ids=None, groups=1):
+    def netF_forward(feats, num_patches=64, patch_ids=None):
         if patch_ids is None:
             patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
             call[0] += 1
-        return base_forward(feats, num_patches, patch_ids, groups)
+        return base_forward(feats, num_patches, patch_ids)
 
     model.netF.forward = netF_forward
+    model.set_dvf_image(torch.from_numpy(g["dvf_image"]))     # the decoded ./deform256.jpg window the reference warped
     A0, B0 = C.image_pair(93, B, size, size)
     model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
     _load(model.netF, st.netF)
@@ -173,6 +174,7 @@ def test_whole_step_golden(golden, O):
         if it == 0:
             close(model.fake_B, g["fake_B"], what="fake_B"); close(model.registered, g["registered"], what="registered")
             close(model.regA, g["regA"], what="regA"); close(model.idt_B, g["idt_B"], what="idt_B")
+            close(model.dvf, g["dvf"], what="dvf")                # row A12, against the reference's own visual
             for nm, o_ in (("G", model.optimizer_G), ("F", model.optimizer_F), ("R", model.optimizer_R)):
                 n2 = float(o_.flat_g.double().pow(2).sum().sqrt())
                 ref = float(g["gradnorm_" + nm])
@@ -194,11 +196,11 @@ def test_key_feature_reuse_is_bit_identical(O):
         base_forward = model.netF.forward
         call = [0]
 
-        def netF_forward(feats, num_patches=64, patch_ids=None, groups=1, base_forward=base_forward, call=call):
+        def netF_forward(feats, num_patches=64, patch_ids=None, base_forward=base_forward, call=call):
             if patch_ids is None:
                 patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
                 call[0] += 1
-            return base_forward(feats, num_patches, patch_ids, groups)
+            return base_forward(feats, num_patches, patch_ids)
 
         model.netF.forward = netF_forward
         A0, B0 = C.image_pair(93, B, size, size)
@@ -238,11 +240,11 @@ def test_stacked_query_passes_match_sequential(O):
         base_forward = model.netF.forward
         call = [0]
 
-        def netF_forward(feats, num_patches=64, patch_ids=None, groups=1, base_forward=base_forward, call=call):
+        def netF_forward(feats, num_patches=64, patch_ids=None, base_forward=base_forward, call=call):
             if patch_ids is None:
                 patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
                 call[0] += 1
-            return base_forward(feats, num_patches, patch_ids, groups)
+            return base_forward(feats, num_patches, patch_ids)
 
         model.netF.forward = netF_forward
         A0, B0 = C.image_pair(93, B, size, size)
@@ -279,11 +281,11 @@ def test_full_size_step_vs_oracle(O):
     call = [0]
     base_forward = model.netF.forward
 
-    def netF_forward(feats, num_patches=64, patch_ids=None, groups=1):
+    def netF_forward(feats, num_patches=64, patch_ids=None):
         if patch_ids is None:
             patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
             call[0] += 1
-        return base_forward(feats, num_patches, patch_ids, groups)
+        return base_forward(feats, num_patches, patch_ids)
 
     model.netF.forward = netF_forward
     model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""], "B_paths": [""]})

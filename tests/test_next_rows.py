@@ -46,6 +46,32 @@ def test_dataset_pipeline(tmp_path):
     assert slice_transform(img, o3).shape == (1, 72, 72)
 
 
+def test_dataset_pipeline_vs_reference_fixture(tmp_path, golden):
+    """Row N3 against the REFERENCE's own UnalignedDataset + get_transform (tests/golden/make_golden.py ran them over
+    the same seeded PNG folders): same files paired, same pixels after grayscale / bicubic resize / random crop /
+    x4 rounding / flips / normalisation -- bit for bit (both sides are the same PIL calls, drawn from the same RNGs)."""
+    import random
+    from tests.golden import common as C
+    from dfmir_amd.data import UnalignedDataset
+    g = golden("dataset.npz")
+    root = str(tmp_path)
+    C.write_slice_folders(root)
+    for tag, no_flip in (("flip", False), ("noflip", True)):
+        opt = default_options(dataroot=root, phase="train", batch_size=1, load_size=30, crop_size=24, no_flip=no_flip,
+                              serial_batches=False, num_threads=0, max_dataset_size=float("inf"),
+                              preprocess="resize_and_crop")
+        ds = UnalignedDataset(opt)
+        assert len(ds) == int(g["len_" + tag])
+        for idx in range(4):
+            random.seed(500 + idx)
+            torch.manual_seed(700 + idx)
+            item = ds[idx]
+            names = os.path.basename(item["A_paths"]) + "|" + os.path.basename(item["B_paths"])
+            assert names == str(g["names_%s_%d" % (tag, idx)])
+            assert np.array_equal(item["A"].numpy(), g["A_%s_%d" % (tag, idx)]), (tag, idx, "A")
+            assert np.array_equal(item["B"].numpy(), g["B_%s_%d" % (tag, idx)]), (tag, idx, "B")
+
+
 def test_visualizer_log_format(tmp_path):
     from collections import OrderedDict
     from dfmir_amd.visualizer import Visualizer
