@@ -6,10 +6,16 @@
 A "step" = REGISTRATIONModel.set_input + optimize_parameters (reference train.py:46-47): forward,
 backward and Adam of G/F/R on one batch of synthetic pairs already resident in HBM.  Workload at
 every N: BASELINE.json configs[1] geometry -- 2-D 256x256, batch 16 PER GPU, ngf 64, fp32 (weak
-scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with `roofline`
-(dominant kernel = the 128x128-tile fp32-MFMA 3x3 implicit-GEMM conv, timed live with HIP events on
-its launch stream) and, at N = 1, `cpu_baseline` (the CPU oracle = a port of the reference's
-PyTorch-CPU path, timed on the host cores on a bounded sample).
+scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with
+  `roofline`      dominant kernel = conv3x3_split_cs_k (3x3 forward/dgrad convs, fp32 operands split into scaled
+                  fp16 pairs, 3 products per MAC on v_mfma_f32_32x32x16_f16), timed live with HIP events on its
+                  launch stream; achieved = ISSUED 16-bit matrix FLOP/s (3 x algorithmic), peak = 2.5 PFLOP/s dense
+                  fp16, frac <= 1; the algorithmic fp32 rate is reported beside it
+  `roofline_hbm`  the trilinear warp (grid_sample) forward / backward at 160x192x224, algorithmic bytes / HIP-event time
+                  against 8 TB/s, measured in the same process
+  `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (conv3d_mfma16_k, fp32 MFMA)
+  `cpu_baseline`  (N = 1) the CPU oracle = a port of the reference's PyTorch-CPU path, timed on the host cores on a
+                  bounded sample.
 """
 import argparse
 import json
@@ -24,6 +30,9 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16), 2.4 GHz
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E
+CS_TRAFFIC_BYTES = 480.5e6      # FETCH_SIZE 346.3 MB + WRITE_SIZE 134.2 MB (profiles/r01_conv3x3s_pmc.md)
 
 
 def synth_pairs(B, H, W, device, seed):
@@ -42,13 +51,20 @@ def synth_pairs(B, H, W, device, seed):
 class KernelTimer(object):
     """Brackets selected kernel launches with HIP events on the launch (= torch current) stream."""
 
-    def __init__(self, kinds):
+    def __init__(self, kinds, every=1):
         self.kinds = set(kinds)
         self.records = {}
         self.enabled = False
+        self.every = every          # bracket every n-th launch of a kind (keeps the events out of the step's way)
+        self.seen = {}
 
     def __call__(self, kind, flops, launch):
         if not self.enabled or kind not in self.kinds:
+            launch()
+            return
+        n = self.seen.get(kind, 0)
+        self.seen[kind] = n + 1
+        if n % self.every:
             launch()
             return
         s = torch.cuda.Event(enable_timing=True)
@@ -122,27 +138,103 @@ def cpu_baseline(size, max_steps=3):
 
 def bench_3d(dev, steps=5, warmup=2):
     """Auxiliary line: the 3-D step of BASELINE configs[4] geometry on ONE GPU -- 160x192x224, batch 1,
-    VxmDense(default features, int_steps 7, bidir) + NCC[9,9,9] + Grad l2, fwd+bwd+Adam."""
+    VxmDense(default features, int_steps 7, bidir) + NCC[9,9,9] + Grad l2, fwd+bwd+Adam.
+    Its roofline: conv3d_mfma16_k (every stride-1 3x3x3 forward / dgrad conv), fp32 MFMA, timed with HIP events."""
+    from dfmir_amd import ops
     from dfmir_amd.registration3d import Registration3DModel
     shape = (160, 192, 224)
     torch.manual_seed(0)
     m = Registration3DModel(shape, None, device=dev)
     A = torch.rand(1, 1, *shape, device=dev) * 2 - 1
     B = 0.5 * A + 0.5 * (torch.rand(1, 1, *shape, device=dev) * 2 - 1)
+    fw_kinds = ["conv3d_" + z for z in ("small", "S", "M", "L")]
+    wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]
+    timer = KernelTimer(fw_kinds + wg_kinds)
+    ops.set_conv_profiler(timer)
     for _ in range(warmup):
         m.set_input({"A": A, "B": B})
         m.optimize_parameters()
     torch.cuda.synchronize()
+    timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(steps):
         m.set_input({"A": A, "B": B})
         m.optimize_parameters()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    timer.enabled = False
+    ops.set_conv_profiler(None)
+    losses = m.get_current_losses()
+    assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
+    ks = timer.summary()
+
+    def agg(kinds):
+        ms = sum(ks[k]["ms"] for k in kinds if k in ks)
+        fl = sum(ks[k]["flops"] for k in kinds if k in ks)
+        n = sum(ks[k]["launches"] for k in kinds if k in ks)
+        return (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), n, ms
+    fw_tf, fw_n, fw_ms = agg(fw_kinds)
+    wg_tf, wg_n, wg_ms = agg(wg_kinds)
     return {"workload": "3-D 160x192x224 volume pair, batch 1, VxmDense default features + NCC[9,9,9] + Grad-l2, "
                         "fwd+bwd+Adam (BASELINE configs[4] geometry, one GPU)",
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
-            "conv_tflops": 2393.0 / dt / 1e3, "dtype": "f32"}
+            "conv_tflops": 2393.0 / dt / 1e3, "dtype": "f32",
+            "losses": {k: round(v, 6) for k, v in losses.items()},
+            "roofline": {"bound": "mfma", "achieved": fw_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fw_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "conv3d_mfma16_k (v_mfma_f32_16x16x4_f32, LDS halo patch per 8-channel chunk): forward + "
+                                   "dgrad of every stride-1 3x3x3 conv; algorithmic FLOPs = 2*N*Cout*D*H*W*Cin*27",
+                         "launches_timed": fw_n, "avg_launch_ms": fw_ms / max(fw_n, 1),
+                         "wgrad_kernel": "conv3d_wgrad16_k", "wgrad_kernel_tflops": wg_tf,
+                         "wgrad_frac": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n}}
+
+
+def bench_warp_hbm(dev, reps=20):
+    """roofline_hbm: the trilinear displacement-field warp (SpatialTransformer = grid_sample, reference
+    models/voxelmorph/torchvoxelmorph/layers.py:30-48) at 160x192x224, C = 1, on a registration-like smooth field
+    (control points every 32 voxels, ~1 voxel rms).  Algorithmic bytes: fwd 4*(C+nd+C)*N_vox,
+    bwd 4*(C [dOut] + C [src] + nd [flow] + C [dSrc] + nd [dFlow])*N_vox; time = HIP events on the launch stream."""
+    from dfmir_amd import ops
+    sp, C, nd = (160, 192, 224), 1, 3
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+    src = torch.randn(1, C, *sp, generator=g).to(dev)
+    coarse = torch.randn(1, nd, *[s // 32 for s in sp], generator=g).to(dev)
+    flow = torch.nn.functional.interpolate(coarse, size=sp, mode='trilinear', align_corners=True).contiguous()
+    dout = torch.randn(1, C, *sp, generator=g).to(dev)
+    dsrc, dflow = torch.zeros_like(src), torch.empty_like(flow)
+    nv = src.numel() // C
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+
+    def bwd():
+        dsrc.zero_()
+        ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
+
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+           "workload": "160x192x224, C=1, smooth field", "kernel": "warp_win_fwd_k<3>"}
+    b_f = 4 * (C + nd + C) * nv
+    ms = timeit(lambda: ops._warp_fwd(src, flow, 0, 0))
+    out.update(achieved=b_f / ms / 1e6, frac=b_f / ms / 1e6 / HBM_PEAK_GBS, bytes=b_f, avg_launch_ms=ms)
+    b_b = 4 * (C + 2 * C + 2 * nd) * nv
+    ms = timeit(bwd)
+    out["bwd"] = {"kernel": "warp_win_bwd_k<3> (d(src) + d(flow), incl. the d(src) zero-fill)", "achieved": b_b / ms / 1e6,
+                  "frac": b_b / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_b, "avg_launch_ms": ms}
+    b_bf = 4 * (C + C + 2 * nd) * nv
+    ms = timeit(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0))
+    out["bwd_dflow_only"] = {"achieved": b_bf / ms / 1e6, "frac": b_bf / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_bf,
+                             "avg_launch_ms": ms}
+    return out
 
 
 def main():
@@ -178,7 +270,7 @@ def main():
                           checkpoints_dir="/tmp/dfmir_bench", name="bench")
     torch.manual_seed(0)                      # same weights on every rank (also broadcast in parallelize())
     model = REGISTRATIONModel(opt)
-    timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"])
+    timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"], every=3)   # 68 + 33 launches per step: a third of them timed
     ops.set_conv_profiler(timer)
 
     batches = [synth_pairs(B, S, S, dev, 1000 * rank + i) for i in range(4)]   # resident in HBM
@@ -234,7 +326,11 @@ def main():
         split = os.environ.get("DFMIR_CONV_FP32") is None
         nprod = 6.0 if os.environ.get("DFMIR_CONV_SPLIT", "f").startswith("b") else 3.0   # bf16x3 / fp16x2 (default)
         form = "bf16x3 (6 products)" if nprod == 6.0 else "scaled fp16x2 (3 products)"
-        issued = ach * nprod * 10.0 / 9.0 if split else ach     # 5 k-steps for 9 taps
+        # The split kernels issue `nprod` 16-bit MFMA products per algorithmic fp32 MAC, with no padded k-step
+        # (conv3x3_split_cs_k: 9 taps x 16 channels = 9 k-steps of K = 16 per chunk): issued = nprod x algorithmic.
+        peak = FP16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        issued = ach * nprod if split else ach
+        wg_issued = wg_tf * nprod if split else wg_tf
         result = {
             "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -244,31 +340,30 @@ def main():
                                    "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
                                    "VoxelMorph + bilinear warps, fwd+bwd+Adam), BASELINE configs[1]" % (S, S, B, args.ngf),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
+                         "frac": issued / peak,
                          # HBM-side bytes of ONE launch of the dominant shape (256->256 3x3 @64^2, n = 32: 154.6 GFLOP,
-                         # 272 MB algorithmic), rocprofv3 PMC passes of scripts/prof_conv.sh (profiles/r01_conv3x3s_pmc.md):
-                         # FETCH_SIZE 346.3 MB (dword gathers: no x2 correction) + WRITE_SIZE 134.2 MB
-                         "traffic": 480.5e6 if split and nprod == 3.0 else None,
+                         # 272 MB algorithmic), rocprofv3 PMC passes of scripts/prof_conv.sh (profiles/*_conv3x3s_pmc.md):
+                         # FETCH_SIZE + WRITE_SIZE
+                         "traffic": CS_TRAFFIC_BYTES if split and nprod == 3.0 else None,
                          "traffic_note": "bytes per launch of the 154.6-GFLOP shape, PMC (FETCH_SIZE + WRITE_SIZE); "
-                                         "algorithmic 272 MB; MFMA-bound: 480 MB in 0.43 ms is 1.1 TB/s",
+                                         "algorithmic 272 MB",
+                         "achieved_note": ("achieved = issued 16-bit matrix FLOP/s = %d x the algorithmic fp32 FLOP/s of the "
+                                           "timed launches (%s); peak = dense fp16 MFMA" % (int(nprod), form)) if split else
+                                          "achieved = algorithmic fp32 FLOP/s; peak = dense fp32 MFMA",
+                         "algorithmic_tflops": ach, "products_per_mac": nprod if split else 1.0,
                          "kernel": ("conv3x3_split_cs_k<true,64,8> (fp32 operands split into 16-bit terms, %s on "
                                     "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; 128 couts x 8x32-pixel tile shared by "
-                                    "two ping-pong wave groups; reflect dgrads = zero-padded form + ring kernel; "
-                                    "conv3x3_split_pp_k for tiles filled < 85 %%)" % form if split else
+                                    "two ping-pong wave groups; reflect dgrads = zero-padded form + ring kernel)" % form if split else
                                     "conv3x3_mfma_k<2,2,2,2,400> (v_mfma_f32_32x32x2_f32; 128 couts x 128 pixels)") +
                                    ": forward + dgrad of every 3x3 conv with Cout > 64",
-                         "clock_note": "these kernels hold the package at its 1400 W cap: sclk 1.75 GHz sustained "
+                         "clock_note": "these kernels hold the package at its 1400 W cap: sclk ~1.75 GHz sustained "
                                        "(profiles/r01_power_clock.md), i.e. a 1.84 PFLOP/s 16-bit roof at that clock",
-                         "peak_note": "peak = dense fp32 MFMA (dtype f32); achieved = algorithmic fp32 FLOP/s" +
-                                      (", above it because the products run on the 16-bit matrix pipe" if split else ""),
-                         "issued_mfma_tflops": issued, "issued_mfma_peak": 2500.0 if split else FP32_MFMA_PEAK_TFLOPS,
-                         "issued_mfma_frac": issued / (2500.0 if split else FP32_MFMA_PEAK_TFLOPS),
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "wgrad_kernel": ("conv3x3_wgrad_split2_k (same split; 64 ci x 128 co x 9 taps per workgroup, runs of "
                                           "2 rows x 16 px, double-buffered LDS, staggered wave groups)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
-                         "wgrad_kernel_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
-                         "wgrad_issued_mfma_frac": (wg_tf * nprod / 2500.0) if split else wg_tf / FP32_MFMA_PEAK_TFLOPS,
+                         "wgrad_achieved": wg_issued, "wgrad_frac": wg_issued / peak,
+                         "wgrad_algorithmic_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
                          "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},
             "losses": {k: round(v, 6) for k, v in losses.items()},
         }
@@ -279,6 +374,8 @@ def main():
         if world == 1 and not args.no_3d:
             model = None
             batches.clear()
+            torch.cuda.empty_cache()
+            result["roofline_hbm"] = bench_warp_hbm(dev)
             torch.cuda.empty_cache()
             result["also_3d"] = bench_3d(dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -125,7 +125,9 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         size = "L" if Cout > 64 else ("M" if Cout > 32 else ("S" if Cout > 4 else "small"))
         is3x3 = (tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and pad[1] == pad[2]
                  and pad[1] in (1, 2) and Cout > 4)
-        prof(("conv3x3_" if is3x3 else "conv_mfma_") + size, flops, launch)
+        is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
+                and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
+        prof(("conv3x3_" if is3x3 else ("conv3d_" if is3d else "conv_mfma_")) + size, flops, launch)
     return y
 
 
@@ -149,7 +151,10 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
         is3x3 = (tuple(K) == (1, 3, 3) and stride == 1 and Di == 1 and pad[1] == 1 and pad[2] == 1
                  and Cout >= 64 and Cin >= 32 and (Hi * Wi) % 32 == 0 and Wi % 32 == 0)
         size = "L" if Cout > 64 else ("M" if Cout > 32 else "S")
-        prof(("wgrad3x3_" if is3x3 else "conv_wgrad_") + size, 2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
+        is3d = (tuple(K) == (3, 3, 3) and stride == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0 and Cout <= 32
+                and Wi % 4 == 0)                          # csrc/conv3d.hip::df_conv3d_wgrad_try
+        prof(("wgrad3x3_" if is3x3 else ("wgrad3d_" if is3d else "conv_wgrad_")) + size,
+             2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
     return dw
 
 
