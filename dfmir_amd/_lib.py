@@ -83,6 +83,12 @@ _SIGS = {
     "dfmir_flow_smooth_bwd": [P, P, P] + [c_int] * 5 + [P],
     "dfmir_ncc_fwd": [P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_ncc_bwd": [P, P, P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
+    "dfmir_patch_gather_fwd_multi": [P, c_int, P, P, c_int, c_int, c_longlong, c_int, P],
+    "dfmir_patch_ids_draw": [P, P, c_int, c_int, c_int, P, P],
+    "dfmir_segment_means_fwd": [P, P, c_int, c_int, c_longlong, c_float, P],
+    "dfmir_segment_means_bwd": [P, P, c_int, c_int, c_longlong, c_float, P],
+    "dfmir_scalar_combine_fwd": [P, c_int, P, c_int, P, P],
+    "dfmir_scalar_combine_bwd": [P, c_int, P, c_int, P, P],
     "dfmir_sum_scaled": [P, P, c_longlong, c_float, P],
     "dfmir_fill_from_scalar": [P, P, c_longlong, c_float, P],
     "dfmir_adam_step": [P, P, P, P, c_longlong] + [c_float] * 7 + [P],

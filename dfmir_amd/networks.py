@@ -440,13 +440,17 @@ class PatchSampleF(nn.Module):
                 patch_id = patch_id[:int(min(num_patches, patch_id.shape[0]))]
             groups = patch_id.shape[0] if patch_id.dim() == 2 else 1
             x = ops.patch_gather(feat, patch_id, groups)      # [C, B*P]
-            if self.use_mlp:
-                mlp = getattr(self, 'mlp_%d' % feat_id)
-                x = mlp[2](mlp[0](x, relu=True))
             return_ids.append(patch_id)
-            x = ops.l2norm_rows(x)
-            return_feats.append(x.t())                        # [B*P, nc] view
+            return_feats.append(self.project(feat_id, x).t())  # [B*P, nc] view
         return return_feats, return_ids
+
+    def project(self, feat_id, x_cm):
+        """Sampled rows of layer `feat_id`, channel-major [C, rows] -> MLP (Linear, ReLU, Linear) -> L2-normalised
+        [nc, rows] (models/networks.py:613-619); the transposed view of the result is what forward() returns."""
+        if self.use_mlp:
+            mlp = getattr(self, 'mlp_%d' % feat_id)
+            x_cm = mlp[2](mlp[0](x_cm, relu=True))
+        return ops.l2norm_rows(x_cm)
 
 
 def define_F(input_nc, netF, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02,

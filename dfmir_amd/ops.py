@@ -1075,6 +1075,140 @@ def patchnce_rows(q, k, groups, T):
     return PatchNCEFn.apply(q, k, groups, T)
 
 
+class NCETermsFn(Function):
+    """Per-row NCE losses of L layers and T stacked terms -> the T per-term losses
+    scale * sum_l mean(rows_l[t])  (registration_model.py:247-253 for every term at once).  q[l], k[l]: channel-major
+    [C, T*seg]; one PatchNCE launch per layer writes into one [L, T*seg] buffer, one launch reduces it."""
+
+    @staticmethod
+    def forward(ctx, groups, temp, scale, n_terms, *qk):
+        L = len(qk) // 2
+        qs = [_c(t) for t in qk[:L]]
+        ks = [_c(t) for t in qk[L:]]
+        _need(*qs)
+        _need(*ks)
+        rows = qs[0].shape[1]
+        if rows % n_terms or rows % groups:
+            raise DfmirHipError("nce_terms: %d rows, %d terms, %d groups" % (rows, n_terms, groups))
+        seg = rows // n_terms
+        R = rows // groups
+        dev = qs[0].device
+        buf = torch.empty((L, rows), device=dev, dtype=torch.float32)
+        probs = []
+        for l in range(L):
+            C = qs[l].shape[0]
+            pr = torch.empty((rows, R + 1), device=dev, dtype=torch.float32)
+            check(lib().dfmir_patchnce_fwd(_p(qs[l]), _p(ks[l]), _VP(buf.data_ptr() + 4 * l * rows), _p(pr), rows, C,
+                                           groups, float(temp), _st()))
+            probs.append(pr)
+        out = torch.empty(n_terms, device=dev, dtype=torch.float32)
+        check(lib().dfmir_segment_means_fwd(_p(buf), _p(out), L, n_terms, seg, float(scale), _st()))
+        ctx.save_for_backward(*(probs + ks))
+        ctx.meta = (L, rows, seg, groups, float(temp), float(scale), n_terms, [q.shape[0] for q in qs])
+        ctx.rows_buf = buf            # kept for inspection (tests read the per-row losses)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        L, rows, seg, groups, temp, scale, n_terms, Cs = ctx.meta
+        saved = ctx.saved_tensors
+        probs, ks = saved[:L], saved[L:]
+        g = _c(g)
+        drows = torch.empty((L, rows), device=g.device, dtype=torch.float32)
+        check(lib().dfmir_segment_means_bwd(_p(g), _p(drows), L, n_terms, seg, scale, _st()))
+        dqs = []
+        for l in range(L):
+            dq = torch.empty_like(ks[l])
+            check(lib().dfmir_patchnce_bwd(_VP(drows.data_ptr() + 4 * l * rows), _p(probs[l]), _p(ks[l]), _p(dq), rows,
+                                           Cs[l], groups, temp, _st()))
+            dqs.append(dq)
+        return (None, None, None, None) + tuple(dqs) + (None,) * L
+
+
+def nce_terms(qs, ks, groups, temp, scale, n_terms):
+    """qs, ks: lists (per layer) of channel-major [C, T*seg] rows -> tensor [n_terms] of per-term losses."""
+    return NCETermsFn.apply(int(groups), temp, scale, int(n_terms), *(list(qs) + [k.detach() for k in ks]))
+
+
+class ScalarCombineFn(Function):
+    """out[j] = sum_i M[j][i] * in_i for 0-dim device scalars in_i (one launch; gradients are M^T g)."""
+
+    @staticmethod
+    def forward(ctx, M, *ins):
+        import numpy as np
+        _need(*ins)
+        n_in, n_out = len(ins), len(M)
+        Mh = np.ascontiguousarray(np.asarray(M, dtype=np.float32).reshape(n_out, n_in))
+        ptrs = (ctypes.c_void_p * n_in)(*[t.data_ptr() for t in ins])
+        out = torch.empty(n_out, device=ins[0].device, dtype=torch.float32)
+        check(lib().dfmir_scalar_combine_fwd(ptrs, n_in, Mh.ctypes.data, n_out, _p(out), _st()))
+        ctx.M = Mh
+        ctx.shapes = [tuple(t.shape) for t in ins]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _c(g)
+        n_out, n_in = ctx.M.shape
+        din = torch.empty(n_in, device=g.device, dtype=torch.float32)
+        check(lib().dfmir_scalar_combine_bwd(_p(g), n_in, ctx.M.ctypes.data, n_out, _p(din), _st()))
+        return (None,) + tuple(din[i].view(ctx.shapes[i]) for i in range(n_in))
+
+
+def scalar_combine(M, ins):
+    """M: n_out rows of n_in coefficients; ins: device scalars (0-dim or 1-element tensors) -> tensor [n_out]."""
+    return ScalarCombineFn.apply(M, *ins)
+
+
+# device-side patch-id generator state: {seed, draw counter, finished-workgroup counter}
+_IDS_STATE = {}
+
+
+def seed_patch_ids(seed, device=None):
+    """(Re)seed the device patch-id generator (default seed: torch's initial_seed at first use)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64).to(device)
+    _IDS_STATE[device] = st
+    return st
+
+
+def draw_patch_ids(sizes, n_sets, P, device):
+    """[n_layers, n_sets, P] int64: for each layer l and set t a uniformly random P-subset of [0, sizes[l])
+    (PatchSampleF's torch.randperm(S)[:P], models/networks.py:609-610), all in ONE launch, no host round trip."""
+    device = torch.device(device)
+    st = _IDS_STATE.get(device)
+    if st is None:
+        st = seed_patch_ids(torch.initial_seed(), device)
+    L = len(sizes)
+    out = torch.empty((L, n_sets, P), device=device, dtype=torch.int64)
+    sz = (ctypes.c_longlong * L)(*[int(s) for s in sizes])
+    check(lib().dfmir_patch_ids_draw(_p(st), sz, L, int(n_sets), int(P), _p(out), _st()))
+    return out
+
+
+def patch_gather_multi(srcs, ids):
+    """srcs: G tensors [Bper, C, *sp] (no gradient: the detached key side); ids [G, P] -> [C, G*Bper*P]."""
+    _need(*srcs)
+    _need(ids)
+    G = len(srcs)
+    srcs = [_c(s) for s in srcs]
+    Bper, C = srcs[0].shape[0], srcs[0].shape[1]
+    S = srcs[0].numel() // (Bper * C)
+    for s_ in srcs:
+        if tuple(s_.shape) != tuple(srcs[0].shape):
+            raise DfmirHipError("patch_gather_multi: sources differ in shape")
+    ids = _c(ids.to(torch.int64))
+    if ids.dim() != 2 or ids.shape[0] != G:
+        raise DfmirHipError("patch_gather_multi: ids must be [G, P]")
+    Pn = ids.shape[1]
+    out = torch.empty((C, G * Bper * Pn), device=srcs[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * G)(*[s_.data_ptr() for s_ in srcs])
+    check(lib().dfmir_patch_gather_fwd_multi(ptrs, G, _p(ids), _p(out), Bper, C, S, Pn, _st()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # scalar losses
 # ------------------------------------------------------------------------------------------------

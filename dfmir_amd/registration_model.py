@@ -180,17 +180,34 @@ class REGISTRATIONModel(BaseModel):
             # draws in the same order -- only the key side draws).  Terms in the reference's order.
             self._nce_terms = self.calculate_NCE_losses_stacked(
                 ((self.real_A, None), (self.real_B, None), (self.real_B, y_output[0])))
-        self.loss_G = self.compute_G_loss()
+        stacked = self._nce_terms is not None
+        if stacked:
+            self.loss_G_GAN = 0.0
+            self.loss_NCE, self.loss_NCE_Y, nce_local = self._nce_terms
+            self._nce_terms = None
+        else:
+            self.loss_G = self.compute_G_loss()
+            nce_local = self.calculate_NCE_loss(self.real_B, y_output[0])
 
         # masks (registration_model.py:160-161) are evaluated inside the fused masked-L1 kernel:
         # mask = (real_B > -0.95) | (registered > -0.95);  mask2 = (idt_B > -0.95) | (registered > -0.95)
-        self.loss_local = (self._nce_terms[2] if self._nce_terms is not None
-                           else self.calculate_NCE_loss(self.real_B, y_output[0])) * 0.25
-        self._nce_terms = None
-        self.loss_R = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold') * 1.0 \
-            + self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold') * 1.0 + self.loss_local * 1.0
-        self.loss_smooth = smooothing_loss(y_pred[1]) * 0.20
-        all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
+        l1_reg = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold')
+        l1_idt = self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold')
+        smooth = smooothing_loss(y_pred[1])
+        if stacked:
+            # registration_model.py:163-166,230-234 as ONE launch (and one for its gradient):
+            #   loss_G = (NCE + NCE_Y) * 0.5;  loss_local = nce_local * 0.25;  loss_R = l1_reg + l1_idt + loss_local
+            #   loss_smooth = smooth * 0.20;   total = loss_R + loss_G + loss_smooth
+            out = ops.scalar_combine(
+                [[0.5, 0.5, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.0, 0.25, 0.0, 0.0, 0.0],
+                 [0.0, 0.0, 0.0, 0.0, 0.0, 0.20], [0.5, 0.5, 0.25, 1.0, 1.0, 0.20]],
+                [self.loss_NCE, self.loss_NCE_Y, nce_local, l1_reg, l1_idt, smooth])
+            self.loss_G, self.loss_R, self.loss_local, self.loss_smooth, all_G_loss = out.unbind(0)
+        else:
+            self.loss_local = nce_local * 0.25
+            self.loss_R = l1_reg * 1.0 + l1_idt * 1.0 + self.loss_local * 1.0
+            self.loss_smooth = smooth * 0.20
+            all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
         with ops.deferred_weight_grads():
             all_G_loss.backward()
         self.sync_gradients()
@@ -238,13 +255,12 @@ class REGISTRATIONModel(BaseModel):
         if self.opt.lambda_GAN > 0.0:
             raise NotImplementedError("the registration model is discriminator-free (lambda_GAN must be 0)")
         self.loss_G_GAN = 0.0
-        terms = getattr(self, '_nce_terms', None)
         if self.opt.lambda_NCE > 0.0:
-            self.loss_NCE = terms[0] if terms is not None else self.calculate_NCE_loss(self.real_A, self.fake_B)
+            self.loss_NCE = self.calculate_NCE_loss(self.real_A, self.fake_B)
         else:
             self.loss_NCE, self.loss_NCE_bd = 0.0, 0.0
         if self.opt.nce_idt and self.opt.lambda_NCE > 0.0:
-            self.loss_NCE_Y = terms[1] if terms is not None else self.calculate_NCE_loss(self.real_B, self.idt_B)
+            self.loss_NCE_Y = self.calculate_NCE_loss(self.real_B, self.idt_B)
             loss_NCE_both = (self.loss_NCE + self.loss_NCE_Y) * 0.5
         else:
             loss_NCE_both = self.loss_NCE
@@ -268,11 +284,35 @@ class REGISTRATIONModel(BaseModel):
     def calculate_NCE_losses_stacked(self, terms):
         """calculate_NCE_loss(real_A, fake_B), (real_B, idt_B), (real_B, regA) with ONE query-side encoder pass over
         cat(fake (= [fake_B; idt_B]), regA).  terms = ((src, tgt or None), ...): the first two targets are the halves
-        of self.fake."""
+        of self.fake.
+
+        Default: everything per layer happens once for the three terms -- one launch draws the 15 patch-id sets on
+        the device, the key rows are gathered from the tapped features of all three sources at once, the MLP runs
+        once over all key rows and once over all query rows, one PatchNCE launch per layer covers the three terms and
+        one reduction yields the three losses.  When `netF.forward` has been replaced on the instance (tests pin the
+        ids by wrapping it with the reference's signature) the key side goes through it term by term, in the
+        reference's order, as before."""
         T = len(terms)
         n_layers = len(self.nce_layers)
         tgt = ops.cat_batch(self.fake, terms[2][1])
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
+        sizes = [f.shape[2] * f.shape[3] for f in feat_q]
+        P = self.opt.num_patches
+        per_term_groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size
+        wrapped = 'forward' in vars(self.netF) or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS')
+        if not wrapped and self.opt.netF == 'mlp_sample' and min(sizes) >= P:
+            ids = self._patch_id_sets(sizes, T, P, feat_q[0].device)          # [L, T, P]
+            with torch.no_grad():
+                keys = {}
+                for src, _ in terms:
+                    if id(src) not in keys:
+                        keys[id(src)] = self._encode_keys(src)
+                k_cm = [self.netF.project(l, ops.patch_gather_multi([keys[id(src)][l] for src, _ in terms], ids[l]))
+                        for l in range(n_layers)]
+            q_cm = [self.netF.project(l, ops.patch_gather(feat_q[l], ids[l], T)) for l in range(n_layers)]
+            losses = ops.nce_terms(q_cm, k_cm, T * per_term_groups, self.opt.nce_T,
+                                   self.opt.lambda_NCE / n_layers, T)
+            return list(losses.unbind(0))
         pools_k, ids_t = [], []
         with torch.no_grad():
             for src, _ in terms:                          # the only random draws, in the reference's order
@@ -290,6 +330,14 @@ class REGISTRATIONModel(BaseModel):
                 total += ops.mean(crit(f_q[t * rows:(t + 1) * rows], pools_k[t][l])) * self.opt.lambda_NCE
             losses.append(total / n_layers)
         return losses
+
+    def _patch_id_sets(self, sizes, n_sets, P, device):
+        """[L, n_sets, P] patch positions; `self.patch_id_source(sizes, n_sets, P)` overrides the device draw
+        (tests pin ids with it)."""
+        src = getattr(self, 'patch_id_source', None)
+        if src is not None:
+            return src(sizes, n_sets, P).to(device)
+        return ops.draw_patch_ids(sizes, n_sets, P, device)
 
     # -- registration_model.py:255-263
     def calculate_L1_loss(self, src, tgt, mask):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 3
+#define DFMIR_ABI_VERSION 4
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -262,6 +262,19 @@ int dfmir_patch_gather_fwd_g(const float* feat, const long long* ids, float* out
                              int G, void* stream);
 int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
                              int G, float* dfeat_amax, void* stream); /* accumulates */
+/* Key side of several NCE terms in one launch: group g gathers its Bper images from srcs[g] ([Bper,C,S]; srcs is a HOST
+ * array of G <= 8 device pointers, copied by value into the launch) at ids[g][0..P) -> out[c][(g*Bper+b)*P+p].
+ * Replaces `feat_k_pool, sample_ids = self.netF(feat_k, num_patches, None)` called once per term
+ * (models/registration_model.py:244-245; gather = models/networks.py:604-611). */
+int dfmir_patch_gather_fwd_multi(const float* const* srcs, int G, const long long* ids, float* out, int Bper, int C,
+                                 long long S, int P, void* stream);
+/* Patch positions drawn on the device: out[layer][set][0..P) = a uniformly random P-subset of [0, sizes[layer]) --
+ * what `torch.randperm(H*W)[:num_patches]` (models/networks.py:609-610) yields per layer and per netF call, for
+ * n_sets calls at once (the set, not its order, is what PatchNCELoss sees).  sizes: HOST array of n_layers <= 8
+ * counts.  state: 3 device uint64 {seed, draw counter, 0}; the kernel advances the counter itself, so a captured
+ * hipGraph draws fresh ids at every replay.  Deterministic for a given (seed, counter).  P <= 1024. */
+int dfmir_patch_ids_draw(unsigned long long* state, const long long* sizes, int n_layers, int n_sets, int P,
+                         long long* out, void* stream);
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
 int dfmir_l2norm_fwd(const float* x, float* y, float* norm, int C, long long rows, float eps, void* stream);
 int dfmir_l2norm_bwd(const float* dy, const float* x, const float* norm, float* dx, int C,
@@ -298,6 +311,16 @@ int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float
 int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
                   const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
                   int win, float eps, void* stream);
+/* out[t] = scale * sum_l mean(rows[l][t*seg..(t+1)*seg)), rows [L][T*seg]: the per-term
+ * `total_nce_loss += loss.mean() * lambda_NCE` ... `/ n_layers` of calculate_NCE_loss (registration_model.py:247-253)
+ * for T terms and L layers at once (scale = lambda_NCE / n_layers); bwd fills drows from gout[T]. */
+int dfmir_segment_means_fwd(const float* rows, float* out, int L, int T, long long seg, float scale, void* stream);
+int dfmir_segment_means_bwd(const float* gout, float* drows, int L, int T, long long seg, float scale, void* stream);
+/* out[j] = sum_i M[j*n_in+i] * *in[i]: the scalar algebra of the step's loss terms (loss_G, loss_R, loss_local,
+ * loss_smooth and their sum; registration_model.py:163-166,230-234) as one launch.  in: HOST array of n_in <= 8 device
+ * scalar pointers, M: HOST row-major [n_out][n_in], both copied by value.  bwd: din[i] = sum_j M[j*n_in+i] * gout[j]. */
+int dfmir_scalar_combine_fwd(const float* const* in, int n_in, const float* M, int n_out, float* out, void* stream);
+int dfmir_scalar_combine_bwd(const float* gout, int n_in, const float* M, int n_out, float* din, void* stream);
 /* out = scale * sum(x) (out zeroed by this call). */
 int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void* stream);
 /* dx[i] = gout[0]*scale */

@@ -1,0 +1,138 @@
+"""GPU: the single-launch PatchNCE head plumbing (csrc/nce_head.hip) -- device patch-id draws, the multi-source key
+gather, the fused per-term loss reduction and the scalar loss algebra -- against torch / the oracle, and the model's
+batched key path against the term-by-term path it replaces on identical ids."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import common as C
+from tests.test_gpu_ops import DEV, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dfmir_amd import ops as _ops
+    return _ops
+
+
+def test_patch_ids_draw_properties(ops):
+    """What torch.randperm(S)[:P] guarantees (models/networks.py:609-610): P distinct positions in [0, S), fresh at
+    every call, every position equally likely.  Plus: reproducible from (seed, counter)."""
+    sizes, T, P = [68644, 65536, 16384, 4096, 4096], 3, 256
+    ops.seed_patch_ids(1234, DEV)
+    a = ops.draw_patch_ids(sizes, T, P, DEV)
+    b = ops.draw_patch_ids(sizes, T, P, DEV)
+    assert a.shape == (5, T, P) and a.dtype == torch.int64
+    for ids in (a, b):
+        for l, S in enumerate(sizes):
+            for t in range(T):
+                v = ids[l, t].cpu().numpy()
+                assert v.min() >= 0 and v.max() < S
+                assert len(np.unique(v)) == P, (l, t)
+    assert not torch.equal(a, b)                                   # the counter advanced on the device
+    assert not torch.equal(a[3, 0], a[3, 1]) and not torch.equal(a[3, 0], a[4, 0])   # sets / layers independent
+    ops.seed_patch_ids(1234, DEV)
+    assert torch.equal(ops.draw_patch_ids(sizes, T, P, DEV), a)   # deterministic replay
+    assert torch.equal(ops.draw_patch_ids(sizes, T, P, DEV), b)
+    # uniformity: 400 sets of 256 out of 1024 positions -> 100 hits per position on average (sigma ~ 8.7)
+    ops.seed_patch_ids(99, DEV)
+    hits = np.zeros(1024)
+    for _ in range(50):
+        d = ops.draw_patch_ids([1024], 8, 256, DEV).cpu().numpy().reshape(-1)
+        hits += np.bincount(d, minlength=1024)
+    assert abs(hits.mean() - 100.0) < 1e-9
+    assert hits.min() > 100 - 6 * 8.7 and hits.max() < 100 + 6 * 8.7, (hits.min(), hits.max())
+    chi2 = float(((hits - 100.0) ** 2 / 100.0).sum())             # ~ 0.75 * 1023 (sampling without replacement)
+    assert 0.55 * 1023 < chi2 < 0.95 * 1023, chi2
+    # P == S: a permutation;  P not a power of two
+    d = ops.draw_patch_ids([300], 2, 300, DEV).cpu().numpy()
+    assert sorted(d[0, 0]) == list(range(300)) and sorted(d[0, 1]) == list(range(300))
+    d = ops.draw_patch_ids([5000, 777], 1, 700, DEV).cpu().numpy()
+    assert len(np.unique(d[0, 0])) == 700 and len(np.unique(d[1, 0])) == 700 and d[1, 0].max() < 777
+
+
+def test_patch_gather_multi(ops):
+    Bper, Cc, H, W, P, G = 2, 5, 7, 9, 16, 3
+    srcs = [C.randn(70 + g, Bper, Cc, H, W) for g in range(2)]
+    srcs = [srcs[0], srcs[1], srcs[1]]                              # real_A, real_B, real_B as in the step
+    ids = torch.stack([C.patch_ids(5 + g, 0, H * W, P) for g in range(G)])
+    got = ops.patch_gather_multi([s.to(DEV) for s in srcs], ids.to(DEV))   # [C, G*Bper*P]
+    ref = torch.cat([s.permute(0, 2, 3, 1).flatten(1, 2)[:, ids[g], :].flatten(0, 1) for g, s in enumerate(srcs)])
+    assert torch.equal(got.t().cpu(), ref)
+
+
+def test_nce_terms_match_sequential(ops):
+    """ops.nce_terms (one PatchNCE launch per layer over the stacked terms + one reduction) == the reference's
+    per-term, per-layer `loss.mean() * lambda_NCE` summed and divided by n_layers (registration_model.py:247-253)."""
+    from oracle import dfmir_oracle as O
+    T, B, P, L, lam = 3, 2, 256, 2, 0.25
+    Cs = [64, 32]
+    qs = [O.l2_normalize(C.randn(80 + l, T * B * P, Cs[l])) for l in range(L)]
+    ks = [O.l2_normalize(C.randn(90 + l, T * B * P, Cs[l])) for l in range(L)]
+    qr = [q.clone().requires_grad_() for q in qs]
+    ref = []
+    for t in range(T):
+        tot = 0.0
+        for l in range(L):
+            sl = slice(t * B * P, (t + 1) * B * P)
+            tot = tot + O.patchnce_loss(qr[l][sl], ks[l][sl], B, 0.07).mean() * lam
+        ref.append(tot / L)
+    w = torch.tensor([0.5, 0.5, 0.25])
+    (torch.stack(ref) * w).sum().backward()
+    qg = [q.t().contiguous().to(DEV).requires_grad_() for q in qs]
+    got = ops.nce_terms(qg, [k.t().contiguous().to(DEV) for k in ks], T * B, 0.07, lam / L, T)
+    close(got, torch.stack(ref), rtol=2e-5, what="nce terms")
+    (got * w.to(DEV)).sum().backward()
+    for l in range(L):
+        close(qg[l].grad.t(), qr[l].grad, rtol=3e-4, what="dq layer %d" % l)
+
+
+def test_scalar_combine(ops):
+    M = [[0.5, 0.5, 0.0], [0.0, 0.25, 1.0], [0.5, 0.75, 1.0]]
+    xs = [torch.tensor(v, device=DEV, requires_grad=True) for v in (1.5, -2.0, 0.125)]
+    out = ops.scalar_combine(M, xs)
+    close(out, torch.tensor([-0.25, -0.375, -0.625]), what="combine")
+    (out * torch.tensor([1.0, 2.0, 3.0], device=DEV)).sum().backward()
+    for x, g in zip(xs, (0.5 + 1.5, 0.5 + 0.5 + 2.25, 2.0 + 3.0)):
+        assert abs(float(x.grad) - g) < 1e-6
+
+
+def test_batched_key_path_matches_term_by_term():
+    """The default step (device-drawn ids, one key gather / MLP / PatchNCE launch per layer for the three terms) gives
+    the losses and gradients of the term-by-term key path (netF called once per term as in
+    registration_model.py:237-253) when both see the same patch ids."""
+    from oracle import dfmir_oracle as O      # noqa: F401  (weights come from the oracle's seeded constructors)
+    from tests.test_gpu_models import _hip_model_from_oracle, _load
+    from tests.test_oracle_golden import make_step
+    res = []
+    for batched in (True, False):
+        st, size, B = make_step()
+        model, opt = _hip_model_from_oracle(st, size, B, 8)
+        A0, B0 = C.image_pair(93, B, size, size)
+        call = [0]
+        base_forward = model.netF.forward
+
+        def pinned(feats, num_patches=64, patch_ids=None, base_forward=base_forward, call=call):
+            if patch_ids is None:
+                patch_ids = [C.patch_ids(call[0], i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)]
+                call[0] += 1
+            return base_forward(feats, num_patches, patch_ids)
+
+        model.netF.forward = pinned
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})   # calls 0, 1
+        _load(model.netF, st.netF)
+        model.setup(opt)
+        model.parallelize()
+        if batched:
+            del model.netF.forward                                   # back to the class method: the default path
+            model.patch_id_source = lambda sizes, n_sets, P: torch.stack(
+                [torch.stack([C.patch_ids(2 + t, l, S, P) for t in range(n_sets)]) for l, S in enumerate(sizes)])
+        A_, B_ = C.image_pair(100, B, size, size)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        res.append(([v for v in model.get_current_losses().values()], [o_.flat_g.clone() for o_ in model.optimizers]))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=3e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm())
