@@ -13,7 +13,8 @@
 //   wins, then the lower thread id) and redraws in the next round.  Deterministic for a given (seed, counter).
 // The generator is counter-based (splitmix64 finaliser over (seed, draw counter, stream, thread, round)); the draw
 // counter lives in device memory and is advanced by the last workgroup to finish, so a captured hipGraph replays
-// fresh ids every step.
+// fresh ids every step.  Needs S >= 2P (every redraw is accepted with probability >= 1/2; the 64-round cap is then
+// never reached: 2^-64 per element); smaller layers go through torch.randperm on the host path.
 // ------------------------------------------------------------------------------------------------
 #define DF_IDS_MAXP 1024
 struct DfIdSizes {
@@ -122,7 +123,7 @@ extern "C" int dfmir_patch_ids_draw(unsigned long long* state, const long long* 
   DF_ARG_CHECK(state && sizes && out && n_layers > 0 && n_layers <= 8 && n_sets > 0 && P > 0 && P <= DF_IDS_MAXP);
   DfIdSizes sz{};
   for (int l = 0; l < n_layers; ++l) {
-    DF_ARG_CHECK(sizes[l] >= P && sizes[l] < (1LL << 40));
+    DF_ARG_CHECK(sizes[l] >= 2LL * P && sizes[l] < (1LL << 40));   // rejection sampling: keep the acceptance rate >= 1/2
     sz.S[l] = sizes[l];
   }
   int Ppad = 1;

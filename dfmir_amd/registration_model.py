@@ -300,7 +300,7 @@ class REGISTRATIONModel(BaseModel):
         P = self.opt.num_patches
         per_term_groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size
         wrapped = 'forward' in vars(self.netF) or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS')
-        if not wrapped and self.opt.netF == 'mlp_sample' and min(sizes) >= P:
+        if not wrapped and self.opt.netF == 'mlp_sample' and min(sizes) >= 2 * P:
             ids = self._patch_id_sets(sizes, T, P, feat_q[0].device)          # [L, T, P]
             with torch.no_grad():
                 keys = {}

@@ -272,7 +272,8 @@ int dfmir_patch_gather_fwd_multi(const float* const* srcs, int G, const long lon
  * what `torch.randperm(H*W)[:num_patches]` (models/networks.py:609-610) yields per layer and per netF call, for
  * n_sets calls at once (the set, not its order, is what PatchNCELoss sees).  sizes: HOST array of n_layers <= 8
  * counts.  state: 3 device uint64 {seed, draw counter, 0}; the kernel advances the counter itself, so a captured
- * hipGraph draws fresh ids at every replay.  Deterministic for a given (seed, counter).  P <= 1024. */
+ * hipGraph draws fresh ids at every replay.  Deterministic for a given (seed, counter).  P <= 1024, sizes[l] >= 2P
+ * (rejection sampling). */
 int dfmir_patch_ids_draw(unsigned long long* state, const long long* sizes, int n_layers, int n_sets, int P,
                          long long* out, void* stream);
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
