@@ -241,12 +241,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ngf", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-3d", action="store_true", help="skip the auxiliary 3-D (config 5 geometry) measurement")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="eager steps after the timed region that time the dominant kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -267,10 +269,10 @@ def main():
 
     B, S = args.batch, args.size
     opt = default_options(batch_size=B, crop_size=S, load_size=S, ngf=args.ngf, gpu_ids=[dev.index],
-                          checkpoints_dir="/tmp/dfmir_bench", name="bench")
+                          checkpoints_dir="/tmp/dfmir_bench", name="bench", capture_step=not args.no_graph)
     torch.manual_seed(0)                      # same weights on every rank (also broadcast in parallelize())
     model = REGISTRATIONModel(opt)
-    timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"], every=3)   # 68 + 33 launches per step: a third of them timed
+    timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"])
     ops.set_conv_profiler(timer)
 
     batches = [synth_pairs(B, S, S, dev, 1000 * rank + i) for i in range(4)]   # resident in HBM
@@ -285,7 +287,10 @@ def main():
         model.data_dependent_initialize(feed(0))
         model.setup(opt)
         model.parallelize()
-    for i in range(args.warmup):
+    # the step's hipGraph is captured on the third optimize_parameters call: with --warmup < 3 the missing steps are
+    # run here as well (untimed), so that the timed region holds K steady-state steps and nothing else
+    n_warm = max(args.warmup, 3) if opt.capture_step else args.warmup
+    for i in range(n_warm):
         model.set_input(feed(i))
         model.optimize_parameters()
 
@@ -294,8 +299,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = bool(opt.capture_step)
+    if graphed:
+        assert model._graph['graph'] is not None
     fence()
-    timer.enabled = True
+    timer.enabled = not graphed                   # HIP events cannot be recorded inside a graph replay
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.set_input(feed(i))
@@ -306,6 +314,17 @@ def main():
     timer.enabled = False
     losses = model.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
+    if graphed:
+        # the dominant kernels, timed live with HIP events on their launch stream over eager steps of the same
+        # workload right after the timed region (same process, same weights stream, same kernels and shapes)
+        model._graph['force_eager'] = True
+        timer.enabled = True
+        for i in range(args.roofline_steps):
+            model.set_input(feed(args.steps + i))
+            model.optimize_parameters()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        model._graph['force_eager'] = False
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -334,7 +353,8 @@ def main():
         result = {
             "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+            "step_submission": "hipGraph replay + eager all-reduce/Adam" if graphed else "eager", "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "2-D %dx%d T1<->T2-shaped synthetic slice pairs, batch %d per GPU, ngf %d: "
                                    "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
@@ -360,6 +380,9 @@ def main():
                          "clock_note": "these kernels hold the package at its 1400 W cap: sclk ~1.75 GHz sustained "
                                        "(profiles/r01_power_clock.md), i.e. a 1.84 PFLOP/s 16-bit roof at that clock",
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+                         "timed_over": ("%d eager steps right after the timed region (which replays one hipGraph per step; "
+                                        "events cannot be recorded inside a replay)" % args.roofline_steps) if graphed else
+                                       "the timed region",
                          "wgrad_kernel": ("conv3x3_wgrad_split2_k (same split; 64 ci x 128 co x 9 taps per workgroup, runs of "
                                           "2 rows x 16 px, double-buffered LDS, staggered wave groups)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
                          "wgrad_achieved": wg_issued, "wgrad_frac": wg_issued / peak,

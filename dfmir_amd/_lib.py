@@ -89,6 +89,7 @@ _SIGS = {
     "dfmir_segment_means_bwd": [P, P, c_int, c_int, c_longlong, c_float, P],
     "dfmir_scalar_combine_fwd": [P, c_int, P, c_int, P, P],
     "dfmir_scalar_combine_bwd": [P, c_int, P, c_int, P, P],
+    "dfmir_fill_zero": [P, c_longlong, P],
     "dfmir_sum_scaled": [P, P, c_longlong, c_float, P],
     "dfmir_fill_from_scalar": [P, P, c_longlong, c_float, P],
     "dfmir_adam_step": [P, P, P, P, c_longlong] + [c_float] * 7 + [P],

@@ -23,6 +23,19 @@ static inline unsigned df_grid(long long n, int bs, long long cap = 1LL << 20) {
   return (unsigned)b;
 }
 
+// Zero a few floats on the stream with a KERNEL.  Not hipMemsetAsync: a captured step turns that into a hipGraph
+// memset node, and on ROCm 7.2 such nodes are not reliably ordered with the kernel nodes around them -- the third of
+// four identical masked-L1 calls in one captured graph read a stale workspace at every replay
+// (scripts/graph_probe.py memset_order).
+static __global__ void df_zero_small_k(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+static inline hipError_t df_zero_async(float* p, int n, hipStream_t st) {
+  df_zero_small_k<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(p, n);
+  return hipGetLastError();
+}
+
 // 64-wide wavefront reductions (CDNA wave = 64 lanes).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void absmax_k(const float* __restrict__ x, lon
 }
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first) {
   if (zero_first) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    hipError_t e = df_zero_async(out, 1, st);
     if (e != hipSuccess) return (int)e;
   }
   long long blocks = (n / 4 + 255) / 256;

@@ -233,7 +233,7 @@ extern "C" int dfmir_masked_l1_fwd(const float* a, const float* b, const unsigne
                                    float* ws, float* out, long long n, void* stream) {
   DF_ARG_CHECK(a && b && ws && out && n > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   masked_l1_fwd_k<<<df_grid(n, 256, 1024), 256, 0, st>>>(a, b, mask, thr, ws, n);
   DF_LAUNCH_CHECK();
@@ -253,7 +253,7 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
                                      int W, void* stream) {
   DF_ARG_CHECK(flow && ws && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   const long long planes = (long long)B * C;
   flow_smooth_fwd_k<<<df_grid(planes * D * H * W, 256, 1024), 256, 0, st>>>(flow, ws, planes, D, H, W);
@@ -288,7 +288,7 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
   const long long N = (long long)B * D * H * W;
   const int r = win / 2;
   const unsigned grid = (unsigned)((N + 255) / 256);
-  hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(float), st);
+  hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   float wn;
   if (D > 1) {
@@ -338,10 +338,24 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
   DF_LAUNCH_CHECK();
   return 0;
 }
+// p[0..n) = 0 as a kernel (see df_zero_async in common.h for why the step never uses hipMemsetAsync)
+__global__ __launch_bounds__(256) void fill_zero_k(float* __restrict__ p, long long n) {
+  const long long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p4[i] = z;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+extern "C" int dfmir_fill_zero(float* p, long long n, void* stream) {
+  DF_ARG_CHECK(p && n > 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  fill_zero_k<<<df_grid((n + 3) / 4, 256, 8192), 256, 0, (hipStream_t)stream>>>(p, n);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void* stream) {
   DF_ARG_CHECK(x && out && n > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  hipError_t e = df_zero_async(out, 1, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   sum_scaled_k<<<df_grid(n, 256, 1024), 256, 0, st>>>(x, out, n, scale);
   DF_LAUNCH_CHECK();

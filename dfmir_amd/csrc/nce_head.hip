@@ -13,10 +13,12 @@
 //   wins, then the lower thread id) and redraws in the next round.  Deterministic for a given (seed, counter).
 // The generator is counter-based (splitmix64 finaliser over (seed, draw counter, stream, thread, round)); the draw
 // counter lives in device memory and is advanced by the last workgroup to finish, so a captured hipGraph replays
-// fresh ids every step.  Needs S >= 2P (every redraw is accepted with probability >= 1/2; the 64-round cap is then
-// never reached: 2^-64 per element); smaller layers go through torch.randperm on the host path.
+// fresh ids every step.  That form needs S >= 2P (every redraw is accepted with probability >= 1/2; the 64-round cap
+// is then never reached: 2^-64 per element).  Denser layers (P <= S < 2P, S <= 4096: the 16x16 maps of a 64x64 run)
+// take the other branch: S random keys sorted in LDS, the first P positions of that permutation.
 // ------------------------------------------------------------------------------------------------
 #define DF_IDS_MAXP 1024
+#define DF_IDS_MAXPERM 4096
 struct DfIdSizes {
   long long S[8];
 };
@@ -32,13 +34,36 @@ __global__ __launch_bounds__(256) void patch_ids_draw_k(unsigned long long* __re
                                                         int n_layers, int n_sets, int P, int Ppad,
                                                         long long* __restrict__ out) {
   // element = (candidate << 12 | fresh << 11 | owner thread) : sorts by candidate, accepted before fresh, then owner
-  __shared__ unsigned long long el[DF_IDS_MAXP];
+  __shared__ unsigned long long el[DF_IDS_MAXPERM];
   __shared__ unsigned char lost[DF_IDS_MAXP];
   __shared__ int pending;
   const int layer = blockIdx.x / n_sets, set = blockIdx.x - layer * n_sets;
   const unsigned long long S = (unsigned long long)sizes.S[layer];
   const unsigned long long seed = state[0], counter = state[1];
   const unsigned long long stream = df_mix64(seed ^ df_mix64(counter * 0x100000001B3ull + (unsigned long long)blockIdx.x));
+  long long* o = out + ((long long)layer * n_sets + set) * P;
+  if (S < 2ull * (unsigned long long)P) {
+    // dense layer: a full random permutation of [0, S) (distinct keys: 52 random bits | position), first P of it
+    int Spad = 1;
+    while (Spad < (int)S) Spad <<= 1;
+    for (int i = threadIdx.x; i < Spad; i += 256)
+      el[i] = i < (int)S ? ((df_mix64(stream ^ ((unsigned long long)i * 0xD6E8FEB86659FD93ull)) >> 12) << 12) | (unsigned long long)i
+                         : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= Spad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < Spad; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = el[i], b = el[ixj];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { el[i] = b; el[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = threadIdx.x; i < P; i += 256) o[i] = (long long)(el[i] & 0xFFFull);
+  } else {
   // each thread owns slots tid, tid+256, ... (P <= 1024)
   long long mine[DF_IDS_MAXP / 256];
   bool fresh[DF_IDS_MAXP / 256];
@@ -99,11 +124,11 @@ __global__ __launch_bounds__(256) void patch_ids_draw_k(unsigned long long* __re
     __syncthreads();
     if (!more) break;
   }
-  long long* o = out + ((long long)layer * n_sets + set) * P;
 #pragma unroll
   for (int j = 0; j < DF_IDS_MAXP / 256; ++j) {
     const int slot = threadIdx.x + j * 256;
     if (slot < P) o[slot] = mine[j];
+  }
   }
   // the last workgroup to finish advances the draw counter
   __syncthreads();
@@ -123,7 +148,8 @@ extern "C" int dfmir_patch_ids_draw(unsigned long long* state, const long long* 
   DF_ARG_CHECK(state && sizes && out && n_layers > 0 && n_layers <= 8 && n_sets > 0 && P > 0 && P <= DF_IDS_MAXP);
   DfIdSizes sz{};
   for (int l = 0; l < n_layers; ++l) {
-    DF_ARG_CHECK(sizes[l] >= 2LL * P && sizes[l] < (1LL << 40));   // rejection sampling: keep the acceptance rate >= 1/2
+    DF_ARG_CHECK(sizes[l] >= P && sizes[l] < (1LL << 40));
+    DF_ARG_CHECK(sizes[l] >= 2LL * P || sizes[l] <= DF_IDS_MAXPERM);   // rejection sampling needs S >= 2P; else sort S keys
     sz.S[l] = sizes[l];
   }
   int Ppad = 1;

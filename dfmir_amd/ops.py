@@ -39,6 +39,25 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def zero_(t):
+    """t.zero_() as a kernel launch.  torch zeroes contiguous tensors with hipMemsetAsync, which a captured step turns
+    into hipGraph memset nodes; those are not reliably ordered with neighbouring kernel nodes on ROCm 7.2
+    (scripts/graph_probe.py memset_order), so nothing on the step path uses torch.zeros / zero_ / zeros_like."""
+    if t.numel():
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise DfmirHipError("ops.zero_: contiguous fp32 device tensors only")
+        check(lib().dfmir_fill_zero(_p(t), t.numel(), _st()))
+    return t
+
+
+def zeros(shape, device):
+    return zero_(torch.empty(shape, device=device, dtype=torch.float32))
+
+
+def zeros_like(t):
+    return zero_(torch.empty_like(t, memory_format=torch.contiguous_format))
+
+
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
@@ -62,11 +81,24 @@ def amax_slot(device, n=1):
     """n floats of zero-initialised device memory (a probe = n partial maxima)."""
     pool = _AMAX_POOL
     if pool["buf"] is None or pool["next"] + n > pool["buf"].numel() or pool["buf"].device != device:
-        pool["buf"] = torch.zeros(max(1 << 18, n), device=device, dtype=torch.float32)
+        if pool.get("capturing") and pool["buf"] is not None:
+            raise DfmirHipError("probe pool exhausted inside a graph capture (a replay would not re-zero the new pool)")
+        pool["buf"] = zeros(max(1 << 18, n), device)
         pool["next"] = 0
     i = pool["next"]
     pool["next"] = i + n
     return pool["buf"][i:i + n]
+
+
+def begin_graph_capture():
+    """Called right before a hipGraph capture of the step: probe slots handed out during the capture must be zeroed by
+    the graph itself at every replay, so the pool is re-created (allocation + zero fill) inside the capture."""
+    _AMAX_POOL["buf"] = None
+    _AMAX_POOL["capturing"] = True
+
+
+def end_graph_capture():
+    _AMAX_POOL["capturing"] = False
 
 
 def absmax(t):
@@ -136,7 +168,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
     N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
     T = K[0] * K[1] * K[2]
-    dw = torch.zeros((T, Cin, Cout), device=x5.device, dtype=torch.float32) if out is None else out
+    dw = zeros((T, Cin, Cout), x5.device) if out is None else out
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
     def launch():
@@ -170,28 +202,36 @@ def weight_pack(w, mode):
 # bumps the weights epoch), so the first request after a bump re-packs EVERY registered buffer whose parameter is still
 # in place with one batched call (2 launches instead of ~170 per train step).
 _PACKS = {"epoch": None, "entries": {}, "key": None, "descs": None, "dev": None}
+_KEEP_TABLES = []     # device job tables are never freed (a few KB each; see _repack_all / _flush_deferred)
 
 
 def packed_weight(owner, w3, mode):
-    """Packed form of owner's weight (w3 = the parameter viewed [Cout, Cin, T...]) for mode 0 (forward) / 1 (dgrad)."""
+    """Packed form of owner's weight (w3 = the parameter viewed [Cout, Cin, T...]) for mode 0 (forward) / 1 (dgrad).
+    The buffer of an (owner, mode) pair is allocated once and refreshed IN PLACE for as long as the parameter keeps its
+    address and shape -- a captured hipGraph holds the buffer's address, and an in-place change of the weights through
+    torch (load_state_dict, a test restoring a snapshot) must not move it."""
     import weakref
     ents = _PACKS["entries"]
     key = (id(owner), mode)
     ep = weights_epoch()
-    sig = (w3.data_ptr(), w3._version, tuple(w3.shape), w3.device)
+    place = (w3.data_ptr(), tuple(w3.shape), w3.device)
     ent = ents.get(key)
-    if ent is not None and (ent["ref"]() is not owner or ent["sig"] != sig):
+    if ent is not None and (ent["ref"]() is not owner or ent["place"] != place):
         ent = None
-    if ent is not None and ent["epoch"] != ep and _PACKS["epoch"] != ep:
-        _repack_all(ep)
-    if ent is not None and ent["epoch"] == ep:
-        return ent["buf"]
     if ent is None:
         buf = weight_pack(w3, mode)
-        ents[key] = {"ref": weakref.ref(owner), "sig": sig, "epoch": ep, "buf": buf, "w": w3.detach(), "mode": mode}
+        ents[key] = {"ref": weakref.ref(owner), "place": place, "version": w3._version, "epoch": ep, "buf": buf,
+                     "w": w3.detach(), "mode": mode}
         _PACKS["key"] = None
         return buf
-    # registered, but the batched pass did not cover it (it ran before this entry existed): refresh in place
+    if ent["version"] != w3._version:            # modified in place through torch since the last pack
+        ent["version"] = w3._version
+        ent["epoch"] = None
+    if ent["epoch"] != ep and _PACKS["epoch"] != ep:
+        _repack_all(ep)
+    if ent["epoch"] == ep:
+        return ent["buf"]
+    # the batched pass did not cover it (it ran before this entry existed / before the in-place change): refresh
     Cout, Cin = w3.shape[0], w3.shape[1]
     check(lib().dfmir_weight_pack(_p(_c(w3)), _p(ent["buf"]), Cout, Cin, w3.numel() // (Cout * Cin), mode, _st()))
     ent["epoch"] = ep
@@ -204,8 +244,7 @@ def _repack_all(ep):
     for k in [k for k, e in ents.items() if e["ref"]() is None]:
         del ents[k]
         _PACKS["key"] = None
-    live = [e for e in ents.values()
-            if e["sig"][:2] == (e["w"].data_ptr(), e["w"]._version) and e["w"].is_contiguous()]
+    live = [e for e in ents.values() if e["place"][0] == e["w"].data_ptr() and e["w"].is_contiguous()]
     _PACKS["epoch"] = ep
     if not live:
         return
@@ -223,11 +262,13 @@ def _repack_all(ep):
             tab[i, 3] = T | (e["mode"] << 32)
         _PACKS["descs"] = tab
         _PACKS["dev"] = torch.empty(len(live) * 8, device=dev, dtype=torch.int64)   # 64 B per job
+        _KEEP_TABLES.append(_PACKS["dev"])       # a captured hipGraph may hold the address of an earlier table
         _PACKS["key"] = key
         upload = 1
     check(lib().dfmir_weight_pack_batch(_PACKS["descs"].ctypes.data, len(live), _p(_PACKS["dev"]), upload, _st()))
     for e in live:
         e["epoch"] = ep
+        e["version"] = e["w"]._version
 
 
 def weight_unpack(g_tcc, shape):
@@ -271,7 +312,7 @@ class deferred_weight_grads:
             # backward raised: the accumulators hold partial sums that only the flush kernel would clear; a caller
             # that catches the error and goes on (skip-batch / OOM-retry loops) must not inherit them
             for _, buf, _ in pending.values():
-                buf.zero_()
+                zero_(buf)
         return False
 
 
@@ -294,6 +335,7 @@ def _flush_deferred(items):
             tab[i, 3] = T
             mx = max(mx, Cout * Cin * T)
         _JOBS["dev"] = torch.from_numpy(tab).to(items[0][1].device)
+        _KEEP_TABLES.append(_JOBS["dev"])
         _JOBS["key"], _JOBS["max"] = key, mx
     check(lib().dfmir_weight_unpack_add_batch(_p(_JOBS["dev"]), len(items), _JOBS["max"], _st()))
 
@@ -301,7 +343,7 @@ def _flush_deferred(items):
 def _deferred_buffer(owner, T, Cin, Cout, shape, device):
     buf = getattr(owner, "_dw_tcc", None)
     if buf is None or buf.shape != (T, Cin, Cout) or buf.device != device:
-        buf = torch.zeros((T, Cin, Cout), device=device, dtype=torch.float32)
+        buf = zeros((T, Cin, Cout), device)
         owner._dw_tcc = buf
     _DEFER["pending"][id(owner)] = (owner, buf, shape)
     return buf
@@ -424,7 +466,7 @@ class ConvFn(Function):
             if bg is not None and bg.is_contiguous():
                 db_buf = bg
             else:
-                db = db_buf = torch.zeros(Cout, device=dy5.device, dtype=torch.float32)
+                db = db_buf = zeros(Cout, dy5.device)
         if ctx.needs_input_grad[1]:
             if defer:
                 T = K[0] * K[1] * K[2]
@@ -500,7 +542,7 @@ class TapSumFn(Function):
             dz = torch.empty((N, C * K * K, H, W), device=dy.device, dtype=torch.float32)
             check(lib().dfmir_tapsum_bwd(_p(dy), _p(dz), N, C, H, W, H, W, K, pad, pad_mode, _st()))
         if ctx.has_bias and ctx.needs_input_grad[1]:
-            db = torch.zeros(C, device=dy.device, dtype=torch.float32)
+            db = zeros(C, dy.device)
             check(lib().dfmir_bias_grad(_p(dy), _p(db), N, C, H * W, _st()))
         return dz, db, None, None, None, None, None, None
 
@@ -532,7 +574,7 @@ class Stem7Fn(Function):
         Cout = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dwb = torch.zeros(Cout * 49 + Cout, device=dy.device, dtype=torch.float32)
+            dwb = zeros(Cout * 49 + Cout, dy.device)
             dbp = dwb[Cout * 49:] if ctx.has_bias else None
             check(lib().dfmir_conv7x7_c1_wgrad(_p(x), _p(dy), _p(dwb), _p(dbp), N, H, W, Cout, ctx.pad_mode, _st()))
             dw = dwb[:Cout * 49].view(Cout, 1, 7, 7)
@@ -843,10 +885,10 @@ class WarpFn(Function):
     def backward(ctx, dout):
         src, flow = ctx.saved_tensors
         dout = _c(dout)
-        dsrc = torch.zeros_like(src) if ctx.needs_input_grad[0] else None
+        dsrc = zeros_like(src) if ctx.needs_input_grad[0] else None
         dflow = None
         if ctx.needs_input_grad[1]:
-            dflow = torch.zeros_like(flow) if ctx.mode == 1 else torch.empty_like(flow)
+            dflow = zeros_like(flow) if ctx.mode == 1 else torch.empty_like(flow)
         if ctx.mode == 1:
             if dsrc is not None:
                 raise DfmirHipError("nearest-mode warp backward is not implemented (inference only)")
@@ -874,7 +916,7 @@ class VecIntStepFn(Function):
     def backward(ctx, dout):
         (v,) = ctx.saved_tensors
         dout = _c(dout)
-        dv = torch.zeros_like(v)
+        dv = zeros_like(v)
         _warp_bwd(dout, v, v, dv, None, 1, 1)
         return dv
 
@@ -937,7 +979,7 @@ class TapForkFn(Function):
         g = g_main
         if stash:
             if g is None:
-                g = torch.zeros(ctx.shape, device=stash[0][0].device, dtype=torch.float32)
+                g = zeros(ctx.shape, stash[0][0].device)
             elif not g.is_contiguous():
                 g = g.contiguous()
             atag = getattr(g, "_df_amax", None)
@@ -1003,7 +1045,7 @@ class PatchGatherFn(Function):
         if ctx.stash is not None:                # collected by TapForkFn.backward, which runs after this node
             ctx.stash.append((dout, ids, ctx.meta))
             return None, None, None
-        dfeat = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        dfeat = zeros(shape, dout.device)
         check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, G, None, _st()))
         return dfeat, None, None
 
@@ -1166,18 +1208,30 @@ def scalar_combine(M, ins):
 _IDS_STATE = {}
 
 
+def _cuda_device(device):
+    device = torch.device("cuda" if device is None else device)
+    if device.type != "cuda":
+        raise DfmirHipError("patch ids are drawn on the HIP device, not on %s" % device)
+    return torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
+
+
 def seed_patch_ids(seed, device=None):
-    """(Re)seed the device patch-id generator (default seed: torch's initial_seed at first use)."""
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    st = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64).to(device)
-    _IDS_STATE[device] = st
+    """(Re)seed the device patch-id generator (default seed: torch's initial_seed at first use).  The state tensor is
+    updated in place once it exists: a captured hipGraph holds its address."""
+    device = _cuda_device(device)
+    new = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64)
+    st = _IDS_STATE.get(device)
+    if st is None:
+        st = _IDS_STATE[device] = new.to(device)
+    else:
+        st.copy_(new)
     return st
 
 
 def draw_patch_ids(sizes, n_sets, P, device):
     """[n_layers, n_sets, P] int64: for each layer l and set t a uniformly random P-subset of [0, sizes[l])
     (PatchSampleF's torch.randperm(S)[:P], models/networks.py:609-610), all in ONE launch, no host round trip."""
-    device = torch.device(device)
+    device = _cuda_device(device)
     st = _IDS_STATE.get(device)
     if st is None:
         st = seed_patch_ids(torch.initial_seed(), device)

@@ -50,7 +50,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self._reattach()
-        self.flat_g.zero_()
+        if self.flat_g.is_cuda:
+            ops.zero_(self.flat_g)       # a kernel, not hipMemsetAsync (graph capture; see ops.zero_)
+        else:
+            self.flat_g.zero_()          # arena bookkeeping exercised on CPU by the gloo tests
 
     @torch.no_grad()
     def step(self, closure=None):

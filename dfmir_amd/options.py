@@ -20,7 +20,8 @@ def default_options(**overrides):
         num_patches=256, flip_equivariance=False,
         dvf_image='synthetic',     # build-defined: None = ./deform256.jpg as in the reference (raises when absent)
         reuse_key_features=True,   # build-defined: tap NCE key features in forward() (exact, see registration_model.forward)
-        batch_query_passes=True)   # build-defined: one encoder pass for the three NCE terms' query batches
+        batch_query_passes=True,   # build-defined: one encoder pass for the three NCE terms' query batches
+        capture_step=False)        # build-defined: replay the steady-state step as one hipGraph (REGISTRATIONModel)
     for k, v in overrides.items():
         setattr(opt, k, v)
     return opt

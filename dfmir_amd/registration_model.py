@@ -117,6 +117,19 @@ class REGISTRATIONModel(BaseModel):
 
     # -- registration_model.py:119-136
     def data_dependent_initialize(self, data):
+        if getattr(self.opt, 'capture_step', False) and self.isTrain and not getattr(self, '_in_side_stream', False):
+            # a model that will capture its step lives on ONE side stream from its first backward on (autograd binds
+            # each parameter's AccumulateGrad node to the stream of its first use; see _optimize_parameters_graphed)
+            side, cur = self._graph_state()['stream'], torch.cuda.current_stream()
+            side.wait_stream(cur)
+            self._in_side_stream = True
+            try:
+                with torch.cuda.stream(side):
+                    self.data_dependent_initialize(data)
+            finally:
+                self._in_side_stream = False
+            cur.wait_stream(side)
+            return
         self.set_input(data)
         bs_per_gpu = self.real_A.size(0) // max(len(self.opt.gpu_ids), 1)
         self.real_A = self.real_A[:bs_per_gpu]
@@ -157,6 +170,83 @@ class REGISTRATIONModel(BaseModel):
 
     # -- registration_model.py:138-171
     def optimize_parameters(self):
+        if getattr(self.opt, 'capture_step', False) and self.isTrain:
+            return self._optimize_parameters_graphed()
+        self._forward_backward()
+        self._apply_updates()
+
+    def _apply_updates(self):
+        """registration_model.py:168-171 (+ the one exchange step of the data-parallel form)."""
+        self.sync_gradients()
+        self.optimizer_G.step()
+        self.optimizer_R.step()
+        if self.opt.netF == 'mlp_sample':
+            self.optimizer_F.step()
+
+    def _optimize_parameters_graphed(self):
+        """The steady-state step as ONE hipGraph launch (opt.capture_step, build-defined): forward, the losses and
+        backward -- ~600 kernel launches that the Python / autograd / ctypes stack needs 40-75 ms of one host core to
+        enqueue -- are captured once (after two eager steps have built every cache: packed-weight tables, deferred
+        weight-gradient buffers, the id generator) and replayed; the gradient all-reduce and the three Adam launches
+        stay eager (bias corrections and the learning rate change per step).  Inputs are copied into static buffers;
+        losses / visuals are the capture's output tensors, overwritten by every replay.  Patch ids come from the
+        device generator, whose counter the graph itself advances.  A change of batch shape re-captures."""
+        st = self._graph_state()
+        # what the captured launches hold by address or by value: batch geometry and the parameter / gradient arenas
+        shape = (tuple(self.real_A.shape), tuple(self.real_B.shape),
+                 tuple((o.flat_p.data_ptr(), o.flat_g.data_ptr()) for o in self.optimizers))
+        if st['graph'] is not None and st['shape'] != shape:
+            st.update(graph=None, eager_steps=0)
+        side, cur = st['stream'], torch.cuda.current_stream()
+
+        def eager_step():
+            # every non-replayed step of this model runs on the capture's side stream: autograd binds a parameter's
+            # AccumulateGrad node to the stream it first ran on and keeps it while any tensor of an old graph lives;
+            # reusing such a node from another stream is a cross-stream sync, illegal while capturing
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._forward_backward()
+            cur.wait_stream(side)
+            self._apply_updates()
+
+        # capture needs two eager steps behind it (caches built) and a step whose random draws live on the device
+        # (the batched NCE path; a wrapped netF / small feature maps / pinned ids go through the host generator)
+        if st['force_eager'] or (st['graph'] is None and (st['eager_steps'] < 2 or not getattr(self, '_nce_on_device', False))):
+            st['eager_steps'] += 1
+            return eager_step()
+        if st['graph'] is None:
+            st['in_A'], st['in_B'] = self.real_A.clone(), self.real_B.clone()
+            self.real_A, self.real_B = st['in_A'], st['in_B']
+            for k, v in list(vars(self).items()):                     # drop the previous step's autograd graph
+                if torch.is_tensor(v) and v.grad_fn is not None:
+                    setattr(self, k, v.detach())
+            self._key_feats = None
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            ops.begin_graph_capture()
+            try:
+                with torch.cuda.graph(graph, stream=side):
+                    self._forward_backward()
+            finally:
+                ops.end_graph_capture()
+            st['outputs'] = {k: v for k, v in vars(self).items()
+                             if torch.is_tensor(v) and (k.startswith('loss_') or k in self.visual_names or k in ('fake', 'real'))}
+            st['outputs']['_loss_inputs'] = self._loss_inputs
+            st.update(graph=graph, shape=shape)
+        else:
+            if self.real_A is not st['in_A']:
+                st['in_A'].copy_(self.real_A, non_blocking=True)
+                st['in_B'].copy_(self.real_B, non_blocking=True)
+            vars(self).update(st['outputs'])
+            self.real_A, self.real_B = st['in_A'], st['in_B']
+        st['graph'].replay()
+        self._apply_updates()
+
+    def _graph_state(self):
+        return self.__dict__.setdefault('_graph', {'eager_steps': 0, 'graph': None, 'shape': None, 'force_eager': False,
+                                                   'stream': torch.cuda.Stream(device=self.device)})
+
+    def _forward_backward(self):
         self.forward()
 
         y_output = self.netR(self.real_A, self.real_B)
@@ -194,6 +284,7 @@ class REGISTRATIONModel(BaseModel):
         l1_reg = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold')
         l1_idt = self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold')
         smooth = smooothing_loss(y_pred[1])
+        self._loss_inputs = (l1_reg, l1_idt, smooth)
         if stacked:
             # registration_model.py:163-166,230-234 as ONE launch (and one for its gradient):
             #   loss_G = (NCE + NCE_Y) * 0.5;  loss_local = nce_local * 0.25;  loss_R = l1_reg + l1_idt + loss_local
@@ -210,11 +301,6 @@ class REGISTRATIONModel(BaseModel):
             all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
         with ops.deferred_weight_grads():
             all_G_loss.backward()
-        self.sync_gradients()
-        self.optimizer_G.step()
-        self.optimizer_R.step()
-        if self.opt.netF == 'mlp_sample':
-            self.optimizer_F.step()
 
     # -- registration_model.py:174-183
     def set_input(self, input):
@@ -300,7 +386,8 @@ class REGISTRATIONModel(BaseModel):
         P = self.opt.num_patches
         per_term_groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size
         wrapped = 'forward' in vars(self.netF) or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS')
-        if not wrapped and self.opt.netF == 'mlp_sample' and min(sizes) >= 2 * P:
+        if not wrapped and self.opt.netF == 'mlp_sample' and all(S >= 2 * P or P <= S <= 4096 for S in sizes):
+            self._nce_on_device = getattr(self, 'patch_id_source', None) is None
             ids = self._patch_id_sets(sizes, T, P, feat_q[0].device)          # [L, T, P]
             with torch.no_grad():
                 keys = {}
@@ -313,6 +400,7 @@ class REGISTRATIONModel(BaseModel):
             losses = ops.nce_terms(q_cm, k_cm, T * per_term_groups, self.opt.nce_T,
                                    self.opt.lambda_NCE / n_layers, T)
             return list(losses.unbind(0))
+        self._nce_on_device = False                       # torch.randperm: host-side generator state
         pools_k, ids_t = [], []
         with torch.no_grad():
             for src, _ in terms:                          # the only random draws, in the reference's order

@@ -272,8 +272,8 @@ int dfmir_patch_gather_fwd_multi(const float* const* srcs, int G, const long lon
  * what `torch.randperm(H*W)[:num_patches]` (models/networks.py:609-610) yields per layer and per netF call, for
  * n_sets calls at once (the set, not its order, is what PatchNCELoss sees).  sizes: HOST array of n_layers <= 8
  * counts.  state: 3 device uint64 {seed, draw counter, 0}; the kernel advances the counter itself, so a captured
- * hipGraph draws fresh ids at every replay.  Deterministic for a given (seed, counter).  P <= 1024, sizes[l] >= 2P
- * (rejection sampling). */
+ * hipGraph draws fresh ids at every replay.  Deterministic for a given (seed, counter).  P <= 1024; sizes[l] >= 2P
+ * (rejection sampling) or P <= sizes[l] <= 4096 (a sorted permutation). */
 int dfmir_patch_ids_draw(unsigned long long* state, const long long* sizes, int n_layers, int n_sets, int P,
                          long long* out, void* stream);
 /* per row: y = x / (sqrt(sum_c x^2) + eps); norm[rows] saved. */
@@ -322,6 +322,10 @@ int dfmir_segment_means_bwd(const float* gout, float* drows, int L, int T, long 
  * scalar pointers, M: HOST row-major [n_out][n_in], both copied by value.  bwd: din[i] = sum_j M[j*n_in+i] * gout[j]. */
 int dfmir_scalar_combine_fwd(const float* const* in, int n_in, const float* M, int n_out, float* out, void* stream);
 int dfmir_scalar_combine_bwd(const float* gout, int n_in, const float* M, int n_out, float* din, void* stream);
+/* p[0..n) = 0 (p 16-byte aligned).  Replaces torch.zeros / Tensor.zero_ on the step (gradient arenas, scatter targets):
+ * those issue hipMemsetAsync, which a captured step turns into hipGraph memset nodes -- not reliably ordered with the
+ * kernel nodes around them on ROCm 7.2. */
+int dfmir_fill_zero(float* p, long long n, void* stream);
 /* out = scale * sum(x) (out zeroed by this call). */
 int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void* stream);
 /* dx[i] = gout[0]*scale */

@@ -261,6 +261,72 @@ def test_stacked_query_passes_match_sequential(O):
         assert float((a - b).norm()) <= 2e-5 * float(b.norm())
 
 
+def test_graph_captured_step_matches_eager(O):
+    """opt.capture_step: two eager steps, then the step is captured as one hipGraph and replayed.  Every replayed step
+    is checked against the SAME step enqueued eagerly from the same state (weights, Adam moments, patch-id generator
+    restored in between): same kernels on the same data, so losses, outputs and gradient arenas agree to the noise of
+    the float atomics.  (Two independent training runs cannot be compared this tightly: Adam turns that noise into
+    lr-sized steps on ill-conditioned weights, and lr = 2e-4 is 10 % of a weight's standard deviation here.)"""
+    from dfmir_amd import ops
+    from tests.test_oracle_golden import make_step
+    st, size, B = make_step()
+    model, opt = _hip_model_from_oracle(st, size, B, 8)
+    opt.capture_step = True
+    ids_state = ops.seed_patch_ids(4242, DEV)
+    A0, B0 = C.image_pair(93, B, size, size)
+    base_forward = model.netF.forward
+    model.netF.forward = lambda feats, num_patches=64, patch_ids=None, bf=base_forward: bf(
+        feats, num_patches, patch_ids if patch_ids is not None else
+        [C.patch_ids(0, i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)])
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    del model.netF.forward
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+
+    def snapshot():
+        return ([(o_.flat_p.clone(), o_.exp_avg.clone(), o_.exp_avg_sq.clone(), o_._steps) for o_ in model.optimizers],
+                ids_state.clone())
+
+    def restore(snap):
+        for o_, (p, m, v, n) in zip(model.optimizers, snap[0]):
+            o_.flat_p.copy_(p); o_.exp_avg.copy_(m); o_.exp_avg_sq.copy_(v); o_._steps = n
+        ids_state.copy_(snap[1])
+        ops.bump_weights_epoch()
+
+    def observe():
+        return (list(model.get_current_losses().values()), model.fake_B.clone(), model.registered.clone(), model.dvf.clone(),
+                [o_.flat_g.clone() for o_ in model.optimizers], [o_.flat_p.clone() for o_ in model.optimizers])
+
+    prev_fake = None
+    for it in range(6):
+        A_, B_ = C.image_pair(200 + 2 * it, B, size, size)
+        data = {"A": A_.to(DEV), "B": B_.to(DEV), "A_paths": [""] * B, "B_paths": [""] * B}
+        snap = snapshot()
+        model._graph_state()['force_eager'] = True
+        model.set_input(data)
+        model.optimize_parameters()
+        ref = observe()
+        model._graph_state()['force_eager'] = False
+        restore(snap)
+        model.set_input(data)
+        model.optimize_parameters()
+        got = observe()
+        if it >= 2:
+            assert model._graph['graph'] is not None          # captured on the third step, replayed from then on
+        np.testing.assert_allclose(got[0], ref[0], rtol=1e-5, atol=1e-9, err_msg="losses, step %d" % it)
+        close(got[1], ref[1], rtol=1e-6, what="fake_B step %d" % it)
+        close(got[2], ref[2], rtol=1e-6, what="registered step %d" % it)
+        close(got[3], ref[3], rtol=1e-6, what="dvf step %d" % it)
+        gscale = max(float(g.norm()) for g in ref[4])
+        for nm, a, b in zip("GRF", got[4], ref[4]):
+            assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 2e-6 * gscale, (it, nm)
+        if prev_fake is not None:
+            assert not torch.equal(got[1], prev_fake)          # replays see new inputs and new weights
+        prev_fake = got[1]
+    assert model._graph['eager_steps'] >= 2
+
+
 def test_full_size_step_vs_oracle(O):
     """256x256, ngf=64 (BASELINE config 2 geometry at batch 1): one step of the HIP path against the
     oracle on identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""

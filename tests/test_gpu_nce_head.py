@@ -51,9 +51,22 @@ def test_patch_ids_draw_properties(ops):
     assert len(np.unique(d[0, 0])) == 300 and len(np.unique(d[0, 1])) == 300 and d.max() < 600
     d = ops.draw_patch_ids([5000, 1400], 1, 700, DEV).cpu().numpy()
     assert len(np.unique(d[0, 0])) == 700 and len(np.unique(d[1, 0])) == 700 and d[1, 0].max() < 1400
+    # dense layers (P <= S < 2P): the sorted-permutation branch; P == S is a permutation of everything
+    d = ops.draw_patch_ids([300, 256, 4096], 3, 256, DEV).cpu().numpy()
+    for t in range(3):
+        assert len(np.unique(d[0, t])) == 256 and d[0, t].max() < 300
+        assert sorted(d[1, t]) == list(range(256))
+        assert len(np.unique(d[2, t])) == 256 and d[2, t].max() < 4096
+    assert not np.array_equal(d[1, 0], d[1, 1])                     # a different order per set
+    hits = np.zeros(300)
+    for _ in range(100):
+        hits += np.bincount(ops.draw_patch_ids([300], 8, 256, DEV).cpu().numpy().reshape(-1), minlength=300)
+    assert abs(hits.mean() - 800 * 256 / 300.0) < 1e-6 and hits.min() > 600 and hits.max() < 760, (hits.min(), hits.max())
     from dfmir_amd._lib import DfmirHipError
     with pytest.raises(DfmirHipError):
-        ops.draw_patch_ids([300], 1, 256, DEV)                      # S < 2P: not this kernel's job
+        ops.draw_patch_ids([200], 1, 256, DEV)                      # S < P: ragged, host path
+    with pytest.raises(DfmirHipError):
+        ops.draw_patch_ids([5000], 1, 3000, DEV)                    # dense and too large for the LDS sort
 
 
 def test_patch_gather_multi(ops):
