@@ -251,17 +251,9 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=3, help="eager steps after the timed region that time the dominant kernels")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    from dfmir_amd import distributed as dfdist
+    rank, world, dev_index = dfdist.init_from_env("nccl")     # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env
+    dev = torch.device("cuda", dev_index)
 
     from dfmir_amd import ops
     from dfmir_amd.options import default_options
@@ -295,8 +287,8 @@ def main():
         model.optimize_parameters()
 
     def fence():
-        if world > 1:
-            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dfdist.barrier()
         torch.cuda.synchronize()
 
     graphed = bool(opt.capture_step)
@@ -326,10 +318,7 @@ def main():
         timer.enabled = False
         model._graph['force_eager'] = False
 
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dfdist.allreduce_max(dt, dev)            # the slowest rank's clock
 
     ks = timer.summary()
     result = None
@@ -390,8 +379,7 @@ def main():
                          "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},
             "losses": {k: round(v, 6) for k, v in losses.items()},
         }
-    if world > 1:
-        torch.distributed.barrier()
+    dfdist.barrier()
     if rank == 0:
         ops.set_conv_profiler(None)
         if world == 1 and not args.no_3d:

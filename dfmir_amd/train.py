@@ -46,15 +46,9 @@ def parse(argv=None):
 
 def main(argv=None):
     opt = parse(argv)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+    from . import distributed as dfdist
+    rank, world, local_rank = dfdist.init_from_env("nccl")
     opt.gpu_ids = [local_rank]
-    torch.cuda.set_device(local_rank)
     dataset = create_dataset(opt)
     model = REGISTRATIONModel(opt)
     vis = Visualizer(opt) if rank == 0 else None
