@@ -327,10 +327,9 @@ def test_graph_captured_step_matches_eager(O):
     assert model._graph['eager_steps'] >= 2
 
 
-def test_full_size_step_vs_oracle(O):
-    """256x256, ngf=64 (BASELINE config 2 geometry at batch 1): one step of the HIP path against the
-    oracle on identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""
-    size, B = 256, 1
+def _full_size_oracle(O, B, double=False):
+    """256x256, ngf 64 oracle step state with seeded weights, pinned ids, a non-vacuous flow head; optionally fp64."""
+    size = 256
     torch.manual_seed(7)
     st = O.RegistrationStep(size, B, ngf=64)
     with torch.no_grad():
@@ -343,6 +342,15 @@ def test_full_size_step_vs_oracle(O):
         for p in st.netF.parameters():
             if p.dim() == 1:
                 p.add_(0.01)
+    if double:
+        for net in (st.netG, st.netF, st.netR):
+            net.double()
+        mk = lambda net: torch.optim.Adam(net.parameters(), lr=st.lr, betas=st.betas)
+        st.opt_G, st.opt_R, st.opt_F = mk(st.netG), mk(st.netR), mk(st.netF)
+    return st, size, A0, B0
+
+
+def _full_size_hip(st, size, B, A0, B0):
     model, opt = _hip_model_from_oracle(st, size, B, 64)
     call = [0]
     base_forward = model.netF.forward
@@ -354,41 +362,99 @@ def test_full_size_step_vs_oracle(O):
         return base_forward(feats, num_patches, patch_ids)
 
     model.netF.forward = netF_forward
-    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""], "B_paths": [""]})
+    paths = [""] * B
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": paths, "B_paths": paths})
     _load(model.netF, st.netF)
     model.setup(opt)
+    return model
+
+
+def test_full_size_step_vs_oracle(O):
+    """256x256, ngf=64 (BASELINE configs[1] geometry) at batch 2: one step of the HIP path against the oracle on
+    identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""
+    B = 2
+    st, size, A0, B0 = _full_size_oracle(O, B)
+    model = _full_size_hip(st, size, B, A0, B0)
     A_, B_ = C.image_pair(11, B, size, size)
     ref = st.step(A_, B_)
-    model.set_input({"A": A_, "B": B_, "A_paths": [""], "B_paths": [""]})
+    model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
     model.optimize_parameters()
     ls = model.get_current_losses()
     close(model.fake_B, st.fake_B, what="fake_B"); close(model.regA, st.regA, what="regA")
-    close(model.registered, st.registered, what="registered")
+    close(model.registered, st.registered, what="registered"); close(model.idt_B, st.idt_B, what="idt_B")
     for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
         assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
-    # gradients of the step (Adam's first update is lr*sign(g), so parameters are compared through g).
-    # Two fp32 implementations of a ~60-op-deep backward differ chaotically at the few activations whose
-    # ReLU / mask decisions sit on a rounding boundary, so deep gradients are compared in L2 / direction.
-    def deep_close(gh, go, what):
-        gh = gh.detach().cpu().double().flatten(); go = go.detach().double().flatten()
-        rel = float((gh - go).norm() / (go.norm() + 1e-300))
-        cos = float((gh @ go) / (gh.norm() * go.norm() + 1e-300))
-        assert rel <= 2e-2 and cos >= 0.9995, "%s: rel L2 err %.3e, cos %.6f" % (what, rel, cos)
-    for (k, po), (k2, ph) in zip(st.netG.named_parameters(), model.netG.named_parameters()):
-        assert k == k2
-        if k.endswith(".bias") and k != "model.30.bias":
-            continue  # zero true gradient (bias in front of InstanceNorm)
-        deep_close(ph.grad, po.grad, "grad G " + k)
-    for (k, po), (k2, ph) in zip(st.netR.named_parameters(), model.netR.named_parameters()):
-        deep_close(ph.grad, po.grad, "grad R " + k)
-    # netF: gradients behind the L2 normalisation are sums of per-row terms orthogonal to the row,
-    # i.e. cancellation-dominated; compare only those that rise above 1e-3 of the network's largest.
-    fmax = max(float(p.grad.abs().max()) for p in st.netF.parameters())
-    for (k, po), (k2, ph) in zip(st.netF.named_parameters(), model.netF.named_parameters()):
-        if float(po.grad.abs().max()) > 1e-3 * fmax:
-            deep_close(ph.grad, po.grad, "grad F " + k)
     moved = (model.netG.state_dict()["model.12.conv_block.1.weight"].cpu() - st.netG.state_dict()["model.12.conv_block.1.weight"]).abs().max()
     assert float(moved) <= 2.0 * 2e-4 * 1.001   # both took one Adam step of size <= lr
+
+
+def test_full_size_gradients_vs_fp64_oracle(O, capsys):
+    """The step's gradients at 256x256, ngf 64 (batch 1), arbitrated by an fp64 run of the oracle: the HIP path's
+    distance to the fp64 gradient is compared with the fp32 CPU oracle's own distance to it, parameter by parameter.
+    A ~60-op-deep fp32 backward differs from fp64 wherever a ReLU / mask decision sits on a rounding boundary, so
+    the yardstick is what plain fp32 PyTorch achieves, not zero.  (Replaces a 2e-2 / cos 0.9995 comparison between
+    the two fp32 implementations.)"""
+    B = 1
+    st32, size, A0, B0 = _full_size_oracle(O, B)
+    st64, _, _, _ = _full_size_oracle(O, B, double=True)
+    model = _full_size_hip(st32, size, B, A0, B0)
+    A_, B_ = C.image_pair(11, B, size, size)
+    st32.step(A_, B_)
+    st64.step(A_.double(), B_.double())
+    model.set_input({"A": A_, "B": B_, "A_paths": [""], "B_paths": [""]})
+    model.optimize_parameters()
+    rows = []
+    fmax = max(float(p.grad.abs().max()) for p in st64.netF.parameters())
+    for tag, n32, n64, nh in (("G", st32.netG, st64.netG, model.netG), ("R", st32.netR, st64.netR, model.netR),
+                              ("F", st32.netF, st64.netF, model.netF)):
+        for (k, p32), (_, p64), (k2, ph) in zip(n32.named_parameters(), n64.named_parameters(), nh.named_parameters()):
+            assert k == k2
+            if tag == "G" and k.endswith(".bias") and k != "model.30.bias":
+                continue  # zero true gradient (bias in front of InstanceNorm)
+            if tag == "F" and float(p64.grad.abs().max()) <= 1e-3 * fmax:
+                continue  # cancellation-dominated sums behind the L2 normalisation
+            g64 = p64.grad.flatten()
+            e_cpu = float((p32.grad.double().flatten() - g64).norm() / g64.norm())
+            e_hip = float((ph.grad.detach().cpu().double().flatten() - g64).norm() / g64.norm())
+            rows.append((e_hip, e_cpu, tag + "." + k))
+    worst = sorted(rows, key=lambda r: -r[0] / (r[1] + 1e-12))[:8] + sorted(rows, reverse=True)[:8]
+    with capsys.disabled():
+        print("\n  rel. L2 error vs the fp64 gradient (HIP, fp32 CPU oracle): worst ratios, then worst absolute")
+        for e_hip, e_cpu, k in worst:
+            print("    %-44s %.2e   %.2e" % (k, e_hip, e_cpu))
+    # measured (MI355X, round 2): HIP 1e-5 .. 2.7e-3 on G / R (the fp32 CPU oracle: 3e-6 .. 2.8e-3, the same layers
+    # at the top: model.1 / 4 / 8 / 12, where the backward is deepest), worst ratio HIP : CPU = 5.0 (model.22);
+    # netF's mlp_0.2.weight 1.1e-2 vs 2.8e-3.  Bounds = measured x 3 in absolute terms, and within 6x of fp32 PyTorch.
+    for e_hip, e_cpu, k in rows:
+        assert e_hip <= 6.0 * e_cpu + 2e-5, "%s: HIP %.3e vs fp64, fp32 CPU oracle %.3e" % (k, e_hip, e_cpu)
+        assert e_hip <= (3.5e-2 if k.startswith("F.") else 8e-3), "%s: HIP %.3e vs fp64" % (k, e_hip)
+
+
+def test_batch16_equals_per_sample_runs(O):
+    """BASELINE configs[1] at its own batch: every kernel on the path is per-sample, so fake_B[i], regA[i], flow[i] and
+    registered[i] of a batch-16 forward equal the batch-1 results sample by sample (up to the split convs' per-tensor
+    power-of-two scale, which depends on the batch maximum)."""
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    size, B = 256, 16
+    torch.manual_seed(5)
+    model = REGISTRATIONModel(default_options(batch_size=B, crop_size=size, load_size=size, ngf=64, gpu_ids=[0],
+                                              checkpoints_dir="/tmp/dfmir_ckpt", name="b16"))
+    with torch.no_grad():
+        model.netR.flow.weight.mul_(1e5)
+    A, Bm = C.image_pair(21, B, size, size)
+    A, Bm = A.to(DEV), Bm.to(DEV)
+    with torch.no_grad():
+        def run(a, b):
+            model.set_input({"A": a, "B": b, "A_paths": [""] * a.shape[0], "B_paths": [""] * a.shape[0]})
+            model.forward()
+            ys, yt, flow = model.netR(model.real_A, model.real_B)
+            return model.fake_B.clone(), model.idt_B.clone(), ys, flow, model.spatialTransformer(model.fake_B, flow)
+        full = run(A, Bm)
+        for i in (0, 7, 15):
+            one = run(A[i:i + 1], Bm[i:i + 1])
+            for nm, f, o in zip(("fake_B", "idt_B", "regA", "flow", "registered"), full, one):
+                close(f[i:i + 1], o, rtol=1e-5, what="%s[%d]" % (nm, i))
 
 
 @pytest.mark.parametrize("shape,plugin", [((32, 32, 32), False), ((64, 64, 64), True)])
