@@ -513,6 +513,38 @@ def test_full_size_conv_adjoint_and_linearity(cfg):
         assert err <= 2e-5 * float(y12.abs().max()), err
 
 
+@pytest.mark.parametrize("cfg", [(34, 32, (160, 192, 224)), (32, 16, (160, 192, 224)), (16, 3, (160, 192, 224)),
+                                 (48, 32, (80, 96, 112)), (34, 16, (128, 128, 128)), (48, 32, (64, 64, 64))],
+                         ids=["34to32@big", "32to16@big", "16to3@big", "48to32@half", "34to16@128", "48to32@64"])
+def test_full_size_conv3d_adjoint_and_linearity(cfg):
+    """BASELINE configs[3] / [4] layer shapes (VxmDense 3-D, plugin features at 128^3, default features at
+    160x192x224, batch 1): the 3x3x3 forward, dgrad and wgrad kernels (conv3d_mfma16_k / conv3d_wgrad16_k) satisfy
+    <conv(x,w), g> = <x, dgrad(g)> = <w, wgrad(x,g)>  and linearity in w to fp32 round-off of the fp64-accumulated
+    inner products -- size-independent identities at sizes no CPU oracle finishes."""
+    from dfmir_amd import ops
+    Cin, Cout, sp = cfg
+    lo = tuple(s // 8 for s in sp)
+    up = lambda t: torch.nn.functional.interpolate(t, size=sp, mode="trilinear", align_corners=True)
+    x = (up(C.randn(121, 1, Cin, *lo).to(DEV)) + 0.05 * torch.randn(1, Cin, *sp, device=DEV,
+         generator=torch.Generator(device=DEV).manual_seed(122))).requires_grad_()
+    w = (C.randn(123, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5).to(DEV).requires_grad_()
+    g = up(C.randn(124, 1, Cout, *lo).to(DEV)) + 0.05 * torch.randn(1, Cout, *sp, device=DEV,
+                                                                  generator=torch.Generator(device=DEV).manual_seed(125))
+    y = ops.conv(x, w, None, None, 1, 1, 0, 0, 0.0)
+    (y * g).sum().backward()
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    yg, xdx, wdw = dot(y, g), dot(x, x.grad), dot(w, w.grad)
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(yg - xdx) <= 2e-6 * scale, (yg, xdx, scale)
+    assert abs(yg - wdw) <= 2e-6 * scale, (yg, wdw, scale)
+    with torch.no_grad():
+        w2 = (C.randn(126, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5).to(DEV)
+        y12 = ops.conv(x, w.detach() + w2, None, None, 1, 1, 0, 0, 0.0)
+        y12 -= y
+        y12 -= ops.conv(x, w2, None, None, 1, 1, 0, 0, 0.0)
+        assert float(y12.abs().max()) <= 2e-5 * float(y.abs().max()), float(y12.abs().max())
+
+
 def test_full_size_warp_properties():
     """160x192x224 (BASELINE configs[4] geometry): zero displacement is the identity, an integer shift moves
     voxels exactly, and the warp is linear in src with d(src) as its adjoint."""
