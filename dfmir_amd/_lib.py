@@ -37,6 +37,11 @@ _SIGS = {
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
     "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],
+    "dfmir_conv3d_split_ok": [_GP],
+    "dfmir_conv3d_split_ws_floats": [c_int, c_int],
+    "dfmir_conv3d_split_fwd": [_GP, P, P, c_int, P, P, P, P, P, P],
+    "dfmir_probe_merge": [P, P, P, P],
+    "dfmir_act_bwd_amax": [P, P, P, c_longlong, c_int, c_float, P, P],
     "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],
     "dfmir_weight_unpack_add_batch": [P, c_int, c_longlong, P],
     "dfmir_conv7x7_c1_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
@@ -116,6 +121,7 @@ def lib():
             fn.argtypes = args
             fn.restype = c_int
         h.dfmir_weight_pack_floats.restype = c_longlong
+        h.dfmir_conv3d_split_ws_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []
         h.dfmir_last_error.restype = ctypes.c_char_p
         _lib = h

@@ -1,0 +1,281 @@
+// 3-D 3x3x3 stride-1 "same" convolution (forward and dgrad) of the VoxelMorph U-Net on the 16-bit matrix cores by
+// operand splitting -- the scaled fp16x2 form of conv3x3s.hip (a = (a0 + a1) / s, a*b ~= a0b0 + a0b1 + a1b0, fp32
+// accumulate) applied to the small-channel, huge-volume layers (16..64 channels, up to 6.9 M voxels) whose fp32-MFMA
+// kernels (conv3d.hip) top out at ~90 TFLOP/s.
+//
+// Workgroup = 256 threads = 4 waves; output tile 4 x 8 x 16 voxels x 32 output channels; wave w owns z-plane w of the
+// tile (128 voxels = 4 MFMA column tiles of 2 rows x 16).  Per chunk of 8 input channels:
+//   * the (4+2) x (8+2) x (16+2) halo patch is split when it is written to LDS: Xs[split][position] x (8 channels x
+//     fp16 = 16 B), zero padding by hardware-bounds-checked buffer loads;
+//   * the chunk's weights arrive pre-split from conv3d_wsplit_k, [chunk][split][28 taps][32 couts] x 16 B, and are
+//     copied to LDS as they are;
+//   * K = 16 of one v_mfma_f32_32x32x16_f16 = 2 taps x 8 channels: lanes 0-31 feed tap 2t, lanes 32-63 tap 2t+1
+//     (their B reads differ by the tap's patch offset); tap 27 pairs with zero weights (3.6 % idle).
+// The next chunk's global loads are issued before the 14 x 12 MFMAs of the current one and converted / stored after it
+// (one LDS buffer, two barriers per chunk).  More than 32 output channels = more workgroups along grid.y.
+// The epilogue rescales by 2^-(ex+ew), adds the bias, applies LeakyReLU and leaves the range probe of its OUTPUT
+// (64 accumulating slots, as the InstanceNorm kernels do) so that the next layer needs no absmax pass.
+#include "conv3x3_common.h"
+
+typedef _Float16 f16x8_3 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int scale_exp3(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  int e = (amax > 0.f) ? 14 - be : 0;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return e;
+}
+__device__ __forceinline__ float pow2f3(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+// (x0, x1) * s -> leading fp16 pair h and residual pair r (see split_pair_scaled in conv3x3s.hip)
+__device__ __forceinline__ void split_pair3(float x0, float x1, float s, unsigned& h, unsigned& r) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_3, a), __builtin_bit_cast(f16x8_3, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight split: w_tcc [27][K][M] fp32 (tap-major packing of dfmir_weight_pack, either mode) ->
+// ws[mtile][chunk][split][28][32] x (8 reduction channels x fp16), scaled by 2^ew with ew from max|w|;
+// trailer (4 floats after the units): [0] = ew as an int.  One workgroup; the layers are tiny (<= 110 K weights).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
+                                                        int M, float* __restrict__ trailer) {
+  __shared__ float sm[17];
+  float m = 0.f;
+  const int total = 27 * K * M;
+  for (int i = threadIdx.x; i < total; i += 1024) m = fmaxf(m, fabsf(w[i]));
+  m = block_max(m, sm);
+  if (!(m == m)) m = __uint_as_float(0x7f800000u);
+  const int ew = scale_exp3(m);
+  const float s = pow2f3(ew);
+  if (threadIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
+  const int nchunk = (K + 7) / 8, nmt = (M + 31) / 32;
+  const int units = nmt * nchunk * 28 * 32;                 // one unit = both splits of (mtile, chunk, tap, cout)
+  for (int u = threadIdx.x; u < units; u += 1024) {
+    const int co = u & 31;
+    int t = u >> 5;
+    const int tap = t % 28; t /= 28;
+    const int ch = t % nchunk, mt = t / nchunk;
+    const int mo = mt * 32 + co;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int kk = ch * 8 + c;
+      v[c] = (tap < 27 && kk < K && mo < M) ? w[((long long)tap * K + kk) * M + mo] : 0.f;
+    }
+    u32x4 h, r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hh, rr;
+      split_pair3(v[2 * q], v[2 * q + 1], s, hh, rr);
+      h[q] = hh; r[q] = rr;
+    }
+    const long long base = (((long long)mt * nchunk + ch) * 2) * (28 * 32);
+    ws[base + tap * 32 + co] = h;
+    ws[base + 28 * 32 + tap * 32 + co] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct C3sP {
+  int N, Cin, Cout, D, H, W;
+  int act;
+  float slope;
+  int nz, ny, nx;                // tiles per axis
+  int nchunk;
+  int x_n;                       // floats of the input range probe
+};
+
+__global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                      const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      float* __restrict__ y_amax, C3sP k) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
+  constexpr int XP = (TZ + 2) * HY * HX;                  // 1080 positions
+  constexpr int NS = (XP + 255) / 256;                    // 5 position slots per thread
+  constexpr int WU = 2 * 28 * 32;                         // 1792 16-B units of one chunk's weights
+  constexpr int NW = WU / 256;                            // 7
+  __shared__ u32x4 Xs[2 * XP];
+  __shared__ u32x4 Ws[WU];
+  __shared__ float red[17];
+  __shared__ unsigned smax;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long S = (long long)k.D * k.H * k.W;
+  int pid = blockIdx.x;
+  const int bx = pid % k.nx; pid /= k.nx;
+  const int by = pid % k.ny; pid /= k.ny;
+  const int bz = pid % k.nz;
+  const int n = pid / k.nz;
+  const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
+  const int mt = blockIdx.y;
+
+  // scales: input scaled by 2^ex when it is split, result rescaled by 2^-ex * 2^-ew
+  const float amax = reduce_absmax(x_amax, k.x_n, red);
+  const int ex = scale_exp3(amax);
+  const int ew = reinterpret_cast<const int*>(w_trailer)[0];
+  const float xscale = pow2f3(ex), oscale = pow2f3(-ex), oscale2 = pow2f3(-ew);
+  if (tid == 0) smax = 0u;
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (long long)n * k.Cin * S), 0, (unsigned)((long long)k.Cin * S * 4), 0x00020000);
+  const unsigned s4 = (unsigned)S * 4u;
+  unsigned gbyte[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pos = tid + 256 * s;
+    unsigned off = OOB;
+    if (pos < XP) {
+      const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
+        off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+    }
+    gbyte[s] = off;
+  }
+  const u32x4* wchunk = wsp + (long long)mt * k.nchunk * WU;
+
+  // this lane's B positions: column tile j = rows 2j, 2j+1 of plane wid; voxel (row, x) = (2j + (l31 >> 4), l31 & 15)
+  int pbase[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pbase[j] = (wid * HY + 2 * j + (l31 >> 4)) * HX + (l31 & 15);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float rx[NS][8];
+  u32x4 rw[NW];
+
+#define C3S_GLOAD(ch_)                                                                            \
+  {                                                                                               \
+    const unsigned cbase = (unsigned)((ch_) * 8) * s4;                                            \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                              \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                             \
+        const bool okc = ((ch_) * 8 + c) < k.Cin;                                                 \
+        rx[s][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                          \
+            x_src, okc ? gbyte[s] + cbase + (unsigned)c * s4 : OOB, 0, 0));                       \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) rw[j] = wchunk[(long long)(ch_) * WU + tid + 256 * j]; \
+  }
+#define C3S_LSTORE()                                                                              \
+  {                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                              \
+      const int pos = tid + 256 * s;                                                              \
+      if (pos < XP) {                                                                             \
+        u32x4 h, r;                                                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                           \
+          unsigned hh, rr;                                                                        \
+          split_pair3(rx[s][2 * q], rx[s][2 * q + 1], xscale, hh, rr);                            \
+          h[q] = hh; r[q] = rr;                                                                   \
+        }                                                                                         \
+        Xs[pos] = h;                                                                              \
+        Xs[XP + pos] = r;                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) Ws[tid + 256 * j] = rw[j];                     \
+  }
+
+  C3S_GLOAD(0);
+  C3S_LSTORE();
+  __syncthreads();
+
+  for (int ch = 0; ch < k.nchunk; ++ch) {
+    const bool more = (ch + 1) < k.nchunk;
+    if (more) C3S_GLOAD(ch + 1);
+#pragma unroll
+    for (int tp = 0; tp < 14; ++tp) {
+      const int t0 = 2 * tp, t1 = (2 * tp + 1) < 27 ? 2 * tp + 1 : 0;     // tap 27: zero weights, any valid offset
+      const int o0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3;
+      const int o1 = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
+      const int toff = hi ? o1 : o0;
+      const int tap = 2 * tp + hi;
+      const u32x4 a0 = Ws[tap * 32 + l31], a1 = Ws[28 * 32 + tap * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 b0 = Xs[pbase[j] + toff], b1 = Xs[XP + pbase[j] + toff];
+        acc[j] = mma3(a1, b0, acc[j]);
+        acc[j] = mma3(a0, b1, acc[j]);
+        acc[j] = mma3(a0, b0, acc[j]);
+      }
+    }
+    if (more) {
+      __syncthreads();
+      C3S_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef C3S_GLOAD
+#undef C3S_LSTORE
+
+  // ---- epilogue: acc[j][r] <-> cout = mt*32 + (r>>2)*8 + hi*4 + (r&3), voxel (wid, 2j + (l31>>4), l31&15)
+  float pm = 0.f;
+  const int gz = z0 + wid;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gy = y0 + 2 * j + (l31 >> 4), gx = x0 + (l31 & 15);
+    if (gz >= k.D || gy >= k.H || gx >= k.W) continue;
+    float* yb = y + (long long)n * k.Cout * S + ((long long)gz * k.H + gy) * k.W + gx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = mt * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+      if (co < k.Cout) {
+        float v = acc[j][r] * oscale * oscale2 + (bias ? bias[co] : 0.f);
+        if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+        else if (k.act == 2) v = tanhf(v);
+        yb[(long long)co * S] = v;
+        pm = fmaxf(pm, fabsf(v));
+      }
+    }
+  }
+  if (y_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, y_amax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool split3d_off() {
+  static int v = -1;
+  if (v < 0) v = (getenv("DFMIR_CONV3D_FP32") || getenv("DFMIR_CONV_FP32")) ? 1 : 0;
+  return v == 1;
+}
+static bool split3d_geom_ok(const DfConvGeom* g) {
+  return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
+         g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
+         g->Cin >= 8 && g->Cout >= 8 && (long long)g->Cin * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;   // buffer offsets, OOB marker
+}
+extern "C" int dfmir_conv3d_split_ok(const DfConvGeom* g) { return (g && !split3d_off() && split3d_geom_ok(g)) ? 1 : 0; }
+extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0) return -1;
+  return (long long)((Cout + 31) / 32) * ((Cin + 7) / 8) * 2 * 28 * 32 * 4 + 4;
+}
+extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                      const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                      void* stream) {
+  DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && w_tcc && ws && y);
+  DF_ARG_CHECK(!split3d_off() && split3d_geom_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (g->Cin + 7) / 8, nmt = (g->Cout + 31) / 32;
+  float* trailer = ws + (long long)nmt * nchunk * 2 * 28 * 32 * 4;
+  conv3d_wsplit_k<<<1, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, g->Cout, trailer);
+  DF_LAUNCH_CHECK();
+  C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
+         nchunk, x_amax_n};
+  const long long nb = (long long)g->N * k.nz * k.ny * k.nx;
+  DF_ARG_CHECK(nb < (1LL << 31));
+  conv3d_split_k<<<dim3((unsigned)nb, (unsigned)nmt), 256, 0, st>>>(x, x_amax, reinterpret_cast<const u32x4*>(ws), trailer,
+                                                                   bias, y, y_amax, k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -289,3 +289,17 @@ extern "C" int dfmir_scalar_combine_bwd(const float* gout, int n_in, const float
   DF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// out[i] = max(a[i], b[i]) over DF_PROBE_SLOTS floats: the range probe of cat([up2(a), b]) from its inputs' probes
+// (nearest up-sampling and concatenation create no new values).
+// ------------------------------------------------------------------------------------------------
+__global__ void probe_merge_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+  out[threadIdx.x] = fmaxf(a[threadIdx.x], b[threadIdx.x]);
+}
+extern "C" int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream) {
+  DF_ARG_CHECK(a && b && out);
+  probe_merge_k<<<1, DF_PROBE_SLOTS, 0, (hipStream_t)stream>>>(a, b, out);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -265,6 +265,36 @@ __global__ void act_bwd_k(const float* __restrict__ dy, const float* __restrict_
   }
 }
 
+// the same, 4 elements per thread, leaving the range probe of dx (DF_PROBE_SLOTS accumulating slots) for the split
+// convolutions that consume it (dgrad / wgrad of the layer in front of the activation)
+__global__ __launch_bounds__(256) void act_bwd_amax_k(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dx, long long n, int act, float slope,
+                                                      float* __restrict__ amax) {
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
+  __syncthreads();
+  const long long n4 = n >> 2;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 yv = reinterpret_cast<const float4*>(y)[i], g = reinterpret_cast<const float4*>(dy)[i];
+    float4 o;
+    o.x = (act == 2) ? g.x * (1.f - yv.x * yv.x) : (yv.x > 0.f ? g.x : g.x * slope);
+    o.y = (act == 2) ? g.y * (1.f - yv.y * yv.y) : (yv.y > 0.f ? g.y : g.y * slope);
+    o.z = (act == 2) ? g.z * (1.f - yv.z * yv.z) : (yv.z > 0.f ? g.z : g.z * slope);
+    o.w = (act == 2) ? g.w * (1.f - yv.w * yv.w) : (yv.w > 0.f ? g.w : g.w * slope);
+    reinterpret_cast<float4*>(dx)[i] = o;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float yv = y[i], g = dy[i];
+    const float o = (act == 2) ? g * (1.f - yv * yv) : (yv > 0.f ? g : g * slope);
+    dx[i] = o;
+    m = fmaxf(m, fabsf(o));
+  }
+  publish_block_absmax_acc(m, &smax, amax);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Downsample: y[oy][ox] = sum_{a,b} f[a]f[b] x[refl(2oy+a-1)][refl(2ox+b-1)], f = [1,2,1]/4
 // ---------------------------------------------------------------------------------------------
@@ -755,6 +785,14 @@ extern "C" int dfmir_act_bwd(const float* dy, const float* y, float* dx, long lo
                              float slope, void* stream) {
   DF_ARG_CHECK(dy && y && dx && n > 0 && (act == 1 || act == 2));
   act_bwd_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, slope);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_act_bwd_amax(const float* dy, const float* y, float* dx, long long n, int act, float slope,
+                                  float* dx_amax, void* stream) {
+  DF_ARG_CHECK(dy && y && dx && dx_amax && n > 0 && (act == 1 || act == 2));
+  DF_ARG_CHECK(((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0);
+  act_bwd_amax_k<<<df_grid((n + 3) / 4, 256, 4096), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, slope, dx_amax);
   DF_LAUNCH_CHECK();
   return 0;
 }

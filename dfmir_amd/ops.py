@@ -119,8 +119,14 @@ def amax_of(t):
     return absmax(t)
 
 
+_NO_SPLIT3D = bool(os.environ.get("DFMIR_CONV3D_FP32") or os.environ.get("DFMIR_CONV_FP32"))
+
+
 def _wants_amax(K, stride, dil, Di, Cin, Cout):
-    """Shapes the split 3x3 kernels take (the C side decides; this only avoids useless probes)."""
+    """Shapes the split kernels take (the C side decides; this only avoids useless probes): 2-D 3x3 with more than
+    32 output channels (csrc/conv3x3s.hip), 3-D 3x3x3 with at least 8 channels on both sides (csrc/conv3ds.hip)."""
+    if tuple(K) == (3, 3, 3):
+        return stride == 1 and dil == 1 and Di > 1 and Cin >= 8 and Cout >= 8 and not _NO_SPLIT3D
     return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
 
 
@@ -134,9 +140,19 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
     fuse_res = (res is not None and not _NO_RES and x_amax is not None and res.is_contiguous() and tuple(res.shape) == tuple(y.shape)
                 and lib().dfmir_conv3x3_res_ok(ctypes.byref(g)))
+    split3d = (x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
+               and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
 
     def launch():
-        if fuse_res or ring is not None:
+        if split3d:
+            # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer
+            ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_split_fwd(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
+                                               _p(bias), _p(y), _p(slot), _st()))
+            tag_amax(y, slot)              # survives as is when y is a backward result (dgrad) ...
+            _LAST_CONV_AMAX[0] = slot      # ... and is re-attached by conv() to the tensor Function.apply returns
+        elif fuse_res or ring is not None:
             check(lib().dfmir_conv3x3_fwd_scaled_res(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc),
                                                      _p(bias), _p(res) if fuse_res else None,
                                                      _p(ring[0]) if ring is not None else None,
@@ -159,7 +175,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                  and pad[1] in (1, 2) and Cout > 4)
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
-        prof(("conv3x3_" if is3x3 else ("conv3d_" if is3d else "conv_mfma_")) + size, flops, launch)
+        prof(("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size, flops, launch)
     return y
 
 
@@ -397,16 +413,23 @@ class ConvFn(Function):
             return (dskip,) + (None,) * 9
         x5, weight, y5 = ctx.saved_tensors
         dy5 = _c(dy) if nd == 3 else _c(dy).unsqueeze(2)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        want_probe = _wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None
+        dy_amax = None
         if act:
             dpre = torch.empty_like(dy5)
-            check(lib().dfmir_act_bwd(_p(dy5), _p(y5), _p(dpre), dy5.numel(), act, float(slope), _st()))
+            if want_probe and nd == 3 and not ((dy5.data_ptr() | y5.data_ptr() | dpre.data_ptr()) & 15):
+                # the activation's backward leaves the range probe of what it writes (3-D tensors are 0.1-1 GB: a
+                # separate absmax pass would cost 10 % of the dgrad it serves)
+                dy_amax = amax_slot(dy5.device, PROBE_SLOTS)
+                check(lib().dfmir_act_bwd_amax(_p(dy5), _p(y5), _p(dpre), dy5.numel(), act, float(slope), _p(dy_amax), _st()))
+            else:
+                check(lib().dfmir_act_bwd(_p(dy5), _p(y5), _p(dpre), dy5.numel(), act, float(slope), _st()))
             dy5 = dpre
         dx = dw = db = None
-        Cout, Cin = weight.shape[0], weight.shape[1]
         # dY feeds the dgrad conv (as its input) and the wgrad: one range probe for both
-        dy_amax = None
-        if _wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None:
-            dy_amax = amax_of(dy) if dy.is_contiguous() else absmax(dy5)
+        if want_probe and dy_amax is None:
+            dy_amax = amax_of(dy) if (dy.is_contiguous() and not act) else absmax(dy5)
         if ctx.needs_input_grad[0]:
             wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
             in_sp = tuple(x5.shape[2:])
@@ -482,8 +505,16 @@ class ConvFn(Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+_LAST_CONV_AMAX = [None]
+
+
 def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0, skip=False):
-    return ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope, skip)
+    _LAST_CONV_AMAX[0] = None
+    out = ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope, skip)
+    if _LAST_CONV_AMAX[0] is not None and not skip:
+        tag_amax(out, _LAST_CONV_AMAX[0])
+        _LAST_CONV_AMAX[0] = None
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -750,8 +781,21 @@ class UpCatFn(Function):
         return da, db
 
 
+def _valid_amax(t):
+    tag = getattr(t, "_df_amax", None)
+    if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() and tag[0].numel() == PROBE_SLOTS:
+        return tag[0]
+    return None
+
+
 def upcat(a, b):
-    return UpCatFn.apply(a, b)
+    y = UpCatFn.apply(a, b)
+    pa, pb = _valid_amax(a), _valid_amax(b)
+    if pa is not None and pb is not None:      # nearest up-sampling + concatenation create no new values
+        slot = amax_slot(y.device, PROBE_SLOTS)
+        check(lib().dfmir_probe_merge(_p(pa), _p(pb), _p(slot), _st()))
+        tag_amax(y, slot)
+    return y
 
 
 class CatChannelsFn(Function):

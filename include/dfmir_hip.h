@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 4
+#define DFMIR_ABI_VERSION 5
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -74,6 +74,18 @@ int dfmir_conv_fwd_scaled(const DfConvGeom* g, const float* x, const float* x_am
  * DFMIR_PROBE_SLOTS after the InstanceNorm entry points). */
 #define DFMIR_PROBE_SLOTS 64
 int dfmir_absmax(const float* x, long long n, float* out, void* stream);
+/* 3-D 3x3x3 stride-1 "same" convolution (Cin, Cout >= 8) on the 16-bit matrix pipe in the scaled fp16x2 split form
+ * (csrc/conv3ds.hip) -- the VoxelMorph U-Net's stride-1 ConvBlocks and their input gradients
+ * (models/voxelmorph/torchvoxelmorph/networks.py:73-86,1506-1521).  x_amax as for dfmir_conv_fwd_scaled (required);
+ * ws: dfmir_conv3d_split_ws_floats(Cin, Cout) floats of 16-byte aligned scratch (the call splits the weights into it);
+ * y_amax (may be NULL): DFMIR_PROBE_SLOTS zero-initialised floats that receive the range probe of y.
+ * dfmir_conv3d_split_ok: 1 when the geometry is taken (0 under DFMIR_CONV3D_FP32=1 / DFMIR_CONV_FP32=1). */
+int dfmir_conv3d_split_ok(const DfConvGeom* g);
+long long dfmir_conv3d_split_ws_floats(int Cin, int Cout);
+int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
+                           float* ws, const float* bias, float* y, float* y_amax, void* stream);
+/* out[0..DFMIR_PROBE_SLOTS) = max(a, b): the probe of cat([nearest_up2(a), b]) from its inputs' probes. */
+int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */
 int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                      void* stream);
@@ -178,6 +190,10 @@ int dfmir_instnorm_bwd_cols(const float* dy, const float* x, const float* mean, 
 /* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
 int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,
                   void* stream);
+/* The same, also leaving the range probe of dx in dx_amax[DFMIR_PROBE_SLOTS] (zero-initialised by the caller; pointers
+ * 16-byte aligned): dx feeds the split dgrad / wgrad of the layer in front of the activation. */
+int dfmir_act_bwd_amax(const float* dy, const float* y, float* dx, long long n, int act, float slope,
+                       float* dx_amax, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Anti-aliased resampling of the generator -- models/networks.py:37-60 (Downsample: reflect pad 1,
