@@ -150,8 +150,9 @@ def bench_3d(dev, steps=5, warmup=2):
     sizes = ("small", "S", "M", "L")
     sp_kinds = ["conv3ds_" + z for z in sizes]          # split fp16x2 kernel (csrc/conv3ds.hip)
     fw_kinds = ["conv3d_" + z for z in sizes]           # fp32-MFMA kernel (csrc/conv3d.hip): Cout < 8 layers, or A/B env
-    wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]
-    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds)
+    wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]      # fp32-MFMA wgrad (Cout < 8 / Cin > 48 layers)
+    wgs_kinds = ["wgrad3ds_" + z for z in ("S", "M", "L")]    # split fp16x2 wgrad
+    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds)
     ops.set_conv_profiler(timer)
     for _ in range(warmup):
         m.set_input({"A": A, "B": B})
@@ -178,6 +179,7 @@ def bench_3d(dev, steps=5, warmup=2):
     sp_tf, sp_n, sp_ms = agg(sp_kinds)
     fw_tf, fw_n, fw_ms = agg(fw_kinds)
     wg_tf, wg_n, wg_ms = agg(wg_kinds)
+    wgs_tf, wgs_n, wgs_ms = agg(wgs_kinds)
     if sp_n:
         roof = {"bound": "mfma", "achieved": 3.0 * sp_tf, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": 3.0 * sp_tf / FP16_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -192,8 +194,14 @@ def bench_3d(dev, steps=5, warmup=2):
                 "frac": fw_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "kernel": "conv3d_mfma16_k (v_mfma_f32_16x16x4_f32): forward + dgrad of every stride-1 3x3x3 conv",
                 "launches_timed": fw_n, "avg_launch_ms": fw_ms / max(fw_n, 1)}
-    roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_kernel_tflops": wg_tf,
-                 "wgrad_frac_of_fp32_peak": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n})
+    if wgs_n:
+        roof.update({"wgrad_kernel": "conv3d_wgrad_split_k (voxels as the matrix K, three x-aligned fp16-pair copies of the "
+                                     "input patch in LDS, accumulators of all (tap, ci) x co resident)",
+                     "wgrad_achieved": 3.0 * wgs_tf, "wgrad_frac": 3.0 * wgs_tf / FP16_MFMA_PEAK_TFLOPS,
+                     "wgrad_algorithmic_tflops": wgs_tf, "wgrad_launches_timed": wgs_n})
+    else:
+        roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_kernel_tflops": wg_tf,
+                     "wgrad_frac_of_fp32_peak": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n})
     return {"workload": "3-D 160x192x224 volume pair, batch 1, VxmDense default features + NCC[9,9,9] + Grad-l2, "
                         "fwd+bwd+Adam (BASELINE configs[4] geometry, one GPU)",
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,

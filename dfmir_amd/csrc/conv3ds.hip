@@ -279,3 +279,244 @@ extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const
   DF_LAUNCH_CHECK();
   return 0;
 }
+
+// ================================================================================================
+// wgrad:  dWt[tap][ci][co] += sum_v X[ci][v + tap] * dY[co][v]   with the VOXEL as the MFMA K (16 consecutive x).
+//
+// Workgroup = 4 waves, persistent over 2 x 4 x 16-voxel patches of its share of the volume, ALL input channels
+// (<= 48, in chunks of 8) and all output channels (<= 32).  MFMA rows = (tap, ci) of a chunk (27 x 8 = 216 -> 7 row
+// tiles of 32), columns = co.  Wave w keeps the accumulators of row tiles {(w+c) mod 4, (w+c) mod 4 + 4} of every
+// chunk c (the padding tile 7 rotates over the waves) and runs all 8 k-steps (x-rows) of a patch for them, so no
+// cross-wave reduction is needed; one atomicAdd per accumulator at the very end (split-K over workgroups).
+// LDS per patch: dY split once, [split][co][row][unit] (unit = 8 voxels x fp16 = 16 B); per chunk: X split into three
+// x-aligned copies [split][dx][ci][hz][hy][unit] (copy dx holds x + dx - 1), so every tap reads 16-B aligned units
+// (an unaligned ds_read_b128 runs at quarter rate).  A thread converts one 18-voxel row: 9 packed pairs serve the
+// copies dx = 0 and dx = 2 (same pairing, one dword apart), v_alignbit makes the dx = 1 pairing.
+// ================================================================================================
+struct W3sP {
+  int N, Cin, Cout, D, H, W;
+  int nz, ny, nx;
+  long long npatch, per_block;
+  int x_n, dy_n;
+  int nchunk;                    // chunks of 8 input channels in the layer; blockIdx.y * NCH = this workgroup's first
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                            const float* __restrict__ dy, const float* __restrict__ dy_amax,
+                                                            float* __restrict__ dwt, W3sP k) {
+  constexpr int PZ = 2, PY = 4, HZ = PZ + 2, HY = PY + 2;
+  constexpr int CIS = HZ * HY * 2 + 1;                    // 49 units: ci stride == 16 B (mod 256 B)
+  constexpr int XSPL = 3 * 8 * CIS;                       // 1176 units per split
+  constexpr int COS = 17, YSPL = 32 * COS;                // dY: co stride 17 units, 544 per split
+  __shared__ u32x4 Xs[2 * XSPL];
+  __shared__ u32x4 Ys[2 * YSPL];
+  __shared__ float red[17];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long S = (long long)k.D * k.H * k.W;
+
+  const int ex = scale_exp3(reduce_absmax(x_amax, k.x_n, red));
+  __syncthreads();
+  const int ed = scale_exp3(reduce_absmax(dy_amax, k.dy_n, red));
+  const float xscale = pow2f3(ex), dscale = pow2f3(ed), oscale = pow2f3(-ex), oscale2 = pow2f3(-ed);
+
+  f32x16 acc[NCH][2];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][s][r] = 0.f;
+
+  // staging roles
+  const bool xrow = tid < 8 * HZ * HY;                    // 192 threads: one (ci, hz, hy) row of 18 voxels each
+  const int xci = tid / (HZ * HY), xrem = tid % (HZ * HY), xhz = xrem / HY, xhy = xrem % HY;
+  const int yco = tid >> 3, yr = tid & 7;                 // dY: (co, row) -> 16 voxels
+  constexpr unsigned OOB = 0x80000000u;
+
+  const int c_base = blockIdx.y * NCH;
+  const long long p_begin = (long long)blockIdx.x * k.per_block;
+  long long p_end = p_begin + k.per_block;
+  if (p_end > k.npatch) p_end = k.npatch;
+  if (p_begin >= p_end) return;
+  const int niter = (int)(p_end - p_begin) * NCH;
+
+  float rx[18];
+  u32x4 ry[4];
+  __amdgpu_buffer_rsrc_t x_src, y_src;
+  int pz0 = 0, py0 = 0, px0 = 0;
+
+#define W3S_GLOAD(it_)                                                                            \
+  {                                                                                               \
+    const long long p_ = p_begin + (it_) / NCH;                                                   \
+    const int c_ = (it_) % NCH;                                                                   \
+    const int ca_ = c_base + c_;                                                                  \
+    long long q_ = p_;                                                                            \
+    const int bx_ = (int)(q_ % k.nx); q_ /= k.nx;                                                 \
+    const int by_ = (int)(q_ % k.ny); q_ /= k.ny;                                                 \
+    const int bz_ = (int)(q_ % k.nz);                                                             \
+    const int n_ = (int)(q_ / k.nz);                                                              \
+    pz0 = bz_ * PZ; py0 = by_ * PY; px0 = bx_ * 16;                                               \
+    x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)n_ * k.Cin * S), 0,   \
+                                              (unsigned)((long long)k.Cin * S * 4), 0x00020000);  \
+    {                                                                                             \
+      const int gz = pz0 - 1 + xhz, gy = py0 - 1 + xhy, ci = ca_ * 8 + xci;                       \
+      const bool rowok = xrow && ci < k.Cin && (unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H;  \
+      const unsigned base = (unsigned)(((long long)ci * S + ((long long)gz * k.H + gy) * k.W + px0 - 1) * 4);  \
+      _Pragma("unroll") for (int j = 0; j < 18; ++j) {                                            \
+        const int gx = px0 - 1 + j;                                                               \
+        rx[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                             \
+            x_src, (rowok && (unsigned)gx < (unsigned)k.W) ? base + 4u * j : OOB, 0, 0));         \
+      }                                                                                           \
+    }                                                                                             \
+    if (c_ == 0) {                                                                                \
+      y_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (long long)n_ * k.Cout * S), 0,   \
+                                                (unsigned)((long long)k.Cout * S * 4), 0x00020000);   \
+      const int gz = pz0 + (yr >> 2), gy = py0 + (yr & 3);                                        \
+      const bool rowok = yco < k.Cout && gz < k.D && gy < k.H;                                    \
+      const unsigned base = (unsigned)(((long long)yco * S + ((long long)gz * k.H + gy) * k.W + px0) * 4);  \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+        ry[q] = __builtin_amdgcn_raw_buffer_load_b128(y_src, (rowok && px0 + 4 * q < k.W) ? base + 16u * q : OOB, 0, 0);  \
+    }                                                                                             \
+  }
+
+  W3S_GLOAD(0);
+  for (int it = 0; it < niter; ++it) {
+    const int c = it % NCH;
+    __syncthreads();                                       // previous compute is done with the LDS buffers
+    if (xrow) {
+      unsigned ph[9], pr[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) split_pair3(rx[2 * j], rx[2 * j + 1], xscale, ph[j], pr[j]);
+      const int ubase = xci * CIS + (xhz * HY + xhy) * 2;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 h0, h1, h2, r0, r1, r2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h0[q] = ph[4 * u + q]; r0[q] = pr[4 * u + q];                               // voxels x-1 .. (copy dx = 0)
+          h2[q] = ph[4 * u + q + 1]; r2[q] = pr[4 * u + q + 1];                       // voxels x+1 .. (copy dx = 2)
+          h1[q] = __builtin_amdgcn_alignbit(ph[4 * u + q + 1], ph[4 * u + q], 16);    // voxels x ..   (copy dx = 1)
+          r1[q] = __builtin_amdgcn_alignbit(pr[4 * u + q + 1], pr[4 * u + q], 16);
+        }
+        Xs[0 * 8 * CIS + ubase + u] = h0; Xs[XSPL + 0 * 8 * CIS + ubase + u] = r0;
+        Xs[1 * 8 * CIS + ubase + u] = h1; Xs[XSPL + 1 * 8 * CIS + ubase + u] = r1;
+        Xs[2 * 8 * CIS + ubase + u] = h2; Xs[XSPL + 2 * 8 * CIS + ubase + u] = r2;
+      }
+    }
+    if (c == 0) {
+      const int ub = yco * COS + yr * 2;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 h, r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const u32x4 v = ry[2 * u + q];
+          unsigned hh, rr;
+          split_pair3(__uint_as_float(v[0]), __uint_as_float(v[1]), dscale, hh, rr);
+          h[2 * q] = hh; r[2 * q] = rr;
+          split_pair3(__uint_as_float(v[2]), __uint_as_float(v[3]), dscale, hh, rr);
+          h[2 * q + 1] = hh; r[2 * q + 1] = rr;
+        }
+        Ys[ub + u] = h;
+        Ys[YSPL + ub + u] = r;
+      }
+    }
+    __syncthreads();
+    if (it + 1 < niter) W3S_GLOAD(it + 1);
+
+    // this wave's two row tiles of chunk c
+    int aoff[2];
+    bool tok[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int tile = ((wid + c) & 3) + 4 * s;
+      tok[s] = tile < 7;
+      int rho = tile * 32 + l31;
+      if (rho > 215) rho = 215;                            // padding rows: any valid address (results discarded)
+      const int tap = rho >> 3, ci = rho & 7;
+      const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
+      aoff[s] = (dx * 8 + ci) * CIS + (dz * HY + dyy) * 2 + hi;
+    }
+    const int boff = l31 * COS + hi;
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) {
+      if (c2 != c || c_base + c >= k.nchunk) continue;     // static accumulator index; a padding chunk has no work
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int zy = ((r >> 2) * HY + (r & 3)) * 2;
+        const u32x4 b0 = Ys[boff + r * 2], b1 = Ys[YSPL + boff + r * 2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (!tok[s]) continue;
+          const u32x4 a0 = Xs[aoff[s] + zy], a1 = Xs[XSPL + aoff[s] + zy];
+          acc[c2][s] = mma3(a1, b0, acc[c2][s]);
+          acc[c2][s] = mma3(a0, b1, acc[c2][s]);
+          acc[c2][s] = mma3(a0, b0, acc[c2][s]);
+        }
+      }
+    }
+  }
+#undef W3S_GLOAD
+
+  // ---- epilogue: acc[c][s][r] <-> row (r>>2)*8 + hi*4 + (r&3) of tile ((wid+c)&3) + 4s, column co = l31
+  const float sc = oscale * oscale2;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int tile = ((wid + c) & 3) + 4 * s;
+      if (tile >= 7 || l31 >= k.Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = tile * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+        const int tap = rho >> 3, ci = (c_base + c) * 8 + (rho & 7);
+        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[((long long)tap * k.Cin + ci) * k.Cout + l31], acc[c][s][r] * sc);
+      }
+    }
+}
+
+static bool split3d_wgrad_geom_ok(const DfConvGeom* g) {
+  return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
+         g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
+         g->Cin >= 8 && g->Cin <= 48 && g->Cout >= 8 && g->Cout <= 32 && (g->Wi & 3) == 0 &&
+         (long long)g->Cin * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL && (long long)g->Cout * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;
+}
+extern "C" int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g) {
+  return (g && !split3d_off() && split3d_wgrad_geom_ok(g)) ? 1 : 0;
+}
+extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                        const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
+                                        void* stream) {
+  DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
+  DF_ARG_CHECK(!split3d_off() && split3d_wgrad_geom_ok(g));
+  hipStream_t st = (hipStream_t)stream;
+  W3sP k{};
+  k.N = g->N; k.Cin = g->Cin; k.Cout = g->Cout; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
+  k.nz = (g->Di + 1) / 2; k.ny = (g->Hi + 3) / 4; k.nx = (g->Wi + 15) / 16;
+  k.npatch = (long long)g->N * k.nz * k.ny * k.nx;
+  long long want = 512;
+  if (want > k.npatch) want = k.npatch;
+  k.per_block = (k.npatch + want - 1) / want;
+  k.x_n = x_amax_n; k.dy_n = dy_amax_n;
+  // <= 3 chunks of accumulators per workgroup (96 AGPRs + staging registers: two workgroups per CU, so that one
+  // converts while the other computes); more input channels = a second workgroup row, which stages dY again
+  k.nchunk = (g->Cin + 7) / 8;
+  const int per_wg = k.nchunk <= 3 ? k.nchunk : (k.nchunk == 4 ? 2 : 3);
+  const unsigned gy = (unsigned)((k.nchunk + per_wg - 1) / per_wg);
+  if (gy > 1) {                                             // keep the number of workgroups
+    want = 512 / gy;
+    if (want > k.npatch) want = k.npatch;
+    k.per_block = (k.npatch + want - 1) / want;
+  }
+  const unsigned nbx = (unsigned)((k.npatch + k.per_block - 1) / k.per_block);
+#define W3S_LAUNCH(N_) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(x, x_amax, dy, dy_amax, dw_tcc, k)
+  if (per_wg == 1) W3S_LAUNCH(1);
+  else if (per_wg == 2) W3S_LAUNCH(2);
+  else W3S_LAUNCH(3);
+#undef W3S_LAUNCH
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -187,7 +187,16 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
     dw = zeros((T, Cin, Cout), x5.device) if out is None else out
     g = DfConvGeom(N, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, K[0], K[1], K[2], stride, 1, pad[0], pad[1],
                    pad[2], pad_mode, 0, 0.0)
+    split3d = (x_amax is not None and dy_amax is not None and tuple(K) == (3, 3, 3)
+               and bool(lib().dfmir_conv3d_split_wgrad_ok(ctypes.byref(g))))
+
     def launch():
+        if split3d:
+            check(lib().dfmir_conv3d_split_wgrad(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax),
+                                                 dy_amax.numel(), _p(dw), _st()))
+            if db is not None:
+                check(lib().dfmir_bias_grad(_p(dy5), _p(db), N, Cout, Do * Ho * Wo, _st()))   # accumulates
+            return
         check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
                                             0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
                                             0 if dy_amax is None else dy_amax.numel(), _p(dw), _p(db), _st()))
@@ -201,7 +210,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
         size = "L" if Cout > 64 else ("M" if Cout > 32 else "S")
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0 and Cout <= 32
                 and Wi % 4 == 0)                          # csrc/conv3d.hip::df_conv3d_wgrad_try
-        prof(("wgrad3x3_" if is3x3 else ("wgrad3d_" if is3d else "conv_wgrad_")) + size,
+        prof(("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size,
              2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
     return dw
 

@@ -84,6 +84,11 @@ int dfmir_conv3d_split_ok(const DfConvGeom* g);
 long long dfmir_conv3d_split_ws_floats(int Cin, int Cout);
 int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
                            float* ws, const float* bias, float* y, float* y_amax, void* stream);
+/* The weight gradient of the same layers in the same split form (Cin <= 48, Cout <= 32, W % 4 == 0), voxels as the
+ * matrix K: dw_tcc[tap][Cin][Cout] += ...   (accumulates, like dfmir_conv_wgrad). */
+int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
+int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
+                             const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);
 /* out[0..DFMIR_PROBE_SLOTS) = max(a, b): the probe of cat([nearest_up2(a), b]) from its inputs' probes. */
 int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */

@@ -40,7 +40,8 @@ for Cin, Cout, sp in ((34, 32, (160, 192, 224)), (32, 16, (160, 192, 224)), (16,
         ref = torch.nn.functional.conv3d(xr, w.double().cpu(), b.double().cpu())      # valid conv: output = voxels 1..c
         got = y[:, :, 1:c + 1, 1:c + 1, 1:c + 1].double().cpu()
         err = float((got - ref).norm() / ref.norm())
-        msw = timeit(lambda: ops.conv_wgrad_raw(x, dy, K, 1, (1, 1, 1), 0), 3)
+        da = ops.absmax(dy)
+        msw = timeit(lambda: ops.conv_wgrad_raw(x, dy, K, 1, (1, 1, 1), 0, x_amax=xa, dy_amax=da), 3)
     print("%2d->%2d @%-12s fwd %7.3f ms %6.1f TF (rel-L2 err vs fp64 %.1e)   wgrad %7.3f ms %6.1f TF" % (
         Cin, Cout, "x".join(map(str, sp)), ms, fl / ms / 1e9, err, msw, fl / msw / 1e9))
     del x, dy, y
