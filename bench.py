@@ -238,8 +238,7 @@ def bench_warp_hbm(dev, reps=20):
         return s.elapsed_time(e) / reps
 
     def bwd():
-        dsrc.zero_()
-        ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
+        ops._warp_bwd_dsrc(dout, src, flow, dflow, 0, 0)
 
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
            "workload": "160x192x224, C=1, smooth field", "kernel": "warp_win_fwd_k<3>"}
@@ -248,7 +247,8 @@ def bench_warp_hbm(dev, reps=20):
     out.update(achieved=b_f / ms / 1e6, frac=b_f / ms / 1e6 / HBM_PEAK_GBS, bytes=b_f, avg_launch_ms=ms)
     b_b = 4 * (C + 2 * C + 2 * nd) * nv
     ms = timeit(bwd)
-    out["bwd"] = {"kernel": "warp_win_bwd_k<3> (d(src) + d(flow), incl. the d(src) zero-fill)", "achieved": b_b / ms / 1e6,
+    out["bwd"] = {"kernel": "warp_win_bwd_own_k<3> + warp_win_gather_k<3> (+ the empty slow-voxel pass): d(src) + d(flow) "
+                            "without device-scope atomics, bit-reproducible", "achieved": b_b / ms / 1e6,
                   "frac": b_b / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_b, "avg_launch_ms": ms}
     b_bf = 4 * (C + C + 2 * nd) * nv
     ms = timeit(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0))

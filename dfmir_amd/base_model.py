@@ -89,9 +89,12 @@ class BaseModel(object):
         from . import ops
         ops.bump_weights_epoch()                          # packed-weight caches: rank 0's weights now
 
-    def sync_gradients(self):
-        if self._ddp:
-            dfdist.allreduce_arenas([o.flat_g for o in self._arena_optimizers()])
+    def sync_gradients(self, async_op=False):
+        """All-reduce every network's flat gradient arena (in self.optimizers order).  async_op=True returns one
+        work handle (or None: already complete) per arena."""
+        if not self._ddp:
+            return []
+        return dfdist.allreduce_arenas([o.flat_g for o in self._arena_optimizers()], async_op=async_op)
 
     # ---- inference -----------------------------------------------------------------------------------
     def eval(self):

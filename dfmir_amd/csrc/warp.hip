@@ -384,6 +384,25 @@ extern "C" int dfmir_warp3d_bwd(const float* dout, const float* src, const float
   DF_LAUNCH_CHECK();
   return 0;
 }
+long long df_warp_win_bwd_own_ws(int nd, int B, int C, int D, int H, int W);
+int df_warp_win_bwd_own_try(int nd, const float* dout, const float* src, const float* flow, float* dsrc, float* dflow,
+                            int B, int C, int D, int H, int W, int add_identity, int flow_into_src, float* ws,
+                            hipStream_t st);
+extern "C" long long dfmir_warp_bwd_own_ws_floats(int nd, int B, int C, int D, int H, int W) {
+  if ((nd != 2 && nd != 3) || B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return -1;
+  return df_warp_win_bwd_own_ws(nd, B, C, nd == 3 ? D : 1, H, W);
+}
+extern "C" int dfmir_warp_bwd_own(int nd, const float* dout, const float* src, const float* flow, float* dsrc,
+                                  float* dflow, int B, int C, int D, int H, int W, int add_identity, int flow_into_src,
+                                  float* ws, void* stream) {
+  DF_ARG_CHECK((nd == 2 || nd == 3) && dout && src && flow && dsrc && ws && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+  DF_ARG_CHECK(!flow_into_src || C == nd);
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && df_warp_win_bwd_own_ws(nd, B, C, nd == 3 ? D : 1, H, W) > 0);
+  const int rc = df_warp_win_bwd_own_try(nd, dout, src, flow, dsrc, dflow, B, C, nd == 3 ? D : 1, H, W, add_identity,
+                                         flow_into_src, ws, (hipStream_t)stream);
+  if (rc != 1) return df_set_error((int)hipErrorInvalidValue, __FILE__, __LINE__);
+  return 0;
+}
 static inline float lin_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 extern "C" int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, int Hi, int Wi, int Do,
                                 int Ho, int Wo, float mult, void* stream) {

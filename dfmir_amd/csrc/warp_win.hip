@@ -65,7 +65,8 @@ __device__ __forceinline__ bool win_tile(int ntx, int nty, int ntz, int B, int& 
 template <int ND>
 __device__ __forceinline__ void win_prologue(const float* __restrict__ flow, int b, int S, int H, int W, int D,
                                              int z, int y, int x, bool active, bool need_own, WinThread<ND>& th,
-                                             int* red, int& oz, int& oy, int& ox) {
+                                             int* red, int& oz, int& oy, int& ox, bool neigh = false, int tz0 = 0,
+                                             int ty0 = 0, int tx0 = 0) {
   using G = WinGeom<ND>;
   const int sp = (z * H + y) * W + x;
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
@@ -105,6 +106,11 @@ __device__ __forceinline__ void win_prologue(const float* __restrict__ flow, int
   mz = red[0]; my = red[1]; mx = red[2];
 #pragma unroll
   for (int k = 1; k < WNT / 64; ++k) { mz = min(mz, red[3 * k]); my = min(my, red[3 * k + 1]); mx = min(mx, red[3 * k + 2]); }
+  if (neigh) {   // owner-gather backward: the window must stay inside the 3x3(x3) tiles around its own tile
+    if (ND == 3) mz = max(tz0 - G::TZ, min(mz, tz0 + 2 * G::TZ - G::EZ));
+    my = max(ty0 - G::TY, min(my, ty0 + 2 * G::TY - G::EY));
+    mx = max(tx0 - WTX, min(mx, tx0 + 2 * WTX - WEX));
+  }
   oz = (ND == 3) ? mz : 0;
   oy = my;
   ox = mx & ~3;
@@ -435,6 +441,211 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_k(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward without device-scope atomics on d(src), bit-reproducible ("owner gathers"):
+//   pass 1  warp_win_bwd_own_k   as warp_win_bwd_k, but the privatised d(src) window is accumulated in 64-bit FIXED
+//           POINT (LDS integer atomics are associative: the sum does not depend on the order the lanes arrive in),
+//           scaled by 2^40 / 2^ceil(log2 max|contribution| of the workgroup), converted back and written DENSELY to a
+//           scratch slot of its tile together with the window origin.  The origin is clamped so that the window stays
+//           inside the 3 x 3 (x 3) tiles around its own; voxels whose taps leave it go to a list.
+//   pass 2  warp_win_gather_k    every d(src) cell sums, in fixed tile order, the windows of its 27 (9) neighbour tiles
+//           that cover it and writes the result (no pre-zeroed d(src) needed).
+//   pass 3  warp_win_slow_k      the listed voxels (none on registration-like fields), scalar routine + atomics.
+// ------------------------------------------------------------------------------------------------
+template <int ND> struct WinOwn { static constexpr int CELLS = WinGeom<ND>::EZ * WinGeom<ND>::EY * WEX; };
+
+template <int ND>
+__global__ __launch_bounds__(WNT) void warp_win_bwd_own_k(const float* __restrict__ dout, const float* __restrict__ src,
+                                                          const float* __restrict__ flow, float* __restrict__ dflow,
+                                                          int B, int C, int D, int H, int W, int add_identity,
+                                                          int flow_into_src, int ntx, int nty, int ntz,
+                                                          float* __restrict__ scratch, int* __restrict__ origins,
+                                                          unsigned* __restrict__ slow) {
+  using GG = WinGeom<ND>;
+  __shared__ long long winq[GG::EZ * GG::EY * WRS];       // phase A: the src window (as floats); phase B: fixed point
+  __shared__ int red[3 * WNT / 64];
+  __shared__ float redf[WNT / 64];
+  float* win = reinterpret_cast<float*>(winq);
+  WIN_THREAD_COORDS();
+  // linear tile id as win_tile decodes it
+  const int tileL = ((b * ntz + tzb_) * nty + tyb_) * ntx + tx_;
+  WinThread<ND> th;
+  int oz, oy, ox;
+  const bool need_own = add_identity || flow_into_src;
+  win_prologue<ND>(flow, b, S, H, W, D, z, y, x, active, need_own, th, red, oz, oy, ox, true, tzb_ * G::TZ, tyb_ * G::TY,
+                   tx_ * WTX);
+  if (t == 0) { origins[tileL * 4] = oz; origins[tileL * 4 + 1] = oy; origins[tileL * 4 + 2] = ox; }
+  float fm[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) fm[e] = ((th.fast >> e) & 1u) ? 1.f : 0.f;
+  // ---- phase A: d(flow) (identical to warp_win_bwd_k)
+  float gz[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gx[4] = {0.f, 0.f, 0.f, 0.f};
+  if (dflow || flow_into_src) {
+    for (int c = 0; c < C; ++c) {
+      const float* sc = src + ((long long)b * C + c) * S;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc), 0, (unsigned)S * 4u, 0x00020000);
+      if (c) __syncthreads();
+      win_load<ND>(rs, win, D, H, W, oz, oy, ox);
+      __syncthreads();
+      if (!active) continue;
+      const float4 g4 = *reinterpret_cast<const float4*>(dout + ((long long)b * C + c) * S + sp);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* p = win + th.base[e];
+        const float g = gg[e] * fm[e];
+        const float wx1 = th.wx1[e], wy1 = th.wy1[e], wz1 = th.wz1[e];
+        const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+        const float c0 = p[0], c1 = p[1], c2 = p[WRS], c3 = p[WRS + 1];
+        if (ND == 3) {
+          const float* q = p + G::EY * WRS;
+          const float c4 = q[0], c5 = q[1], c6 = q[WRS], c7 = q[WRS + 1];
+          const float p0 = wy0 * (wx0 * c0 + wx1 * c1) + wy1 * (wx0 * c2 + wx1 * c3);
+          const float p1 = wy0 * (wx0 * c4 + wx1 * c5) + wy1 * (wx0 * c6 + wx1 * c7);
+          gz[e] += g * (p1 - p0);
+          gy[e] += g * (wz0 * (wx0 * (c2 - c0) + wx1 * (c3 - c1)) + wz1 * (wx0 * (c6 - c4) + wx1 * (c7 - c5)));
+          gx[e] += g * (wz0 * (wy0 * (c1 - c0) + wy1 * (c3 - c2)) + wz1 * (wy0 * (c5 - c4) + wy1 * (c7 - c6)));
+        } else {
+          gy[e] += g * (wx0 * (c2 - c0) + wx1 * (c3 - c1));
+          gx[e] += g * (wy0 * (c1 - c0) + wy1 * (c3 - c2));
+        }
+      }
+    }
+    if (active && !flow_into_src && dflow) {
+      float* fb = dflow + (long long)b * ND * S + sp;
+      // slow voxels: their d(flow) is written by pass 3; fast ones here (a float4 store covers both: pass 3 runs later)
+      if (ND == 3) *reinterpret_cast<float4*>(fb) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+      *reinterpret_cast<float4*>(fb + (long long)(ND - 2) * S) = make_float4(gy[0], gy[1], gy[2], gy[3]);
+      *reinterpret_cast<float4*>(fb + (long long)(ND - 1) * S) = make_float4(gx[0], gx[1], gx[2], gx[3]);
+    }
+  }
+  // ---- phase B: d(src) of the fast voxels, fixed point in LDS, dense store of the window
+  constexpr int NW = GG::EZ * GG::EY * WRS;
+  const int own = ((z - oz) * G::EY + (y - oy)) * WRS + (x - ox);
+  for (int c = 0; c < C; ++c) {
+    float gg[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+    float m = 0.f;
+    if (active && th.fast) {
+      const float4 g4 = *reinterpret_cast<const float4*>(dout + ((long long)b * C + c) * S + sp);
+      gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gg[e] *= fm[e];
+        ov[e] = add_identity ? gg[e] : 0.f;
+        if (flow_into_src) ov[e] += fm[e] * ((ND == 3) ? (c == 0 ? gz[e] : (c == 1 ? gy[e] : gx[e])) : (c == 0 ? gy[e] : gx[e]));
+        m = fmaxf(m, fmaxf(fabsf(gg[e]), fabsf(ov[e])));
+      }
+    }
+    // workgroup maximum of |contribution| -> power-of-two scale (NaN / inf propagate as a saturated scale)
+    m = wave_max(m);
+    __syncthreads();                                        // phase A / previous channel is done with the window
+    if ((t & 63) == 0) redf[t >> 6] = m;
+    for (int u = t; u < NW; u += WNT) winq[u] = 0;
+    __syncthreads();
+    float bm = redf[0];
+#pragma unroll
+    for (int q = 1; q < WNT / 64; ++q) bm = fmaxf(bm, redf[q]);
+    int be = (int)((__float_as_uint(bm) >> 23) & 0xffu) - 127;          // |v| < 2^(be+1)
+    be = bm > 0.f ? (be > 60 ? 60 : (be < -60 ? -60 : be)) : 0;
+    const float up = __uint_as_float((unsigned)(40 - be - 1 + 127) << 23);   // 2^(39-be): |v * up| < 2^40
+    const float dn = __uint_as_float((unsigned)(be + 1 - 40 + 127) << 23);
+    if (active && th.fast) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!((th.fast >> e) & 1u)) continue;
+        long long* p = winq + th.base[e];
+        const float g = gg[e] * up;
+        const float wx1 = th.wx1[e], wy1 = th.wy1[e], wz1 = th.wz1[e];
+        const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
+#define OWN_ADD(ptr_, val_) atomicAdd(reinterpret_cast<unsigned long long*>(ptr_), (unsigned long long)__float2ll_rn(val_))
+        if (ND == 3) {
+          long long* q = p + G::EY * WRS;
+          OWN_ADD(p, g * wz0 * wy0 * wx0);
+          OWN_ADD(p + 1, g * wz0 * wy0 * wx1);
+          OWN_ADD(p + WRS, g * wz0 * wy1 * wx0);
+          OWN_ADD(p + WRS + 1, g * wz0 * wy1 * wx1);
+          OWN_ADD(q, g * wz1 * wy0 * wx0);
+          OWN_ADD(q + 1, g * wz1 * wy0 * wx1);
+          OWN_ADD(q + WRS, g * wz1 * wy1 * wx0);
+          OWN_ADD(q + WRS + 1, g * wz1 * wy1 * wx1);
+        } else {
+          OWN_ADD(p, g * wy0 * wx0);
+          OWN_ADD(p + 1, g * wy0 * wx1);
+          OWN_ADD(p + WRS, g * wy1 * wx0);
+          OWN_ADD(p + WRS + 1, g * wy1 * wx1);
+        }
+        if (need_own) OWN_ADD(winq + own + e, ov[e] * up);
+#undef OWN_ADD
+      }
+    }
+    __syncthreads();
+    float* slot = scratch + ((long long)tileL * C + c) * WinOwn<ND>::CELLS;
+    for (int u = t; u < WinOwn<ND>::CELLS; u += WNT) {
+      const int lx = u % WEX, r = u / WEX;
+      slot[u] = (float)winq[r * WRS + lx] * dn;
+    }
+  }
+  // ---- the voxels whose taps leave the window: listed for pass 3
+  if (active && th.fast != 15u) {
+    const unsigned sl = ~th.fast & 15u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((sl >> e) & 1u) {
+        const unsigned i = atomicAdd(slow, 1u);
+        slow[1 + i] = (unsigned)(b * S + sp + e);
+      }
+  }
+}
+
+template <int ND>
+__global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict__ scratch, const int* __restrict__ origins,
+                                                         float* __restrict__ dsrc, int B, int C, int D, int H, int W,
+                                                         int ntx, int nty, int ntz) {
+  // one workgroup per tile, the thread <-> voxel-quad map of pass 1: the 27 (9) neighbour origins are workgroup-uniform
+  // (scalar loads), the per-quad coverage test is a few integer compares, only covering windows are read
+  WIN_THREAD_COORDS();
+  if (!active) return;
+  constexpr int NZ = (ND == 3) ? 3 : 1;
+  for (int c = 0; c < C; ++c) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int iz = 0; iz < NZ; ++iz)
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 3; ++ix) {
+          const int nz = tzb_ + (ND == 3 ? iz - 1 : 0), ny = tyb_ + iy - 1, nx = tx_ + ix - 1;
+          if ((unsigned)nz >= (unsigned)ntz || (unsigned)ny >= (unsigned)nty || (unsigned)nx >= (unsigned)ntx) continue;
+          const int tl = ((b * ntz + nz) * nty + ny) * ntx + nx;
+          const int oz = origins[tl * 4], oy = origins[tl * 4 + 1], ox = origins[tl * 4 + 2];
+          const int lz = z - oz, ly = y - oy, lx = x - ox;           // ox is a multiple of 4: the quad is whole or absent
+          if ((unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY && (unsigned)lx <= (unsigned)(WEX - 4)) {
+            const float4 v = *reinterpret_cast<const float4*>(scratch + ((long long)tl * C + c) * WinOwn<ND>::CELLS +
+                                                              (lz * G::EY + ly) * WEX + lx);
+            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+          }
+        }
+    *reinterpret_cast<float4*>(dsrc + ((long long)b * C + c) * S + sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void warp_win_slow_k(const float* __restrict__ dout, const float* __restrict__ src,
+                                                       const float* __restrict__ flow, float* __restrict__ dsrc,
+                                                       float* __restrict__ dflow, int B, int C, int D, int H, int W,
+                                                       int add_identity, int flow_into_src, const unsigned* __restrict__ slow) {
+  const unsigned n = slow[0];
+  const int S = D * H * W;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned v = slow[1 + i];
+    const int b = (int)(v / (unsigned)S), sp = (int)(v - (unsigned)b * (unsigned)S);
+    const int x = sp % W, y = (sp / W) % H, z = sp / (W * H);
+    voxel_bwd_slow<ND>(dout + (long long)b * C * S, src + (long long)b * C * S, flow + (long long)b * ND * S,
+                       dsrc + (long long)b * C * S, dflow ? dflow + (long long)b * ND * S : nullptr, C, D, H, W, S, z, y, x,
+                       add_identity, flow_into_src);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host side: returns 1 when the windowed kernel took the launch, 0 when the shape is not eligible.
 template <int ND>
 static bool win_eligible(int B, int C, int D, int H, int W, int& ntx, int& nty, int& ntz, long long& grid) {
@@ -476,4 +687,43 @@ int df_warp_win_bwd_try(int nd, const float* dout, const float* src, const float
                                                       flow_into_src, ntx, nty, ntz);
   }
   return 1;
+}
+
+// owner-gather backward: scratch = [origins: 4 ints per tile][slow: 1 + B*S uints][windows: tiles * C * CELLS floats]
+template <int ND>
+static long long own_ws_floats(int B, int C, int D, int H, int W) {
+  int ntx, nty, ntz; long long grid;
+  if (!win_eligible<ND>(B, C, D, H, W, ntx, nty, ntz, grid)) return 0;
+  const long long T = (long long)ntx * nty * ntz * B, S = (long long)D * H * W;
+  long long n = 4 * T + 1 + (long long)B * S;
+  n = (n + 3) & ~3LL;
+  return n + T * C * WinOwn<ND>::CELLS;
+}
+long long df_warp_win_bwd_own_ws(int nd, int B, int C, int D, int H, int W) {
+  if ((long long)B * D * H * W >= (1LL << 31)) return 0;
+  return nd == 3 ? own_ws_floats<3>(B, C, D, H, W) : own_ws_floats<2>(B, C, 1, H, W);
+}
+template <int ND>
+static int own_launch(const float* dout, const float* src, const float* flow, float* dsrc, float* dflow, int B, int C, int D,
+                      int H, int W, int add_identity, int flow_into_src, float* ws, hipStream_t st) {
+  int ntx, nty, ntz; long long grid;
+  if (!win_eligible<ND>(B, C, D, H, W, ntx, nty, ntz, grid)) return 0;
+  const long long T = (long long)ntx * nty * ntz * B, S = (long long)D * H * W;
+  int* origins = reinterpret_cast<int*>(ws);
+  unsigned* slow = reinterpret_cast<unsigned*>(ws) + 4 * T;
+  long long off = 4 * T + 1 + (long long)B * S;
+  off = (off + 3) & ~3LL;
+  float* windows = ws + off;
+  if (df_zero_async(reinterpret_cast<float*>(slow), 1, st) != hipSuccess) return -1;
+  warp_win_bwd_own_k<ND><<<(unsigned)grid, WNT, 0, st>>>(dout, src, flow, dflow, B, C, D, H, W, add_identity, flow_into_src,
+                                                         ntx, nty, ntz, windows, origins, slow);
+  warp_win_gather_k<ND><<<(unsigned)grid, WNT, 0, st>>>(windows, origins, dsrc, B, C, D, H, W, ntx, nty, ntz);
+  warp_win_slow_k<ND><<<64, 256, 0, st>>>(dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src, slow);
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+int df_warp_win_bwd_own_try(int nd, const float* dout, const float* src, const float* flow, float* dsrc, float* dflow,
+                            int B, int C, int D, int H, int W, int add_identity, int flow_into_src, float* ws,
+                            hipStream_t st) {
+  return nd == 3 ? own_launch<3>(dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src, ws, st)
+                 : own_launch<2>(dout, src, flow, dsrc, dflow, B, C, 1, H, W, add_identity, flow_into_src, ws, st);
 }

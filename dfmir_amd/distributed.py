@@ -66,11 +66,11 @@ def allreduce_arenas(flats, async_op=False):
             h = f.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             f.copy_(h)
+            works.append(None)
         else:
             w = dist.all_reduce(f, op=dist.ReduceOp.SUM, async_op=async_op)
-            if async_op:
-                works.append(w)
-    return works
+            works.append(w if async_op else None)
+    return works if async_op else []
 
 
 def allreduce_max(value, device):

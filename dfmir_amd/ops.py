@@ -920,6 +920,27 @@ def _warp_bwd(dout, src, flow, dsrc, dflow, add_identity, into_src):
                                      add_identity, into_src, _st()))
 
 
+_WARP_ATOMIC = bool(os.environ.get("DFMIR_WARP_ATOMIC"))     # A/B switch: d(src) through global atomics
+
+
+def _warp_bwd_dsrc(dout, src, flow, dflow, add_identity, into_src):
+    """Backward of a warp that needs d(src): the atomic-free, bit-reproducible owner-gather kernels where the shape is
+    eligible (W % 4 == 0), else the scatter with global atomics into a zeroed buffer.  Returns d(src)."""
+    nd = src.dim() - 2
+    B, C = src.shape[0], src.shape[1]
+    D, H, W = (src.shape[2:] if nd == 3 else (1,) + tuple(src.shape[2:]))
+    n = 0 if _WARP_ATOMIC else lib().dfmir_warp_bwd_own_ws_floats(nd, B, C, D, H, W)
+    if n > 0:
+        dsrc = torch.empty_like(src)
+        ws = torch.empty(n, device=src.device, dtype=torch.float32)
+        check(lib().dfmir_warp_bwd_own(nd, _p(dout), _p(src), _p(flow), _p(dsrc), _p(dflow), B, C, D, H, W, add_identity,
+                                       into_src, _p(ws), _st()))
+        return dsrc
+    dsrc = zeros_like(src)
+    _warp_bwd(dout, src, flow, dsrc, dflow, add_identity, into_src)
+    return dsrc
+
+
 class WarpFn(Function):
     @staticmethod
     def forward(ctx, src, flow, mode):
@@ -938,16 +959,17 @@ class WarpFn(Function):
     def backward(ctx, dout):
         src, flow = ctx.saved_tensors
         dout = _c(dout)
-        dsrc = zeros_like(src) if ctx.needs_input_grad[0] else None
         dflow = None
         if ctx.needs_input_grad[1]:
             dflow = zeros_like(flow) if ctx.mode == 1 else torch.empty_like(flow)
         if ctx.mode == 1:
-            if dsrc is not None:
+            if ctx.needs_input_grad[0]:
                 raise DfmirHipError("nearest-mode warp backward is not implemented (inference only)")
-            return dsrc, dflow, None
-        _warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
-        return dsrc, dflow, None
+            return None, dflow, None
+        if ctx.needs_input_grad[0]:
+            return _warp_bwd_dsrc(dout, src, flow, dflow, 0, 0), dflow, None
+        _warp_bwd(dout, src, flow, None, dflow, 0, 0)
+        return None, dflow, None
 
 
 def warp(src, flow, mode="bilinear"):
@@ -969,9 +991,7 @@ class VecIntStepFn(Function):
     def backward(ctx, dout):
         (v,) = ctx.saved_tensors
         dout = _c(dout)
-        dv = zeros_like(v)
-        _warp_bwd(dout, v, v, dv, None, 1, 1)
-        return dv
+        return _warp_bwd_dsrc(dout, v, v, None, 1, 1)
 
 
 def vecint_step(v):

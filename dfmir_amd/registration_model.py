@@ -176,12 +176,15 @@ class REGISTRATIONModel(BaseModel):
         self._apply_updates()
 
     def _apply_updates(self):
-        """registration_model.py:168-171 (+ the one exchange step of the data-parallel form)."""
-        self.sync_gradients()
-        self.optimizer_G.step()
-        self.optimizer_R.step()
-        if self.opt.netF == 'mlp_sample':
-            self.optimizer_F.step()
+        """registration_model.py:168-171 (+ the one exchange step of the data-parallel form).  Under RCCL the three
+        arena all-reduces are issued back to back (G 45.5 MB first, then R, F) and each network's Adam launch waits
+        only for its own: R's and F's exchange overlaps G's optimizer pass instead of following it."""
+        opts = [self.optimizer_G, self.optimizer_R] + ([self.optimizer_F] if self.opt.netF == 'mlp_sample' else [])
+        works = self.sync_gradients(async_op=True)
+        for i, o in enumerate(opts):
+            if works and i < len(works) and works[i] is not None:
+                works[i].wait()
+            o.step()
 
     def _optimize_parameters_graphed(self):
         """The steady-state step as ONE hipGraph launch (opt.capture_step, build-defined): forward, the losses and

@@ -252,6 +252,15 @@ int dfmir_warp3d_fwd(const float* src, const float* flow, float* out, int B, int
 int dfmir_warp3d_bwd(const float* dout, const float* src, const float* flow, float* dsrc,
                      float* dflow, int B, int C, int D, int H, int W, int add_identity,
                      int flow_into_src, void* stream);
+/* The same adjoint WITHOUT device-scope atomics on d(src), bit-reproducible (csrc/warp_win.hip, "owner gathers"): every
+ * workgroup accumulates its tile's scatter in a fixed-point LDS window, writes it densely to a scratch slot, and a
+ * second pass lets each d(src) cell sum the neighbouring tiles' windows that cover it, in fixed order; voxels displaced
+ * beyond the 3x3(x3)-tile neighbourhood go through a list and the scalar routine (atomics).  nd = 2 (D ignored) or 3;
+ * W % 4 == 0.  dsrc is written entirely (no zero-fill needed); ws = dfmir_warp_bwd_own_ws_floats(...) floats of
+ * 16-byte aligned scratch (0: shape not eligible -> use dfmir_warp{2,3}d_bwd). */
+long long dfmir_warp_bwd_own_ws_floats(int nd, int B, int C, int D, int H, int W);
+int dfmir_warp_bwd_own(int nd, const float* dout, const float* src, const float* flow, float* dsrc, float* dflow, int B,
+                       int C, int D, int H, int W, int add_identity, int flow_into_src, float* ws, void* stream);
 
 /* ResizeTransform (layers.py:71-97): F.interpolate(align_corners=True, bi/tri-linear) fused with the
  * scalar rescale `mult`.  D == 1 for 2-D.  bwd is the adjoint in gather form (writes dx; no atomics). */

@@ -614,3 +614,37 @@ def test_stem7_direct(ops, cfg):
     close(xg.grad, xr.grad, rtol=3e-4, what="dx")
     close(wg.grad, wr.grad, rtol=3e-4, atol=1e-4 * float(wr.grad.abs().max()), what="dw")
     close(bg.grad, br.grad, rtol=3e-4, atol=1e-4 * float(br.grad.abs().max()), what="db")
+
+
+@pytest.mark.parametrize("case", ["3d_smooth", "3d_rough", "2d_self"])
+def test_warp_backward_is_reproducible_and_matches_atomic_path(ops, case):
+    """d(src) of the warp without device-scope atomics (owner-gather kernels, fixed-point LDS accumulation): two runs
+    are bit-equal, and the result equals the atomic scatter path (DFMIR_WARP_ATOMIC semantics, ops._warp_bwd into a
+    zeroed buffer) to float round-off -- on a smooth field (no voxel leaves its window), on a rough one (the slow-voxel
+    list is exercised) and on the VecInt self-warp form (v + warp(v, v): own term and flow gradient into d(src))."""
+    if case == "2d_self":
+        shp, nd, C_ = (3, 64, 96), 2, 2
+    else:
+        shp, nd, C_ = (1, 24, 40, 64), 3, 2
+    B, sp = shp[0], shp[1:]
+    amp, cell = (6.0, 4) if case == "3d_rough" else (0.4, 8)      # smooth: no tap leaves its tile's window
+    coarse = C.randn(131, B, nd, *[max(2, s_ // cell) for s_ in sp]) * amp
+    flow = torch.nn.functional.interpolate(coarse, size=sp, mode="trilinear" if nd == 3 else "bilinear",
+                                           align_corners=True).contiguous().to(DEV)
+    self_warp = case == "2d_self"
+    src = flow if self_warp else C.randn(132, B, C_, *sp).to(DEV)
+    dout = C.randn(133, *src.shape).to(DEV)
+    runs = []
+    for _ in range(2):
+        dflow = None if self_warp else torch.empty_like(flow)
+        dsrc = ops._warp_bwd_dsrc(dout, src, flow, dflow, int(self_warp), int(self_warp))
+        runs.append((dsrc.clone(), None if dflow is None else dflow.clone()))
+    if case != "3d_rough":       # (listed slow voxels still go through float atomics)
+        assert torch.equal(runs[0][0], runs[1][0]), "d(src) must be bit-reproducible"
+    ref = torch.zeros_like(src)
+    dflow_ref = None if self_warp else torch.empty_like(flow)
+    ops._warp_bwd(dout, src, flow, ref, dflow_ref, int(self_warp), int(self_warp))
+    close(runs[0][0], ref, rtol=2e-6, what="dsrc vs atomic path")
+    if not self_warp:
+        assert torch.equal(runs[0][1], runs[1][1])
+        close(runs[0][1], dflow_ref, rtol=2e-6, what="dflow vs atomic path")
