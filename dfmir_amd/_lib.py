@@ -36,6 +36,10 @@ _SIGS = {
     "dfmir_conv3x3_reflect_ring": [_GP, P, P, P, c_int, P, P, P],
     "dfmir_conv_fwd_scaled": [_GP, P, P, c_int, P, P, P, P],
     "dfmir_conv_wgrad_scaled": [_GP, P, P, c_int, P, P, c_int, P, P, P],
+    "dfmir_conv_wgrad_scaled_ch": [_GP, P, P, c_int, P, P, c_int, P, P, P, P],
+    "dfmir_instnorm_bwd_pmax_ok": [c_longlong],
+    "dfmir_instnorm_bwd_pmax": [P, P, P, P, P, c_int, c_longlong, c_int, P, P, c_int, P, P],
+    "dfmir_patch_gather_bwd_gp": [P, P, P, c_int, c_int, c_longlong, c_int, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],
     "dfmir_conv3d_split_ok": [_GP],
     "dfmir_conv3d_split_ws_floats": [c_int, c_int],

@@ -548,7 +548,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
                               hipStream_t st, int* rc);
 int df_conv3x3_split_res_ok(const DfConvGeom* g);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc);
+                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc,
+                                const float* dy_pmax);
 int df_weight_split_launch(const float* w_tcc, float* packed, int K, int M, int npart, hipStream_t st);
 float* df_weight_probe_slots(float* packed, int K, int M);
 int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bool zero_first);
@@ -662,7 +663,13 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
 }
 
 static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream);
+                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream,
+                           const float* dy_pmax = nullptr);
+extern "C" int dfmir_conv_wgrad_scaled_ch(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                          const float* dy, const float* dy_amax, int dy_amax_n, const float* dy_pmax,
+                                          float* dw_tcc, float* db, void* stream) {
+  return conv_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream, dy_pmax);
+}
 extern "C" int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc,
                                 void* stream) {
   return conv_wgrad_impl(g, x, nullptr, 0, dy, nullptr, 0, dw_tcc, nullptr, stream);
@@ -674,13 +681,13 @@ extern "C" int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, cons
 }
 static int bias_grad_launch(const float* dy, float* db, int N, int C, long long S, hipStream_t st);
 static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream) {
+                           const float* dy_amax, int dy_n, float* dw_tcc, float* db, void* stream, const float* dy_pmax) {
   DF_ARG_CHECK(check_geom(g) == 0 && x && dy && dw_tcc);
   DF_ARG_CHECK(g->dil == 1 && g->Cin < (1 << 19));
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
-    if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, db, st, &rc)) return rc;   // db fused
+    if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, db, st, &rc, dy_pmax)) return rc;   // db fused
   }
   if (db) {   // every other kernel: the bias gradient is its own pass over dY
     const int rcb = bias_grad_launch(dy, db, g->N, g->Cout, (long long)g->Do * g->Ho * g->Wo, st);

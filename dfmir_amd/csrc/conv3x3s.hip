@@ -1080,6 +1080,7 @@ struct WS3P {
   const float* dy_amax;
   int x_n, dy_n;
   float* db;              // optional: bias gradient db[co] += sum_{n,p} dY, taken from the dY units as they pass
+  const float* dy_pmax;   // optional (split2 kernel): max |dY| per (n, co) plane, [N][Cout] -> one scale per output channel
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -1481,11 +1482,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   const int ex = scale_exp(reduce_absmax(k.x_amax, k.x_n, red));
   __syncthreads();
   const int ed = scale_exp(reduce_absmax(k.dy_amax, k.dy_n, red));
-  const float xscale = pow2f(ex), dscale = pow2f(ed), oscale = pow2f(-ex), oscale2 = pow2f(-ed);
+  // dY is scaled per OUTPUT CHANNEL when the per-plane maxima are known: the scale is uniform along the MFMA K (pixels
+  // of one channel), so a channel whose gradient is 1e-6 of the tensor's largest keeps its 22 bits; the column's
+  // factor 2^-ed[co] goes into the epilogue.  Without them: one scale for the tensor.
+  __shared__ int edc[BC];
+  if (tid < BC) {
+    int e = ed;
+    if (k.dy_pmax) {
+      float m = 0.f;
+      if (co0 + tid < k.Cout)
+        for (int n = 0; n < k.N; ++n) m = fmaxf(m, k.dy_pmax[(long long)n * k.Cout + co0 + tid]);
+      e = scale_exp(m);
+    }
+    edc[tid] = e;
+  }
+  __syncthreads();
 
   // loader roles: X group (patch row xr 0..3, half xu, channel xc 0..63), dY group (k-step dk, half du, channel dc)
   const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
   const int dc = tid & (BC - 1), du = (tid >> 7) & 1, dk = tid >> 8;
+  const float xscale = pow2f(ex), dscale = pow2f(edc[dc]), oscale = pow2f(-ex), oscale2 = pow2f(-edc[wc * 32 + l31]);
   const unsigned hw4 = (unsigned)HW * 4u;
   constexpr unsigned OOB = 0x80000000u;
 
@@ -1659,7 +1675,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 }
 
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
-                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc) {
+                                const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc,
+                                const float* dy_pmax) {
   const int mode = df_split_mode();
   if (mode == 0 || (mode == 2 && !(x_amax && dy_amax && x_n > 0 && dy_n > 0))) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
@@ -1670,7 +1687,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax};
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
                                                          const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i,
                                                          float* __restrict__ dx, int relu,
-                                                         float* __restrict__ amax, float* __restrict__ cols, int W) {
+                                                         float* __restrict__ amax, float* __restrict__ cols, int W,
+                                                         float* __restrict__ pmax) {
+  // pmax (optional, needs amax): pmax[plane] <- max |dx| of this plane (per-channel scales of the split wgrad)
   // cols (optional, W % 4 == 0): cols[plane][2][H] <- the first and last column of dx, for the ring kernel of a
   // reflect-padded conv's dgrad (a column of an NCHW tensor is one cache line per element to read back)
   __shared__ float sm[17];
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_reg_k(const float* __restrict
     }
   }
   if (amax) publish_block_absmax_acc(am, &smax, amax);
+  if (amax && pmax && threadIdx.x == 0) pmax[blockIdx.x] = __uint_as_float(smax);
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy * [xhat>0 if relu]
@@ -749,7 +752,15 @@ extern "C" int dfmir_instnorm_bwd_cols_ok(long long S, int W) {
   return ((S == 4096 || S == 16384) && W >= 4 && (W & 3) == 0 && S % W == 0) ? 1 : 0;
 }
 static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
-                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream);
+                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream,
+                             float* dx_pmax = nullptr);
+extern "C" int dfmir_instnorm_bwd_pmax_ok(long long S) { return (S == 4096 || S == 16384 || S == 65536) ? 1 : 0; }
+extern "C" int dfmir_instnorm_bwd_pmax(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
+                                       int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W,
+                                       float* dx_pmax, void* stream) {
+  DF_ARG_CHECK(dx_amax && dx_pmax && dfmir_instnorm_bwd_pmax_ok(S) && (!dx_cols || dfmir_instnorm_bwd_cols_ok(S, W)));
+  return instnorm_bwd_impl(dy, x, mean, rstd, dx, planes, S, relu, dx_amax, dx_cols, W, stream, dx_pmax);
+}
 extern "C" int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                   float* dx, int planes, long long S, int relu, float* dx_amax, void* stream) {
   return instnorm_bwd_impl(dy, x, mean, rstd, dx, planes, S, relu, dx_amax, nullptr, 0, stream);
@@ -761,15 +772,16 @@ extern "C" int dfmir_instnorm_bwd_cols(const float* dy, const float* x, const fl
   return instnorm_bwd_impl(dy, x, mean, rstd, dx, planes, S, relu, dx_amax, dx_cols, W, stream);
 }
 static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, float* dx,
-                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream) {
+                             int planes, long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream,
+                             float* dx_pmax) {
   DF_ARG_CHECK(dy && x && mean && rstd && dx && planes > 0 && S > 0);
   hipStream_t st = (hipStream_t)stream;
-  if (S == 4096 && dx_cols) instnorm_bwd_reg_k<256, 4, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
-  else if (S == 4096) instnorm_bwd_reg_k<256, 4, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
-  else if (S == 16384 && dx_cols) instnorm_bwd_reg_k<256, 16, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W);
-  else if (S == 16384) instnorm_bwd_reg_k<256, 16, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
+  if (S == 4096 && dx_cols) instnorm_bwd_reg_k<256, 4, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W, dx_pmax);
+  else if (S == 4096) instnorm_bwd_reg_k<256, 4, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0, dx_pmax);
+  else if (S == 16384 && dx_cols) instnorm_bwd_reg_k<256, 16, true><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, dx_cols, W, dx_pmax);
+  else if (S == 16384) instnorm_bwd_reg_k<256, 16, false><<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0, dx_pmax);
   else if (S == 65536 && dx_cols) return df_set_error(-1, __FILE__, __LINE__);     // dfmir_instnorm_bwd_cols_ok excludes it
-  else if (S == 65536) instnorm_bwd_reg_k<1024, 16, false><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0);
+  else if (S == 65536) instnorm_bwd_reg_k<1024, 16, false><<<planes, 1024, 0, st>>>(dy, x, mean, rstd, dx, relu, dx_amax, nullptr, 0, dx_pmax);
   else {
     instnorm_bwd_k<<<planes, 256, 0, st>>>(dy, x, mean, rstd, dx, S, relu);
     if (dx_amax) {

@@ -20,7 +20,7 @@ __global__ void patch_gather_fwd_k(const float* __restrict__ feat, const long lo
 // by raising a slot to |new value| of every element this scatter touches (ids are distinct within a plane)
 __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long long* __restrict__ ids,
                                    float* __restrict__ dfeat, int B, int C, long long S, int P, int bpg,
-                                   unsigned* __restrict__ amax) {
+                                   unsigned* __restrict__ amax, unsigned* __restrict__ pmax = nullptr) {
   const long long total = (long long)B * C * P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -34,6 +34,7 @@ __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long lo
       if (!(nv == nv)) nv = __uint_as_float(0x7f800000u);
       unsigned* sl = amax + (bc & (DF_PROBE_SLOTS - 1));
       if (__float_as_uint(nv) > *reinterpret_cast<volatile unsigned*>(sl)) atomicMax(sl, __float_as_uint(nv));
+      if (pmax && __float_as_uint(nv) > *reinterpret_cast<volatile unsigned*>(pmax + bc)) atomicMax(pmax + bc, __float_as_uint(nv));
     }
   }
 }
@@ -411,6 +412,14 @@ extern "C" int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids,
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
   patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
       dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax));
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids, float* dfeat, int B, int C,
+                                         long long S, int P, int G, float* dfeat_amax, float* dfeat_pmax, void* stream) {
+  DF_ARG_CHECK(dout && ids && dfeat && dfeat_amax && dfeat_pmax && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
+  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax), reinterpret_cast<unsigned*>(dfeat_pmax));
   DF_LAUNCH_CHECK();
   return 0;
 }

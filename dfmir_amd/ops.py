@@ -179,7 +179,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     return y
 
 
-def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None):
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None):
     """dW in the tap-major packing; `out` (same packing) is accumulated into when given."""
     N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
@@ -197,9 +197,10 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             if db is not None:
                 check(lib().dfmir_bias_grad(_p(dy5), _p(db), N, Cout, Do * Ho * Wo, _st()))   # accumulates
             return
-        check(lib().dfmir_conv_wgrad_scaled(ctypes.byref(g), _p(x5), _p(x_amax),
-                                            0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
-                                            0 if dy_amax is None else dy_amax.numel(), _p(dw), _p(db), _st()))
+        pm = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and dy_amax is not None) else None
+        check(lib().dfmir_conv_wgrad_scaled_ch(ctypes.byref(g), _p(x5), _p(x_amax),
+                                               0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
+                                               0 if dy_amax is None else dy_amax.numel(), _p(pm), _p(dw), _p(db), _st()))
 
     prof = _CONV_PROFILER[0]
     if prof is None:
@@ -319,6 +320,7 @@ def bump_weights_epoch():
 # bias gradients straight into `bias.grad`; the buffers are unpacked into `weight.grad` once, on exit.
 # Without it every pass pays a zero-fill, an unpack and an autograd `add` per parameter (~900 tiny launches).
 _NO_RES = bool(os.environ.get("DFMIR_NO_RES"))       # A/B switch: residual added by a separate kernel
+_NO_CH_SCALE = bool(os.environ.get("DFMIR_NO_CH_SCALE"))   # A/B switch: one dY scale per tensor in the split wgrad
 _NO_RING = bool(os.environ.get("DFMIR_NO_RING"))     # A/B switch: reflect dgrad as padded-frame conv + fold
 _DEFER = {"on": False, "pending": {}}
 
@@ -500,13 +502,17 @@ class ConvFn(Function):
             else:
                 db = db_buf = zeros(Cout, dy5.device)
         if ctx.needs_input_grad[1]:
+            ptag = getattr(dy, "_df_pmax", None) if not act else None     # per-plane maxima of dY (InstanceNorm backward)
+            dy_pmax = ptag[0] if (ptag is not None and ptag[1] == dy._version and ptag[2] == dy.data_ptr()
+                                  and dy.is_contiguous() and not _NO_CH_SCALE) else None
             if defer:
                 T = K[0] * K[1] * K[2]
                 conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode,
                                out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device),
-                               x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf)
+                               x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf, dy_pmax=dy_pmax)
             else:
-                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf)
+                dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf,
+                                     dy_pmax=dy_pmax)
                 dw = weight_unpack(dwt, tuple(weight.shape))
         elif db_buf is not None:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
@@ -679,15 +685,23 @@ class InstNormFn(Function):
             dx = torch.empty_like(x)
             slot = amax_slot(x.device, PROBE_SLOTS)
             W = x.shape[-1]
-            if x.dim() == 4 and W <= 94 and S // W <= 94 and lib().dfmir_instnorm_bwd_cols_ok(S, W):   # ring-kernel sizes
-                # first / last column of dx on the side: the dgrad of a reflect-padded conv reads them (ring kernel)
-                cols = torch.empty(planes * 2 * (S // W), device=x.device, dtype=torch.float32)
+            want_cols = x.dim() == 4 and W <= 94 and S // W <= 94 and lib().dfmir_instnorm_bwd_cols_ok(S, W)   # ring-kernel sizes
+            # first / last column of dx on the side: the dgrad of a reflect-padded conv reads them (ring kernel)
+            cols = torch.empty(planes * 2 * (S // W), device=x.device, dtype=torch.float32) if want_cols else None
+            if x.dim() == 4 and lib().dfmir_instnorm_bwd_pmax_ok(S):
+                # + the maximum of every (n, c) plane: per-output-channel dY scales for the split weight gradient
+                pmax = torch.empty(planes, device=x.device, dtype=torch.float32)
+                check(lib().dfmir_instnorm_bwd_pmax(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
+                                                    _p(slot), _p(cols), W if want_cols else 0, _p(pmax), _st()))
+                dx._df_pmax = (pmax, dx._version, dx.data_ptr())
+            elif want_cols:
                 check(lib().dfmir_instnorm_bwd_cols(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
                                                     _p(slot), _p(cols), W, _st()))
-                dx._df_cols = (cols, dx._version, dx.data_ptr())
             else:
                 check(lib().dfmir_instnorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(dx), planes, S, ctx.relu,
                                                _p(slot), _st()))
+            if want_cols:
+                dx._df_cols = (cols, dx._version, dx.data_ptr())
             tag_amax(dx, slot)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[1]) else None
         return dx, dres, None, None
@@ -1058,15 +1072,29 @@ class TapForkFn(Function):
             atag = getattr(g, "_df_amax", None)
             if atag is not None and not (atag[1] == g._version and atag[2] == g.data_ptr()):
                 atag = None
+            ptag = getattr(g, "_df_pmax", None)
+            if ptag is not None and not (ptag[1] == g._version and ptag[2] == g.data_ptr()):
+                ptag = None
             for dout, ids, (shape, B, C, S, Pn, G) in stash:
                 if atag is not None and atag[0].numel() != PROBE_SLOTS:
                     atag = None
-                # with a probe: keep g's range probe (from the InstanceNorm backward that produced it) valid
-                check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(g), B, C, S, Pn, G,
-                                                     _p(atag[0]) if atag is not None else None, _st()))
+                if ptag is not None and (atag is None or ptag[0].numel() != B * C):
+                    ptag = None
+                # with a probe: keep g's range probes (from the InstanceNorm backward that produced it) valid
+                if ptag is not None:
+                    check(lib().dfmir_patch_gather_bwd_gp(_p(dout), _p(ids), _p(g), B, C, S, Pn, G, _p(atag[0]),
+                                                          _p(ptag[0]), _st()))
+                else:
+                    check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(g), B, C, S, Pn, G,
+                                                         _p(atag[0]) if atag is not None else None, _st()))
             del stash[:]
             # modified through the raw pointer: tags that were not maintained would be stale
-            for tag in (("_df_cols",) if atag is not None else ("_df_amax", "_df_cols")):
+            stale = ["_df_cols"]
+            if atag is None:
+                stale.append("_df_amax")
+            if ptag is None:
+                stale.append("_df_pmax")
+            for tag in stale:
                 if hasattr(g, tag):
                     delattr(g, tag)
         if g_tap is not None:                    # a dense gradient on the tap (some other use of it)

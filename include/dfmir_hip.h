@@ -99,6 +99,12 @@ int dfmir_conv_wgrad(const DfConvGeom* g, const float* x, const float* dy, float
 int dfmir_conv_wgrad_scaled(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                             const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
                             void* stream);
+/* The same with the maxima of |dy| PER PLANE, dy_pmax[N][Cout] (as dfmir_instnorm_bwd_pmax leaves them; NULL = as
+ * above): the fp16x2 weight-gradient kernel (Cout > 64) then scales dY per output channel -- the scale is uniform along
+ * its reduction axis -- so a channel far below the tensor maximum keeps its 22 bits. */
+int dfmir_conv_wgrad_scaled_ch(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
+                               const float* dy_amax, int dy_amax_n, const float* dy_pmax, float* dw_tcc, float* db,
+                               void* stream);
 /* db[C] += sum_{n,s} dy[n,C,s]   (accumulates). */
 int dfmir_bias_grad(const float* dy, float* db, int N, int C, long long S, void* stream);
 /* mode 0: w_tcc[t][ci][co] = w[co][ci][t]           (forward packing)
@@ -191,6 +197,10 @@ int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const
 int dfmir_instnorm_bwd_cols_ok(long long S, int W);
 int dfmir_instnorm_bwd_cols(const float* dy, const float* x, const float* mean, const float* rstd, float* dx, int planes,
                             long long S, int relu, float* dx_amax, float* dx_cols, int W, void* stream);
+/* Superset of the two (S in {4096, 16384, 65536}; dx_cols may be NULL): also dx_pmax[planes] <- max |dx| of each plane. */
+int dfmir_instnorm_bwd_pmax_ok(long long S);
+int dfmir_instnorm_bwd_pmax(const float* dy, const float* x, const float* mean, const float* rstd, float* dx, int planes,
+                            long long S, int relu, float* dx_amax, float* dx_cols, int W, float* dx_pmax, void* stream);
 
 /* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
 int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,
@@ -291,7 +301,10 @@ int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* 
 int dfmir_patch_gather_fwd_g(const float* feat, const long long* ids, float* out, int B, int C, long long S, int P,
                              int G, void* stream);
 int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
-                             int G, float* dfeat_amax, void* stream); /* accumulates */
+                             int G, float* dfeat_amax, void* stream);
+/* bwd_g that also keeps the per-plane maxima dfeat_pmax[B*C] (see dfmir_instnorm_bwd_pmax) valid.  accumulates */
+int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
+                              int G, float* dfeat_amax, float* dfeat_pmax, void* stream); /* accumulates */
 /* Key side of several NCE terms in one launch: group g gathers its Bper images from srcs[g] ([Bper,C,S]; srcs is a HOST
  * array of G <= 8 device pointers, copied by value into the launch) at ids[g][0..P) -> out[c][(g*Bper+b)*P+p].
  * Replaces `feat_k_pool, sample_ids = self.netF(feat_k, num_patches, None)` called once per term

@@ -133,19 +133,46 @@ def test_conv3x3_split_dynamic_range(ops, xs, ws, gs):
 
 
 def test_conv3x3_split_channel_magnitude_spread(ops):
-    """Per-tensor scaling with output-gradient channels 1e6 apart: every channel's weight gradient must still be
-    accurate relative to ITS OWN scale (the small channels sit 2^-20 below the tensor maximum)."""
+    """Output-gradient channels 1e6 apart.  With the per-plane maxima of dY (what InstanceNorm's backward leaves) the
+    split weight-gradient kernel scales dY per output channel, so EVERY channel's weight gradient is accurate relative to
+    its own magnitude (< 1e-5, fp32 accumulation level); with one scale for the tensor the small channels sit 2^-20
+    below the maximum and degrade to ~1e-4 (the documented behaviour of the per-tensor form, kept as the A/B)."""
     Cin, Cout, N, H, W = 64, 128, 2, 16, 32
     x = C.randn(81, N, Cin, H, W).to(DEV)
     mag = torch.logspace(0, -6, Cout).view(1, Cout, 1, 1)
     dy = (C.randn(82, N, Cout, H, W) * mag).to(DEV)
-    dwt = ops.conv_wgrad_raw(x.unsqueeze(2), dy.unsqueeze(2), (1, 3, 3), 1, (0, 1, 1), 0,
-                             x_amax=ops.absmax(x), dy_amax=ops.absmax(dy))
-    dw = ops.weight_unpack(dwt, (Cout, Cin, 3, 3)).double()
     ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
-    per_ch_err = (dw - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
-    assert float(per_ch_err.max()) < 2e-4, per_ch_err.max()
-    assert float(per_ch_err[:64].max()) < 2e-6, per_ch_err[:64].max()   # channels within 1e-3 of the maximum
+
+    def per_channel_error(pmax):
+        dwt = ops.conv_wgrad_raw(x.unsqueeze(2), dy.unsqueeze(2), (1, 3, 3), 1, (0, 1, 1), 0,
+                                 x_amax=ops.absmax(x), dy_amax=ops.absmax(dy), dy_pmax=pmax)
+        dw = ops.weight_unpack(dwt, (Cout, Cin, 3, 3)).double()
+        return (dw - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)
+
+    e_ch = per_channel_error(dy.abs().amax(dim=(2, 3)).contiguous())          # [N, Cout] plane maxima
+    assert float(e_ch.max()) < 1e-5, e_ch.max()
+    e_t = per_channel_error(None)
+    assert float(e_t.max()) < 2e-4 and float(e_t[:64].max()) < 2e-6, (e_t.max(), e_t[:64].max())
+    assert float(e_ch.max()) < 0.2 * float(e_t.max())
+
+
+def test_instnorm_backward_plane_maxima_feed_the_wgrad(ops):
+    """InstanceNorm backward leaves max |dx| per (n, c) plane; the conv in front of it picks them up for its weight
+    gradient (tag on the gradient tensor), and the result matches fp64."""
+    from dfmir_amd import networks as N_
+    conv = N_.Conv2d(64, 128, 3, padding=1).to(DEV)
+    inn = N_.InstanceNorm2d(128)
+    x = C.randn(85, 2, 64, 64, 64).to(DEV)
+    cot = (C.randn(86, 2, 128, 64, 64) * torch.logspace(0, -5, 128).view(1, 128, 1, 1)).to(DEV)
+    y = inn(conv(x), relu=True)
+    (y * cot).sum().backward()
+    xr = x.double().cpu()
+    wr = conv.weight.detach().double().cpu().requires_grad_()
+    br = conv.bias.detach().double().cpu().requires_grad_()
+    yr = torch.relu(torch.nn.functional.instance_norm(torch.nn.functional.conv2d(xr, wr, br, padding=1), eps=1e-5))
+    (yr * cot.double().cpu()).sum().backward()
+    e = (conv.weight.grad.double().cpu() - wr.grad).flatten(1).norm(dim=1) / wr.grad.flatten(1).norm(dim=1)
+    assert float(e.max()) < 2e-5, e.max()
 
 
 @pytest.mark.parametrize("cfg", [(1, 64, 7, 3, True, 0, 2, 20, 24), (64, 1, 7, 3, True, 2, 2, 20, 24),
