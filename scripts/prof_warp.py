@@ -18,8 +18,7 @@ dsrc = torch.zeros_like(src); dflow = torch.empty_like(flow)
 reps = int(os.environ.get("REPS", "10"))
 for _ in range(reps):
     ops._warp_fwd(src, flow, 0, 0)
-    dsrc.zero_()
-    ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
+    ops._warp_bwd_dsrc(dout, src, flow, dflow, 0, 0)      # owner-gather kernels (no device-scope atomics)
 torch.cuda.synchronize()
 def tm(fn, reps=20):
     torch.cuda.synchronize()
@@ -32,4 +31,4 @@ def tm(fn, reps=20):
 print("cell %d amp %.1f: fwd %.1f us  bwd(dflow only) %.1f us  bwd(dsrc+dflow) %.1f us" % (
     cell, amp, tm(lambda: ops._warp_fwd(src, flow, 0, 0)),
     tm(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0)),
-    tm(lambda: ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0))))
+    tm(lambda: ops._warp_bwd_dsrc(dout, src, flow, dflow, 0, 0))))
