@@ -41,11 +41,14 @@ for name, shp, C, cell, amp in (("warp3d 160x192x224 C=1 smooth", (1, 160, 192, 
     dsrc = torch.zeros_like(src); dflow = torch.empty_like(flow)
     ms = timeit(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0))
     report(name + " bwd d(flow) only", 4 * (C + C + 2 * nd) * nv, ms)
-    def bwd():
-        dsrc.zero_()
+    ms = timeit(lambda: ops._warp_bwd_dsrc(dout, src, flow, dflow, 0, 0))
+    report(name + " bwd d(src)+d(flow), owner-gather", 4 * (C + 2 * C + 2 * nd) * nv, ms)
+
+    def bwd_atomic():
+        ops.zero_(dsrc)
         ops._warp_bwd(dout, src, flow, dsrc, dflow, 0, 0)
-    ms = timeit(bwd)
-    report(name + " bwd (incl. dsrc memset)", 4 * (C + 2 * C + 2 * nd) * nv, ms)
+    ms = timeit(bwd_atomic)
+    report(name + " bwd d(src)+d(flow), atomic form", 4 * (C + 2 * C + 2 * nd) * nv, ms)
 # ---- InstanceNorm
 for name, shp in (("instnorm [32,128,256,256]", (32, 128, 256, 256)), ("instnorm [32,256,64,64]", (32, 256, 64, 64))):
     x = torch.randn(*shp, device=dev)
