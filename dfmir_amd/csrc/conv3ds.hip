@@ -89,6 +89,7 @@ struct C3sP {
   int nz, ny, nx;                // tiles per axis
   int nchunk;
   int x_n;                       // floats of the input range probe
+  int cout_used;                 // output channels to compute (<= Cout; the rest of y is left untouched)
 };
 
 __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = mt * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-      if (co < k.Cout) {
+      if (co < k.cout_used) {
         float v = acc[j][r] * oscale * oscale2 + (bias ? bias[co] : 0.f);
         if (k.act == 1) v = v > 0.f ? v : v * k.slope;
         else if (k.act == 2) v = tanhf(v);
@@ -260,9 +261,23 @@ extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0) return -1;
   return (long long)((Cout + 31) / 32) * ((Cin + 7) / 8) * 2 * 28 * 32 * 4 + 4;
 }
+static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                 const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                 int cout_used, void* stream);
 extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                       const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
                                       void* stream) {
+  return conv3d_split_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, ws, bias, y, y_amax, g ? g->Cout : 0, stream);
+}
+extern "C" int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                          const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                          int cout_used, void* stream) {
+  DF_ARG_CHECK(g && cout_used > 0 && cout_used <= g->Cout);
+  return conv3d_split_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, ws, bias, y, y_amax, cout_used, stream);
+}
+static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                 const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                 int cout_used, void* stream) {
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && w_tcc && ws && y);
   DF_ARG_CHECK(!split3d_off() && split3d_geom_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
@@ -271,10 +286,10 @@ extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const
   conv3d_wsplit_k<<<1, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, g->Cout, trailer);
   DF_LAUNCH_CHECK();
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
-         nchunk, x_amax_n};
+         nchunk, x_amax_n, cout_used};
   const long long nb = (long long)g->N * k.nz * k.ny * k.nx;
   DF_ARG_CHECK(nb < (1LL << 31));
-  conv3d_split_k<<<dim3((unsigned)nb, (unsigned)nmt), 256, 0, st>>>(x, x_amax, reinterpret_cast<const u32x4*>(ws), trailer,
+  conv3d_split_k<<<dim3((unsigned)nb, (unsigned)((cout_used + 31) / 32)), 256, 0, st>>>(x, x_amax, reinterpret_cast<const u32x4*>(ws), trailer,
                                                                    bias, y, y_amax, k);
   DF_LAUNCH_CHECK();
   return 0;

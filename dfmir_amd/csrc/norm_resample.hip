@@ -903,14 +903,18 @@ extern "C" int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, 
 }
 extern "C" int dfmir_upcat_bwd(const float* dy, float* da, float* db, int N, int Ca, int Cb, int Da,
                                int Ha, int Wa, int sd, void* stream) {
-  DF_ARG_CHECK(dy && da && db && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));
+  DF_ARG_CHECK(dy && (da || db) && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));   // NULL: that gradient is not wanted
   const long long Sa = (long long)Da * Ha * Wa, So = Sa * sd * 4;
-  upcat_bwd_a_k<<<df_grid((long long)N * Ca * Sa, 256, 16384), 256, 0, (hipStream_t)stream>>>(
-      dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
-  DF_LAUNCH_CHECK();
-  upcat_bwd_b_k<<<df_grid((long long)N * Cb * So, 256, 16384), 256, 0, (hipStream_t)stream>>>(
-      dy, db, N, Ca, Cb, So);
-  DF_LAUNCH_CHECK();
+  if (da) {
+    upcat_bwd_a_k<<<df_grid((long long)N * Ca * Sa, 256, 16384), 256, 0, (hipStream_t)stream>>>(
+        dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+    DF_LAUNCH_CHECK();
+  }
+  if (db) {
+    upcat_bwd_b_k<<<df_grid((long long)N * Cb * So, 256, 16384), 256, 0, (hipStream_t)stream>>>(
+        dy, db, N, Ca, Cb, So);
+    DF_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int dfmir_cat_channels_fwd(const float* a, const float* b, float* y, long long N, long long SA,

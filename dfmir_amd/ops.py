@@ -130,7 +130,8 @@ def _wants_amax(K, stride, dil, Di, Cin, Cout):
     return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
 
 
-def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None, ring=None):
+def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None, ring=None,
+             cout_used=None):
     """res (optional, shape of the output): y = act(conv + bias) + res, inside the kernel's epilogue where the
     library has one (dfmir_conv3x3_res_ok), else by a separate add.  ring = (buffer, row length) of
     dfmir_conv3x3_reflect_ring: folded in by the same epilogue (the caller checked dfmir_conv3x3_res_ok)."""
@@ -142,14 +143,17 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                 and lib().dfmir_conv3x3_res_ok(ctypes.byref(g)))
     split3d = (x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
+    if cout_used is not None and not split3d:
+        cout_used = None                                     # only the split 3-D kernel computes a channel subset
 
     def launch():
         if split3d:
             # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer
             ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
             slot = amax_slot(x5.device, PROBE_SLOTS)
-            check(lib().dfmir_conv3d_split_fwd(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
-                                               _p(bias), _p(y), _p(slot), _st()))
+            check(lib().dfmir_conv3d_split_fwd_sub(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
+                                                   _p(bias), _p(y), _p(slot), Cout if cout_used is None else cout_used,
+                                                   _st()))
             tag_amax(y, slot)              # survives as is when y is a backward result (dgrad) ...
             _LAST_CONV_AMAX[0] = slot      # ... and is re-attached by conv() to the tensor Function.apply returns
         elif fuse_res or ring is not None:
@@ -320,6 +324,7 @@ def bump_weights_epoch():
 # bias gradients straight into `bias.grad`; the buffers are unpacked into `weight.grad` once, on exit.
 # Without it every pass pays a zero-fill, an unpack and an autograd `add` per parameter (~900 tiny launches).
 _NO_RES = bool(os.environ.get("DFMIR_NO_RES"))       # A/B switch: residual added by a separate kernel
+_NO_DEAD_TAIL = bool(os.environ.get("DFMIR_NO_DEAD_TAIL"))   # A/B switch: dgrad also for skip channels that need none
 _NO_CH_SCALE = bool(os.environ.get("DFMIR_NO_CH_SCALE"))   # A/B switch: one dY scale per tensor in the split wgrad
 _NO_RING = bool(os.environ.get("DFMIR_NO_RING"))     # A/B switch: reflect dgrad as padded-frame conv + fold
 _DEFER = {"on": False, "pending": {}}
@@ -404,6 +409,8 @@ class ConvFn(Function):
             x_amax = amax_of(x) if x.is_contiguous() else absmax(x5)
         y5 = conv_raw(x5, w_tcc, bias, weight.shape[0], K, stride, p3, 1, pad_mode, act, slope, out_sp, x_amax)
         ctx.x_amax = x_amax
+        # trailing input channels that need no gradient (cat([up2(a), b]) with b = the network's input images)
+        ctx.dead_tail = int(getattr(x, "_df_nograd_tail", 0))
         ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
         ctx.save_for_backward(x5, weight, y5 if act else None)
         ctx.has_bias = bias is not None
@@ -486,7 +493,8 @@ class ConvFn(Function):
                                                         p3[1], _st()))
             else:
                 padp = tuple(K[i] - 1 - p3[i] for i in range(3))
-                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax)
+                used = Cin - ctx.dead_tail if (ctx.dead_tail and stride == 1 and not _NO_DEAD_TAIL) else None
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax, cout_used=used)
             dx = dx5 if nd == 3 else dx5.squeeze(2)
         if dskip is not None:       # not folded in above (x needs no conv-path gradient, or non-reflect dgrad)
             dx = dskip if dx is None else dx + dskip
@@ -798,9 +806,10 @@ class UpCatFn(Function):
     def backward(ctx, dy):
         ash, bsh, N, Ca, Cb, Da, Ha, Wa, sd = ctx.meta
         dy = _c(dy)
-        da = torch.empty(ash, device=dy.device, dtype=torch.float32)
-        db = torch.empty(bsh, device=dy.device, dtype=torch.float32)
-        check(lib().dfmir_upcat_bwd(_p(dy), _p(da), _p(db), N, Ca, Cb, Da, Ha, Wa, sd, _st()))
+        da = torch.empty(ash, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        db = torch.empty(bsh, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:   # (the skip part of dy may be unwritten when it needs no gradient)
+            check(lib().dfmir_upcat_bwd(_p(dy), _p(da), _p(db), N, Ca, Cb, Da, Ha, Wa, sd, _st()))
         return da, db
 
 
@@ -813,6 +822,8 @@ def _valid_amax(t):
 
 def upcat(a, b):
     y = UpCatFn.apply(a, b)
+    if torch.is_grad_enabled() and a.requires_grad and not b.requires_grad:
+        y._df_nograd_tail = int(b.shape[1])    # the consumer conv's dgrad skips these channels (ConvFn)
     pa, pb = _valid_amax(a), _valid_amax(b)
     if pa is not None and pb is not None:      # nearest up-sampling + concatenation create no new values
         slot = amax_slot(y.device, PROBE_SLOTS)

@@ -84,6 +84,11 @@ int dfmir_conv3d_split_ok(const DfConvGeom* g);
 long long dfmir_conv3d_split_ws_floats(int Cin, int Cout);
 int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
                            float* ws, const float* bias, float* y, float* y_amax, void* stream);
+/* The same, computing output channels [0, cout_used) only (y keeps Cout planes; the others are left untouched): the
+ * input gradient of a layer fed by cat([up2(a), b]) whose skip part b needs no gradient (the two image channels at the
+ * top of the U-Net, networks.py:97-100). */
+int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
+                               float* ws, const float* bias, float* y, float* y_amax, int cout_used, void* stream);
 /* The weight gradient of the same layers in the same split form (Cin <= 48, Cout <= 32, W % 4 == 0), voxels as the
  * matrix K: dw_tcc[tap][Cin][Cout] += ...   (accumulates, like dfmir_conv_wgrad). */
 int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
