@@ -61,6 +61,9 @@ _SIGS = {
     "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P, P],
     "dfmir_instnorm_bwd_cols_ok": [c_longlong, c_int],
     "dfmir_instnorm_bwd_cols": [P, P, P, P, P, c_int, c_longlong, c_int, P, P, c_int, P],
+    "dfmir_in_relu_blurdown_ok": [c_int, c_int],
+    "dfmir_in_relu_blurdown_fwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P],
+    "dfmir_in_relu_blurdown_bwd": [P, P, P, P, P, c_int, c_int, c_int, P, P, P],
     "dfmir_act_bwd": [P, P, P, c_longlong, c_int, c_float, P],
     "dfmir_blur_down_fwd": [P, P, c_int, c_int, c_int, P],
     "dfmir_blur_down_bwd": [P, P, c_int, c_int, c_int, P],

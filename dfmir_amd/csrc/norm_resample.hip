@@ -377,6 +377,152 @@ __global__ void blur_down_bwd_k(const float* __restrict__ dy, float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// InstanceNorm + ReLU + Downsample in one pass over the plane (models/networks.py:984-996: the full-resolution
+// IN/ReLU output feeds only the blur-pool and is needed by nobody's backward -- InstanceNorm's adjoint wants x, mean,
+// rstd; the blur's wants only its output gradient).  Forward: the plane is read once into registers (as
+// instnorm_fwd_reg_k), normalised, and pushed band by band (RB = NT*4/W rows) through a 2*RB-row LDS ring from which
+// every thread takes one output of the 3x3 [1 2 1]^2/16 stride-2 stencil (reflect at row / column -1): 1.25 plane
+// transfers instead of 3.25.  Backward: d(IN output) is the blur's adjoint of dz, gathered from LDS-staged dz rows
+// (<= 2x2 taps per pixel, blur_down_adj), once for the two InstanceNorm sums and once more for the result, so that
+// only x stays in registers (the 1024-thread form has 128): 2.25-2.5 transfers instead of 4.25.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void in_relu_blurdown_fwd_k(const float* __restrict__ x, float* __restrict__ z,
+                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                             int W, float eps, float* __restrict__ amax) {
+  constexpr long long S = (long long)NT * 4 * E;
+  extern __shared__ float ring[];                        // 2*RB rows x W
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
+  const int H = (int)(S / W), Wo = W >> 1, Ho = H >> 1, RB = NT * 4 / W;
+  const long long base = (long long)blockIdx.x * S;
+  const float4* x4 = reinterpret_cast<const float4*>(x + base);
+  float4 v[E];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    v[i] = x4[threadIdx.x + NT * i];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = block_sum(s, sm) / (float)S;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = block_sum(q, sm) / (float)S;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[blockIdx.x] = mean;
+    rstd_o[blockIdx.x] = rstd;
+  }
+  float* zp = z + (long long)blockIdx.x * Ho * Wo;
+  const int lrow = (threadIdx.x * 4) / W, lcol = (threadIdx.x * 4) % W;   // this thread's place inside a band
+  const int orow = threadIdx.x / Wo, ocol = threadIdx.x % Wo;            // ... and its output inside the band's outputs
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    float4 o;
+    o.x = fmaxf((v[i].x - mean) * rstd, 0.f); o.y = fmaxf((v[i].y - mean) * rstd, 0.f);
+    o.z = fmaxf((v[i].z - mean) * rstd, 0.f); o.w = fmaxf((v[i].w - mean) * rstd, 0.f);
+    am = fmaxf(fmaxf(am, fmaxf(o.x, o.y)), fmaxf(o.z, o.w));
+    __syncthreads();                                     // readers of the half about to be overwritten are done
+    *reinterpret_cast<float4*>(&ring[(((i & 1) * RB) + lrow) * W + lcol]) = o;
+    __syncthreads();
+    // output row oy = i*RB/2 + orow reads input rows 2oy-1 .. 2oy+1 (row -1 reflects to row 1)
+    const int oy = i * (RB >> 1) + orow;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int gr = 2 * oy + a - 1;
+      gr = gr < 0 ? -gr : gr;
+      const float* row = ring + (gr % (2 * RB)) * W;
+      const int c1 = 2 * ocol, c0 = c1 == 0 ? 1 : c1 - 1, c2 = c1 + 1;
+      const float r = 0.25f * row[c0] + 0.5f * row[c1] + 0.25f * row[c2];
+      acc += (a == 1 ? 0.5f : 0.25f) * r;
+    }
+    zp[oy * Wo + ocol] = acc;
+  }
+  if (amax) publish_block_absmax_acc(am, &smax, amax);     // bounds the blur's output too (convex combination)
+}
+
+template <int NT, int E>
+__global__ __launch_bounds__(NT) void in_relu_blurdown_bwd_k(const float* __restrict__ dz, const float* __restrict__ x,
+                                                             const float* __restrict__ mean_i,
+                                                             const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                             int W, float* __restrict__ amax, float* __restrict__ pmax) {
+  // x is NOT kept in registers here (2 x E unrolled bands with the blur's tap geometry on top of 4*E registers of x
+  // spilled in every form tried): both passes stream it band by band, one band ahead; the second read of the 64-256 KB
+  // plane comes back from L2 / the Infinity Cache.
+  constexpr long long S = (long long)NT * 4 * E;
+  extern __shared__ float zr[];                          // (RB/2 + 1) rows of dz x Wo
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  if (threadIdx.x == 0) smax = 0u;
+  const int H = (int)(S / W), Wo = W >> 1, Ho = H >> 1, RB = NT * 4 / W, ZR = (RB >> 1) + 1;
+  const long long base = (long long)blockIdx.x * S;
+  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
+  const float4* x4 = reinterpret_cast<const float4*>(x + base);
+  const float* gz = dz + (long long)blockIdx.x * Ho * Wo;
+  const int lrow = (threadIdx.x * 4) / W, ix = (threadIdx.x * 4) % W;
+  const int c = ix >> 1;                                 // dz columns c, c+1, c+2 serve inputs ix..ix+3
+  const bool c2 = c + 2 < Wo;
+  float m1 = 0.f, m2 = 0.f, s1 = 0.f, s2 = 0.f, am = 0.f;
+  float4* d4 = reinterpret_cast<float4*>(dx + base);
+  for (int pass = 0; pass < 2; ++pass) {
+    float4 xn = x4[threadIdx.x];
+#pragma unroll 1
+    for (int i = 0; i < E; ++i) {
+      const float4 xv = xn;
+      if (i + 1 < E) xn = x4[threadIdx.x + NT * (i + 1)];
+      __syncthreads();
+      const int z0 = i * (RB >> 1);
+      for (int u = threadIdx.x; u < ZR * Wo; u += NT) {
+        const int zrow = z0 + u / Wo;
+        zr[u] = zrow < Ho ? gz[zrow * Wo + (u % Wo)] : 0.f;
+      }
+      __syncthreads();
+      // g = blur adjoint of dz at this thread's float4 of band i, masked by ReLU (xhat > 0)
+      int oy[3]; float wy[3];
+      blur_down_adj(i * RB + lrow, H, Ho, oy, wy);
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (wy[a] == 0.f) continue;
+        const float* row = zr + (oy[a] - z0) * Wo + c;
+        const float g0 = row[0], g1 = row[1], g2 = c2 ? row[2] : 0.f;
+        g[0] += wy[a] * (0.5f * g0);
+        g[1] += wy[a] * (0.25f * g0 + 0.25f * g1 + (ix == 0 ? 0.25f * g0 : 0.f));   // column 1 also gets the reflected -1
+        g[2] += wy[a] * (0.5f * g1);
+        g[3] += wy[a] * (0.25f * g1 + 0.25f * g2);
+      }
+      const float h[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(h[e] > 0.f)) g[e] = 0.f;
+      if (pass == 0) {
+        s1 += (g[0] + g[1]) + (g[2] + g[3]);
+        s2 += (g[0] * h[0] + g[1] * h[1]) + (g[2] * h[2] + g[3] * h[3]);
+      } else {
+        float4 o;
+        o.x = rstd * (g[0] - m1 - h[0] * m2); o.y = rstd * (g[1] - m1 - h[1] * m2);
+        o.z = rstd * (g[2] - m1 - h[2] * m2); o.w = rstd * (g[3] - m1 - h[3] * m2);
+        d4[threadIdx.x + NT * i] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      }
+    }
+    if (pass == 0) {
+      m1 = block_sum(s1, sm) / (float)S;
+      m2 = block_sum(s2, sm) / (float)S;
+    }
+  }
+  if (amax) publish_block_absmax_acc(am, &smax, amax);
+  if (amax && pmax && threadIdx.x == 0) pmax[blockIdx.x] = __uint_as_float(smax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Upsample (replicate pad 1 + conv_transpose 4x4 stride 2 pad 2, cropped) == per axis
 //   out[2m]   = 0.75 x[m] + 0.25 x[max(m-1,0)]
 //   out[2m+1] = 0.75 x[m] + 0.25 x[min(m+1,L-1)]
@@ -790,6 +936,27 @@ static int instnorm_bwd_impl(const float* dy, const float* x, const float* mean,
       if (rc) return df_set_error(rc, __FILE__, __LINE__);
     }
   }
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_in_relu_blurdown_ok(int H, int W) {
+  return ((H == 256 && W == 256) || (H == 128 && W == 128)) ? 1 : 0;
+}
+extern "C" int dfmir_in_relu_blurdown_fwd(const float* x, float* z, float* mean, float* rstd, int planes, int H, int W,
+                                          float eps, float* z_amax, void* stream) {
+  DF_ARG_CHECK(x && z && mean && rstd && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 256) in_relu_blurdown_fwd_k<1024, 16><<<planes, 1024, 2 * 16 * 256 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
+  else in_relu_blurdown_fwd_k<256, 16><<<planes, 256, 2 * 8 * 128 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_in_relu_blurdown_bwd(const float* dz, const float* x, const float* mean, const float* rstd, float* dx,
+                                          int planes, int H, int W, float* dx_amax, float* dx_pmax, void* stream) {
+  DF_ARG_CHECK(dz && x && mean && rstd && dx && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 256) in_relu_blurdown_bwd_k<1024, 16><<<planes, 1024, (8 + 1) * 128 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);
+  else in_relu_blurdown_bwd_k<256, 16><<<planes, 256, (4 + 1) * 64 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);
   DF_LAUNCH_CHECK();
   return 0;
 }

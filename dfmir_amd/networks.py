@@ -334,6 +334,13 @@ class ResnetGenerator(nn.Module):
                         return feat, feats, True
                     i += 1
                 continue
+            if (isinstance(m, InstanceNorm2d) and i + 2 < n and isinstance(mods[i + 1], ReLU)
+                    and isinstance(mods[i + 2], Downsample) and not ({i, i + 1, i + 2} & want)
+                    and ops.in_relu_blurdown_ok(feat)):
+                # InstanceNorm + ReLU + blur-pool in one pass: the full-resolution normalised tensor feeds nothing else
+                feat = ops.instance_norm_relu_blur_down(feat, m.eps)
+                i += 3
+                continue
             if isinstance(m, InstanceNorm2d):
                 relu = i + 1 < n and isinstance(mods[i + 1], ReLU)
                 feat = m(feat, relu=relu)

@@ -723,6 +723,54 @@ def instance_norm(x, res=None, relu=False, eps=1e-5):
     return tag_amax(y, _LAST_AMAX[0])
 
 
+_NO_IN_BLUR = bool(os.environ.get("DFMIR_NO_IN_BLUR"))     # A/B switch: InstanceNorm+ReLU and Downsample as two passes
+
+
+class InstNormReluBlurDownFn(Function):
+    """Downsample(ReLU(InstanceNorm2d(x))) in one pass per plane (csrc/norm_resample.hip in_relu_blurdown_*): the
+    full-resolution normalised tensor is never written -- it feeds only the blur and no backward needs it."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _need(x)
+        x = _c(x)
+        N, C, H, W = x.shape
+        planes = N * C
+        z = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        mean = torch.empty(planes, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        slot = amax_slot(x.device, PROBE_SLOTS)
+        check(lib().dfmir_in_relu_blurdown_fwd(_p(x), _p(z), _p(mean), _p(rstd), planes, H, W, float(eps), _p(slot), _st()))
+        _LAST_AMAX[0] = slot
+        ctx.save_for_backward(x, mean, rstd)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, mean, rstd = ctx.saved_tensors
+        dz = _c(dz)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        slot = amax_slot(x.device, PROBE_SLOTS)
+        pmax = torch.empty(N * C, device=x.device, dtype=torch.float32)
+        check(lib().dfmir_in_relu_blurdown_bwd(_p(dz), _p(x), _p(mean), _p(rstd), _p(dx), N * C, H, W, _p(slot), _p(pmax),
+                                               _st()))
+        dx._df_pmax = (pmax, dx._version, dx.data_ptr())
+        tag_amax(dx, slot)
+        return dx, None
+
+
+def in_relu_blurdown_ok(x):
+    return (not _NO_IN_BLUR and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32
+            and bool(lib().dfmir_in_relu_blurdown_ok(int(x.shape[2]), int(x.shape[3]))))
+
+
+def instance_norm_relu_blur_down(x, eps=1e-5):
+    z = InstNormReluBlurDownFn.apply(x, eps)
+    return tag_amax(z, _LAST_AMAX[0])
+
+
 # ------------------------------------------------------------------------------------------------
 # plane-wise resampling
 # ------------------------------------------------------------------------------------------------

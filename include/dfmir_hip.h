@@ -207,6 +207,17 @@ int dfmir_instnorm_bwd_pmax_ok(long long S);
 int dfmir_instnorm_bwd_pmax(const float* dy, const float* x, const float* mean, const float* rstd, float* dx, int planes,
                             long long S, int relu, float* dx_amax, float* dx_cols, int W, float* dx_pmax, void* stream);
 
+/* InstanceNorm2d + ReLU + Downsample (blur-pool) as one pass per plane: models/networks.py:984-996, modules
+ * (5,6,7) and (9,10,11) of the generator -- the full-resolution normalised tensor feeds only the blur and no backward
+ * needs it.  H x W = 256 x 256 or 128 x 128 (dfmir_in_relu_blurdown_ok).  z [planes, H/2, W/2]; mean / rstd [planes]
+ * saved for backward; z_amax (may be NULL): DFMIR_PROBE_SLOTS zero-initialised floats, a bound of max|z|.
+ * bwd: dx from dz, x, mean, rstd; dx_amax / dx_pmax as dfmir_instnorm_bwd_pmax (may be NULL). */
+int dfmir_in_relu_blurdown_ok(int H, int W);
+int dfmir_in_relu_blurdown_fwd(const float* x, float* z, float* mean, float* rstd, int planes, int H, int W, float eps,
+                               float* z_amax, void* stream);
+int dfmir_in_relu_blurdown_bwd(const float* dz, const float* x, const float* mean, const float* rstd, float* dx,
+                               int planes, int H, int W, float* dx_amax, float* dx_pmax, void* stream);
+
 /* elementwise activation backward from the saved OUTPUT y: act 1 leaky(slope), 2 tanh. */
 int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act, float slope,
                   void* stream);

@@ -675,3 +675,28 @@ def test_warp_backward_is_reproducible_and_matches_atomic_path(ops, case):
     if not self_warp:
         assert torch.equal(runs[0][1], runs[1][1])
         close(runs[0][1], dflow_ref, rtol=2e-6, what="dflow vs atomic path")
+
+
+@pytest.mark.parametrize("H", [256, 128])
+def test_in_relu_blurdown_fused_matches_two_passes(ops, H):
+    """InstanceNorm + ReLU + Downsample in one pass per plane == the two kernels it replaces (instance_norm(relu) then
+    blur_down), forward and backward, and == torch (instance_norm / relu / reflect-pad + [1 2 1]^2/16 stride-2 conv,
+    models/networks.py:37-60,984-996)."""
+    x = (C.randn(141, 2, 3, H, H) * torch.tensor([0.5, 2.0, 1.0]).view(1, 3, 1, 1) + 0.3).to(DEV)
+    cot = C.randn(142, 2, 3, H // 2, H // 2).to(DEV)
+    xa = x.clone().requires_grad_()
+    za = ops.instance_norm_relu_blur_down(xa)
+    (za * cot).sum().backward()
+    xb = x.clone().requires_grad_()
+    zb = ops.blur_down(ops.instance_norm(xb, None, True))
+    (zb * cot).sum().backward()
+    close(za, zb, rtol=2e-6, what="z vs two passes")
+    close(xa.grad, xb.grad, rtol=2e-5, what="dx vs two passes")
+    xr = x.double().cpu().requires_grad_()
+    y = torch.relu(F.instance_norm(xr, eps=1e-5))
+    f = torch.tensor([1.0, 2.0, 1.0], dtype=torch.float64)
+    k = (f[:, None] * f[None, :] / 16.0)[None, None].repeat(3, 1, 1, 1)
+    zr = F.conv2d(F.pad(y, (1, 1, 1, 1), mode="reflect"), k, stride=2, groups=3)
+    (zr * cot.double().cpu()).sum().backward()
+    close(za, zr, rtol=1e-5, what="z vs torch")
+    close(xa.grad, xr.grad, rtol=1e-4, what="dx vs torch")
