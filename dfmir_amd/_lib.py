@@ -47,6 +47,7 @@ _SIGS = {
     "dfmir_conv3d_split_fwd_sub": [_GP, P, P, c_int, P, P, P, P, P, c_int, P],
     "dfmir_conv3d_split_wgrad_ok": [_GP],
     "dfmir_conv3d_split_wgrad": [_GP, P, P, c_int, P, P, c_int, P, P],
+    "dfmir_conv3d_split_wgrad_db": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_probe_merge": [P, P, P, P],
     "dfmir_act_bwd_amax": [P, P, P, c_longlong, c_int, c_float, P, P],
     "dfmir_weight_unpack": [P, P, c_int, c_int, c_int, P],

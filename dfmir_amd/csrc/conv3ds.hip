@@ -314,6 +314,10 @@ struct W3sP {
   long long npatch, per_block;
   int x_n, dy_n;
   int nchunk;                    // chunks of 8 input channels in the layer; blockIdx.y * NCH = this workgroup's first
+  long long s_tap, s_row, s_col; // output index = tap' * s_tap + ci * s_row + co * s_col, tap' = flip ? 26 - tap : tap
+  int flip;
+  float* db;                     // optional bias gradient: db[.] += sum over voxels of the layer's output gradient
+  int db_from_x;                 // 0: db indexed by co, summed from the dY operand;  1: by ci, from the X operand (swapped roles)
 };
 
 template <int NCH>
@@ -362,6 +366,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
   u32x4 ry[4];
   __amdgpu_buffer_rsrc_t x_src, y_src;
   int pz0 = 0, py0 = 0, px0 = 0;
+  float bacc = 0.f;                                       // this thread's share of the bias gradient
+  const bool db_y = k.db && !k.db_from_x && blockIdx.y == 0;
+  const bool db_x = k.db && k.db_from_x && xrow && xhz >= 1 && xhz <= PZ && xhy >= 1 && xhy <= PY;   // the patch's own rows
 
 #define W3S_GLOAD(it_)                                                                            \
   {                                                                                               \
@@ -401,6 +408,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
   for (int it = 0; it < niter; ++it) {
     const int c = it % NCH;
     __syncthreads();                                       // previous compute is done with the LDS buffers
+    if (db_x) {
+#pragma unroll
+      for (int j = 1; j <= 16; ++j) bacc += rx[j];          // loads outside the frame returned 0
+    }
     if (xrow) {
       unsigned ph[9], pr[9];
 #pragma unroll
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const u32x4 v = ry[2 * u + q];
+          if (db_y) bacc += (__uint_as_float(v[0]) + __uint_as_float(v[1])) + (__uint_as_float(v[2]) + __uint_as_float(v[3]));
           unsigned hh, rr;
           split_pair3(__uint_as_float(v[0]), __uint_as_float(v[1]), dscale, hh, rr);
           h[2 * q] = hh; r[2 * q] = rr;
@@ -488,37 +500,78 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
       for (int r = 0; r < 16; ++r) {
         const int rho = tile * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
         const int tap = rho >> 3, ci = (c_base + c) * 8 + (rho & 7);
-        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[((long long)tap * k.Cin + ci) * k.Cout + l31], acc[c][s][r] * sc);
+        const int to = k.flip ? 26 - tap : tap;
+        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + l31 * k.s_col], acc[c][s][r] * sc);
       }
     }
+  if (db_y && yco < k.Cout) atomicAdd(&k.db[yco], bacc);
+  if (db_x) {
+    // the X rows of chunk c were summed while c was staged; bacc mixes the chunks of this workgroup row only when
+    // NCH > 1, which the swapped-role launch (one chunk) never has
+    const int ci = c_base * 8 + xci;
+    if (ci < k.Cin) atomicAdd(&k.db[ci], bacc);
+  }
 }
 
-static bool split3d_wgrad_geom_ok(const DfConvGeom* g) {
+static bool split3d_wgrad_common_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
          g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
-         g->Cin >= 8 && g->Cin <= 48 && g->Cout >= 8 && g->Cout <= 32 && (g->Wi & 3) == 0 &&
-         (long long)g->Cin * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL && (long long)g->Cout * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;
+         (g->Wi & 3) == 0 && (long long)g->Cin * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL &&
+         (long long)g->Cout * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;
+}
+// normal roles: rows = (tap, ci), columns = co.  Few output channels (the 16 -> 3 flow conv): SWAPPED roles -- rows =
+// (tap, co) gathered from shifted dY, columns = ci: dW[t][ci][co] = sum_u X[ci][u] * dY[co][u - t], i.e. the same kernel
+// on (x := dY, dy := X) with the taps flipped and the output transposed (one 8-channel chunk instead of Cin / 8).
+static bool split3d_wgrad_geom_ok(const DfConvGeom* g) {
+  return split3d_wgrad_common_ok(g) && g->Cin >= 8 && g->Cin <= 48 && g->Cout >= 8 && g->Cout <= 32;
+}
+static bool split3d_wgrad_swapped_ok(const DfConvGeom* g) {
+  return split3d_wgrad_common_ok(g) && g->Cout >= 1 && g->Cout < 8 && g->Cin >= 8 && g->Cin <= 32;
 }
 extern "C" int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g) {
-  return (g && !split3d_off() && split3d_wgrad_geom_ok(g)) ? 1 : 0;
+  return (g && !split3d_off() && (split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g))) ? 1 : 0;
 }
+static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                   const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
+                                   void* stream);
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                         const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                         void* stream) {
+  return conv3d_split_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, nullptr, stream);
+}
+extern "C" int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                           const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
+                                           float* db, void* stream) {
+  return conv3d_split_wgrad_impl(g, x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream);
+}
+static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                   const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
+                                   void* stream) {
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
-  DF_ARG_CHECK(!split3d_off() && split3d_wgrad_geom_ok(g));
+  DF_ARG_CHECK(!split3d_off() && (split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
   hipStream_t st = (hipStream_t)stream;
+  const bool swapped = !split3d_wgrad_geom_ok(g);
   W3sP k{};
-  k.N = g->N; k.Cin = g->Cin; k.Cout = g->Cout; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
+  k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
+  if (swapped) {
+    k.Cin = g->Cout; k.Cout = g->Cin;                        // kernel roles
+    k.s_tap = (long long)g->Cin * g->Cout; k.s_row = 1; k.s_col = g->Cout; k.flip = 1;
+    k.x_n = dy_amax_n; k.dy_n = x_amax_n;
+    k.db = db; k.db_from_x = 1;
+  } else {
+    k.Cin = g->Cin; k.Cout = g->Cout;
+    k.s_tap = (long long)g->Cin * g->Cout; k.s_row = g->Cout; k.s_col = 1; k.flip = 0;
+    k.x_n = x_amax_n; k.dy_n = dy_amax_n;
+    k.db = db; k.db_from_x = 0;
+  }
   k.nz = (g->Di + 1) / 2; k.ny = (g->Hi + 3) / 4; k.nx = (g->Wi + 15) / 16;
   k.npatch = (long long)g->N * k.nz * k.ny * k.nx;
   long long want = 512;
   if (want > k.npatch) want = k.npatch;
   k.per_block = (k.npatch + want - 1) / want;
-  k.x_n = x_amax_n; k.dy_n = dy_amax_n;
   // <= 3 chunks of accumulators per workgroup (96 AGPRs + staging registers: two workgroups per CU, so that one
   // converts while the other computes); more input channels = a second workgroup row, which stages dY again
-  k.nchunk = (g->Cin + 7) / 8;
+  k.nchunk = (k.Cin + 7) / 8;
   const int per_wg = k.nchunk <= 3 ? k.nchunk : (k.nchunk == 4 ? 2 : 3);
   const unsigned gy = (unsigned)((k.nchunk + per_wg - 1) / per_wg);
   if (gy > 1) {                                             // keep the number of workgroups
@@ -527,7 +580,8 @@ extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, con
     k.per_block = (k.npatch + want - 1) / want;
   }
   const unsigned nbx = (unsigned)((k.npatch + k.per_block - 1) / k.per_block);
-#define W3S_LAUNCH(N_) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(x, x_amax, dy, dy_amax, dw_tcc, k)
+  const float *kx = swapped ? dy : x, *kxa = swapped ? dy_amax : x_amax, *kdy = swapped ? x : dy, *kda = swapped ? x_amax : dy_amax;
+#define W3S_LAUNCH(N_) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k)
   if (per_wg == 1) W3S_LAUNCH(1);
   else if (per_wg == 2) W3S_LAUNCH(2);
   else W3S_LAUNCH(3);

@@ -125,8 +125,8 @@ _NO_SPLIT3D = bool(os.environ.get("DFMIR_CONV3D_FP32") or os.environ.get("DFMIR_
 def _wants_amax(K, stride, dil, Di, Cin, Cout):
     """Shapes the split kernels take (the C side decides; this only avoids useless probes): 2-D 3x3 with more than
     32 output channels (csrc/conv3x3s.hip), 3-D 3x3x3 with at least 8 channels on both sides (csrc/conv3ds.hip)."""
-    if tuple(K) == (3, 3, 3):
-        return stride == 1 and dil == 1 and Di > 1 and Cin >= 8 and Cout >= 8 and not _NO_SPLIT3D
+    if tuple(K) == (3, 3, 3):   # Cout < 8 (the flow conv): only its weight gradient is split (swapped operand roles)
+        return stride == 1 and dil == 1 and Di > 1 and Cin >= 8 and Cout >= 1 and not _NO_SPLIT3D
     return tuple(K) == (1, 3, 3) and stride == 1 and dil == 1 and Di == 1 and Cout > 32 and Cin >= 16
 
 
@@ -196,10 +196,8 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
 
     def launch():
         if split3d:
-            check(lib().dfmir_conv3d_split_wgrad(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax),
-                                                 dy_amax.numel(), _p(dw), _st()))
-            if db is not None:
-                check(lib().dfmir_bias_grad(_p(dy5), _p(db), N, Cout, Do * Ho * Wo, _st()))   # accumulates
+            check(lib().dfmir_conv3d_split_wgrad_db(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(dy5),
+                                                    _p(dy_amax), dy_amax.numel(), _p(dw), _p(db), _st()))   # db fused
             return
         pm = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and dy_amax is not None) else None
         check(lib().dfmir_conv_wgrad_scaled_ch(ctypes.byref(g), _p(x5), _p(x_amax),

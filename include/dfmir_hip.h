@@ -89,11 +89,16 @@ int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_a
  * top of the U-Net, networks.py:97-100). */
 int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
                                float* ws, const float* bias, float* y, float* y_amax, int cout_used, void* stream);
-/* The weight gradient of the same layers in the same split form (Cin <= 48, Cout <= 32, W % 4 == 0), voxels as the
+/* The weight gradient of the same layers in the same split form (8 <= Cin <= 48, 8 <= Cout <= 32, or Cout < 8 with Cin <= 32; W % 4 == 0), voxels as the
  * matrix K: dw_tcc[tap][Cin][Cout] += ...   (accumulates, like dfmir_conv_wgrad). */
 int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
 int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
                              const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);
+/* The same, also accumulating the bias gradient db[Cout] += sum dy from the units it stages anyway (db may be NULL).
+ * Layers with fewer than 8 output channels (the 16 -> 3 flow conv, networks.py:1077) are taken with the operand roles
+ * swapped: rows = (tap, co) from shifted dy, columns = ci. */
+int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
+                                const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db, void* stream);
 /* out[0..DFMIR_PROBE_SLOTS) = max(a, b): the probe of cat([nearest_up2(a), b]) from its inputs' probes. */
 int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */

@@ -21,7 +21,7 @@ def timeit(fn, reps=5):
 
 print("split3d" if not os.environ.get("DFMIR_CONV3D_FP32") else "fp32 MFMA")
 for Cin, Cout, sp in ((34, 32, (160, 192, 224)), (32, 16, (160, 192, 224)), (16, 16, (160, 192, 224)), (48, 32, (80, 96, 112)),
-                      (64, 32, (40, 48, 56)), (32, 34, (160, 192, 224)), (16, 32, (160, 192, 224))):
+                      (64, 32, (40, 48, 56)), (32, 34, (160, 192, 224)), (16, 32, (160, 192, 224)), (16, 3, (160, 192, 224))):
     g = torch.Generator(device=dev); g.manual_seed(1)
     x = torch.randn(1, Cin, *sp, device=dev, generator=g)
     w = (torch.randn(Cout, Cin, 3, 3, 3, device=dev, generator=g) / (Cin * 27) ** 0.5)
