@@ -41,7 +41,8 @@ __device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
 // ------------------------------------------------------------------------------------------------
 // Weight split: w_tcc [27][K][M] fp32 (tap-major packing of dfmir_weight_pack, either mode) ->
 // ws[mtile][chunk][split][28][32] x (8 reduction channels x fp16), scaled by 2^ew with ew from max|w|;
-// trailer (4 floats after the units): [0] = ew as an int.  One workgroup; the layers are tiny (<= 110 K weights).
+// trailer (4 floats after the units): [0] = ew as an int.  The layers are tiny (<= 110 K weights): every workgroup
+// reduces the maximum itself (L2-resident) and packs its share of the units.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
                                                         int M, float* __restrict__ trailer) {
@@ -53,10 +54,10 @@ __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict_
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
   const float s = pow2f3(ew);
-  if (threadIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
+  if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
   const int nchunk = (K + 7) / 8, nmt = (M + 31) / 32;
   const int units = nmt * nchunk * 28 * 32;                 // one unit = both splits of (mtile, chunk, tap, cout)
-  for (int u = threadIdx.x; u < units; u += 1024) {
+  for (int u = blockIdx.x * 1024 + threadIdx.x; u < units; u += gridDim.x * 1024) {
     const int co = u & 31;
     int t = u >> 5;
     const int tap = t % 28; t /= 28;
@@ -283,7 +284,7 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = (g->Cin + 7) / 8, nmt = (g->Cout + 31) / 32;
   float* trailer = ws + (long long)nmt * nchunk * 2 * 28 * 32 * 4;
-  conv3d_wsplit_k<<<1, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, g->Cout, trailer);
+  conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, g->Cout, trailer);
   DF_LAUNCH_CHECK();
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used};
