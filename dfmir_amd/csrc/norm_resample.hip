@@ -812,6 +812,30 @@ __global__ void upcat_fwd_k(const float* __restrict__ a, const float* __restrict
     y[i] = v;
   }
 }
+// the same, 4 x-consecutive outputs per thread (Wa even): one float2 of `a` (or one float4 of `b`) -> one float4 store
+__global__ __launch_bounds__(256) void upcat_fwd_v4_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ y, int N, int Ca, int Cb, int Da, int Ha,
+                                                      int Wa, int sd) {
+  const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb, Wq = Wo >> 2;
+  const long long So = (long long)Do * Ho * Wo, Sa = (long long)Da * Ha * Wa;
+  const long long total = (long long)N * C * Do * Ho * Wq;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xq = (int)(i % Wq);
+    long long r = i / Wq;
+    const int yy = (int)(r % Ho); r /= Ho;
+    const int z = (int)(r % Do); r /= Do;
+    const int c = (int)(r % C);
+    const long long n = r / C;
+    float4 v;
+    if (c < Ca) {
+      const float2 t = *reinterpret_cast<const float2*>(a + (n * Ca + c) * Sa + ((long long)(z / sd) * Ha + (yy >> 1)) * Wa + 2 * xq);
+      v = make_float4(t.x, t.x, t.y, t.y);
+    } else {
+      v = *reinterpret_cast<const float4*>(b + (n * Cb + (c - Ca)) * So + ((long long)z * Ho + yy) * Wo + 4 * xq);
+    }
+    *reinterpret_cast<float4*>(y + ((n * C + c) * Do + z) * (long long)Ho * Wo + (long long)yy * Wo + 4 * xq) = v;
+  }
+}
 __global__ void upcat_bwd_a_k(const float* __restrict__ dy, float* __restrict__ da, int N, int Ca, int Cb,
                               int Da, int Ha, int Wa, int sd) {
   const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb;
@@ -1064,7 +1088,10 @@ extern "C" int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, 
                                int Ha, int Wa, int sd, void* stream) {
   DF_ARG_CHECK(a && b && y && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));
   const long long total = (long long)N * (Ca + Cb) * Da * sd * Ha * 2 * Wa * 2;
-  upcat_fwd_k<<<df_grid(total, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
+  if ((Wa & 1) == 0 && ((reinterpret_cast<uintptr_t>(a) & 7) | (reinterpret_cast<uintptr_t>(b) & 15) | (reinterpret_cast<uintptr_t>(y) & 15)) == 0)
+    upcat_fwd_v4_k<<<df_grid(total / 4, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
+  else
+    upcat_fwd_k<<<df_grid(total, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
   DF_LAUNCH_CHECK();
   return 0;
 }
