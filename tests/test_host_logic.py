@@ -106,3 +106,37 @@ def test_flat_adam_arena_aliases_parameters():
     assert float(o.flat_g.abs().sum()) == 0
     with pytest.raises(DfmirHipError):            # the fused Adam kernel is HIP-only: no CPU fallback
         o.step()
+
+
+def test_unet_channel_plan_matches_reference_layouts():
+    """(cin, cout) of every U-Net conv for the two feature lists on the path (reference networks.py:60-86; SURVEY
+    Appendix A): the plugin's 6-level 2-D list and the stock 4-level default."""
+    down, up, extras = V.unet_channel_plan([16, 32, 32, 64, 64, 64], [64, 64, 64, 32, 32, 32, 16])
+    assert down == [(2, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 64)]
+    assert up == [(64, 64), (128, 64), (128, 64), (96, 32), (64, 32), (48, 32)]
+    assert extras == [(34, 16)]
+    enc, dec = V.default_unet_features()
+    down, up, extras = V.unet_channel_plan(enc, dec)
+    assert down == [(2, 16), (16, 32), (32, 32), (32, 32)]
+    assert up == [(32, 32), (64, 32), (64, 32), (48, 32)]
+    assert extras == [(34, 32), (32, 16), (16, 16)]
+
+
+def test_base_model_surface_and_graph_defaults():
+    """The plugin surface train.py / test.py drive and the build-defined options' defaults."""
+    from dfmir_amd.base_model import BaseModel
+    from dfmir_amd.options import default_options
+    for name in ("setup", "parallelize", "data_dependent_initialize", "set_input", "forward", "optimize_parameters", "eval",
+                 "test", "compute_visuals", "get_image_paths", "update_learning_rate", "get_current_visuals",
+                 "get_current_losses", "save_networks", "load_networks", "print_networks", "sync_gradients"):
+        assert callable(getattr(BaseModel, name)), name
+    opt = default_options()
+    assert opt.capture_step is False and opt.dvf_image == 'synthetic' and opt.reuse_key_features and opt.batch_query_passes
+
+
+def test_distributed_helpers_single_process():
+    from dfmir_amd import distributed as D
+    assert not D.is_distributed() and D.world_size() == 1
+    assert D.allreduce_arenas([torch.zeros(3)]) == [] and D.allreduce_arenas([torch.zeros(3)], async_op=True) == []
+    assert D.allreduce_max(1.5, "cpu") == 1.5
+    D.barrier()
