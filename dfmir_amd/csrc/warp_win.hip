@@ -603,27 +603,33 @@ __global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict
   // one workgroup per tile, the thread <-> voxel-quad map of pass 1: the 27 (9) neighbour origins are workgroup-uniform
   // (scalar loads), the per-quad coverage test is a few integer compares, only covering windows are read
   WIN_THREAD_COORDS();
+  constexpr int NZ = (ND == 3) ? 3 : 1, NN = NZ * 9;
+  // the neighbour tiles' window origins, fetched once per workgroup (one lane each) and kept in LDS; -1 = no such tile
+  __shared__ int org[NN][4];
+  if (t < NN) {
+    const int iz = t / 9, iy = (t / 3) % 3, ix = t % 3;
+    const int nz = tzb_ + (ND == 3 ? iz - 1 : 0), ny = tyb_ + iy - 1, nx = tx_ + ix - 1;
+    const bool ok = (unsigned)nz < (unsigned)ntz && (unsigned)ny < (unsigned)nty && (unsigned)nx < (unsigned)ntx;
+    const int tl = ok ? ((b * ntz + nz) * nty + ny) * ntx + nx : -1;
+    org[t][0] = ok ? origins[tl * 4] : 0;
+    org[t][1] = ok ? origins[tl * 4 + 1] : 0;
+    org[t][2] = ok ? origins[tl * 4 + 2] : 0;
+    org[t][3] = tl;
+  }
+  __syncthreads();
   if (!active) return;
-  constexpr int NZ = (ND == 3) ? 3 : 1;
   for (int c = 0; c < C; ++c) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int iz = 0; iz < NZ; ++iz)
-#pragma unroll
-      for (int iy = 0; iy < 3; ++iy)
-#pragma unroll
-        for (int ix = 0; ix < 3; ++ix) {
-          const int nz = tzb_ + (ND == 3 ? iz - 1 : 0), ny = tyb_ + iy - 1, nx = tx_ + ix - 1;
-          if ((unsigned)nz >= (unsigned)ntz || (unsigned)ny >= (unsigned)nty || (unsigned)nx >= (unsigned)ntx) continue;
-          const int tl = ((b * ntz + nz) * nty + ny) * ntx + nx;
-          const int oz = origins[tl * 4], oy = origins[tl * 4 + 1], ox = origins[tl * 4 + 2];
-          const int lz = z - oz, ly = y - oy, lx = x - ox;           // ox is a multiple of 4: the quad is whole or absent
-          if ((unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY && (unsigned)lx <= (unsigned)(WEX - 4)) {
-            const float4 v = *reinterpret_cast<const float4*>(scratch + ((long long)tl * C + c) * WinOwn<ND>::CELLS +
-                                                              (lz * G::EY + ly) * WEX + lx);
-            acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-          }
-        }
+    for (int i = 0; i < NN; ++i) {
+      const int tl = org[i][3];
+      const int lz = z - org[i][0], ly = y - org[i][1], lx = x - org[i][2];   // ox is a multiple of 4: whole quad or none
+      if (tl >= 0 && (unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY && (unsigned)lx <= (unsigned)(WEX - 4)) {
+        const float4 v = *reinterpret_cast<const float4*>(scratch + ((long long)tl * C + c) * WinOwn<ND>::CELLS +
+                                                          (lz * G::EY + ly) * WEX + lx);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      }
+    }
     *reinterpret_cast<float4*>(dsrc + ((long long)b * C + c) * S + sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
