@@ -15,7 +15,28 @@
 // (one LDS buffer, two barriers per chunk).  More than 32 output channels = more workgroups along grid.y.
 // The epilogue rescales by 2^-(ex+ew), adds the bias, applies LeakyReLU and leaves the range probe of its OUTPUT
 // (64 accumulating slots, as the InstanceNorm kernels do) so that the next layer needs no absmax pass.
+//
+// PAIR form (<= 16 output channels: half of the 32 MFMA rows would be padding): the rows are (plane p, cout) -- rows
+// 0-15 compute z-plane 2q, rows 16-31 plane 2q+1 of the SAME 16 output channels.  Both planes read the four input
+// planes 2q-1 .. 2q+2, so K runs over 36 taps' = (dz' in 0..3, dy, dx) and the weight rows of plane p hold
+// W[dz' - p] (zero where dz' - p is outside 0..2): 75 % of the issued products are useful instead of 50 %.  Wave w
+// owns plane pair w & 1 and the y-half w >> 1 of the tile (2 column tiles), 18 k-steps x 6 MFMAs per chunk.
 #include "conv3x3_common.h"
+#ifdef C3S_TRACE      // timing build: per-phase s_memtime sums of every wave 0 -> dfmir_c3s_trace()
+__device__ unsigned long long c3s_trace[16];
+#define C3S_T(i_) { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&c3s_trace[i_], t_ - tlast); tlast = t_; } }
+#define C3S_T0() unsigned long long tlast = __builtin_readcyclecounter();
+extern "C" void dfmir_c3s_trace(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(c3s_trace), sizeof(c3s_trace));
+  if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(c3s_trace), z, sizeof(z)); }
+}
+#else
+#define C3S_T(i_)
+#define C3S_T0()
+#endif
+#ifndef C3S_KO
+#define C3S_KO 0     // knock-out builds for timing: 1 = no MFMAs, 2 = no prefetch loads, 4 = no convert + LDS store
+#endif
 
 typedef _Float16 f16x8_3 __attribute__((ext_vector_type(8)));
 
@@ -44,8 +65,9 @@ __device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
 // trailer (4 floats after the units): [0] = ew as an int.  The layers are tiny (<= 110 K weights): every workgroup
 // reduces the maximum itself (L2-resident) and packs its share of the units.
 // ------------------------------------------------------------------------------------------------
+// pair != 0 (M <= 16): 36 taps' per chunk, row (p, co) = p * 16 + co holds W[dz' - p] (see the PAIR form above).
 __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
-                                                        int M, float* __restrict__ trailer) {
+                                                        int M, float* __restrict__ trailer, int pair) {
   __shared__ float sm[17];
   float m = 0.f;
   const int total = 27 * K * M;
@@ -55,19 +77,27 @@ __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict_
   const int ew = scale_exp3(m);
   const float s = pow2f3(ew);
   if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
-  const int nchunk = (K + 7) / 8, nmt = (M + 31) / 32;
-  const int units = nmt * nchunk * 28 * 32;                 // one unit = both splits of (mtile, chunk, tap, cout)
+  const int nchunk = (K + 7) / 8, nmt = pair ? 1 : (M + 31) / 32;
+  const int NT = pair ? 36 : 28;
+  const int units = nmt * nchunk * NT * 32;                 // one unit = both splits of (mtile, chunk, tap, row)
   for (int u = blockIdx.x * 1024 + threadIdx.x; u < units; u += gridDim.x * 1024) {
     const int co = u & 31;
     int t = u >> 5;
-    const int tap = t % 28; t /= 28;
+    int tap = t % NT; t /= NT;
     const int ch = t % nchunk, mt = t / nchunk;
-    const int mo = mt * 32 + co;
+    int mo = mt * 32 + co;
+    bool tok = tap < 27;
+    if (pair) {
+      const int dz = tap / 9 - (co >> 4);
+      tok = (unsigned)dz < 3u;
+      tap = dz * 9 + tap % 9;
+      mo = co & 15;
+    }
     float v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int kk = ch * 8 + c;
-      v[c] = (tap < 27 && kk < K && mo < M) ? w[((long long)tap * K + kk) * M + mo] : 0.f;
+      v[c] = (tok && kk < K && mo < M) ? w[((long long)tap * K + kk) * M + mo] : 0.f;
     }
     u32x4 h, r;
 #pragma unroll
@@ -76,9 +106,10 @@ __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict_
       split_pair3(v[2 * q], v[2 * q + 1], s, hh, rr);
       h[q] = hh; r[q] = rr;
     }
-    const long long base = (((long long)mt * nchunk + ch) * 2) * (28 * 32);
-    ws[base + tap * 32 + co] = h;
-    ws[base + 28 * 32 + tap * 32 + co] = r;
+    const int tu = (u >> 5) % NT;
+    const long long base = (((long long)mt * nchunk + ch) * 2) * (NT * 32);
+    ws[base + tu * 32 + co] = h;
+    ws[base + NT * 32 + tu * 32 + co] = r;
   }
 }
 
@@ -91,8 +122,10 @@ struct C3sP {
   int nchunk;
   int x_n;                       // floats of the input range probe
   int cout_used;                 // output channels to compute (<= Cout; the rest of y is left untouched)
+  long long ntile;               // N * nz * ny * nx
 };
 
+template <bool PAIR, bool VEC>
 __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
                                                       const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
                                                       const float* __restrict__ bias, float* __restrict__ y,
@@ -100,8 +133,11 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
   constexpr int XP = (TZ + 2) * HY * HX;                  // 1080 positions
   constexpr int NS = (XP + 255) / 256;                    // 5 position slots per thread
-  constexpr int WU = 2 * 28 * 32;                         // 1792 16-B units of one chunk's weights
-  constexpr int NW = WU / 256;                            // 7
+  constexpr int NT = PAIR ? 36 : 28;                      // taps (taps') per chunk in the weight units
+  constexpr int WU = 2 * NT * 32;                         // 1792 / 2304 16-B units of one chunk's weights
+  constexpr int NW = WU / 256;                            // 7 / 9
+  constexpr int NJ = PAIR ? 2 : 4;                        // column tiles (2 rows x 16 voxels) per wave
+  constexpr unsigned OOB = 0x80000000u;
   __shared__ u32x4 Xs[2 * XP];
   __shared__ u32x4 Ws[WU];
   __shared__ float red[17];
@@ -110,11 +146,17 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const long long S = (long long)k.D * k.H * k.W;
-  int pid = blockIdx.x;
-  const int bx = pid % k.nx; pid /= k.nx;
-  const int by = pid % k.ny; pid /= k.ny;
-  const int bz = pid % k.nz;
-  const int n = pid / k.nz;
+  C3S_T0()
+  // workgroup -> tile: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (one L2 each), so ids
+  // with the same residue get one contiguous eighth of the tiles; within it x runs fastest, then z, then y: the
+  // z-halo (2 of 6 planes) of a tile is the previous x-row's data, still in that XCD's L2.
+  const long long per_xcd = (k.ntile + 7) / 8;
+  long long pid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (pid >= k.ntile) return;
+  const int bx = (int)(pid % k.nx); pid /= k.nx;
+  const int bz = (int)(pid % k.nz); pid /= k.nz;
+  const int by = (int)(pid % k.ny);
+  const int n = (int)(pid / k.ny);
   const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
   const int mt = blockIdx.y;
 
@@ -125,125 +167,244 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   const float xscale = pow2f3(ex), oscale = pow2f3(-ex), oscale2 = pow2f3(-ew);
   if (tid == 0) smax = 0u;
 
-  constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (long long)n * k.Cin * S), 0, (unsigned)((long long)k.Cin * S * 4), 0x00020000);
   const unsigned s4 = (unsigned)S * 4u;
+  // Patch loads.  VEC (W % 4 == 0): thread t < 240 owns the 16-B quad q = t & 3 of halo row t >> 2 (rows = 6 planes x
+  // 10 y; the quad covers patch columns 1 + 4q .. 4 + 4q, i.e. x0 + 4q ..) in all 8 channels of the chunk -- 8
+  // buffer_load_dwordx4, converted to 4 LDS units -- and thread t < 120 additionally the left / right halo column
+  // (t & 1) of row t >> 1 (8 buffer_load_dword -> 1 unit).  Otherwise: 5 patch positions per thread, 8 dword loads each.
+  constexpr int NPART = VEC ? 8 : NS;                     // load parts of a chunk (spread over the k-steps)
   unsigned gbyte[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int pos = tid + 256 * s;
-    unsigned off = OOB;
-    if (pos < XP) {
-      const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;
-      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
-        off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+  unsigned gq = OOB, gh = OOB;
+  int posq = -1, posh = -1;
+  if constexpr (VEC) {
+    if (tid < 240) {
+      const int row = tid >> 2, q = tid & 3;
+      const int hz = row / HY, hy = row % HY;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 + 4 * q;
+      posq = row * HX + 1 + 4 * q;
+      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && gx < k.W)
+        gq = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
     }
-    gbyte[s] = off;
+    if (tid < 120) {
+      const int row = tid >> 1, side = tid & 1;
+      const int hz = row / HY, hy = row % HY;
+      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = side ? x0 + TX : x0 - 1;
+      posh = row * HX + (side ? HX - 1 : 0);
+      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
+        gh = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int pos = tid + 256 * s;
+      unsigned off = OOB;
+      if (pos < XP) {
+        const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
+          off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+      }
+      gbyte[s] = off;
+    }
   }
   const u32x4* wchunk = wsp + (long long)mt * k.nchunk * WU;
 
-  // this lane's B positions: column tile j = rows 2j, 2j+1 of plane wid; voxel (row, x) = (2j + (l31 >> 4), l31 & 15)
-  int pbase[4];
+  // this lane's B positions: column tile j = rows 2j, 2j+1 of plane wid; voxel (row, x) = (2j + (l31 >> 4), lx) with
+  // lx = l31 & 15 in the even row and (l31 - 2) & 15 in the odd one: with the row stride of 18 units that rotation
+  // puts the 16 lanes a ds_read_b128 serves together ({0-3,12-15,20-27}, {4-11,16-19,28-31}) on 16 distinct bank quads
+  // (PAIR: planes 2 (wid & 1) + p, rows 4 (wid >> 1) + 2j, 2j+1)
+  const int wz = PAIR ? 2 * (wid & 1) : wid, wy = PAIR ? 4 * (wid >> 1) : 0;
+  int pbase[NJ];
+  const int lx = (l31 - 2 * (l31 >> 4)) & 15;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) pbase[j] = (wid * HY + 2 * j + (l31 >> 4)) * HX + (l31 & 15);
+  for (int j = 0; j < NJ; ++j) pbase[j] = (wz * HY + wy + 2 * j + (l31 >> 4)) * HX + lx;
 
-  f32x16 acc[4];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  float rx[NS][8];
+  float rx[NS][8];                                         // !VEC: [slot][channel];  VEC: rx[0][c] = halo column
+  u32x4 rq[8];                                             // VEC: the quad of channel c
   u32x4 rw[NW];
 
-#define C3S_GLOAD(ch_)                                                                            \
+  // Global loads of a chunk, in NS + 1 parts that the compute loop spreads over its first k-steps.  No branches: a
+  // channel past Cin (padding of the last chunk, or the chunk after the last) is past the descriptor's range and
+  // reads as zero without touching memory; the same holds for the weight units past the last chunk.
+  const __amdgpu_buffer_rsrc_t w_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(wsp + (long long)mt * k.nchunk * WU), 0, (unsigned)(k.nchunk * WU * 16), 0x00020000);
+#define C3S_GLOAD_X(ch_, s_)                                                                      \
   {                                                                                               \
     const unsigned cbase = (unsigned)((ch_) * 8) * s4;                                            \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                              \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                             \
-        const bool okc = ((ch_) * 8 + c) < k.Cin;                                                 \
-        rx[s][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                          \
-            x_src, okc ? gbyte[s] + cbase + (unsigned)c * s4 : OOB, 0, 0));                       \
-      }                                                                                           \
+    if constexpr (VEC) {                                                                          \
+      const unsigned co_ = cbase + (unsigned)(s_) * s4;                                           \
+      rq[s_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + co_, 0, 0);    \
+      rx[0][s_] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_src, gh == OOB ? OOB : gh + co_, 0, 0)); \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                               \
+        rx[s_][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                         \
+            x_src, gbyte[s_] == OOB ? OOB : gbyte[s_] + cbase + (unsigned)c * s4, 0, 0));         \
     }                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < NW; ++j) rw[j] = wchunk[(long long)(ch_) * WU + tid + 256 * j]; \
+  }
+#define C3S_GLOAD_W(ch_)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NW; ++j)                                                  \
+    rw[j] = __builtin_amdgcn_raw_buffer_load_b128(w_src, (unsigned)(((ch_) * WU + tid + 256 * j) * 16), 0, 0);
+#define C3S_SPLIT8(v_, h_, r_)                                                                    \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+    unsigned hh, rr;                                                                              \
+    split_pair3(v_[2 * q], v_[2 * q + 1], xscale, hh, rr);                                        \
+    h_[q] = hh; r_[q] = rr;                                                                       \
   }
 #define C3S_LSTORE()                                                                              \
   {                                                                                               \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                              \
-      const int pos = tid + 256 * s;                                                              \
-      if (pos < XP) {                                                                             \
-        u32x4 h, r;                                                                               \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                           \
-          unsigned hh, rr;                                                                        \
-          split_pair3(rx[s][2 * q], rx[s][2 * q + 1], xscale, hh, rr);                            \
-          h[q] = hh; r[q] = rr;                                                                   \
+    if constexpr (VEC) {                                                                          \
+      if (posq >= 0) {                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+          float v[8];                                                                             \
+          _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rq[c][e]);         \
+          u32x4 h, r;                                                                             \
+          C3S_SPLIT8(v, h, r)                                                                     \
+          Xs[posq + e] = h;                                                                       \
+          Xs[XP + posq + e] = r;                                                                  \
         }                                                                                         \
-        Xs[pos] = h;                                                                              \
-        Xs[XP + pos] = r;                                                                         \
+      }                                                                                           \
+      if (posh >= 0) {                                                                            \
+        u32x4 h, r;                                                                               \
+        C3S_SPLIT8(rx[0], h, r)                                                                   \
+        Xs[posh] = h;                                                                             \
+        Xs[XP + posh] = r;                                                                        \
+      }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                            \
+        const int pos = tid + 256 * s;                                                            \
+        if (pos < XP) {                                                                           \
+          u32x4 h, r;                                                                             \
+          C3S_SPLIT8(rx[s], h, r)                                                                 \
+          Xs[pos] = h;                                                                            \
+          Xs[XP + pos] = r;                                                                       \
+        }                                                                                         \
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) Ws[tid + 256 * j] = rw[j];                     \
   }
+  // operands of k-step tp_ (taps 2tp, 2tp+1; tap 27 of the 28-tap form has zero weights, any valid offset) -> set b_
+#define C3S_OPLOAD(b_, tp_)                                                                       \
+  {                                                                                               \
+    const int t0 = 2 * (tp_), t1 = (PAIR || (2 * (tp_) + 1) < 27) ? 2 * (tp_) + 1 : 0;            \
+    const int o0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3;                                  \
+    const int o1 = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;                                  \
+    const int toff = hi ? o1 : o0;                                                                \
+    const int tap = 2 * (tp_) + hi;                                                               \
+    A0[b_] = Ws[tap * 32 + l31];                                                                  \
+    A1[b_] = Ws[NT * 32 + tap * 32 + l31];                                                        \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                              \
+      B0[b_][j] = Xs[pbase[j] + toff];                                                            \
+      B1[b_][j] = Xs[XP + pbase[j] + toff];                                                       \
+    }                                                                                             \
+  }
 
-  C3S_GLOAD(0);
+  u32x4 A0[2], A1[2], B0[2][NJ], B1[2][NJ];
+#pragma unroll
+  for (int s = 0; s < NPART; ++s) C3S_GLOAD_X(0, s);
+  C3S_GLOAD_W(0);
+  C3S_T(0)
   C3S_LSTORE();
+  C3S_T(1)
   __syncthreads();
+  C3S_T(2)
 
   for (int ch = 0; ch < k.nchunk; ++ch) {
-    const bool more = (ch + 1) < k.nchunk;
-    if (more) C3S_GLOAD(ch + 1);
+    C3S_OPLOAD(0, 0);
+    // one k-step: the next step's 2 + 2 NJ operand reads and one part of the next chunk's global loads are pinned
+    // between this step's 3 NJ MFMAs (one MFMA, one LDS read, one buffer load, ...), so the wave never waits on
+    // a read it has just issued
 #pragma unroll
-    for (int tp = 0; tp < 14; ++tp) {
-      const int t0 = 2 * tp, t1 = (2 * tp + 1) < 27 ? 2 * tp + 1 : 0;     // tap 27: zero weights, any valid offset
-      const int o0 = ((t0 / 9) * HY + (t0 / 3) % 3) * HX + t0 % 3;
-      const int o1 = ((t1 / 9) * HY + (t1 / 3) % 3) * HX + t1 % 3;
-      const int toff = hi ? o1 : o0;
-      const int tap = 2 * tp + hi;
-      const u32x4 a0 = Ws[tap * 32 + l31], a1 = Ws[28 * 32 + tap * 32 + l31];
+    for (int tp = 0; tp < NT / 2; ++tp) {
+      const int cur = tp & 1;
+      if (!(C3S_KO & 2)) {
+        if (tp < NPART) C3S_GLOAD_X(ch + 1, tp);
+        if (tp == NPART) C3S_GLOAD_W(ch + 1);
+      }
+      if (tp + 1 < NT / 2) C3S_OPLOAD(cur ^ 1, tp + 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32x4 b0 = Xs[pbase[j] + toff], b1 = Xs[XP + pbase[j] + toff];
-        acc[j] = mma3(a1, b0, acc[j]);
-        acc[j] = mma3(a0, b1, acc[j]);
-        acc[j] = mma3(a0, b0, acc[j]);
+      for (int j = 0; j < NJ; ++j) {
+#if (C3S_KO & 1)
+        acc[j][0] += __uint_as_float(B0[cur][j][0] ^ B1[cur][j][1] ^ A0[cur][0] ^ A1[cur][1]);
+#else
+        acc[j] = mma3(A1[cur], B0[cur][j], acc[j]);
+        acc[j] = mma3(A0[cur], B1[cur][j], acc[j]);
+        acc[j] = mma3(A0[cur], B0[cur][j], acc[j]);
+#endif
+      }
+#pragma unroll
+      for (int i = 0; i < 3 * NJ; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
       }
     }
-    if (more) {
+    C3S_T(3)
+    if ((ch + 1) < k.nchunk) {
       __syncthreads();
-      C3S_LSTORE();
+      C3S_T(4)
+      if (!(C3S_KO & 4)) C3S_LSTORE();
+      C3S_T(5)
       __syncthreads();
+      C3S_T(6)
     }
   }
-#undef C3S_GLOAD
+#undef C3S_GLOAD_X
+#undef C3S_GLOAD_W
+#undef C3S_OPLOAD
 #undef C3S_LSTORE
+#undef C3S_SPLIT8
 
-  // ---- epilogue: acc[j][r] <-> cout = mt*32 + (r>>2)*8 + hi*4 + (r&3), voxel (wid, 2j + (l31>>4), l31&15)
-  float pm = 0.f;
-  const int gz = z0 + wid;
+  // ---- epilogue: acc[j][r] <-> row = (r>>2)*8 + hi*4 + (r&3) = cout - mt*32 (PAIR: plane * 16 + cout),
+  //      voxel (wz [+ plane], wy + 2j + (l31>>4), l31&15)
+  // Stores go through a buffer descriptor with 32-bit offsets (voxel part per lane, channel part uniform) and the 16
+  // bias values of this lane are fetched BEFORE the first store: loads and stores share vmcnt on gfx9, so a bias load
+  // between stores would wait for every store issued before it.
+  float bv[16];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gy = y0 + 2 * j + (l31 >> 4), gx = x0 + (l31 & 15);
-    if (gz >= k.D || gy >= k.H || gx >= k.W) continue;
-    float* yb = y + (long long)n * k.Cout * S + ((long long)gz * k.H + gy) * k.W + gx;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r >> 2) * 8 + hi * 4 + (r & 3);
+    const int co = PAIR ? (row & 15) : mt * 32 + row;
+    bv[r] = (bias && co < k.cout_used) ? bias[co] : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
+      y + (long long)n * k.Cout * S, 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+  const unsigned plane4 = (unsigned)(k.H * k.W) * 4u;
+  const float osc = oscale * oscale2;
+  float pm = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+    const bool vok = gy < k.H && gx < k.W;
+    // lane part of the offset: voxel + the hi * 4 channels (PAIR: rows 16.. are plane 1 -> hi never changes the plane)
+    const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = mt * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-      if (co < k.cout_used) {
-        float v = acc[j][r] * oscale * oscale2 + (bias ? bias[co] : 0.f);
-        if (k.act == 1) v = v > 0.f ? v : v * k.slope;
-        else if (k.act == 2) v = tanhf(v);
-        yb[(long long)co * S] = v;
-        pm = fmaxf(pm, fabsf(v));
-      }
+      const int rowu = (r >> 2) * 8 + (r & 3);                       // row without the hi * 4 part
+      const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;
+      const int pz = PAIR ? (rowu >> 4) : 0;
+      const bool ok = vok && (cou + hi * 4) < k.cout_used && (z0 + wz + pz) < k.D;
+      float v = acc[j][r] * osc + bv[r];
+      if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+      else if (k.act == 2) v = tanhf(v);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo + (unsigned)pz * plane4 : OOB,
+                                            (unsigned)cou * s4, 0);
+      pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
     }
   }
+  C3S_T(7)
   if (y_amax) {
     __syncthreads();
     publish_block_absmax_acc(pm, &smax, y_amax);
   }
+  C3S_T(8)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,15 +413,20 @@ static bool split3d_off() {
   if (v < 0) v = (getenv("DFMIR_CONV3D_FP32") || getenv("DFMIR_CONV_FP32")) ? 1 : 0;
   return v == 1;
 }
+static bool pair3d_off() {
+  static int v = -1;
+  if (v < 0) v = getenv("DFMIR_CONV3D_NO_PAIR") ? 1 : 0;
+  return v == 1;
+}
 static bool split3d_geom_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
          g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
-         g->Cin >= 8 && g->Cout >= 8 && (long long)g->Cin * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;   // buffer offsets, OOB marker
+         g->Cin >= 8 && g->Cout >= 8 && (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;   // buffer offsets, OOB marker
 }
 extern "C" int dfmir_conv3d_split_ok(const DfConvGeom* g) { return (g && !split3d_off() && split3d_geom_ok(g)) ? 1 : 0; }
 extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
   if (Cin <= 0 || Cout <= 0) return -1;
-  return (long long)((Cout + 31) / 32) * ((Cin + 7) / 8) * 2 * 28 * 32 * 4 + 4;
+  return (long long)((Cout + 31) / 32) * ((Cin + 7) / 8) * 2 * 36 * 32 * 4 + 4;     // 36: the PAIR form's taps'
 }
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
@@ -283,15 +449,22 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   DF_ARG_CHECK(!split3d_off() && split3d_geom_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = (g->Cin + 7) / 8, nmt = (g->Cout + 31) / 32;
-  float* trailer = ws + (long long)nmt * nchunk * 2 * 28 * 32 * 4;
-  conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, g->Cout, trailer);
+  float* trailer = ws + dfmir_conv3d_split_ws_floats(g->Cin, g->Cout) - 4;          // after the largest unit layout
+  const bool pair = cout_used <= 16 && !pair3d_off();
+  conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
   DF_LAUNCH_CHECK();
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
-         nchunk, x_amax_n, cout_used};
-  const long long nb = (long long)g->N * k.nz * k.ny * k.nx;
+         nchunk, x_amax_n, cout_used, 0};
+  k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
+  const long long nb = 8 * ((k.ntile + 7) / 8);
   DF_ARG_CHECK(nb < (1LL << 31));
-  conv3d_split_k<<<dim3((unsigned)nb, (unsigned)((cout_used + 31) / 32)), 256, 0, st>>>(x, x_amax, reinterpret_cast<const u32x4*>(ws), trailer,
-                                                                   bias, y, y_amax, k);
+  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
+  const dim3 grid((unsigned)nb, pair ? 1u : (unsigned)((cout_used + 31) / 32));
+  const u32x4* wsu = reinterpret_cast<const u32x4*>(ws);
+  if (pair && vec) conv3d_split_k<true, true><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (pair) conv3d_split_k<true, false><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (vec) conv3d_split_k<false, true><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else conv3d_split_k<false, false><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   DF_LAUNCH_CHECK();
   return 0;
 }

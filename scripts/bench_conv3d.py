@@ -20,8 +20,11 @@ def timeit(fn, reps=5):
     return s.elapsed_time(e) / reps
 
 print("split3d" if not os.environ.get("DFMIR_CONV3D_FP32") else "fp32 MFMA")
+ONLY = os.environ.get("ONLY")          # e.g. ONLY=34-32,16-16
 for Cin, Cout, sp in ((34, 32, (160, 192, 224)), (32, 16, (160, 192, 224)), (16, 16, (160, 192, 224)), (48, 32, (80, 96, 112)),
                       (64, 32, (40, 48, 56)), (32, 34, (160, 192, 224)), (16, 32, (160, 192, 224)), (16, 3, (160, 192, 224))):
+    if ONLY and "%d-%d" % (Cin, Cout) not in ONLY.split(","):
+        continue
     g = torch.Generator(device=dev); g.manual_seed(1)
     x = torch.randn(1, Cin, *sp, device=dev, generator=g)
     w = (torch.randn(Cout, Cin, 3, 3, 3, device=dev, generator=g) / (Cin * 27) ** 0.5)

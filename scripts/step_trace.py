@@ -1,10 +1,11 @@
 """Aggregate the LAST train step of a rocprofv3 --kernel-trace CSV: busy fraction, time per kernel, torch elementwise
-kernels bucketed by duration.  usage: python scripts/step_trace.py <kernel_trace.csv>"""
-import csv, sys, collections
+kernels bucketed by duration.  usage: python scripts/step_trace.py <kernel_trace.csv> [rows] ; ADAMS=<Adam launches per step, default 3>"""
+import csv, os, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam_k" in r["Kernel_Name"]]
-ends = [i for k, i in enumerate(adam) if k % 3 == 2]           # a step ends with the 3 Adam launches
+NA = int(os.environ.get("ADAMS", 3))
+ends = [i for k, i in enumerate(adam) if k % NA == NA - 1]     # a step ends with its Adam launches (3 in the 2-D step)
 step = rows[ends[-2] + 1:ends[-1] + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)

@@ -212,6 +212,10 @@ CONV3D = [
     (48, 32, 3, 1, 1, 1, 4, 12, 24),
     (64, 32, 3, 1, 1, 1, 3, 8, 16),
     (32, 34, 3, 1, 1, 1, 4, 8, 12),
+    # <= 16 output channels: the plane-pair form of conv3d_split_k (odd depth: the second plane of the last pair is outside)
+    (16, 16, 3, 1, 1, 1, 7, 9, 19),
+    (40, 12, 3, 1, 1, 1, 6, 7, 17),
+    (8, 9, 3, 1, 1, 2, 1 + 2, 8, 16),
 ]
 
 
