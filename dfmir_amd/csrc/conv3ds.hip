@@ -687,6 +687,285 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
   }
 }
 
+// ================================================================================================
+// wgrad, transpose-read form (default):  the same GEMM -- rows (tap, ci), columns co, K = voxels -- but the operands
+// are read from the FORWARD kernel's LDS images with ds_read_b64_tr_b16 (gfx950): X as [position][8 channels x fp16]
+// (16 B per position and split), dY as [voxel][32 output channels x fp16] (64 B).  In a 16-lane group the hardware
+// hands lane 4q + c, element j the c-th fp16 at the address supplied by lane 4j + q: with lane (j, q) pointing at
+// (voxel j, channel quad q) every lane receives 4 consecutive voxels of its own row -- a K-major MFMA operand out of a
+// channel-major image.  A tap is then nothing but a position offset (16-B granular, so dx shifts stay aligned): ONE
+// copy of the patch instead of three, the patch is staged exactly like the forward kernel's (8 x buffer_load_dwordx4
+// per thread, 4 v_fma_mix per value pair), and a tile can be four times larger for the same LDS.
+//
+// Workgroup = 4 waves, persistent over 2 x 8 x 16-voxel tiles (16 k-steps = x-rows of 16 voxels); per tile the dY
+// image is staged once and the X patch (4 x 10 x 18 positions) once per 8-channel chunk.  Row tile T of a chunk =
+// taps 4T .. 4T+3 x 8 channels (7 tiles, tap 27 is padding); wave w owns tiles (w + c) & 3 and that + 4 of chunk c
+// (accumulators of <= 3 chunks resident: 96 AGPRs, two workgroups per CU so that one stages while the other computes).
+// Bank behaviour of the reads: the 32 lanes served together cover 4 taps x 4 x-positions x 16 B; taps of one
+// (dz, dy) are contiguous, the next (dz, dy) must start 112..192 B further (mod 256): row stride 24 positions, plane
+// stride 248.  dY: 4 voxels x 64 B contiguous; the channel group is XORed with (voxel >> 2) & 3 so that the staging
+// stores of a wave (one channel group, 4 voxel quads) spread over the banks.
+// ================================================================================================
+typedef short s16x4_3 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_3* lds_tr_ptr;
+__device__ __forceinline__ uint2 tr_read8(unsigned byte_addr) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)byte_addr));
+}
+#define TR_PAIR(dst_, addr_)                                                                      \
+  {                                                                                               \
+    const uint2 u0_ = tr_read8(addr_), u1_ = tr_read8((addr_) + 64u);                             \
+    dst_ = u32x4{u0_.x, u0_.y, u1_.x, u1_.y};                                                     \
+  }
+
+template <int NCH>
+struct W3T {
+  static constexpr int TZ = 2, TY = 8, TX = 16, HZ = 4, HY = 10, HXP = 24, SZP = HY * HXP + 8;
+  static constexpr int XPOS = HZ * SZP;                  // 992 units per split
+  static constexpr int YU = TZ * TY * TX * 4;            // 1024 units per split
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                         const float* __restrict__ dy, const float* __restrict__ dy_amax,
+                                                         float* __restrict__ dwt, W3sP k) {
+  using G = W3T<NCH>;
+  constexpr int TZ = G::TZ, TY = G::TY, HY = G::HY, HXP = G::HXP, SZP = G::SZP, XPOS = G::XPOS, YU = G::YU;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ u32x4 Xs[2 * XPOS];
+  __shared__ u32x4 Ys[2 * YU];
+  __shared__ float red[17];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long S = (long long)k.D * k.H * k.W;
+  const unsigned s4 = (unsigned)S * 4u;
+
+  const int ex = scale_exp3(reduce_absmax(x_amax, k.x_n, red));
+  __syncthreads();
+  const int ed = scale_exp3(reduce_absmax(dy_amax, k.dy_n, red));
+  const float xscale = pow2f3(ex), dscale = pow2f3(ed), oscale = pow2f3(-ex), oscale2 = pow2f3(-ed);
+
+  f32x16 acc[NCH][2];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][s][r] = 0.f;
+
+  const int c_base = blockIdx.y * NCH;
+  int nc = k.nchunk - c_base;                              // chunks of this workgroup row
+  if (nc > NCH) nc = NCH;
+  const long long p_begin = (long long)blockIdx.x * k.per_block;
+  long long p_end = p_begin + k.per_block;
+  if (p_end > k.npatch) p_end = k.npatch;
+  if (p_begin >= p_end || nc <= 0) return;
+
+  // ---- staging roles.  X: thread t < 240 owns the aligned quad qq (x0 - 4 + 4 qq ..) of halo row t / 6 (40 rows of
+  // 6 quads; quads 0 and 5 contribute one position each) in the 8 channels of the chunk.  dY: wave w owns channel
+  // group w, thread = (row 0..15, quad 0..3) of the tile.
+  const bool xt = tid < 240;
+  const int xrow = tid / 6, xqq = tid - 6 * xrow;
+  const int xhz = xrow / HY, xhy = xrow - HY * xhz;
+  const int xpos0 = xhz * SZP + xhy * HXP + 4 * xqq - 3;   // unit of element e: xpos0 + e
+  const int xe0 = xqq == 0 ? 3 : 0, xe1 = xqq == 5 ? 1 : 4;
+  const int yq = tid & 3, yrow = (tid >> 2) & 15;
+  const bool yt = wid * 8 < k.Cout;
+  const int yunit0 = (yrow * 16 + 4 * yq) * 4 + (wid ^ yq);   // unit of element e: yunit0 + 4 e
+  const bool db_y = k.db && !k.db_from_x && blockIdx.y == 0 && yt;
+  const bool db_x = k.db && k.db_from_x && xt && xhz >= 1 && xhz <= TZ && xhy >= 1 && xhy <= TY && xqq >= 1 && xqq <= 4;
+  float bacc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bacc[c] = 0.f;
+
+  // ---- operand addresses (bytes in LDS).  Source role of this lane in its 16-lane group: j = voxel, q = channel quad.
+  const int sj = (lane & 15) >> 2, sq = lane & 3, sg = (lane >> 4) & 1;
+  const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Xs;
+  const unsigned ys_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Ys;
+  // B (dY): voxel = s * 16 + 8 hi + 4 i + j, channel quad = 4 sg + sq -> unit (2 sg + (sq >> 1)) ^ ((2 hi + i) & 3)
+  unsigned baddr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    baddr[i] = ys_base + (unsigned)(((8 * hi + 4 * i + sj) * 4 + ((2 * sg + (sq >> 1)) ^ ((2 * hi + i) & 3))) * 16 + (sq & 1) * 8);
+
+  u32x4 rq[8], ry[8];
+  int tn, tz, ty, tx;                                      // tile being LOADED (runs one phase ahead of the compute)
+  {
+    long long q_ = p_begin;
+    tx = (int)(q_ % k.nx); q_ /= k.nx;
+    ty = (int)(q_ % k.ny); q_ /= k.ny;
+    tz = (int)(q_ % k.nz);
+    tn = (int)(q_ / k.nz);
+  }
+  long long p_load = p_begin;
+  unsigned gq = OOB, gy_ = OOB;
+  __amdgpu_buffer_rsrc_t x_src, y_src;
+#define W3T_TILE_ADDR()                                                                           \
+  {                                                                                               \
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;                                           \
+    x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)tn * k.Cin * S), 0,   \
+                                              (unsigned)((long long)k.Cin * S * 4), 0x00020000);  \
+    y_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (long long)tn * k.Cout * S), 0, \
+                                              (unsigned)((long long)k.Cout * S * 4), 0x00020000); \
+    {                                                                                             \
+      const int gz = z0 - 1 + xhz, gyy = y0 - 1 + xhy, gx = x0 - 4 + 4 * xqq;                     \
+      gq = (xt && (unsigned)gz < (unsigned)k.D && (unsigned)gyy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+               ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB;                              \
+    }                                                                                             \
+    {                                                                                             \
+      const int gz = z0 + (yrow >> 3), gyy = y0 + (yrow & 7), gx = x0 + 4 * yq;                   \
+      gy_ = (yt && gz < k.D && gyy < k.H && gx < k.W) ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB; \
+    }                                                                                             \
+  }
+#define W3T_GLOAD_X1(ca_, c_)                                                                     \
+  rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + (unsigned)((ca_) * 8 + (c_)) * s4, 0, 0);
+#define W3T_GLOAD_Y1(c_)                                                                          \
+  ry[c_] = __builtin_amdgcn_raw_buffer_load_b128(y_src, gy_ == OOB ? OOB : gy_ + (unsigned)(wid * 8 + (c_)) * s4, 0, 0);
+#define W3T_STORE_X()                                                                             \
+  if (xt) {                                                                                       \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+      if (e < xe0 || e >= xe1) continue;                                                          \
+      u32x4 h, r;                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        unsigned hh, rr;                                                                          \
+        split_pair3(__uint_as_float(rq[2 * q][e]), __uint_as_float(rq[2 * q + 1][e]), xscale, hh, rr); \
+        h[q] = hh; r[q] = rr;                                                                     \
+      }                                                                                           \
+      Xs[xpos0 + e] = h;                                                                          \
+      Xs[XPOS + xpos0 + e] = r;                                                                   \
+    }                                                                                             \
+    if (db_x) {                                                                                   \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                               \
+        bacc[c] += (__uint_as_float(rq[c][0]) + __uint_as_float(rq[c][1])) + (__uint_as_float(rq[c][2]) + __uint_as_float(rq[c][3])); \
+    }                                                                                             \
+  }
+#define W3T_STORE_Y()                                                                             \
+  if (yt) {                                                                                       \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+      u32x4 h, r;                                                                                 \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+        unsigned hh, rr;                                                                          \
+        split_pair3(__uint_as_float(ry[2 * q][e]), __uint_as_float(ry[2 * q + 1][e]), dscale, hh, rr); \
+        h[q] = hh; r[q] = rr;                                                                     \
+      }                                                                                           \
+      Ys[yunit0 + 4 * e] = h;                                                                     \
+      Ys[YU + yunit0 + 4 * e] = r;                                                                \
+    }                                                                                             \
+    if (db_y) {                                                                                   \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                               \
+        bacc[c] += (__uint_as_float(ry[c][0]) + __uint_as_float(ry[c][1])) + (__uint_as_float(ry[c][2]) + __uint_as_float(ry[c][3])); \
+    }                                                                                             \
+  }
+  // operands of k-step s_ (x-row (z, y) = (s_ >> 3, s_ & 7)) into register set b_
+#define W3T_OPLOAD(b_, s_)                                                                        \
+  {                                                                                               \
+    const unsigned ko = (unsigned)((((s_) >> 3) * SZP + ((s_) & 7) * HXP) * 16);                  \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                               \
+      TR_PAIR(A0[b_][t], aaddr[t] + ko)                                                           \
+      TR_PAIR(A1[b_][t], aaddr[t] + ko + XPOS * 16u)                                              \
+    }                                                                                             \
+    {                                                                                             \
+      const uint2 u0_ = tr_read8(baddr[0] + (unsigned)(s_) * 1024u), u1_ = tr_read8(baddr[1] + (unsigned)(s_) * 1024u); \
+      B0[b_] = u32x4{u0_.x, u0_.y, u1_.x, u1_.y};                                                 \
+      const uint2 v0_ = tr_read8(baddr[0] + (unsigned)(s_) * 1024u + YU * 16u), v1_ = tr_read8(baddr[1] + (unsigned)(s_) * 1024u + YU * 16u); \
+      B1[b_] = u32x4{v0_.x, v0_.y, v1_.x, v1_.y};                                                 \
+    }                                                                                             \
+  }
+
+  u32x4 A0[2][2], A1[2][2], B0[2], B1[2];
+  unsigned aaddr[2];
+
+  // prologue: first tile's dY and chunk 0
+  W3T_TILE_ADDR();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { W3T_GLOAD_X1(c_base, c); W3T_GLOAD_Y1(c); }
+  W3T_STORE_X();
+  W3T_STORE_Y();
+  __syncthreads();
+
+  for (long long p = p_begin; p < p_end; ++p) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c >= nc) continue;
+      const bool last = (c + 1 == nc);                     // the next phase starts a new tile (or nothing)
+      const bool more = !last || (p + 1 < p_end);
+      if (last) {                                          // advance the load cursor to the next tile
+        if (++tx == k.nx) { tx = 0; if (++ty == k.ny) { ty = 0; if (++tz == k.nz) { tz = 0; ++tn; } } }
+        ++p_load;
+        if (more) { W3T_TILE_ADDR(); } else { gq = OOB; gy_ = OOB; }
+      }
+      const int ca_next = last ? c_base : c_base + c + 1;
+      // this wave's two row tiles of chunk c: lane (j, q, g) of tile T supplies tap 4T + 2g + (q >> 1), channel quad q & 1
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tile = ((wid + c) & 3) + 4 * t;
+        int tap = tile * 4 + 2 * sg + (sq >> 1);
+        if (tap > 26) tap = 26;                            // padding rows: any valid address (results discarded)
+        const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
+        aaddr[t] = xs_base + (unsigned)((dz * SZP + dyy * HXP + dx + 8 * hi + sj) * 16 + (sq & 1) * 8);
+      }
+      W3T_OPLOAD(0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int cur = s & 1;
+        if (s < 8) { W3T_GLOAD_X1(ca_next, s); }
+        else if (last) { W3T_GLOAD_Y1(s - 8); }
+        if (s + 1 < 16) W3T_OPLOAD(cur ^ 1, s + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[c][t] = mma3(A1[cur][t], B0[cur], acc[c][t]);
+          acc[c][t] = mma3(A0[cur][t], B1[cur], acc[c][t]);
+          acc[c][t] = mma3(A0[cur][t], B0[cur], acc[c][t]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS read
+          if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+      }
+      if (more) {
+        __syncthreads();
+        W3T_STORE_X();
+        if (last) W3T_STORE_Y();
+        __syncthreads();
+      }
+    }
+  }
+#undef W3T_TILE_ADDR
+#undef W3T_GLOAD_X1
+#undef W3T_GLOAD_Y1
+#undef W3T_STORE_X
+#undef W3T_STORE_Y
+#undef W3T_OPLOAD
+
+  // ---- epilogue: acc[c][s][r] <-> row (r>>2)*8 + hi*4 + (r&3) of tile ((wid+c)&3) + 4s, column co = l31
+  const float sc = oscale * oscale2;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int tile = ((wid + c) & 3) + 4 * s;
+      if (c >= nc || tile >= 7 || l31 >= k.Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = tile * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+        const int tap = rho >> 3, ci = (c_base + c) * 8 + (rho & 7);
+        const int to = k.flip ? 26 - tap : tap;
+        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + l31 * k.s_col], acc[c][s][r] * sc);
+      }
+    }
+  if (k.db) {                                              // wave-uniform: every lane of a wave holds the same 8 channels
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float t = wave_sum((db_y || db_x) ? bacc[c] : 0.f);
+      const int ch = k.db_from_x ? c_base * 8 + c : wid * 8 + c;
+      const int lim = k.db_from_x ? k.Cin : k.Cout;
+      if (lane == 0 && ch < lim && t != 0.f) atomicAdd(&k.db[ch], t);
+    }
+  }
+}
+
 static bool split3d_wgrad_common_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
          g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
@@ -738,7 +1017,8 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
     k.x_n = x_amax_n; k.dy_n = dy_amax_n;
     k.db = db; k.db_from_x = 0;
   }
-  k.nz = (g->Di + 1) / 2; k.ny = (g->Hi + 3) / 4; k.nx = (g->Wi + 15) / 16;
+  static const bool tr_off = getenv("DFMIR_CONV3D_WGRAD_COPIES") != nullptr;   // A/B: the three-copy kernel
+  k.nz = (g->Di + 1) / 2; k.ny = tr_off ? (g->Hi + 3) / 4 : (g->Hi + 7) / 8; k.nx = (g->Wi + 15) / 16;
   k.npatch = (long long)g->N * k.nz * k.ny * k.nx;
   long long want = 512;
   if (want > k.npatch) want = k.npatch;
@@ -755,10 +1035,14 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   }
   const unsigned nbx = (unsigned)((k.npatch + k.per_block - 1) / k.per_block);
   const float *kx = swapped ? dy : x, *kxa = swapped ? dy_amax : x_amax, *kdy = swapped ? x : dy, *kda = swapped ? x_amax : dy_amax;
-#define W3S_LAUNCH(N_) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k)
-  if (per_wg == 1) W3S_LAUNCH(1);
-  else if (per_wg == 2) W3S_LAUNCH(2);
-  else W3S_LAUNCH(3);
+#define W3S_LAUNCH(N_)                                                                            \
+  {                                                                                               \
+    if (tr_off) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
+    else conv3d_wgrad_tr_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);      \
+  }
+  if (per_wg == 1) W3S_LAUNCH(1)
+  else if (per_wg == 2) W3S_LAUNCH(2)
+  else W3S_LAUNCH(3)
 #undef W3S_LAUNCH
   DF_LAUNCH_CHECK();
   return 0;
