@@ -486,6 +486,7 @@ struct W3sP {
   int N, Cin, Cout, D, H, W;
   int nz, ny, nx;
   long long npatch, per_block;
+  long long nslot;               // tr kernel: workgroups per XCD along grid.x (per_block = tiles per XCD)
   int x_n, dy_n;
   int nchunk;                    // chunks of 8 input channels in the layer; blockIdx.y * NCH = this workgroup's first
   long long s_tap, s_row, s_col; // output index = tap' * s_tap + ci * s_row + co * s_col, tap' = flip ? 26 - tap : tap
@@ -702,14 +703,18 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
 // taps 4T .. 4T+3 x 8 channels (7 tiles, tap 27 is padding); wave w owns tiles (w + c) & 3 and that + 4 of chunk c
 // (accumulators of <= 3 chunks resident: 96 AGPRs, two workgroups per CU so that one stages while the other computes).
 // Bank behaviour of the reads: the 32 lanes served together cover 4 taps x 4 x-positions x 16 B; taps of one
-// (dz, dy) are contiguous, the next (dz, dy) must start 112..192 B further (mod 256): row stride 24 positions, plane
-// stride 248.  dY: 4 voxels x 64 B contiguous; the channel group is XORed with (voxel >> 2) & 3 so that the staging
+// (dz, dy) are contiguous, the next (dz, dy) must start 112..192 B further (mod 256): row stride 25 positions, plane
+// stride 250 -- odd, so that the staging stores of 4 consecutive rows x 2 quads (one ds_write_b128 lane group) fall on
+// 8 different 16-B bank slots (measured: all of the kernel's bank conflicts were these stores at stride 24).  dY: 4 voxels x 64 B contiguous; the channel group is XORed with (voxel >> 2) & 3 so that the staging
 // stores of a wave (one channel group, 4 voxel quads) spread over the banks.
 // ================================================================================================
+#ifndef W3T_KO
+#define W3T_KO 0     // knock-out builds for timing: 1 = no MFMAs, 2 = no prefetch loads, 4 = no convert + LDS store, 8 = no operand reads
+#endif
 typedef short s16x4_3 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_3* lds_tr_ptr;
 __device__ __forceinline__ uint2 tr_read8(unsigned byte_addr) {
-  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)byte_addr));
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(uintptr_t)byte_addr));
 }
 #define TR_PAIR(dst_, addr_)                                                                      \
   {                                                                                               \
@@ -719,8 +724,8 @@ __device__ __forceinline__ uint2 tr_read8(unsigned byte_addr) {
 
 template <int NCH>
 struct W3T {
-  static constexpr int TZ = 2, TY = 8, TX = 16, HZ = 4, HY = 10, HXP = 24, SZP = HY * HXP + 8;
-  static constexpr int XPOS = HZ * SZP;                  // 992 units per split
+  static constexpr int TZ = 2, TY = 8, TX = 16, HZ = 4, HY = 10, HXP = 25, SZP = HY * HXP;
+  static constexpr int XPOS = HZ * SZP;                  // 1000 units per split
   static constexpr int YU = TZ * TY * TX * 4;            // 1024 units per split
 };
 
@@ -756,16 +761,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   const int c_base = blockIdx.y * NCH;
   int nc = k.nchunk - c_base;                              // chunks of this workgroup row
   if (nc > NCH) nc = NCH;
-  const long long p_begin = (long long)blockIdx.x * k.per_block;
-  long long p_end = p_begin + k.per_block;
-  if (p_end > k.npatch) p_end = k.npatch;
-  if (p_begin >= p_end || nc <= 0) return;
+  // Tiles: workgroup ids go round-robin to the 8 XCDs (one L2 each), so XCD e = id & 7 owns the e-th eighth of the
+  // tile list and its J workgroups (slot j = id >> 3) walk it together: in iteration i they hold the J consecutive
+  // tiles i J .. i J + J - 1 of the eighth.  The list runs x fastest, then over 2 x 2 blocks of (z, y): a window of J
+  // tiles is a few full x-rows of neighbouring (z, y), so the halos (3.75x the tile in the patch) are mostly L2 hits.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long long t_first = (long long)xcd * k.per_block + slot;       // per_block = tiles per XCD
+  long long t_lim = (long long)(xcd + 1) * k.per_block;
+  if (t_lim > k.npatch) t_lim = k.npatch;
+  const int J = (int)k.nslot;
+  if (t_first >= t_lim || nc <= 0) return;
+  const int niter = (int)((t_lim - t_first + J - 1) / J);
 
   // ---- staging roles.  X: thread t < 240 owns the aligned quad qq (x0 - 4 + 4 qq ..) of halo row t / 6 (40 rows of
   // 6 quads; quads 0 and 5 contribute one position each) in the 8 channels of the chunk.  dY: wave w owns channel
   // group w, thread = (row 0..15, quad 0..3) of the tile.
   const bool xt = tid < 240;
-  const int xrow = tid / 6, xqq = tid - 6 * xrow;
+  const int xm = tid / 80, xr80 = tid - 80 * xm;           // quad pair m = 0..2; 8 consecutive lanes = 4 rows x 2 quads
+  const int xrow = xr80 >> 1, xqq = 2 * xm + (xr80 & 1);
   const int xhz = xrow / HY, xhy = xrow - HY * xhz;
   const int xpos0 = xhz * SZP + xhy * HXP + 4 * xqq - 3;   // unit of element e: xpos0 + e
   const int xe0 = xqq == 0 ? 3 : 0, xe1 = xqq == 5 ? 1 : 4;
@@ -790,14 +803,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
 
   u32x4 rq[8], ry[8];
   int tn, tz, ty, tx;                                      // tile being LOADED (runs one phase ahead of the compute)
-  {
-    long long q_ = p_begin;
-    tx = (int)(q_ % k.nx); q_ /= k.nx;
-    ty = (int)(q_ % k.ny); q_ /= k.ny;
-    tz = (int)(q_ % k.nz);
-    tn = (int)(q_ / k.nz);
+  const int nzb = (k.nz + 1) >> 1;
+  const int cells = 4 * nzb * ((k.ny + 1) >> 1);           // (z, y) cells per image incl. the phantom ones of odd counts
+#define W3T_DECODE(t_)                                                                            \
+  {                                                                                               \
+    long long q_ = (t_);                                                                          \
+    tx = (int)(q_ % k.nx); q_ /= k.nx;                                                            \
+    const int u_ = (int)(q_ % cells);                                                             \
+    tn = (int)(q_ / cells);                                                                       \
+    const int b_ = u_ >> 2;                                                                       \
+    tz = 2 * (b_ % nzb) + (u_ & 1);                                                               \
+    ty = 2 * (b_ / nzb) + ((u_ >> 1) & 1);                                                        \
   }
-  long long p_load = p_begin;
+  W3T_DECODE(t_first)
   unsigned gq = OOB, gy_ = OOB;
   __amdgpu_buffer_rsrc_t x_src, y_src;
 #define W3T_TILE_ADDR()                                                                           \
@@ -809,12 +827,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
                                               (unsigned)((long long)k.Cout * S * 4), 0x00020000); \
     {                                                                                             \
       const int gz = z0 - 1 + xhz, gyy = y0 - 1 + xhy, gx = x0 - 4 + 4 * xqq;                     \
-      gq = (xt && (unsigned)gz < (unsigned)k.D && (unsigned)gyy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+      gq = (xt && tz < k.nz && ty < k.ny && (unsigned)gz < (unsigned)k.D && (unsigned)gyy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
                ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB;                              \
     }                                                                                             \
     {                                                                                             \
       const int gz = z0 + (yrow >> 3), gyy = y0 + (yrow & 7), gx = x0 + 4 * yq;                   \
-      gy_ = (yt && gz < k.D && gyy < k.H && gx < k.W) ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB; \
+      gy_ = (yt && tz < k.nz && ty < k.ny && gz < k.D && gyy < k.H && gx < k.W) ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB; \
     }                                                                                             \
   }
 #define W3T_GLOAD_X1(ca_, c_)                                                                     \
@@ -857,22 +875,66 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
     }                                                                                             \
   }
   // operands of k-step s_ (x-row (z, y) = (s_ >> 3, s_ & 7)) into register set b_
-#define W3T_OPLOAD(b_, s_)                                                                        \
+  // Operand reads of k-step s_ (x-row (z, y) = (s_ >> 3, s_ & 7)).  A (one row tile) is single-buffered and fetched one
+  // HALF-step ahead -- tile 1's while tile 0's three MFMAs run and vice versa -- B (shared by both tiles) is
+  // double-buffered and fetched one step ahead: 32 operand registers instead of 48 (three chunks of accumulators +
+  // both staging sets + 48 did not fit 256 registers).
+#define W3T_READ_A(t_, s_)                                                                        \
   {                                                                                               \
     const unsigned ko = (unsigned)((((s_) >> 3) * SZP + ((s_) & 7) * HXP) * 16);                  \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                               \
-      TR_PAIR(A0[b_][t], aaddr[t] + ko)                                                           \
-      TR_PAIR(A1[b_][t], aaddr[t] + ko + XPOS * 16u)                                              \
-    }                                                                                             \
-    {                                                                                             \
-      const uint2 u0_ = tr_read8(baddr[0] + (unsigned)(s_) * 1024u), u1_ = tr_read8(baddr[1] + (unsigned)(s_) * 1024u); \
-      B0[b_] = u32x4{u0_.x, u0_.y, u1_.x, u1_.y};                                                 \
-      const uint2 v0_ = tr_read8(baddr[0] + (unsigned)(s_) * 1024u + YU * 16u), v1_ = tr_read8(baddr[1] + (unsigned)(s_) * 1024u + YU * 16u); \
-      B1[b_] = u32x4{v0_.x, v0_.y, v1_.x, v1_.y};                                                 \
+    TR_PAIR(A1[t_], aaddr[t_] + ko + XPOS * 16u)                                                  \
+    TR_PAIR(A0[t_], aaddr[t_] + ko)                                                               \
+  }
+#define W3T_READ_B(B_, b_, s_, off_)                                                              \
+  {                                                                                               \
+    const uint2 u0_ = tr_read8(baddr[0] + (unsigned)(s_) * 1024u + (off_)), u1_ = tr_read8(baddr[1] + (unsigned)(s_) * 1024u + (off_)); \
+    B_[b_] = u32x4{u0_.x, u0_.y, u1_.x, u1_.y};                                                   \
+  }
+  // the 16 k-steps of chunk c_ (LAST_: the next phase starts a new tile, so dY is prefetched too -- a wave-uniform
+  // branch around one load per step; two copies of the loop behind one branch cost 32 registers of accumulator copies)
+#define W3T_KLOOP(c_, LAST_)                                                                      \
+  {                                                                                               \
+    W3T_READ_B(B0, 0, 0, 0u) W3T_READ_B(B1, 0, 0, YU * 16u) W3T_READ_A(0, 0)                      \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                              \
+      const int cur = s & 1;                                                                      \
+      if (!(W3T_KO & 8)) {                                                                        \
+        W3T_READ_A(1, s)                                                                          \
+        if (s + 1 < 16) W3T_READ_B(B0, cur ^ 1, s + 1, 0u)                                        \
+      }                                                                                           \
+      if (!(W3T_KO & 2)) {                                                                        \
+        if (s < 8) { W3T_GLOAD_X1(ca_next, s); }                                                  \
+        else if (LAST_) { W3T_GLOAD_Y1(s - 8); }                                                  \
+      }                                                                                           \
+      W3T_MMA(c_, 0)                                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      if (s + 1 < 16 && !(W3T_KO & 8)) {                                                          \
+        W3T_READ_A(0, s + 1)                                                                      \
+        W3T_READ_B(B1, cur ^ 1, s + 1, YU * 16u)                                                  \
+      }                                                                                           \
+      W3T_MMA(c_, 1)                                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
+#if (W3T_KO & 1)
+#define W3T_MMA(c_, t) acc[c_][t][0] += __uint_as_float(A1[t][0] ^ B0[cur][1] ^ A0[t][2] ^ B1[cur][3]);
+#else
+#define W3T_MMA(c_, t)                                                                            \
+  acc[c_][t] = mma3(A1[t], B0[cur], acc[c_][t]);                                                  \
+  acc[c_][t] = mma3(A0[t], B1[cur], acc[c_][t]);                                                  \
+  acc[c_][t] = mma3(A0[t], B0[cur], acc[c_][t]);
+#endif
 
-  u32x4 A0[2][2], A1[2][2], B0[2], B1[2];
+  u32x4 A0[2], A1[2], B0[2], B1[2];
   unsigned aaddr[2];
 
   // prologue: first tile's dY and chunk 0
@@ -883,16 +945,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   W3T_STORE_Y();
   __syncthreads();
 
-  for (long long p = p_begin; p < p_end; ++p) {
+  for (int it = 0; it < niter; ++it) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c >= nc) continue;
       const bool last = (c + 1 == nc);                     // the next phase starts a new tile (or nothing)
-      const bool more = !last || (p + 1 < p_end);
+      const bool more = !last || (it + 1 < niter);
       if (last) {                                          // advance the load cursor to the next tile
-        if (++tx == k.nx) { tx = 0; if (++ty == k.ny) { ty = 0; if (++tz == k.nz) { tz = 0; ++tn; } } }
-        ++p_load;
-        if (more) { W3T_TILE_ADDR(); } else { gq = OOB; gy_ = OOB; }
+        if (more) { W3T_DECODE(t_first + (long long)(it + 1) * J) W3T_TILE_ADDR(); } else { gq = OOB; gy_ = OOB; }
       }
       const int ca_next = last ? c_base : c_base + c + 1;
       // this wave's two row tiles of chunk c: lane (j, q, g) of tile T supplies tap 4T + 2g + (q >> 1), channel quad q & 1
@@ -904,40 +964,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
         const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
         aaddr[t] = xs_base + (unsigned)((dz * SZP + dyy * HXP + dx + 8 * hi + sj) * 16 + (sq & 1) * 8);
       }
-      W3T_OPLOAD(0, 0);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int cur = s & 1;
-        if (s < 8) { W3T_GLOAD_X1(ca_next, s); }
-        else if (last) { W3T_GLOAD_Y1(s - 8); }
-        if (s + 1 < 16) W3T_OPLOAD(cur ^ 1, s + 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          acc[c][t] = mma3(A1[cur][t], B0[cur], acc[c][t]);
-          acc[c][t] = mma3(A0[cur][t], B1[cur], acc[c][t]);
-          acc[c][t] = mma3(A0[cur][t], B0[cur], acc[c][t]);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS read
-          if (i == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-      }
+      W3T_KLOOP(c, last)
       if (more) {
         __syncthreads();
-        W3T_STORE_X();
-        if (last) W3T_STORE_Y();
+        if (!(W3T_KO & 4)) {
+          W3T_STORE_X();
+          if (last) W3T_STORE_Y();
+        }
         __syncthreads();
       }
     }
   }
 #undef W3T_TILE_ADDR
+#undef W3T_DECODE
 #undef W3T_GLOAD_X1
 #undef W3T_GLOAD_Y1
 #undef W3T_STORE_X
 #undef W3T_STORE_Y
-#undef W3T_OPLOAD
+#undef W3T_READ_A
+#undef W3T_READ_B
+#undef W3T_KLOOP
+#undef W3T_MMA
 
   // ---- epilogue: acc[c][s][r] <-> row (r>>2)*8 + hi*4 + (r&3) of tile ((wid+c)&3) + 4s, column co = l31
   const float sc = oscale * oscale2;
@@ -1033,7 +1080,17 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
     if (want > k.npatch) want = k.npatch;
     k.per_block = (k.npatch + want - 1) / want;
   }
-  const unsigned nbx = (unsigned)((k.npatch + k.per_block - 1) / k.per_block);
+  unsigned nbx = (unsigned)((k.npatch + k.per_block - 1) / k.per_block);
+  if (!tr_off) {
+    // tr kernel: the tile list includes the phantom (z, y) cells of odd tile counts (they load nothing); 8 XCD shares,
+    // nslot workgroups each (see the kernel)
+    k.npatch = (long long)g->N * k.nx * 4 * ((k.nz + 1) / 2) * ((k.ny + 1) / 2);
+    k.per_block = (k.npatch + 7) / 8;
+    k.nslot = (long long)(512 / gy / 8);
+    if (k.nslot > k.per_block) k.nslot = k.per_block;
+    if (k.nslot < 1) k.nslot = 1;
+    nbx = (unsigned)(8 * k.nslot);
+  }
   const float *kx = swapped ? dy : x, *kxa = swapped ? dy_amax : x_amax, *kdy = swapped ? x : dy, *kda = swapped ? x_amax : dy_amax;
 #define W3S_LAUNCH(N_)                                                                            \
   {                                                                                               \
