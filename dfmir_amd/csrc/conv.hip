@@ -20,6 +20,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvK {
   DfConvGeom g;
   int kc, nchunks;
+  // DIL2 form (dgrad of a stride-2 conv = conv over the zero-dilated dY): output voxels are enumerated parity class
+  // by parity class (class-major: p = (((cls N + n) Dm + mz) Hm + my) Wm + mx, o = 2 m + parity), so that the voxels
+  // of one workgroup share the taps that meet non-zero input -- (1 or 2) per axis instead of 3
+  int Dm, Hm, Wm, ncx, ncy, ncz;       // sub-grid extents and parity classes per axis (1 or 2)
 };
 
 static inline void df_chunking(int Cin, int& kc, int& nchunks) {
@@ -32,7 +36,32 @@ static inline void df_chunking(int Cin, int& kc, int& nchunks) {
 // ---------------------------------------------------------------------------------------------
 // forward / dgrad kernel
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+// pixel index -> output voxel; DIL2: class-major enumeration (phantom voxels of odd extents are invalid)
+template <bool DIL2>
+__device__ __forceinline__ bool conv_pixel(const ConvK& k, long long pp, long long P, int& n, int& oz, int& oy, int& ox,
+                                           int& cls) {
+  const DfConvGeom& g = k.g;
+  cls = 0;
+  if (pp >= P) { n = oz = oy = ox = 0; return false; }
+  long long t = pp;
+  if constexpr (DIL2) {
+    const int mx = (int)(t % k.Wm); t /= k.Wm;
+    const int my = (int)(t % k.Hm); t /= k.Hm;
+    const int mz = (int)(t % k.Dm); t /= k.Dm;
+    n = (int)(t % g.N);
+    cls = (int)(t / g.N);
+    const int px = cls % k.ncx, py = (cls / k.ncx) % k.ncy, pz = cls / (k.ncx * k.ncy);
+    ox = k.ncx * mx + px; oy = k.ncy * my + py; oz = k.ncz * mz + pz;
+    return ox < g.Wo && oy < g.Ho && oz < g.Do;
+  } else {
+    ox = (int)(t % g.Wo); t /= g.Wo;
+    oy = (int)(t % g.Ho); t /= g.Ho;
+    oz = (int)(t % g.Do); n = (int)(t / g.Do);
+    return true;
+  }
+}
+
+template <int WM, int WN, int TM, int TN, bool DIL2 = false>
 __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
                                                    const float* __restrict__ wt,
                                                    const float* __restrict__ bias,
@@ -45,26 +74,41 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
   static_assert(BN <= 256 && BM <= 256, "tile");
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
+  __shared__ int taplist[DIL2 ? 128 : 1];
+  __shared__ int ntap_s;
 
   const DfConvGeom& g = k.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const long long DHWi = (long long)g.Di * g.Hi * g.Wi;
   const long long DHWo = (long long)g.Do * g.Ho * g.Wo;
-  const long long P = (long long)g.N * DHWo;
+  const long long P = DIL2 ? (long long)k.ncx * k.ncy * k.ncz * g.N * k.Dm * k.Hm * k.Wm : (long long)g.N * DHWo;
   const long long p0 = (long long)blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
 
   // ---- the pixel this thread gathers for the B tile
   const int bcol = tid % BN, brow0 = tid / BN;
   const long long pp = p0 + bcol;
-  const bool pv = pp < P;
-  int ox = 0, oy = 0, oz = 0, n = 0;
-  if (pv) {
-    long long t = pp;
-    ox = (int)(t % g.Wo); t /= g.Wo;
-    oy = (int)(t % g.Ho); t /= g.Ho;
-    oz = (int)(t % g.Do); n = (int)(t / g.Do);
+  int ox, oy, oz, n, cls;
+  const bool pv = conv_pixel<DIL2>(k, pp, P, n, oz, oy, ox, cls);
+  if constexpr (DIL2) {
+    // taps that can meet a non-zero of the dilated input: per axis (parity - pad + t) even.  A workgroup whose voxels
+    // span two classes (only at class boundaries) walks every tap.
+    if (tid == 0) {
+      const long long per_cls = (long long)g.N * k.Dm * k.Hm * k.Wm;
+      const long long pl = (p0 + BN - 1 < P ? p0 + BN - 1 : P - 1);
+      const int c0 = (int)(p0 / per_cls), c1 = (int)(pl / per_cls);
+      const int px = c0 % k.ncx, py = (c0 / k.ncx) % k.ncy, pz = c0 / (k.ncx * k.ncy);
+      int nt = 0;
+      for (int t = 0; t < g.KD * g.KH * g.KW && nt < 128; ++t) {
+        const int kw_ = t % g.KW, kh_ = (t / g.KW) % g.KH, kd_ = t / (g.KW * g.KH);
+        const bool ok = c0 != c1 || ((k.ncx == 1 || ((px - g.pw + kw_) & 1) == 0) && (k.ncy == 1 || ((py - g.ph + kh_) & 1) == 0) &&
+                                     (k.ncz == 1 || ((pz - g.pd + kd_) & 1) == 0));
+        if (ok) taplist[nt++] = t;
+      }
+      ntap_s = nt;
+    }
+    __syncthreads();
   }
   // hardware-bounds-checked buffer loads: padding / tile overrun = an out-of-range offset = 0.0,
   // so the gather is branch-free (host guarantees every tensor here is < 2 GiB)
@@ -88,12 +132,13 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nks = g.KD * g.KH * g.KW * k.nchunks;
+  const int nks = (DIL2 ? ntap_s : g.KD * g.KH * g.KW) * k.nchunks;
 
 #define CONV_GLOAD(ks_)                                                                          \
   {                                                                                              \
-    const int tap = (ks_) / k.nchunks;                                                           \
-    const int ci0 = ((ks_) - tap * k.nchunks) * k.kc;                                            \
+    const int tq_ = (ks_) / k.nchunks;                                                           \
+    const int tap = DIL2 ? taplist[tq_] : tq_;                                                   \
+    const int ci0 = ((ks_) - tq_ * k.nchunks) * k.kc;                                            \
     const int kw_ = tap % g.KW;                                                                  \
     const int t2_ = tap / g.KW;                                                                  \
     const int kh_ = t2_ % g.KH;                                                                  \
@@ -158,9 +203,17 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const float* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long long pq = p0 + (wn * TN + j) * 32 + l31;
-    if (pq >= P) continue;
-    const long long nn = pq / DHWo;
-    const long long so = pq - nn * DHWo;
+    long long nn, so;
+    if constexpr (DIL2) {
+      int qn, qz, qy, qx, qc;
+      if (!conv_pixel<true>(k, pq, P, qn, qz, qy, qx, qc)) continue;
+      nn = qn;
+      so = ((long long)qz * g.Ho + qy) * g.Wo + qx;
+    } else {
+      if (pq >= P) continue;
+      nn = pq / DHWo;
+      so = pq - nn * DHWo;
+    }
     float* yb = y + nn * g.Cout * DHWo + so;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -640,8 +693,24 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     df_chunking(g->Cin, k.kc, k.nchunks);
     const float* xs = x + (long long)n0 * (in_img / 4);
     float* ys = y + (long long)n0 * (out_img / 4);
-    const long long Ps = (long long)k.g.N * g->Do * g->Ho * g->Wo;
-    if (g->Cout > 64) {
+    long long Ps = (long long)k.g.N * g->Do * g->Ho * g->Wo;
+    // dgrad of a stride-2 conv: parity-class enumeration (taps that only meet the inserted zeros are skipped)
+    static const bool dil2_off = getenv("DFMIR_NO_DIL2") != nullptr;
+    const bool dil2 = g->dil == 2 && g->stride == 1 && g->pad_mode == 0 && g->KD * g->KH * g->KW <= 128 && g->Cout <= 64 && !dil2_off;
+    k.ncx = k.ncy = k.ncz = 1;
+    k.Dm = g->Do; k.Hm = g->Ho; k.Wm = g->Wo;
+    if (dil2) {
+      // an axis has two classes when the input is really dilated along it (2-D convs: Di == 1, KD == 1 stays one class)
+      if (g->Wi > 1 || g->KW > 1) { k.ncx = 2; k.Wm = (g->Wo + 1) / 2; }
+      if (g->Hi > 1 || g->KH > 1) { k.ncy = 2; k.Hm = (g->Ho + 1) / 2; }
+      if (g->Di > 1 || g->KD > 1) { k.ncz = 2; k.Dm = (g->Do + 1) / 2; }
+      Ps = (long long)k.ncx * k.ncy * k.ncz * k.g.N * k.Dm * k.Hm * k.Wm;
+    }
+    if (dil2) {
+      dim3 grid((unsigned)((Ps + 255) / 256), 1);
+      if (g->Cout > 32) conv_mfma_k<1, 4, 2, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      else conv_mfma_k<1, 4, 1, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+    } else if (g->Cout > 64) {
       const long long big = ((Ps + 127) / 128) * ((g->Cout + 127) / 128);
       if (big < 256) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
         dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));

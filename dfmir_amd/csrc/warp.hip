@@ -304,16 +304,42 @@ __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy
   lin_range(iy, sh, Ho, yl, yh);
   lin_range(ix, sw, Wo, xl, xh);
   float acc = 0.f;
-  for (int oz = zl; oz <= zh; ++oz) {
-    const float wz = lin_weight(oz, sd, Di, iz);
-    if (wz == 0.f) continue;
-    for (int oy = yl; oy <= yh; ++oy) {
-      const float wy = lin_weight(oy, sh, Hi, iy);
-      if (wy == 0.f) continue;
-      const float* row = gp + ((long long)oz * Ho + oy) * Wo;
-      float racc = 0.f;
-      for (int ox = xl; ox <= xh; ++ox) racc += lin_weight(ox, sw, Wi, ix) * row[ox];
-      acc += wz * wy * racc;
+  constexpr int MW = 8;                       // windows of the x2 / x0.5 resizes of the path are 7 / 4 candidates wide
+  if (zh - zl < MW && yh - yl < MW && xh - xl < MW) {
+    // per-axis weights once per thread (the triple loop used to recompute lin_weight for every candidate)
+    float wzv[MW], wyv[MW], wxv[MW];
+#pragma unroll
+    for (int t = 0; t < MW; ++t) {
+      wzv[t] = (zl + t <= zh) ? lin_weight(zl + t, sd, Di, iz) : 0.f;
+      wyv[t] = (yl + t <= yh) ? lin_weight(yl + t, sh, Hi, iy) : 0.f;
+      wxv[t] = (xl + t <= xh) ? lin_weight(xl + t, sw, Wi, ix) : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < MW; ++a) {
+      if (wzv[a] == 0.f) continue;
+#pragma unroll
+      for (int b = 0; b < MW; ++b) {
+        if (wyv[b] == 0.f) continue;
+        const float* row = gp + ((long long)(zl + a) * Ho + (yl + b)) * Wo + xl;
+        float racc = 0.f;
+#pragma unroll
+        for (int c = 0; c < MW; ++c)
+          if (wxv[c] != 0.f) racc += wxv[c] * row[c];
+        acc += wzv[a] * wyv[b] * racc;
+      }
+    }
+  } else {
+    for (int oz = zl; oz <= zh; ++oz) {
+      const float wz = lin_weight(oz, sd, Di, iz);
+      if (wz == 0.f) continue;
+      for (int oy = yl; oy <= yh; ++oy) {
+        const float wy = lin_weight(oy, sh, Hi, iy);
+        if (wy == 0.f) continue;
+        const float* row = gp + ((long long)oz * Ho + oy) * Wo;
+        float racc = 0.f;
+        for (int ox = xl; ox <= xh; ++ox) racc += lin_weight(ox, sw, Wi, ix) * row[ox];
+        acc += wz * wy * racc;
+      }
     }
   }
   dx[i] = mult * acc;
