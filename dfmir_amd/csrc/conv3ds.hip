@@ -421,7 +421,7 @@ static bool pair3d_off() {
 static bool split3d_geom_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
          g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && g->Di > 1 &&
-         g->Cin >= 8 && g->Cout >= 8 && (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;   // buffer offsets, OOB marker
+         g->Cin >= 1 && g->Cout >= 1 && (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;   // buffer offsets, OOB marker
 }
 extern "C" int dfmir_conv3d_split_ok(const DfConvGeom* g) { return (g && !split3d_off() && split3d_geom_ok(g)) ? 1 : 0; }
 extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
@@ -1023,7 +1023,7 @@ static bool split3d_wgrad_common_ok(const DfConvGeom* g) {
 // (tap, co) gathered from shifted dY, columns = ci: dW[t][ci][co] = sum_u X[ci][u] * dY[co][u - t], i.e. the same kernel
 // on (x := dY, dy := X) with the taps flipped and the output transposed (one 8-channel chunk instead of Cin / 8).
 static bool split3d_wgrad_geom_ok(const DfConvGeom* g) {
-  return split3d_wgrad_common_ok(g) && g->Cin >= 8 && g->Cin <= 48 && g->Cout >= 8 && g->Cout <= 32;
+  return split3d_wgrad_common_ok(g) && g->Cin >= 8 && g->Cin <= 128 && g->Cout >= 8 && g->Cout <= 32;
 }
 static bool split3d_wgrad_swapped_ok(const DfConvGeom* g) {
   return split3d_wgrad_common_ok(g) && g->Cout >= 1 && g->Cout < 8 && g->Cin >= 8 && g->Cin <= 32;

@@ -151,6 +151,59 @@ __global__ __launch_bounds__(256) void box_axis_k(const float* __restrict__ in, 
     out[f * N + i] = s;
   }
 }
+// The same sums along an axis with stride > 1 (H, D), marching: a thread owns SEG consecutive outputs of one line and
+// keeps the 2R + 1 window values in a register ring -- every input is loaded once (box_axis_k: 2R + 1 times, from
+// L1 / L2), consecutive threads hold consecutive lines, so every load / store instruction is contiguous.  Each output
+// is the plain sum of its window (no running difference: the variance terms cancel to 1e-3 of the sums).
+template <int R, int SEG>
+__global__ __launch_bounds__(256) void box_axis_march_k(const float* __restrict__ in, float* __restrict__ out, int nf,
+                                                        long long N, long long stride, int len) {
+  constexpr int WN = 2 * R + 1;
+  static_assert(SEG % WN == 0, "segment = whole turns of the ring");
+  const long long nline = N / len;
+  const int nseg = (len + SEG - 1) / SEG;
+  const long long per_f = nline * nseg;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= per_f * nf) return;
+  const int f = (int)(t / per_f);
+  const long long u = t - (long long)f * per_f;
+  const int sg = (int)(u / nline);
+  const long long l = u - (long long)sg * nline;
+  const long long outer = l / stride, inner = l - outer * stride;
+  const float* p = in + (long long)f * N + outer * len * stride + inner;
+  float* q = out + (long long)f * N + outer * len * stride + inner;
+  const int c0 = sg * SEG;
+  float ring[WN];
+#pragma unroll
+  for (int j = 0; j < WN - 1; ++j) {
+    const int cc = c0 - R + j;
+    ring[j] = ((unsigned)cc < (unsigned)len) ? p[(long long)cc * stride] : 0.f;
+  }
+  for (int k0 = 0; k0 < SEG; k0 += WN) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int c = c0 + k0 + j;
+      if (c < len) {
+        const int cc = c + R;
+        ring[(WN - 1 + j) % WN] = (cc < len) ? p[(long long)cc * stride] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) sacc += ring[w];
+        q[(long long)c * stride] = sacc;
+      }
+    }
+  }
+}
+static void box_axis_launch(const float* in, float* out, int nf, long long N, long long stride, int len, int r,
+                            hipStream_t st) {
+  if (r == 4 && stride > 1 && N % len == 0) {
+    constexpr int SEG = 36;
+    const long long thr = (N / len) * ((len + SEG - 1) / SEG) * nf;
+    box_axis_march_k<4, SEG><<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(in, out, nf, N, stride, len);
+  } else {
+    box_axis_k<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(in, out, nf, N, stride, len, r);
+  }
+}
 struct NccTerms { float cross, Iv, Jv, uI, uJ, den; };
 __device__ __forceinline__ NccTerms ncc_terms(const float* s, long long N, long long i, float wn, float eps) {
   const float Is = s[i], Js = s[N + i], I2 = s[2 * N + i], J2 = s[3 * N + i], IJ = s[4 * N + i];
@@ -294,15 +347,15 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
   if (D > 1) {
     ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp, N, W, r);
     DF_LAUNCH_CHECK();
-    box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 5, N, W, H, r);
+    box_axis_launch(tmp, tmp2, 5, N, W, H, r, st);
     DF_LAUNCH_CHECK();
-    box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 5, N, (long long)H * W, D, r);
+    box_axis_launch(tmp2, tmp, 5, N, (long long)H * W, D, r, st);
     DF_LAUNCH_CHECK();
     wn = (float)win * win * win;
   } else {
     ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp2, N, W, r);
     DF_LAUNCH_CHECK();
-    box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 5, N, W, H, r);
+    box_axis_launch(tmp2, tmp, 5, N, W, H, r, st);
     DF_LAUNCH_CHECK();
     wn = (float)win * win;
   }
@@ -326,11 +379,11 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
   DF_LAUNCH_CHECK();
   box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 3, N, 1, W, r);
   DF_LAUNCH_CHECK();
-  box_axis_k<<<grid, 256, 0, st>>>(tmp2, tmp, 3, N, W, H, r);
+  box_axis_launch(tmp2, tmp, 3, N, W, H, r, st);
   DF_LAUNCH_CHECK();
   const float* fin = tmp;
   if (D > 1) {
-    box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 3, N, (long long)H * W, D, r);
+    box_axis_launch(tmp, tmp2, 3, N, (long long)H * W, D, r, st);
     DF_LAUNCH_CHECK();
     fin = tmp2;
   }
