@@ -45,6 +45,7 @@ _SIGS = {
     "dfmir_conv3d_split_ws_floats": [c_int, c_int],
     "dfmir_conv3d_split_fwd": [_GP, P, P, c_int, P, P, P, P, P, P],
     "dfmir_conv3d_split_fwd_sub": [_GP, P, P, c_int, P, P, P, P, P, c_int, P],
+    "dfmir_conv3d_split_fwd_actgrad": [_GP, P, P, c_int, P, P, P, P, P, c_int, P, c_float, P],
     "dfmir_conv3d_split_wgrad_ok": [_GP],
     "dfmir_conv3d_split_wgrad": [_GP, P, P, c_int, P, P, c_int, P, P],
     "dfmir_conv3d_split_wgrad_db": [_GP, P, P, c_int, P, P, c_int, P, P, P],

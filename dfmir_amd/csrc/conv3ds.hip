@@ -123,6 +123,11 @@ struct C3sP {
   int x_n;                       // floats of the input range probe
   int cout_used;                 // output channels to compute (<= Cout; the rest of y is left untouched)
   long long ntile;               // N * nz * ny * nx
+  // dgrad whose result is the gradient w.r.t. the OUTPUT of a LeakyReLU (act_src = that output, same shape as y):
+  // the epilogue multiplies by the activation's derivative, i.e. it writes the gradient w.r.t. the pre-activation,
+  // and the separate act_bwd pass over the tensor (read dy, read y, write: 3 transfers of up to 0.9 GB) disappears
+  const float* act_src;
+  float act_slope;
 };
 
 template <bool PAIR, bool VEC>
@@ -379,6 +384,28 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   const unsigned plane4 = (unsigned)(k.H * k.W) * 4u;
   const float osc = oscale * oscale2;
   float pm = 0.f;
+  // activation-derivative source values of all column tiles first (the operand registers are dead by now): loads and
+  // stores share vmcnt, so a load issued between the stores would wait for every store before it
+  float av[NJ][16];
+  if (k.act_src) {
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(k.act_src + (long long)n * k.Cout * S), 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+      const bool vok = gy < k.H && gx < k.W;
+      const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowu = (r >> 2) * 8 + (r & 3);
+        const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;
+        const int pz = PAIR ? (rowu >> 4) : 0;
+        const bool ok = vok && (cou + hi * 4) < k.cout_used && (z0 + wz + pz) < k.D;
+        av[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(a_src, ok ? vo + (unsigned)pz * plane4 : OOB,
+                                                                         (unsigned)cou * s4, 0));
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
@@ -394,6 +421,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
       float v = acc[j][r] * osc + bv[r];
       if (k.act == 1) v = v > 0.f ? v : v * k.slope;
       else if (k.act == 2) v = tanhf(v);
+      if (k.act_src) v = av[j][r] > 0.f ? v : v * k.act_slope;
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo + (unsigned)pz * plane4 : OOB,
                                             (unsigned)cou * s4, 0);
       pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
@@ -430,7 +458,13 @@ extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
 }
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
-                                 int cout_used, void* stream);
+                                 int cout_used, void* stream, const float* act_src = nullptr, float act_slope = 0.f);
+extern "C" int dfmir_conv3d_split_fwd_actgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                              const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                              int cout_used, const float* act_src, float act_slope, void* stream) {
+  DF_ARG_CHECK(g && cout_used > 0 && cout_used <= g->Cout && act_src && g->act == 0);
+  return conv3d_split_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, ws, bias, y, y_amax, cout_used, stream, act_src, act_slope);
+}
 extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                       const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
                                       void* stream) {
@@ -444,7 +478,7 @@ extern "C" int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, c
 }
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
-                                 int cout_used, void* stream) {
+                                 int cout_used, void* stream, const float* act_src, float act_slope) {
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && w_tcc && ws && y);
   DF_ARG_CHECK(!split3d_off() && split3d_geom_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
@@ -454,7 +488,7 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
   DF_LAUNCH_CHECK();
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
-         nchunk, x_amax_n, cout_used, 0};
+         nchunk, x_amax_n, cout_used, 0, act_src, act_slope};
   k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
   const long long nb = 8 * ((k.ntile + 7) / 8);
   DF_ARG_CHECK(nb < (1LL << 31));

@@ -49,9 +49,9 @@ class _ConvNd(nn.Module):
     def packed(self, mode):
         return ops.packed_weight(self, self.weight.detach(), mode)
 
-    def forward(self, x, act=0, slope=0.0, reflect=False):
+    def forward(self, x, act=0, slope=0.0, reflect=False, sole=False):
         return ops.conv(x, self.weight, self.bias, self, self.stride, self.padding,
-                        1 if reflect else 0, act, slope)
+                        1 if reflect else 0, act, slope, sole=sole)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d, padding=%d" % (

@@ -131,7 +131,7 @@ def _wants_amax(K, stride, dil, Di, Cin, Cout):
 
 
 def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, out_sp, x_amax=None, res=None, ring=None,
-             cout_used=None):
+             cout_used=None, act_src=None, act_slope=0.0):
     """res (optional, shape of the output): y = act(conv + bias) + res, inside the kernel's epilogue where the
     library has one (dfmir_conv3x3_res_ok), else by a separate add.  ring = (buffer, row length) of
     dfmir_conv3x3_reflect_ring: folded in by the same epilogue (the caller checked dfmir_conv3x3_res_ok)."""
@@ -145,15 +145,25 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
     if cout_used is not None and not split3d:
         cout_used = None                                     # only the split 3-D kernel computes a channel subset
+    if act_src is not None and not (split3d and act == 0 and tuple(act_src.shape) == tuple(y.shape) and act_src.is_contiguous()):
+        act_src = None                                       # ... and only its epilogue applies an activation derivative
+    _LAST_ACTGRAD[0] = act_src is not None
 
     def launch():
         if split3d:
             # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer
             ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
             slot = amax_slot(x5.device, PROBE_SLOTS)
-            check(lib().dfmir_conv3d_split_fwd_sub(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
-                                                   _p(bias), _p(y), _p(slot), Cout if cout_used is None else cout_used,
-                                                   _st()))
+            if act_src is not None:
+                # dgrad into the output of a LeakyReLU: the epilogue applies the activation's derivative (csrc/conv3ds.hip)
+                check(lib().dfmir_conv3d_split_fwd_actgrad(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc),
+                                                           _p(ws), _p(bias), _p(y), _p(slot),
+                                                           Cout if cout_used is None else cout_used, _p(act_src),
+                                                           float(act_slope), _st()))
+            else:
+                check(lib().dfmir_conv3d_split_fwd_sub(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
+                                                       _p(bias), _p(y), _p(slot), Cout if cout_used is None else cout_used,
+                                                       _st()))
             tag_amax(y, slot)              # survives as is when y is a backward result (dgrad) ...
             _LAST_CONV_AMAX[0] = slot      # ... and is re-attached by conv() to the tensor Function.apply returns
         elif fuse_res or ring is not None:
@@ -181,6 +191,14 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
         prof(("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size, flops, launch)
     return y
+
+
+_LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
+_NO_ACTGRAD = bool(os.environ.get("DFMIR_NO_ACTGRAD"))     # A/B switch: LeakyReLU backward always as its own pass
+
+
+def _tag_ok(t, tag):
+    return tag is not None and tag[-2] == t._version and tag[-1] == t.data_ptr()
 
 
 def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None):
@@ -409,6 +427,10 @@ class ConvFn(Function):
         ctx.x_amax = x_amax
         # trailing input channels that need no gradient (cat([up2(a), b]) with b = the network's input images)
         ctx.dead_tail = int(getattr(x, "_df_nograd_tail", 0))
+        # x = the output of a LeakyReLU ConvBlock that feeds nothing but this conv (declared by the caller, conv(sole=True)):
+        # this conv's dgrad can then return the gradient w.r.t. that block's PRE-activation (see backward)
+        ta = getattr(x, "_df_act_sole", None)
+        ctx.in_act = (ta[0], ta[1]) if (_tag_ok(x, ta) and x.is_contiguous() and not _NO_ACTGRAD) else None
         ctx.cfg = (nd, K, stride, p3, pad_mode, act, slope, owner)
         ctx.save_for_backward(x5, weight, y5 if act else None)
         ctx.has_bias = bias is not None
@@ -432,7 +454,9 @@ class ConvFn(Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         want_probe = _wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None
         dy_amax = None
-        if act:
+        if act and _tag_ok(dy, getattr(dy, "_df_premasked", None)) and dy.is_contiguous():
+            pass      # the producing dgrad already multiplied by this activation's derivative (and left the range probe)
+        elif act:
             dpre = torch.empty_like(dy5)
             if want_probe and nd == 3 and not ((dy5.data_ptr() | y5.data_ptr() | dpre.data_ptr()) & 15):
                 # the activation's backward leaves the range probe of what it writes (3-D tensors are 0.1-1 GB: a
@@ -445,7 +469,7 @@ class ConvFn(Function):
         dx = dw = db = None
         # dY feeds the dgrad conv (as its input) and the wgrad: one range probe for both
         if want_probe and dy_amax is None:
-            dy_amax = amax_of(dy) if (dy.is_contiguous() and not act) else absmax(dy5)
+            dy_amax = amax_of(dy) if (dy.is_contiguous() and (not act or dy5.data_ptr() == dy.data_ptr())) else absmax(dy5)
         if ctx.needs_input_grad[0]:
             wd = owner.packed(1) if owner is not None else weight_pack(weight, 1)
             in_sp = tuple(x5.shape[2:])
@@ -492,7 +516,11 @@ class ConvFn(Function):
             else:
                 padp = tuple(K[i] - 1 - p3[i] for i in range(3))
                 used = Cin - ctx.dead_tail if (ctx.dead_tail and stride == 1 and not _NO_DEAD_TAIL) else None
-                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax, cout_used=used)
+                ia = ctx.in_act if (stride == 1 and nd == 3) else None
+                dx5 = conv_raw(dy5, wd, None, Cin, K, 1, padp, stride, 0, 0, 0.0, in_sp, dy_amax, cout_used=used,
+                               act_src=x5 if ia else None, act_slope=ia[1] if ia else 0.0)
+                if ia and _LAST_ACTGRAD[0]:
+                    dx5._df_premasked = (dx5._version, dx5.data_ptr())
             dx = dx5 if nd == 3 else dx5.squeeze(2)
         if dskip is not None:       # not folded in above (x needs no conv-path gradient, or non-reflect dgrad)
             dx = dskip if dx is None else dx + dskip
@@ -529,12 +557,16 @@ class ConvFn(Function):
 _LAST_CONV_AMAX = [None]
 
 
-def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0, skip=False):
+def conv(x, weight, bias=None, owner=None, stride=1, pad=0, pad_mode=0, act=0, slope=0.0, skip=False, sole=False):
+    """sole=True: the caller guarantees that the returned tensor feeds exactly ONE consumer (the next conv of a chain);
+    with a LeakyReLU epilogue that consumer's dgrad may then fold this activation's backward into its own epilogue."""
     _LAST_CONV_AMAX[0] = None
     out = ConvFn.apply(x, weight, bias, owner, stride, pad, pad_mode, act, slope, skip)
     if _LAST_CONV_AMAX[0] is not None and not skip:
         tag_amax(out, _LAST_CONV_AMAX[0])
         _LAST_CONV_AMAX[0] = None
+    if sole and act == 1 and not skip and x.dim() == 5:
+        out._df_act_sole = (act, float(slope), out._version, out.data_ptr())
     return out
 
 

@@ -79,8 +79,9 @@ class ConvBlock(nn.Module):
         self.main = (Conv2d, Conv3d)[ndims - 2](in_channels, out_channels, 3, stride, 1)
         self.activation = nn.LeakyReLU(0.2)  # parameter-free marker; fused into the conv epilogue
 
-    def forward(self, x):
-        return self.main(x, act=1, slope=0.2)
+    def forward(self, x, sole=False):
+        # sole=True: the result feeds exactly one consumer (the next conv): see ops.conv
+        return self.main(x, act=1, slope=0.2, sole=sole)
 
 
 def unet_channel_plan(enc_nf, dec_nf, in_channels=2):
@@ -132,7 +133,7 @@ class Unet(nn.Module):
             x = layer(x)
             x = ops.upcat(x, x_enc.pop())
         for layer in self.extras:
-            x = layer(x)
+            x = layer(x, sole=True)     # a chain: each output feeds the next ConvBlock (the last one the flow head) only
         return x
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 5
+#define DFMIR_ABI_VERSION 6
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -91,6 +91,14 @@ int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float*
                                float* ws, const float* bias, float* y, float* y_amax, int cout_used, void* stream);
 /* The weight gradient of the same layers in the same split form (8 <= Cin <= 48, 8 <= Cout <= 32, or Cout < 8 with Cin <= 32; W % 4 == 0), voxels as the
  * matrix K: dw_tcc[tap][Cin][Cout] += ...   (accumulates, like dfmir_conv_wgrad). */
+/* As dfmir_conv3d_split_fwd_sub for a dgrad (g->act == 0) whose result is the gradient w.r.t. the OUTPUT of a
+ * LeakyReLU: act_src = that output (shape of y); the epilogue multiplies by the activation's derivative
+ * (act_src > 0 ? 1 : act_slope), so y receives the gradient w.r.t. the pre-activation and y_amax its range probe.
+ * Replaces the `F.leaky_relu` backward pass between two ConvBlocks
+ * (models/voxelmorph/torchvoxelmorph/networks.py:1506-1521, autograd of nn.LeakyReLU(0.2)). */
+int dfmir_conv3d_split_fwd_actgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                   const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
+                                   int cout_used, const float* act_src, float act_slope, void* stream);
 int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
 int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
                              const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);

@@ -240,6 +240,69 @@ def test_conv3d(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
 
 
+def test_conv3d_chain_folds_leaky_relu_backward(ops):
+    """A chain of LeakyReLU ConvBlocks whose outputs feed only the next conv (conv(sole=True)): the consumer's dgrad
+    epilogue applies the activation's derivative (dfmir_conv3d_split_fwd_actgrad), so no act_bwd pass runs between
+    them.  Same gradients as the unfused chain (same arithmetic: one multiply per element) and as torch."""
+    from dfmir_amd import networks as N_
+    torch.manual_seed(0)
+    convs = [N_.Conv3d(8, 16, 3, padding=1), N_.Conv3d(16, 16, 3, padding=1), N_.Conv3d(16, 3, 3, padding=1)]
+    for c in convs:
+        c.to(DEV)
+    x = C.randn(91, 1, 8, 6, 10, 16).to(DEV)
+    cot = C.randn(92, 1, 3, 6, 10, 16).to(DEV)
+
+    def run(sole):
+        for c in convs:
+            c.weight.grad = None
+            c.bias.grad = None
+        xg = x.clone().requires_grad_()
+        h = convs[0](xg, act=1, slope=0.2, sole=sole)
+        h = convs[1](h, act=1, slope=0.2, sole=sole)
+        y = convs[2](h)
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        return [y.detach(), xg.grad] + [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs]
+
+    L, cnt = ops.lib(), [0]
+    o1, o2 = L.dfmir_act_bwd_amax, L.dfmir_act_bwd
+
+    def counted(f):
+        def g(*a):
+            cnt[0] += 1
+            return f(*a)
+        return g
+
+    L.dfmir_act_bwd_amax, L.dfmir_act_bwd = counted(o1), counted(o2)
+    try:
+        fused = run(True)
+        n_fused, cnt[0] = cnt[0], 0
+        plain = run(False)
+        n_plain = cnt[0]
+    finally:
+        L.dfmir_act_bwd_amax, L.dfmir_act_bwd = o1, o2
+    assert (n_fused, n_plain) == (0, 2), (n_fused, n_plain)      # no standalone LeakyReLU backward pass in the fused chain
+    for a, b in zip(fused, plain):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+    # torch reference
+    xr = x.cpu().double().requires_grad_()
+    ws = [c.weight.detach().cpu().double().requires_grad_() for c in convs]
+    bs = [c.bias.detach().cpu().double().requires_grad_() for c in convs]
+    h = F.leaky_relu(F.conv3d(xr, ws[0], bs[0], padding=1), 0.2)
+    h = F.leaky_relu(F.conv3d(h, ws[1], bs[1], padding=1), 0.2)
+    yr = F.conv3d(h, ws[2], bs[2], padding=1)
+    (yr * cot.cpu().double()).sum().backward()
+    close(fused[0], yr.detach().float(), what="y")
+    close(fused[1], xr.grad.float(), what="dx")
+    for i in range(3):
+        close(fused[2 + i], ws[i].grad.float(), rtol=3e-4, what="dw%d" % i)
+        close(fused[5 + i], bs[i].grad.float(), rtol=3e-4, what="db%d" % i)
+    # the fused run really skipped the standalone passes: the tag protocol marks the gradient tensors
+    xg = x.clone().requires_grad_()
+    h0 = convs[0](xg, act=1, slope=0.2, sole=True)
+    assert getattr(h0, "_df_act_sole", None) is not None
+
+
 # --------------------------------------------------------------------------------- norm / resample
 @pytest.mark.parametrize("shape,relu,res", [((2, 5, 16, 16), True, False), ((2, 7, 9, 11), False, True),
                                             ((1, 3, 64, 64), True, True), ((3, 4, 5, 5), False, False),
