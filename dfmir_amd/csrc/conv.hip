@@ -706,10 +706,22 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
       if (g->Di > 1 || g->KD > 1) { k.ncz = 2; k.Dm = (g->Do + 1) / 2; }
       Ps = (long long)k.ncx * k.ncy * k.ncz * k.g.N * k.Dm * k.Hm * k.Wm;
     }
+    // few output voxels (the deep U-Net levels: 8^2 .. 32^2 x 16 images, 10x12x14 voxels): 256-pixel tiles leave most
+    // CUs idle while each workgroup walks the whole K loop; 64 x 64 tiles give 4x the workgroups at a quarter of the work
+    static const bool small_off = getenv("DFMIR_NO_SMALL_TILES") != nullptr;
+    const bool small_p = !small_off && (Ps + 255) / 256 < 192 && g->Cout > 8;
     if (dil2) {
-      dim3 grid((unsigned)((Ps + 255) / 256), 1);
-      if (g->Cout > 32) conv_mfma_k<1, 4, 2, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
-      else conv_mfma_k<1, 4, 1, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      if (small_p) {
+        dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));
+        conv_mfma_k<2, 2, 1, 1, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      } else {
+        dim3 grid((unsigned)((Ps + 255) / 256), 1);
+        if (g->Cout > 32) conv_mfma_k<1, 4, 2, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+        else conv_mfma_k<1, 4, 1, 2, true><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
+      }
+    } else if (small_p && g->Cout <= 64) {
+      dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));
+      conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
     } else if (g->Cout > 64) {
       const long long big = ((Ps + 127) / 128) * ((g->Cout + 127) / 128);
       if (big < 256) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
