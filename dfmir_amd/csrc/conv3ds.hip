@@ -763,7 +763,13 @@ struct W3T {
   static constexpr int YU = TZ * TY * TX * 4;            // 1024 units per split
 };
 
-template <int NCH>
+// PAIR form (<= 16 output channels: half of the 32 MFMA columns would be padding): the columns are (plane p, co) --
+// columns 0-15 take dY of the tile's z-plane 0, columns 16-31 the SAME voxel (y, x) of plane 1 -- and K runs over
+// plane 0 only (8 k-steps).  Rows then are (tap', ci) with tap' = (dz' in 0..3, dy, dx) over the patch's four planes:
+// row (dz', .) x column (p, .) is a term of dW[dz' - p] (dropped where dz' - p is outside 0..2): 9 row tiles x 8
+// k-steps instead of 7 x 16.  A wave owns tiles w and w + 4 and k-steps 2w, 2w + 1 of tile 8 (the partial sums meet
+// in the atomics of the epilogue): 18 tile-steps per wave and phase instead of 32.
+template <int NCH, bool PAIR>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restrict__ x, const float* __restrict__ x_amax,
                                                          const float* __restrict__ dy, const float* __restrict__ dy_amax,
                                                          float* __restrict__ dwt, W3sP k) {
@@ -784,11 +790,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   const int ed = scale_exp3(reduce_absmax(dy_amax, k.dy_n, red));
   const float xscale = pow2f3(ex), dscale = pow2f3(ed), oscale = pow2f3(-ex), oscale2 = pow2f3(-ed);
 
-  f32x16 acc[NCH][2];
+  constexpr int NA = PAIR ? 3 : 2;                         // accumulators (row tiles) per chunk and wave
+  constexpr int NKS = PAIR ? 8 : 16;                       // k-steps per phase
+  f32x16 acc[NCH][NA];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NA; ++s)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][s][r] = 0.f;
 
@@ -818,7 +826,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   const int xe0 = xqq == 0 ? 3 : 0, xe1 = xqq == 5 ? 1 : 4;
   const int yq = tid & 3, yrow = (tid >> 2) & 15;
   const bool yt = wid * 8 < k.Cout;
-  const int yunit0 = (yrow * 16 + 4 * yq) * 4 + (wid ^ yq);   // unit of element e: yunit0 + 4 e
+  // unit of element e: yunit0 + 4 e  (PAIR: plane 1 takes the other 32-B half of the voxel's 64 B, so that the columns
+  // of both planes, read together, fall on different banks)
+  const int yunit0 = (yrow * 16 + 4 * yq) * 4 + (wid ^ yq ^ (PAIR ? (yrow >> 3) * 2 : 0));
   const bool db_y = k.db && !k.db_from_x && blockIdx.y == 0 && yt;
   const bool db_x = k.db && k.db_from_x && xt && xhz >= 1 && xhz <= TZ && xhy >= 1 && xhy <= TY && xqq >= 1 && xqq <= 4;
   float bacc[8];
@@ -830,10 +840,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   const unsigned xs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Xs;
   const unsigned ys_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Ys;
   // B (dY): voxel = s * 16 + 8 hi + 4 i + j, channel quad = 4 sg + sq -> unit (2 sg + (sq >> 1)) ^ ((2 hi + i) & 3)
+  // PAIR: column group sg = plane, voxel + 128 sg, channel quad sq -> unit (sq >> 1) ^ ((2 hi + i) & 3) ^ 2 sg
   unsigned baddr[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
-    baddr[i] = ys_base + (unsigned)(((8 * hi + 4 * i + sj) * 4 + ((2 * sg + (sq >> 1)) ^ ((2 * hi + i) & 3))) * 16 + (sq & 1) * 8);
+    baddr[i] = PAIR ? ys_base + (unsigned)(((128 * sg + 8 * hi + 4 * i + sj) * 4 + ((sq >> 1) ^ ((2 * hi + i) & 3) ^ (2 * sg))) * 16 + (sq & 1) * 8)
+                    : ys_base + (unsigned)(((8 * hi + 4 * i + sj) * 4 + ((2 * sg + (sq >> 1)) ^ ((2 * hi + i) & 3))) * 16 + (sq & 1) * 8);
 
   u32x4 rq[8], ry[8];
   int tn, tz, ty, tx;                                      // tile being LOADED (runs one phase ahead of the compute)
@@ -930,11 +942,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
   {                                                                                               \
     W3T_READ_B(B0, 0, 0, 0u) W3T_READ_B(B1, 0, 0, YU * 16u) W3T_READ_A(0, 0)                      \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                              \
+    _Pragma("unroll") for (int s = 0; s < NKS; ++s) {                                             \
       const int cur = s & 1;                                                                      \
       if (!(W3T_KO & 8)) {                                                                        \
         W3T_READ_A(1, s)                                                                          \
-        if (s + 1 < 16) W3T_READ_B(B0, cur ^ 1, s + 1, 0u)                                        \
+        if (s + 1 < NKS) W3T_READ_B(B0, cur ^ 1, s + 1, 0u)                                       \
       }                                                                                           \
       if (!(W3T_KO & 2)) {                                                                        \
         if (s < 8) { W3T_GLOAD_X1(ca_next, s); }                                                  \
@@ -947,15 +959,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                          \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      if (s + 1 < 16 && !(W3T_KO & 8)) {                                                          \
+      if (s + 1 < NKS && !(W3T_KO & 8)) {                                                         \
         W3T_READ_A(0, s + 1)                                                                      \
         W3T_READ_B(B1, cur ^ 1, s + 1, YU * 16u)                                                  \
       }                                                                                           \
+      if (PAIR && (LAST_) && !(W3T_KO & 2)) { W3T_GLOAD_Y1(s); }   /* 8 k-steps: dY rides in the second half-steps */ \
       W3T_MMA(c_, 1)                                                                              \
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      if (PAIR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                \
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    if constexpr (PAIR) {                                                                         \
+      /* tile 8, k-steps 2 wid and 2 wid + 1 (wave-uniform offsets: one add per address) */        \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
+        const unsigned ko = (unsigned)((2 * wid + u) * HXP * 16), kb = (unsigned)(2 * wid + u) * 1024u; \
+        TR_PAIR(A1[u], aaddr[2] + ko + XPOS * 16u)                                                \
+        TR_PAIR(A0[u], aaddr[2] + ko)                                                             \
+        { const uint2 u0_ = tr_read8(baddr[0] + kb), u1_ = tr_read8(baddr[1] + kb);               \
+          B0[u] = u32x4{u0_.x, u0_.y, u1_.x, u1_.y}; }                                            \
+        { const uint2 v0_ = tr_read8(baddr[0] + kb + YU * 16u), v1_ = tr_read8(baddr[1] + kb + YU * 16u); \
+          B1[u] = u32x4{v0_.x, v0_.y, v1_.x, v1_.y}; }                                            \
+      }                                                                                           \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                             \
+        acc[c_][NA - 1] = mma3(A1[u], B0[u], acc[c_][NA - 1]);                                    \
+        acc[c_][NA - 1] = mma3(A0[u], B1[u], acc[c_][NA - 1]);                                    \
+        acc[c_][NA - 1] = mma3(A0[u], B0[u], acc[c_][NA - 1]);                                    \
+      }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
   }
@@ -969,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
 #endif
 
   u32x4 A0[2], A1[2], B0[2], B1[2];
-  unsigned aaddr[2];
+  unsigned aaddr[NA];
 
   // prologue: first tile's dY and chunk 0
   W3T_TILE_ADDR();
@@ -991,10 +1023,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
       const int ca_next = last ? c_base : c_base + c + 1;
       // this wave's two row tiles of chunk c: lane (j, q, g) of tile T supplies tap 4T + 2g + (q >> 1), channel quad q & 1
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int tile = ((wid + c) & 3) + 4 * t;
-        int tap = tile * 4 + 2 * sg + (sq >> 1);
-        if (tap > 26) tap = 26;                            // padding rows: any valid address (results discarded)
+      for (int t = 0; t < NA; ++t) {
+        const int tile = PAIR ? (t < 2 ? wid + 4 * t : 8) : ((wid + c) & 3) + 4 * t;
+        int tap = tile * 4 + 2 * sg + (sq >> 1);           // PAIR: tap' of 36 (dz' = tap' / 9 in 0..3)
+        if (!PAIR && tap > 26) tap = 26;                   // padding rows: any valid address (results discarded)
         const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
         aaddr[t] = xs_base + (unsigned)((dz * SZP + dyy * HXP + dx + 8 * hi + sj) * 16 + (sq & 1) * 8);
       }
@@ -1025,15 +1057,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int tile = ((wid + c) & 3) + 4 * s;
-      if (c >= nc || tile >= 7 || l31 >= k.Cout) continue;
+    for (int s = 0; s < NA; ++s) {
+      const int tile = PAIR ? (s < 2 ? wid + 4 * s : 8) : ((wid + c) & 3) + 4 * s;
+      const int co = PAIR ? (l31 & 15) : l31, pl = PAIR ? (l31 >> 4) : 0;
+      if (c >= nc || (!PAIR && tile >= 7) || co >= k.Cout) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rho = tile * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-        const int tap = rho >> 3, ci = (c_base + c) * 8 + (rho & 7);
+        int tap = rho >> 3;
+        const int ci = (c_base + c) * 8 + (rho & 7);
+        bool ok = ci < k.Cin;
+        if constexpr (PAIR) {
+          const int dz = tap / 9 - pl;                     // row plane dz' against column plane p
+          ok = ok && (unsigned)dz < 3u;
+          tap = dz * 9 + tap % 9;
+        } else {
+          ok = ok && rho < 216;
+        }
         const int to = k.flip ? 26 - tap : tap;
-        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + l31 * k.s_col], acc[c][s][r] * sc);
+        if (ok) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + co * k.s_col], acc[c][s][r] * sc);
       }
     }
   if (k.db) {                                              // wave-uniform: every lane of a wave holds the same 8 channels
@@ -1107,7 +1149,9 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   // <= 3 chunks of accumulators per workgroup (96 AGPRs + staging registers: two workgroups per CU, so that one
   // converts while the other computes); more input channels = a second workgroup row, which stages dY again
   k.nchunk = (k.Cin + 7) / 8;
-  const int per_wg = k.nchunk <= 3 ? k.nchunk : (k.nchunk == 4 ? 2 : 3);
+  static const bool pair_off = getenv("DFMIR_CONV3D_WGRAD_NO_PAIR") != nullptr;
+  const bool pairw = !tr_off && !pair_off && !swapped && k.Cout <= 16;   // (swapped flow head: measured slower, 0.44 vs 0.31 ms)         // (kernel roles) plane-pair columns: 3 accumulators per chunk
+  const int per_wg = pairw ? (k.nchunk < 2 ? k.nchunk : 2) : (k.nchunk <= 3 ? k.nchunk : (k.nchunk == 4 ? 2 : 3));
   const unsigned gy = (unsigned)((k.nchunk + per_wg - 1) / per_wg);
   if (gy > 1) {                                             // keep the number of workgroups
     want = 512 / gy;
@@ -1129,9 +1173,11 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
 #define W3S_LAUNCH(N_)                                                                            \
   {                                                                                               \
     if (tr_off) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
-    else conv3d_wgrad_tr_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);      \
+    else conv3d_wgrad_tr_k<N_, false><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
   }
-  if (per_wg == 1) W3S_LAUNCH(1)
+  if (pairw && per_wg == 1) conv3d_wgrad_tr_k<1, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  else if (pairw) conv3d_wgrad_tr_k<2, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  else if (per_wg == 1) W3S_LAUNCH(1)
   else if (per_wg == 2) W3S_LAUNCH(2)
   else W3S_LAUNCH(3)
 #undef W3S_LAUNCH
