@@ -187,7 +187,7 @@ def bench_3d(dev, steps=5, warmup=2):
                                  "products per MAC); algorithmic FLOPs = 2*N*Cout*D*H*W*Cin*27 of the timed launches",
                 "algorithmic_tflops": sp_tf, "products_per_mac": 3.0,
                 "kernel": "conv3d_split_k (v_mfma_f32_32x32x16_f16, 4x8x16-voxel x 32-cout tiles, LDS halo patch split into "
-                          "fp16 pairs per 8-channel chunk): forward + dgrad of every stride-1 3x3x3 conv with >= 8 channels",
+                          "fp16 pairs per 8-channel chunk): forward + dgrad of every stride-1 3x3x3 conv",
                 "launches_timed": sp_n, "avg_launch_ms": sp_ms / max(sp_n, 1)}
     else:
         roof = {"bound": "mfma", "achieved": fw_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -195,8 +195,9 @@ def bench_3d(dev, steps=5, warmup=2):
                 "kernel": "conv3d_mfma16_k (v_mfma_f32_16x16x4_f32): forward + dgrad of every stride-1 3x3x3 conv",
                 "launches_timed": fw_n, "avg_launch_ms": fw_ms / max(fw_n, 1)}
     if wgs_n:
-        roof.update({"wgrad_kernel": "conv3d_wgrad_split_k (voxels as the matrix K, three x-aligned fp16-pair copies of the "
-                                     "input patch in LDS, accumulators of all (tap, ci) x co resident)",
+        roof.update({"wgrad_kernel": "conv3d_wgrad_tr_k (voxels as the matrix K; operands read with ds_read_b64_tr_b16 from "
+                                     "channel-major fp16-pair LDS images of the patch and of dY; plane-pair columns for "
+                                     "<= 16 output channels)",
                      "wgrad_achieved": 3.0 * wgs_tf, "wgrad_frac": 3.0 * wgs_tf / FP16_MFMA_PEAK_TFLOPS,
                      "wgrad_algorithmic_tflops": wgs_tf, "wgrad_launches_timed": wgs_n})
     else:
