@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
       }
+#ifdef C3S_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     C3S_T(3)
     if ((ch + 1) < k.nchunk) {

@@ -898,11 +898,26 @@ def _valid_amax(t):
     return None
 
 
+def _probe64(t):
+    """A PROBE_SLOTS-wide range probe of t by a standalone pass (slot 0 = max |t|, the rest stay 0); tags t."""
+    slot = amax_slot(t.device, PROBE_SLOTS)
+    tc = _c(t)
+    check(lib().dfmir_absmax(_p(tc), tc.numel(), _p(slot), _st()))
+    if tc.data_ptr() == t.data_ptr():
+        tag_amax(t, slot)
+    return slot
+
+
 def upcat(a, b):
     y = UpCatFn.apply(a, b)
     if torch.is_grad_enabled() and a.requires_grad and not b.requires_grad:
         y._df_nograd_tail = int(b.shape[1])    # the consumer conv's dgrad skips these channels (ConvFn)
     pa, pb = _valid_amax(a), _valid_amax(b)
+    if a.dim() == 5 and not _NO_SPLIT3D:
+        # 3-D: the consumer is a split conv that needs the range of y.  A part without a probe (skip tensors made by the
+        # stride-2 convs, the 2-channel input) is measured on its own: 1/17 .. 1/3 of a pass over the concatenation
+        pa = _probe64(a) if pa is None else pa
+        pb = _probe64(b) if pb is None else pb
     if pa is not None and pb is not None:      # nearest up-sampling + concatenation create no new values
         slot = amax_slot(y.device, PROBE_SLOTS)
         check(lib().dfmir_probe_merge(_p(pa), _p(pb), _p(slot), _st()))
