@@ -25,6 +25,7 @@ typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 template <int ND> struct WinGeom;
 template <> struct WinGeom<3> { static constexpr int TZ = 8, TY = 8, EZ = 12, EY = 12; };
 template <> struct WinGeom<2> { static constexpr int TZ = 1, TY = 64, EZ = 1, EY = 68; };
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 static constexpr int WTX = 32;        // tile width (8 lanes x 4 voxels)
 static constexpr int WEX = 40;        // window width
 static constexpr int WRS = 41;        // LDS row stride (== 9 mod 32: see the bank note above)
@@ -618,17 +619,34 @@ __global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict
   }
   __syncthreads();
   if (!active) return;
+  // Branch-free: a window that does not cover the quad gets an out-of-range buffer offset (reads 0.0 without touching
+  // memory), so the loads of 9 neighbours are in flight together instead of one conditional load after the other
+  // (the sum keeps its fixed neighbour order: bit-reproducible as before).
+  constexpr unsigned OOBG = 0x80000000u;
+  unsigned off[NN];
+#pragma unroll
+  for (int i = 0; i < NN; ++i) {
+    const int lz = z - org[i][0], ly = y - org[i][1], lx = x - org[i][2];     // ox is a multiple of 4: whole quad or none
+    const bool cov = org[i][3] >= 0 && (unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY &&
+                     (unsigned)lx <= (unsigned)(WEX - 4);
+    off[i] = cov ? (unsigned)(((lz * G::EY + ly) * WEX + lx) * 4) : OOBG;
+  }
   for (int c = 0; c < C; ++c) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NN; ++i) {
-      const int tl = org[i][3];
-      const int lz = z - org[i][0], ly = y - org[i][1], lx = x - org[i][2];   // ox is a multiple of 4: whole quad or none
-      if (tl >= 0 && (unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY && (unsigned)lx <= (unsigned)(WEX - 4)) {
-        const float4 v = *reinterpret_cast<const float4*>(scratch + ((long long)tl * C + c) * WinOwn<ND>::CELLS +
-                                                          (lz * G::EY + ly) * WEX + lx);
-        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+    for (int g0 = 0; g0 < NN; g0 += 9) {
+      float4 v[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int tl = org[g0 + i][3] < 0 ? 0 : org[g0 + i][3];
+        const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(scratch + ((long long)tl * C + c) * WinOwn<ND>::CELLS), 0,
+            (unsigned)(WinOwn<ND>::CELLS * 4), 0x00020000);
+        const u32x4w q = __builtin_amdgcn_raw_buffer_load_b128(wsrc, off[g0 + i], 0, 0);
+        v[i] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
       }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { acc[0] += v[i].x; acc[1] += v[i].y; acc[2] += v[i].z; acc[3] += v[i].w; }
     }
     *reinterpret_cast<float4*>(dsrc + ((long long)b * C + c) * S + sp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }

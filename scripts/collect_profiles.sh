@@ -9,6 +9,9 @@ python scripts/bench_conv.py 32 > $O/bench_conv.txt 2>&1
 python scripts/bench_conv3d.py > $O/bench_conv3d.txt 2>&1
 DFMIR_CONV3D_FP32=1 python scripts/bench_conv3d.py > $O/bench_conv3d_fp32.txt 2>&1
 python scripts/bench_warp_roofline.py > $O/bench_warp_roofline.json 2>&1
+python scripts/bench_wgrad3d.py > $O/bench_wgrad3d.txt 2>&1
+DFMIR_CONV3D_WGRAD_COPIES=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
+DFMIR_CONV3D_WGRAD_NO_PAIR=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
 python scripts/launch_census.py capture_step=False > $O/launch_census.txt 2>&1
 for u in mfma_peak lds_unaligned valu_under_mfma; do   # built from source on the box (binaries are not tracked)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u scripts/ubench/$u.hip && /tmp/$u > $O/ubench_$u.txt 2>&1
@@ -26,4 +29,7 @@ cd $R
 bash scripts/prof_conv.sh fwd 256 256 64 32 > $O/pmc_conv_fwd.txt 2>&1
 bash scripts/prof_conv.sh wgrad 256 256 64 32 > $O/pmc_conv_wgrad.txt 2>&1
 CELL=32 AMP=1.0 bash scripts/prof_warp.sh > $O/pmc_warp.txt 2>&1
-rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof
+ONLY=34-32 bash scripts/prof_conv3d.sh > $O/pmc_conv3d_34_32.txt 2>&1
+ONLY=32-16 bash scripts/prof_conv3d.sh > $O/pmc_conv3d_32_16.txt 2>&1
+bash scripts/prof_3d_step.sh 60 > $O/step_trace_3d.txt 2>&1
+rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d
