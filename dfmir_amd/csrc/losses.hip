@@ -51,20 +51,30 @@ __global__ __launch_bounds__(256) void masked_l1_bwd_k(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------ flow smoothness
+// One workgroup = RB consecutive rows (a row = W values at fixed plane, z, y): the row's coordinates are decoded once per
+// row with wave-uniform arithmetic, lanes run along x -- no per-element divisions (they used to cost more than the
+// memory traffic), every load a contiguous run.  <= 2048 workgroups: each ends in three same-address atomics.
 __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict__ f, float* __restrict__ ws,
-                                                         long long planes, int D, int H, int W) {
+                                                         long long planes, int D, int H, int W, int RB) {
   __shared__ float sm[17];
-  const long long S = (long long)D * H * W, total = planes * S;
+  const long long rows = planes * D * H, HW = (long long)H * W;
   float sd = 0.f, sh = 0.f, sw = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int x = (int)(i % W);
-    long long r = i / W;
-    const int y = (int)(r % H); r /= H;
-    const int z = (int)(r % D);
-    const float v = f[i];
-    if (x + 1 < W) { const float d = f[i + 1] - v; sw += d * d; }
-    if (y + 1 < H) { const float d = f[i + W] - v; sh += d * d; }
-    if (z + 1 < D) { const float d = f[i + (long long)H * W] - v; sd += d * d; }
+  const long long row0 = (long long)blockIdx.x * RB;
+  int y = (int)(row0 % H), z = (int)((row0 / H) % D);      // advanced incrementally: one division per workgroup
+  for (int x = threadIdx.x; x < W; x += 256) {
+    int yy = y, zz = z;
+#pragma unroll 4
+    for (int rr = 0; rr < RB; ++rr) {                       // (independent iterations: 4 rows of loads in flight)
+      const long long row = row0 + rr;
+      if (row < rows) {
+        const float* p = f + row * W;
+        const float v = p[x];
+        if (x + 1 < W) { const float d = p[x + 1] - v; sw += d * d; }
+        if (yy + 1 < H) { const float d = p[x + W] - v; sh += d * d; }
+        if (zz + 1 < D) { const float d = p[x + HW] - v; sd += d * d; }
+      }
+      if (++yy == H) { yy = 0; if (++zz == D) zz = 0; }
+    }
   }
   sd = block_sum(sd, sm);
   sh = block_sum(sh, sm);
@@ -82,18 +92,19 @@ __global__ void flow_smooth_fin_k(const float* ws, float* out, float cd, float c
   if (cw > 0.f) s += ws[2] / cw;
   out[0] = s / nd;
 }
+template <typename IDX>
 __global__ __launch_bounds__(256) void flow_smooth_bwd_k(const float* __restrict__ f,
                                                          const float* __restrict__ gout,
                                                          float* __restrict__ df, long long planes, int D,
                                                          int H, int W, float kd, float kh, float kw) {
-  const long long S = (long long)D * H * W, total = planes * S;
+  const IDX S = (IDX)D * H * W, total = (IDX)planes * S;
   const float g = gout[0];
-  const long long HW = (long long)H * W;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int x = (int)(i % W);
-    long long r = i / W;
-    const int y = (int)(r % H); r /= H;
-    const int z = (int)(r % D);
+  const IDX HW = (IDX)H * W;
+  for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+    const int x = (int)(i % (IDX)W);
+    IDX r = i / (IDX)W;
+    const int y = (int)(r % (IDX)H); r /= (IDX)H;
+    const int z = (int)(r % (IDX)D);
     const float v = f[i];
     float acc = 0.f;
     if (W > 1) {
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void ncc_prod_boxw_k(const float* __restrict__
                                                        float* __restrict__ o, long long N, int W, int r) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const int x = (int)(i % W);
+  const int x = N < 0x7FFFFFFFLL ? (int)((unsigned)i % (unsigned)W) : (int)(i % W);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
   for (int d = -r; d <= r; ++d) {
     const int xx = x + d;
@@ -140,7 +151,8 @@ __global__ __launch_bounds__(256) void box_axis_k(const float* __restrict__ in, 
                                                   int nf, long long N, long long stride, int len, int r) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const int c = (int)((i / stride) % len);
+  const int c = (N < 0x7FFFFFFFLL && stride < 0x7FFFFFFFLL) ? (int)(((unsigned)i / (unsigned)stride) % (unsigned)len)
+                                                             : (int)((i / stride) % len);
   for (int f = 0; f < nf; ++f) {
     const float* p = in + f * N + i;
     float s = 0.f;
@@ -309,7 +321,9 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
   hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   const long long planes = (long long)B * C;
-  flow_smooth_fwd_k<<<df_grid(planes * D * H * W, 256, 1024), 256, 0, st>>>(flow, ws, planes, D, H, W);
+  const long long nrow = planes * D * H;
+  const int rb = (int)((nrow + 2047) / 2048);
+  flow_smooth_fwd_k<<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
   DF_LAUNCH_CHECK();
   const float cd = (float)((double)planes * (D - 1) * H * W), ch = (float)((double)planes * D * (H - 1) * W),
               cw = (float)((double)planes * D * H * (W - 1));
@@ -327,8 +341,12 @@ extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float
   const double nd = (D > 1) ? 3.0 : 2.0;
   const float kd = cd > 0 ? (float)(2.0 / (cd * nd)) : 0.f, kh = ch > 0 ? (float)(2.0 / (ch * nd)) : 0.f,
               kw = cw > 0 ? (float)(2.0 / (cw * nd)) : 0.f;
-  flow_smooth_bwd_k<<<df_grid(planes * D * H * W, 256, 4096), 256, 0, (hipStream_t)stream>>>(
-      flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  if (planes * D * H * W < 0x7FFFFFFFLL)
+    flow_smooth_bwd_k<unsigned><<<df_grid(planes * D * H * W, 256, 1 << 16), 256, 0, (hipStream_t)stream>>>(
+        flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  else
+    flow_smooth_bwd_k<long long><<<df_grid(planes * D * H * W, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+        flow, gout, dflow, planes, D, H, W, kd, kh, kw);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -250,11 +250,21 @@ __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x,
   const long long total = (long long)planes * So;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int ox = (int)(i % Wo);
-  long long r = i / Wo;
-  const int oy = (int)(r % Ho); r /= Ho;
-  const int oz = (int)(r % Do);
-  const long long pl = r / Do;
+  int ox, oy, oz;
+  long long pl;
+  if (total < 0x7FFFFFFFLL) {        // 32-bit coordinate decode (the 64-bit divisions cost more than the 8 taps)
+    unsigned r = (unsigned)i;
+    ox = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
+    oy = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+    oz = (int)(r % (unsigned)Do);
+    pl = r / (unsigned)Do;
+  } else {
+    long long r = i;
+    ox = (int)(r % Wo); r /= Wo;
+    oy = (int)(r % Ho); r /= Ho;
+    oz = (int)(r % Do);
+    pl = r / Do;
+  }
   int z0, z1, y0, y1, x0, x1;
   float lz, ly, lx;
   lin_src(oz, sd, Di, z0, z1, lz);
@@ -293,11 +303,21 @@ __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy
   const long long total = (long long)planes * Si;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int ix = (int)(i % Wi);
-  long long r = i / Wi;
-  const int iy = (int)(r % Hi); r /= Hi;
-  const int iz = (int)(r % Di);
-  const long long pl = r / Di;
+  int ix, iy, iz;
+  long long pl;
+  if (total < 0x7FFFFFFFLL) {
+    unsigned r = (unsigned)i;
+    ix = (int)(r % (unsigned)Wi); r /= (unsigned)Wi;
+    iy = (int)(r % (unsigned)Hi); r /= (unsigned)Hi;
+    iz = (int)(r % (unsigned)Di);
+    pl = r / (unsigned)Di;
+  } else {
+    long long r = i;
+    ix = (int)(r % Wi); r /= Wi;
+    iy = (int)(r % Hi); r /= Hi;
+    iz = (int)(r % Di);
+    pl = r / Di;
+  }
   const float* gp = dy + pl * So;
   int zl, zh, yl, yh, xl, xh;
   lin_range(iz, sd, Do, zl, zh);

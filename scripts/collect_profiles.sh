@@ -29,7 +29,7 @@ cd $R
 bash scripts/prof_conv.sh fwd 256 256 64 32 > $O/pmc_conv_fwd.txt 2>&1
 bash scripts/prof_conv.sh wgrad 256 256 64 32 > $O/pmc_conv_wgrad.txt 2>&1
 CELL=32 AMP=1.0 bash scripts/prof_warp.sh > $O/pmc_warp.txt 2>&1
-ONLY=34-32 bash scripts/prof_conv3d.sh > $O/pmc_conv3d_34_32.txt 2>&1
-ONLY=32-16 bash scripts/prof_conv3d.sh > $O/pmc_conv3d_32_16.txt 2>&1
+bash scripts/prof_conv3d.sh 34-32 > $O/pmc_conv3d_34_32.txt 2>&1
+bash scripts/prof_conv3d.sh 32-16 > $O/pmc_conv3d_32_16.txt 2>&1
 bash scripts/prof_3d_step.sh 60 > $O/step_trace_3d.txt 2>&1
 rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d
