@@ -130,8 +130,11 @@ struct C3sP {
   float act_slope;
 };
 
-template <bool PAIR, bool VEC>
-__global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+// TT > 1 (multi-tile form): a workgroup computes TT tiles stacked along y with ONE staging of each chunk's weights -- the
+// pre-split weights (29 / 37 KB per chunk) were re-read from L2 for every tile, as much as the patch itself, and in the
+// plane-pair form (108 MFMAs per chunk instead of 168) that put the texture path at ~70 % and the matrix pipe at 40 %.
+template <bool PAIR, bool VEC, int TT>
+__global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict__ x, const float* __restrict__ x_amax,
                                                       const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       float* __restrict__ y_amax, C3sP k) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   const int bz = (int)(pid % k.nz); pid /= k.nz;
   const int by = (int)(pid % k.ny);
   const int n = (int)(pid / k.ny);
-  const int z0 = bz * TZ, y0 = by * TY, x0 = bx * TX;
+  const int z0 = bz * TZ, y0 = by * TY * TT, x0 = bx * TX;      // (k.ny counts groups of TT tiles)
   const int mt = blockIdx.y;
 
   // scales: input scaled by 2^ex when it is split, result rescaled by 2^-ex * 2^-ew
@@ -183,37 +186,43 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   unsigned gbyte[NS];
   unsigned gq = OOB, gh = OOB;
   int posq = -1, posh = -1;
-  if constexpr (VEC) {
-    if (tid < 240) {
-      const int row = tid >> 2, q = tid & 3;
-      const int hz = row / HY, hy = row % HY;
-      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 + 4 * q;
-      posq = row * HX + 1 + 4 * q;
-      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && gx < k.W)
-        gq = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
-    }
-    if (tid < 120) {
-      const int row = tid >> 1, side = tid & 1;
-      const int hz = row / HY, hy = row % HY;
-      const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = side ? x0 + TX : x0 - 1;
-      posh = row * HX + (side ? HX - 1 : 0);
-      if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
-        gh = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int pos = tid + 256 * s;
-      unsigned off = OOB;
-      if (pos < XP) {
-        const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
-          off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
-      }
-      gbyte[s] = off;
-    }
+  // global offsets of this thread's patch loads for tile t_ of the group (rows y0 + t_ * TY ..)
+#define C3S_OFFS(t_)                                                                              \
+  {                                                                                               \
+    const int yt0_ = y0 + (t_) * TY;                                                              \
+    if constexpr (VEC) {                                                                          \
+      gq = OOB; gh = OOB;                                                                         \
+      if (tid < 240) {                                                                            \
+        const int row = tid >> 2, q = tid & 3;                                                    \
+        const int hz = row / HY, hy = row % HY;                                                   \
+        const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = x0 + 4 * q;                          \
+        posq = row * HX + 1 + 4 * q;                                                              \
+        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && gx < k.W)             \
+          gq = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                       \
+      }                                                                                           \
+      if (tid < 120) {                                                                            \
+        const int row = tid >> 1, side = tid & 1;                                                 \
+        const int hz = row / HY, hy = row % HY;                                                   \
+        const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = side ? x0 + TX : x0 - 1;             \
+        posh = row * HX + (side ? HX - 1 : 0);                                                    \
+        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+          gh = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                       \
+      }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                            \
+        const int pos = tid + 256 * s;                                                            \
+        unsigned off = OOB;                                                                       \
+        if (pos < XP) {                                                                           \
+          const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;                        \
+          const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = x0 - 1 + hx;                       \
+          if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+            off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                    \
+        }                                                                                         \
+        gbyte[s] = off;                                                                           \
+      }                                                                                           \
+    }                                                                                             \
   }
+  C3S_OFFS(0)
   const u32x4* wchunk = wsp + (long long)mt * k.nchunk * WU;
 
   // this lane's B positions: column tile j = rows 2j, 2j+1 of plane wid; voxel (row, x) = (2j + (l31 >> 4), lx) with
@@ -226,11 +235,13 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) pbase[j] = (wz * HY + wy + 2 * j + (l31 >> 4)) * HX + lx;
 
-  f32x16 acc[NJ];
+  f32x16 acc[TT][NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
   float rx[NS][8];                                         // !VEC: [slot][channel];  VEC: rx[0][c] = halo column
   u32x4 rq[8];                                             // VEC: the quad of channel c
@@ -293,8 +304,8 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
         }                                                                                         \
       }                                                                                           \
     }                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < NW; ++j) Ws[tid + 256 * j] = rw[j];                     \
   }
+#define C3S_LSTORE_W() _Pragma("unroll") for (int j = 0; j < NW; ++j) Ws[tid + 256 * j] = rw[j];
   // operands of k-step tp_ (taps 2tp, 2tp+1; tap 27 of the 28-tap form has zero weights, any valid offset) -> set b_
 #define C3S_OPLOAD(b_, tp_)                                                                       \
   {                                                                                               \
@@ -317,11 +328,17 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   C3S_GLOAD_W(0);
   C3S_T(0)
   C3S_LSTORE();
+  C3S_LSTORE_W();
   C3S_T(1)
   __syncthreads();
   C3S_T(2)
 
   for (int ch = 0; ch < k.nchunk; ++ch) {
+#pragma unroll
+   for (int tt = 0; tt < TT; ++tt) {
+    // the phase after this one: the next tile of the group on the same chunk, or tile 0 of the next chunk (+ its weights)
+    const int nch = (tt + 1 < TT) ? ch : ch + 1;
+    if (TT > 1) C3S_OFFS((tt + 1) % TT)
     C3S_OPLOAD(0, 0);
     // one k-step: the next step's 2 + 2 NJ operand reads and one part of the next chunk's global loads are pinned
     // between this step's 3 NJ MFMAs (one MFMA, one LDS read, one buffer load, ...), so the wave never waits on
@@ -330,18 +347,23 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
     for (int tp = 0; tp < NT / 2; ++tp) {
       const int cur = tp & 1;
       if (!(C3S_KO & 2)) {
-        if (tp < NPART) C3S_GLOAD_X(ch + 1, tp);
-        if (tp == NPART) C3S_GLOAD_W(ch + 1);
+#ifdef C3S_EARLY
+        if (2 * tp < NPART) { C3S_GLOAD_X(nch, 2 * tp); if (2 * tp + 1 < NPART) C3S_GLOAD_X(nch, 2 * tp + 1); }
+        if (2 * tp == NPART && tt + 1 == TT) C3S_GLOAD_W(ch + 1);
+#else
+        if (tp < NPART) C3S_GLOAD_X(nch, tp);
+        if (tp == NPART && tt + 1 == TT) C3S_GLOAD_W(ch + 1);
+#endif
       }
       if (tp + 1 < NT / 2) C3S_OPLOAD(cur ^ 1, tp + 1);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #if (C3S_KO & 1)
-        acc[j][0] += __uint_as_float(B0[cur][j][0] ^ B1[cur][j][1] ^ A0[cur][0] ^ A1[cur][1]);
+        acc[tt][j][0] += __uint_as_float(B0[cur][j][0] ^ B1[cur][j][1] ^ A0[cur][0] ^ A1[cur][1]);
 #else
-        acc[j] = mma3(A1[cur], B0[cur][j], acc[j]);
-        acc[j] = mma3(A0[cur], B1[cur][j], acc[j]);
-        acc[j] = mma3(A0[cur], B0[cur][j], acc[j]);
+        acc[tt][j] = mma3(A1[cur], B0[cur][j], acc[tt][j]);
+        acc[tt][j] = mma3(A0[cur], B1[cur][j], acc[tt][j]);
+        acc[tt][j] = mma3(A0[cur], B0[cur][j], acc[tt][j]);
 #endif
       }
 #pragma unroll
@@ -355,19 +377,25 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
 #endif
     }
     C3S_T(3)
-    if ((ch + 1) < k.nchunk) {
+    if ((ch + 1) < k.nchunk || tt + 1 < TT) {
       __syncthreads();
       C3S_T(4)
-      if (!(C3S_KO & 4)) C3S_LSTORE();
+      if (!(C3S_KO & 4)) {
+        C3S_LSTORE();
+        if (tt + 1 == TT) { C3S_LSTORE_W(); }
+      }
       C3S_T(5)
       __syncthreads();
       C3S_T(6)
     }
+   }
   }
 #undef C3S_GLOAD_X
 #undef C3S_GLOAD_W
 #undef C3S_OPLOAD
 #undef C3S_LSTORE
+#undef C3S_LSTORE_W
+#undef C3S_OFFS
 #undef C3S_SPLIT8
 
   // ---- epilogue: acc[j][r] <-> row = (r>>2)*8 + hi*4 + (r&3) = cout - mt*32 (PAIR: plane * 16 + cout),
@@ -387,6 +415,9 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   const unsigned plane4 = (unsigned)(k.H * k.W) * 4u;
   const float osc = oscale * oscale2;
   float pm = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+  const int yt0 = y0 + tt * TY;
   // activation-derivative source values of all column tiles first (the operand registers are dead by now): loads and
   // stores share vmcnt, so a load issued between the stores would wait for every store before it
   float av[NJ][16];
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
         const_cast<float*>(k.act_src + (long long)n * k.Cout * S), 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+      const int gy = yt0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
       const bool vok = gy < k.H && gx < k.W;
       const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
 #pragma unroll
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+    const int gy = yt0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
     const bool vok = gy < k.H && gx < k.W;
     // lane part of the offset: voxel + the hi * 4 channels (PAIR: rows 16.. are plane 1 -> hi never changes the plane)
     const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
@@ -421,7 +452,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
       const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;
       const int pz = PAIR ? (rowu >> 4) : 0;
       const bool ok = vok && (cou + hi * 4) < k.cout_used && (z0 + wz + pz) < k.D;
-      float v = acc[j][r] * osc + bv[r];
+      float v = acc[tt][j][r] * osc + bv[r];
       if (k.act == 1) v = v > 0.f ? v : v * k.slope;
       else if (k.act == 2) v = tanhf(v);
       if (k.act_src) v = av[j][r] > 0.f ? v : v * k.act_slope;
@@ -429,6 +460,7 @@ __global__ __launch_bounds__(256) void conv3d_split_k(const float* __restrict__ 
                                             (unsigned)cou * s4, 0);
       pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
     }
+  }
   }
   C3S_T(7)
   if (y_amax) {
@@ -492,16 +524,21 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   DF_LAUNCH_CHECK();
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used, 0, act_src, act_slope};
+  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
+  // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
+  static const bool multi_off = getenv("DFMIR_CONV3D_NO_MULTI") != nullptr;
+  const int tt = (pair && vec && !multi_off && k.ny >= 3) ? 3 : 1;
+  k.ny = (k.ny + tt - 1) / tt;
   k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
   const long long nb = 8 * ((k.ntile + 7) / 8);
   DF_ARG_CHECK(nb < (1LL << 31));
-  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
   const dim3 grid((unsigned)nb, pair ? 1u : (unsigned)((cout_used + 31) / 32));
   const u32x4* wsu = reinterpret_cast<const u32x4*>(ws);
-  if (pair && vec) conv3d_split_k<true, true><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
-  else if (pair) conv3d_split_k<true, false><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
-  else if (vec) conv3d_split_k<false, true><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
-  else conv3d_split_k<false, false><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  if (pair && vec && tt == 3) conv3d_split_k<true, true, 3><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (pair && vec) conv3d_split_k<true, true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (pair) conv3d_split_k<true, false, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (vec) conv3d_split_k<false, true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else conv3d_split_k<false, false, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -216,6 +216,10 @@ CONV3D = [
     (16, 16, 3, 1, 1, 1, 7, 9, 19),
     (40, 12, 3, 1, 1, 1, 6, 7, 17),
     (8, 9, 3, 1, 1, 2, 1 + 2, 8, 16),
+    # multi-tile plane-pair form (three y-stacked tiles per workgroup share the weights): 4 tile rows = one full group +
+    # one with two phantom tiles; the flow-head shape (Cout 3) with 5 tile rows
+    (16, 16, 3, 1, 1, 1, 5, 26, 16),
+    (16, 3, 3, 1, 1, 1, 6, 40, 8),
 ]
 
 
