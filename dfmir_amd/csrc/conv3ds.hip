@@ -158,15 +158,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
   // workgroup -> tile: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (one L2 each), so ids
   // with the same residue get one contiguous eighth of the tiles; within it x runs fastest, then z, then y: the
   // z-halo (2 of 6 planes) of a tile is the previous x-row's data, still in that XCD's L2.
+  // PERSISTENT: the J = gridDim.x / 8 workgroups of an XCD walk its eighth together (iteration i: tiles i J .. i J + J - 1),
+  // and the prefetch of a tile's last phase already fetches the first chunk of the workgroup's NEXT tile, so only the
+  // first tile of a workgroup pays the exposed prologue (a per-phase trace had it at 10-23 % of a one-tile workgroup).
   const long long per_xcd = (k.ntile + 7) / 8;
-  long long pid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (pid >= k.ntile) return;
-  const int bx = (int)(pid % k.nx); pid /= k.nx;
-  const int bz = (int)(pid % k.nz); pid /= k.nz;
-  const int by = (int)(pid % k.ny);
-  const int n = (int)(pid / k.ny);
-  const int z0 = bz * TZ, y0 = by * TY * TT, x0 = bx * TX;      // (k.ny counts groups of TT tiles)
+  const int J = (int)(gridDim.x >> 3);
+  const long long t_first = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  long long t_lim = (long long)((blockIdx.x & 7) + 1) * per_xcd;
+  if (t_lim > k.ntile) t_lim = k.ntile;
+  if (t_first >= t_lim) return;
+  const int niter = (int)((t_lim - t_first + J - 1) / J);
+  int n, z0, y0, x0;                                        // the tile being LOADED (one phase ahead of the compute)
+#define C3S_DECODE(t_)                                                                            \
+  {                                                                                               \
+    long long pid_ = (t_);                                                                        \
+    const int bx_ = (int)(pid_ % k.nx); pid_ /= k.nx;                                             \
+    const int bz_ = (int)(pid_ % k.nz); pid_ /= k.nz;                                             \
+    const int by_ = (int)(pid_ % k.ny);                                                           \
+    n = (int)(pid_ / k.ny);                                                                       \
+    z0 = bz_ * TZ; y0 = by_ * TY * TT; x0 = bx_ * TX;      /* (k.ny counts groups of TT tiles) */  \
+  }
+  C3S_DECODE(t_first)
   const int mt = blockIdx.y;
+#ifdef C3S_STAGGER
+  // the second workgroup of a CU starts half a phase late, so that the pair does not stage / compute in lockstep
+  if ((blockIdx.x >> 3) & 32) { for (int i_ = 0; i_ < C3S_STAGGER; ++i_) __builtin_amdgcn_s_sleep(64); }
+#endif
 
   // scales: input scaled by 2^ex when it is split, result rescaled by 2^-ex * 2^-ew
   const float amax = reduce_absmax(x_amax, k.x_n, red);
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
   const float xscale = pow2f3(ex), oscale = pow2f3(-ex), oscale2 = pow2f3(-ew);
   if (tid == 0) smax = 0u;
 
-  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+  __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (long long)n * k.Cin * S), 0, (unsigned)((long long)k.Cin * S * 4), 0x00020000);
   const unsigned s4 = (unsigned)S * 4u;
   // Patch loads.  VEC (W % 4 == 0): thread t < 240 owns the 16-B quad q = t & 3 of halo row t >> 2 (rows = 6 planes x
@@ -236,12 +253,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
   for (int j = 0; j < NJ; ++j) pbase[j] = (wz * HY + wy + 2 * j + (l31 >> 4)) * HX + lx;
 
   f32x16 acc[TT][NJ];
-#pragma unroll
-  for (int t = 0; t < TT; ++t)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
   float rx[NS][8];                                         // !VEC: [slot][channel];  VEC: rx[0][c] = halo column
   u32x4 rq[8];                                             // VEC: the quad of channel c
@@ -333,12 +344,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
   __syncthreads();
   C3S_T(2)
 
-  for (int ch = 0; ch < k.nchunk; ++ch) {
+  float pm = 0.f;
+  int cn = n, cz0 = z0, cy0 = y0, cx0 = x0;                 // the tile being computed
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+  // ONE flat loop over (tile, chunk) -- nested loops made the register allocator keep a second copy of the accumulators
+  int it = 0, ch = 0;
+  for (int q = 0; q < niter * k.nchunk; ++q) {
+  {
 #pragma unroll
    for (int tt = 0; tt < TT; ++tt) {
-    // the phase after this one: the next tile of the group on the same chunk, or tile 0 of the next chunk (+ its weights)
-    const int nch = (tt + 1 < TT) ? ch : ch + 1;
-    if (TT > 1) C3S_OFFS((tt + 1) % TT)
+    // the phase after this one: the next tile of the group on the same chunk, tile 0 of the next chunk (+ its weights),
+    // or chunk 0 of this workgroup's next tile
+    const bool tile_end = (ch + 1 == k.nchunk) && (tt + 1 == TT);
+    const bool more = !tile_end || (it + 1 < niter);
+    const int nch = tile_end ? 0 : ((tt + 1 < TT) ? ch : ch + 1);
+    const int wch = tile_end ? 0 : ch + 1;
+    if (tile_end && more) {
+      C3S_DECODE(t_first + (long long)(it + 1) * J)
+      x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)n * k.Cin * S), 0,
+                                                (unsigned)((long long)k.Cin * S * 4), 0x00020000);
+    }
+    if (TT > 1 || tile_end) C3S_OFFS((tt + 1) % TT)
     C3S_OPLOAD(0, 0);
     // one k-step: the next step's 2 + 2 NJ operand reads and one part of the next chunk's global loads are pinned
     // between this step's 3 NJ MFMAs (one MFMA, one LDS read, one buffer load, ...), so the wave never waits on
@@ -349,10 +380,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
       if (!(C3S_KO & 2)) {
 #ifdef C3S_EARLY
         if (2 * tp < NPART) { C3S_GLOAD_X(nch, 2 * tp); if (2 * tp + 1 < NPART) C3S_GLOAD_X(nch, 2 * tp + 1); }
-        if (2 * tp == NPART && tt + 1 == TT) C3S_GLOAD_W(ch + 1);
+        if (2 * tp == NPART && tt + 1 == TT) C3S_GLOAD_W(wch);
 #else
         if (tp < NPART) C3S_GLOAD_X(nch, tp);
-        if (tp == NPART && tt + 1 == TT) C3S_GLOAD_W(ch + 1);
+        if (tp == NPART && tt + 1 == TT) C3S_GLOAD_W(wch);
 #endif
       }
       if (tp + 1 < NT / 2) C3S_OPLOAD(cur ^ 1, tp + 1);
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
 #endif
     }
     C3S_T(3)
-    if ((ch + 1) < k.nchunk || tt + 1 < TT) {
+    if (more) {
       __syncthreads();
       C3S_T(4)
       if (!(C3S_KO & 4)) {
@@ -390,12 +421,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
     }
    }
   }
+  const bool tile_done = (ch + 1 == k.nchunk);
+  if (!tile_done) { ++ch; continue; }
 #undef C3S_GLOAD_X
 #undef C3S_GLOAD_W
 #undef C3S_OPLOAD
 #undef C3S_LSTORE
 #undef C3S_LSTORE_W
 #undef C3S_OFFS
+#undef C3S_DECODE
 #undef C3S_SPLIT8
 
   // ---- epilogue: acc[j][r] <-> row = (r>>2)*8 + hi*4 + (r&3) = cout - mt*32 (PAIR: plane * 16 + cout),
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
   // Stores go through a buffer descriptor with 32-bit offsets (voxel part per lane, channel part uniform) and the 16
   // bias values of this lane are fetched BEFORE the first store: loads and stores share vmcnt on gfx9, so a bias load
   // between stores would wait for every store issued before it.
+  __builtin_amdgcn_sched_barrier(0);
   float bv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -411,57 +446,67 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
     bv[r] = (bias && co < k.cout_used) ? bias[co] : 0.f;
   }
   const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
-      y + (long long)n * k.Cout * S, 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+      y + (long long)cn * k.Cout * S, 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
   const unsigned plane4 = (unsigned)(k.H * k.W) * 4u;
   const float osc = oscale * oscale2;
-  float pm = 0.f;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-  const int yt0 = y0 + tt * TY;
-  // activation-derivative source values of all column tiles first (the operand registers are dead by now): loads and
-  // stores share vmcnt, so a load issued between the stores would wait for every store before it
-  float av[NJ][16];
-  if (k.act_src) {
-    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(k.act_src + (long long)n * k.Cout * S), 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int gy = yt0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
-      const bool vok = gy < k.H && gx < k.W;
-      const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowu = (r >> 2) * 8 + (r & 3);
-        const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;
-        const int pz = PAIR ? (rowu >> 4) : 0;
-        const bool ok = vok && (cou + hi * 4) < k.cout_used && (z0 + wz + pz) < k.D;
-        av[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(a_src, ok ? vo + (unsigned)pz * plane4 : OOB,
-                                                                         (unsigned)cou * s4, 0));
-      }
-    }
+  const int yt0 = cy0 + tt * TY;
+  // activation-derivative source values one column tile AHEAD of the stores: loads and stores share vmcnt (in order), so a
+  // load issued after a batch of stores would wait for all of them; issued before, it only lets them stay in flight
+  float av[2][16];
+  const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((k.act_src ? k.act_src : y) + (long long)cn * k.Cout * S), 0,
+      (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+#define C3S_AVLOAD(set_, j_)                                                                      \
+  if (k.act_src) {                                                                                \
+    const int gy = yt0 + wy + 2 * (j_) + (l31 >> 4), gx = cx0 + lx;                               \
+    const bool vok = gy < k.H && gx < k.W;                                                        \
+    const unsigned vo = (unsigned)(((cz0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4; \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                              \
+      const int rowu = (r >> 2) * 8 + (r & 3);                                                    \
+      const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;                                        \
+      const int pz = PAIR ? (rowu >> 4) : 0;                                                      \
+      const bool ok = vok && (cou + hi * 4) < k.cout_used && (cz0 + wz + pz) < k.D;               \
+      av[set_][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(a_src, ok ? vo + (unsigned)pz * plane4 : OOB, \
+                                                                            (unsigned)cou * s4, 0)); \
+    }                                                                                             \
   }
+  C3S_AVLOAD(0, 0)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int gy = yt0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+    if (j + 1 < NJ) C3S_AVLOAD((j + 1) & 1, j + 1)
+    const int gy = yt0 + wy + 2 * j + (l31 >> 4), gx = cx0 + lx;
     const bool vok = gy < k.H && gx < k.W;
     // lane part of the offset: voxel + the hi * 4 channels (PAIR: rows 16.. are plane 1 -> hi never changes the plane)
-    const unsigned vo = (unsigned)(((z0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
+    const unsigned vo = (unsigned)(((cz0 + wz) * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rowu = (r >> 2) * 8 + (r & 3);                       // row without the hi * 4 part
       const int cou = PAIR ? (rowu & 15) : mt * 32 + rowu;
       const int pz = PAIR ? (rowu >> 4) : 0;
-      const bool ok = vok && (cou + hi * 4) < k.cout_used && (z0 + wz + pz) < k.D;
+      const bool ok = vok && (cou + hi * 4) < k.cout_used && (cz0 + wz + pz) < k.D;
       float v = acc[tt][j][r] * osc + bv[r];
       if (k.act == 1) v = v > 0.f ? v : v * k.slope;
       else if (k.act == 2) v = tanhf(v);
-      if (k.act_src) v = av[j][r] > 0.f ? v : v * k.act_slope;
+      if (k.act_src) v = av[j & 1][r] > 0.f ? v : v * k.act_slope;
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo + (unsigned)pz * plane4 : OOB,
                                             (unsigned)cou * s4, 0);
       pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
     }
   }
+#undef C3S_AVLOAD
   }
+  // next tile of this workgroup: fresh accumulators, the coordinates the prefetch already moved to
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+  cn = n; cz0 = z0; cy0 = y0; cx0 = x0;
+  ch = 0; ++it;
+  }   // (tile, chunk) phases of this workgroup
   C3S_T(7)
   if (y_amax) {
     __syncthreads();
@@ -530,9 +575,16 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   const int tt = (pair && vec && !multi_off && k.ny >= 3) ? 3 : 1;
   k.ny = (k.ny + tt - 1) / tt;
   k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
-  const long long nb = 8 * ((k.ntile + 7) / 8);
-  DF_ARG_CHECK(nb < (1LL << 31));
-  const dim3 grid((unsigned)nb, pair ? 1u : (unsigned)((cout_used + 31) / 32));
+  // One tile (group) per workgroup by default.  DFMIR_CONV3D_WGS=<n> caps the workgroups (512 = two per CU = fully
+  // persistent: each then walks several tiles with the next tile's first chunk prefetched under the last phase of the
+  // current one).  Measured equal within the box-to-box noise on every layer shape (the kernel is bound by the
+  // package power, not by the exposed prologue), and the dispatcher balances one-tile workgroups better.
+  const unsigned gy = pair ? 1u : (unsigned)((cout_used + 31) / 32);
+  static const int wg_cap = getenv("DFMIR_CONV3D_WGS") ? atoi(getenv("DFMIR_CONV3D_WGS")) : (1 << 30);
+  long long nb = 8 * ((k.ntile + 7) / 8);
+  const long long cap = 8 * (((long long)wg_cap / gy + 7) / 8);
+  if (nb > cap) nb = cap;
+  const dim3 grid((unsigned)nb, gy);
   const u32x4* wsu = reinterpret_cast<const u32x4*>(ws);
   if (pair && vec && tt == 3) conv3d_split_k<true, true, 3><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   else if (pair && vec) conv3d_split_k<true, true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
