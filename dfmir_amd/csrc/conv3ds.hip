@@ -834,6 +834,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
 // 8 different 16-B bank slots (measured: all of the kernel's bank conflicts were these stores at stride 24).  dY: 4 voxels x 64 B contiguous; the channel group is XORed with (voxel >> 2) & 3 so that the staging
 // stores of a wave (one channel group, 4 voxel quads) spread over the banks.
 // ================================================================================================
+#ifndef W3T_NOSKIP
+#define W3T_NOSKIP 0
+#endif
 #ifndef W3T_KO
 #define W3T_KO 0     // knock-out builds for timing: 1 = no MFMAs, 2 = no prefetch loads, 4 = no convert + LDS store, 8 = no operand reads
 #endif
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
     _Pragma("unroll") for (int s = 0; s < NKS; ++s) {                                             \
       const int cur = s & 1;                                                                      \
       if (!(W3T_KO & 8)) {                                                                        \
-        W3T_READ_A(1, s)                                                                          \
+        if (tok1) { W3T_READ_A(1, s) }                                                            \
         if (s + 1 < NKS) W3T_READ_B(B0, cur ^ 1, s + 1, 0u)                                       \
       }                                                                                           \
       if (!(W3T_KO & 2)) {                                                                        \
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
         W3T_READ_B(B1, cur ^ 1, s + 1, YU * 16u)                                                  \
       }                                                                                           \
       if (PAIR && (LAST_) && !(W3T_KO & 2)) { W3T_GLOAD_Y1(s); }   /* 8 k-steps: dY rides in the second half-steps */ \
-      W3T_MMA(c_, 1)                                                                              \
+      if (tok1) { W3T_MMA(c_, 1) }                                                                \
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
@@ -1122,6 +1125,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
         const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
         aaddr[t] = xs_base + (unsigned)((dz * SZP + dyy * HXP + dx + 8 * hi + sj) * 16 + (sq & 1) * 8);
       }
+      // the wave whose second row tile is the padding tile 7 skips its reads and MFMAs (wave-uniform): no time gained
+      // (the phase ends at the barrier) but 1/8 of the matrix and LDS energy of a kernel that sits on the power cap
+      const bool tok1 = PAIR || (((wid + c) & 3) != 3) || W3T_NOSKIP;
       W3T_KLOOP(c, last)
       if (more) {
         __syncthreads();
