@@ -18,17 +18,33 @@ __global__ void patch_gather_fwd_k(const float* __restrict__ feat, const long lo
 }
 // amax (optional): the range probe of dfeat (DF_PROBE_SLOTS floats, as left by the InstanceNorm kernels); kept valid
 // by raising a slot to |new value| of every element this scatter touches (ids are distinct within a plane)
+// DISTINCT: the ids of a group are a P-SUBSET (as torch.randperm / dfmir_patch_ids_draw yield them), so no two threads of
+// the launch touch the same element and the scatter is a plain load + store -- 3.1 M returning L2 atomics per layer
+// were the whole cost of this kernel (125 -> ~35 us).  The non-DISTINCT form accumulates arbitrary ids with atomics.
+template <bool DISTINCT>
 __global__ void patch_gather_bwd_k(const float* __restrict__ dout, const long long* __restrict__ ids,
                                    float* __restrict__ dfeat, int B, int C, long long S, int P, int bpg,
                                    unsigned* __restrict__ amax, unsigned* __restrict__ pmax = nullptr) {
   const long long total = (long long)B * C * P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(i % P);
-    const long long bc = i / P;
-    const long long b = bc / C, c = bc - b * C;
+    int p;
+    long long bc, b, c;
+    if (total < 0x7FFFFFFFLL) {
+      const unsigned u = (unsigned)i;
+      p = (int)(u % (unsigned)P);
+      const unsigned ubc = u / (unsigned)P;
+      bc = ubc; b = ubc / (unsigned)C; c = ubc - (unsigned)b * (unsigned)C;
+    } else {
+      p = (int)(i % P);
+      bc = i / P;
+      b = bc / C; c = bc - b * C;
+    }
     const float v = dout[c * ((long long)B * P) + b * P + p];
-    const float old = atomicAdd(&dfeat[bc * S + ids[(b / bpg) * P + p]], v);
+    float* dst = &dfeat[bc * S + ids[(b / bpg) * P + p]];
+    float old;
+    if (DISTINCT) { old = *dst; *dst = old + v; }
+    else old = atomicAdd(dst, v);
     if (amax) {
       float nv = fabsf(old + v);
       if (!(nv == nv)) nv = __uint_as_float(0x7f800000u);
@@ -410,7 +426,7 @@ extern "C" int dfmir_patch_gather_fwd_g(const float* feat, const long long* ids,
 extern "C" int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfeat, int B, int C,
                                         long long S, int P, int G, float* dfeat_amax, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
-  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+  patch_gather_bwd_k<true><<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
       dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax));
   DF_LAUNCH_CHECK();
   return 0;
@@ -418,7 +434,7 @@ extern "C" int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids,
 extern "C" int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids, float* dfeat, int B, int C,
                                          long long S, int P, int G, float* dfeat_amax, float* dfeat_pmax, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && dfeat_amax && dfeat_pmax && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
-  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+  patch_gather_bwd_k<true><<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
       dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax), reinterpret_cast<unsigned*>(dfeat_pmax));
   DF_LAUNCH_CHECK();
   return 0;
@@ -426,7 +442,7 @@ extern "C" int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids
 extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0);
-  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+  patch_gather_bwd_k<false><<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
       dout, ids, dfeat, B, C, S, P, B, nullptr);
   DF_LAUNCH_CHECK();
   return 0;
@@ -434,7 +450,7 @@ extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, f
 extern "C" int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C,
                                            long long S, int P, float* dfeat_amax, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && dfeat_amax && B > 0 && C > 0 && S > 0 && P > 0);
-  patch_gather_bwd_k<<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+  patch_gather_bwd_k<true><<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
       dout, ids, dfeat, B, C, S, P, B, reinterpret_cast<unsigned*>(dfeat_amax));
   DF_LAUNCH_CHECK();
   return 0;

@@ -320,7 +320,9 @@ int dfmir_patch_gather_fwd(const float* feat, const long long* ids, float* out, 
                            long long S, int P, void* stream);
 int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
                            long long S, int P, void* stream);
-/* The same scatter into a gradient that already holds another consumer's contribution, keeping its per-plane range
+/* The same scatter into a gradient that already holds another consumer's contribution (ids must be DISTINCT -- a
+ * P-subset, as torch.randperm yields them, networks.py:609-610: plain load + store instead of atomics; this also
+ * holds for the grouped forms below), keeping its per-plane range
  * probe valid: dfeat_amax[DFMIR_PROBE_SLOTS] (the dx_amax of dfmir_instnorm_bwd) is raised to |new value| where needed. */
 int dfmir_patch_gather_bwd_amax(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S,
                                 int P, float* dfeat_amax, void* stream);
