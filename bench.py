@@ -13,7 +13,8 @@ scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with
                   fp16, frac <= 1; the algorithmic fp32 rate is reported beside it
   `roofline_hbm`  the trilinear warp (grid_sample) forward / backward at 160x192x224, algorithmic bytes / HIP-event time
                   against 8 TB/s, measured in the same process
-  `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (conv3d_mfma16_k, fp32 MFMA)
+  `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (conv3d_split_k forward / dgrad and
+                  conv3d_wgrad_tr_k, both scaled fp16x2 on the 16-bit matrix pipe, issued FLOP/s against 2.5 PFLOP/s)
   `cpu_baseline`  (N = 1) the CPU oracle = a port of the reference's PyTorch-CPU path, timed on the host cores on a
                   bounded sample.
 """
