@@ -559,14 +559,18 @@ extern "C" int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, c
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
                                  int cout_used, void* stream, const float* act_src, float act_slope) {
-  DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && w_tcc && ws && y);
+  // w_tcc == NULL: ws already holds the split of this layer's weights for this cout_used (a host that keeps ws per
+  // (layer, mode) and re-splits only after an optimizer step saves the conv3d_wsplit_k launch of every call)
+  DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && ws && y);
   DF_ARG_CHECK(!split3d_off() && split3d_geom_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = (g->Cin + 7) / 8, nmt = (g->Cout + 31) / 32;
   float* trailer = ws + dfmir_conv3d_split_ws_floats(g->Cin, g->Cout) - 4;          // after the largest unit layout
   const bool pair = cout_used <= 16 && !pair3d_off();
-  conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
-  DF_LAUNCH_CHECK();
+  if (w_tcc) {
+    conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
+    DF_LAUNCH_CHECK();
+  }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used, 0, act_src, act_slope};
   const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");

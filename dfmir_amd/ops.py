@@ -151,19 +151,33 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
     def launch():
         if split3d:
-            # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer
-            ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
+            # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer.
+            # The split weights are kept per packed-weight buffer and re-made only when that buffer was re-packed.
+            cu = Cout if cout_used is None else cout_used
+            # (the generation and the cache live ON the persistent packed buffer's tensor object: a temporary packing
+            # has neither, and an address recycled by the allocator cannot alias a stale entry)
+            wkey = (Cin, Cout, cu)
+            gen = getattr(w_tcc, "_df_gen", None)
+            cache = getattr(w_tcc, "_df_ws3d", None) if gen is not None else None
+            ent = cache.get(wkey) if cache is not None else None
+            if ent is not None and ent[0] == gen:
+                ws, w_arg = ent[1], None
+            else:
+                ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
+                w_arg = w_tcc
+                if gen is not None:
+                    if cache is None:
+                        cache = w_tcc._df_ws3d = {}
+                    cache[wkey] = (gen, ws)
             slot = amax_slot(x5.device, PROBE_SLOTS)
             if act_src is not None:
                 # dgrad into the output of a LeakyReLU: the epilogue applies the activation's derivative (csrc/conv3ds.hip)
-                check(lib().dfmir_conv3d_split_fwd_actgrad(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc),
-                                                           _p(ws), _p(bias), _p(y), _p(slot),
-                                                           Cout if cout_used is None else cout_used, _p(act_src),
+                check(lib().dfmir_conv3d_split_fwd_actgrad(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_arg),
+                                                           _p(ws), _p(bias), _p(y), _p(slot), cu, _p(act_src),
                                                            float(act_slope), _st()))
             else:
-                check(lib().dfmir_conv3d_split_fwd_sub(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(ws),
-                                                       _p(bias), _p(y), _p(slot), Cout if cout_used is None else cout_used,
-                                                       _st()))
+                check(lib().dfmir_conv3d_split_fwd_sub(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_arg), _p(ws),
+                                                       _p(bias), _p(y), _p(slot), cu, _st()))
             tag_amax(y, slot)              # survives as is when y is a backward result (dgrad) ...
             _LAST_CONV_AMAX[0] = slot      # ... and is re-attached by conv() to the tensor Function.apply returns
         elif fuse_res or ring is not None:
@@ -248,6 +262,9 @@ def weight_pack(w, mode):
 # bumps the weights epoch), so the first request after a bump re-packs EVERY registered buffer whose parameter is still
 # in place with one batched call (2 launches instead of ~170 per train step).
 _PACKS = {"epoch": None, "entries": {}, "key": None, "descs": None, "dev": None}
+def _bump_gen(buf):
+    """Generation of a persistent packed-weight buffer (bumped whenever it is re-packed): keys what is derived from it."""
+    buf._df_gen = getattr(buf, "_df_gen", 0) + 1
 _KEEP_TABLES = []     # device job tables are never freed (a few KB each; see _repack_all / _flush_deferred)
 
 
@@ -266,6 +283,7 @@ def packed_weight(owner, w3, mode):
         ent = None
     if ent is None:
         buf = weight_pack(w3, mode)
+        _bump_gen(buf)
         ents[key] = {"ref": weakref.ref(owner), "place": place, "version": w3._version, "epoch": ep, "buf": buf,
                      "w": w3.detach(), "mode": mode}
         _PACKS["key"] = None
@@ -280,6 +298,7 @@ def packed_weight(owner, w3, mode):
     # the batched pass did not cover it (it ran before this entry existed / before the in-place change): refresh
     Cout, Cin = w3.shape[0], w3.shape[1]
     check(lib().dfmir_weight_pack(_p(_c(w3)), _p(ent["buf"]), Cout, Cin, w3.numel() // (Cout * Cin), mode, _st()))
+    _bump_gen(ent["buf"])
     ent["epoch"] = ep
     return ent["buf"]
 
@@ -315,6 +334,7 @@ def _repack_all(ep):
     for e in live:
         e["epoch"] = ep
         e["version"] = e["w"]._version
+        _bump_gen(e["buf"])
 
 
 def weight_unpack(g_tcc, shape):

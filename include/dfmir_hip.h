@@ -87,6 +87,8 @@ int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_a
 /* The same, computing output channels [0, cout_used) only (y keeps Cout planes; the others are left untouched): the
  * input gradient of a layer fed by cat([up2(a), b]) whose skip part b needs no gradient (the two image channels at the
  * top of the U-Net, networks.py:97-100). */
+/* (w_tcc may be NULL in the _sub / _actgrad forms: `ws` then already holds the split of these weights for this
+ * cout_used, left by an earlier call -- weights only change at the optimizer step.) */
 int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
                                float* ws, const float* bias, float* y, float* y_amax, int cout_used, void* stream);
 /* The weight gradient of the same layers in the same split form (8 <= Cin <= 48, 8 <= Cout <= 32, or Cout < 8 with Cin <= 32; W % 4 == 0), voxels as the
