@@ -568,7 +568,14 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   float* trailer = ws + dfmir_conv3d_split_ws_floats(g->Cin, g->Cout) - 4;          // after the largest unit layout
   const bool pair = cout_used <= 16 && !pair3d_off();
   if (w_tcc) {
-    conv3d_wsplit_k<<<8, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
+    // one unit per thread where possible: every workgroup re-reduces max|w| itself (L2-resident), the packing is what
+    // parallelises (8 workgroups took 25 us on the 64 -> 64 layers, a latency chain of strided loads)
+    static const int ws_wgs = getenv("DFMIR_WSPLIT_WGS") ? atoi(getenv("DFMIR_WSPLIT_WGS")) : 32;
+    const long long units = (long long)(pair ? 1 : nmt) * nchunk * (pair ? 36 : 28) * 32;
+    long long nwg = (units + 1023) / 1024;
+    if (nwg > ws_wgs) nwg = ws_wgs;
+    if (nwg < 1) nwg = 1;
+    conv3d_wsplit_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
     DF_LAUNCH_CHECK();
   }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
