@@ -545,6 +545,41 @@ def test_full_size_conv3d_adjoint_and_linearity(cfg):
         assert float(y12.abs().max()) <= 2e-5 * float(y.abs().max()), float(y12.abs().max())
 
 
+def test_registration3d_captured_step_matches_eager():
+    """Registration3DModel(capture_step=True): a replayed step equals the same step enqueued eagerly from the same
+    restored state (weights, Adam moments) -- losses, outputs and the gradient arena."""
+    from dfmir_amd import ops
+    from dfmir_amd.registration3d import Registration3DModel
+    shape = (32, 32, 32)
+    torch.manual_seed(0)
+    m = Registration3DModel(shape, None, capture_step=True, device=DEV)
+    A = C.randn(141, 1, 1, *shape).to(DEV).clamp(-1, 1)
+    B = (0.5 * A + 0.5 * C.randn(142, 1, 1, *shape).to(DEV)).clamp(-1, 1)
+    for _ in range(3):                                    # two eager steps, then the capture
+        m.set_input({"A": A, "B": B}); m.optimize_parameters()
+    assert m._graph['graph'] is not None
+    o = m.optimizer_R
+    for _ in range(2):
+        snap = (o.flat_p.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o._steps)
+        m.set_input({"A": A, "B": B}); m.optimize_parameters()          # replay
+        torch.cuda.synchronize()
+        got = (m.get_current_losses(), m.regA.clone(), m.flow.clone(), o.flat_g.clone(), o.flat_p.clone())
+        with torch.no_grad():
+            o.flat_p.copy_(snap[0]); o.exp_avg.copy_(snap[1]); o.exp_avg_sq.copy_(snap[2])
+        o._steps = snap[3]
+        ops.bump_weights_epoch()
+        m._graph['force_eager'] = True
+        m.set_input({"A": A, "B": B}); m.optimize_parameters()          # the same step, eager
+        m._graph['force_eager'] = False
+        torch.cuda.synchronize()
+        ref = (m.get_current_losses(), m.regA, m.flow, o.flat_g, o.flat_p)
+        for k in ref[0]:
+            assert abs(got[0][k] - ref[0][k]) <= 1e-5 * max(abs(ref[0][k]), 1e-8), (k, got[0][k], ref[0][k])
+        for a, b, tol, what in ((got[1], ref[1], 1e-6, "regA"), (got[2], ref[2], 1e-5, "flow"), (got[3], ref[3], 5e-5, "grads")):
+            err = float((a - b).abs().max())
+            assert err <= tol * float(b.abs().max()) + 1e-12, (what, err, float(b.abs().max()))
+
+
 def test_full_size_warp_properties():
     """160x192x224 (BASELINE configs[4] geometry): zero displacement is the identity, an integer shift moves
     voxels exactly, and the warp is linear in src with d(src) as its adjoint."""
