@@ -9,14 +9,16 @@ every N: BASELINE.json configs[1] geometry -- 2-D 256x256, batch 16 PER GPU, ngf
 scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with
   `roofline`      dominant kernel = conv3x3_split_cs_k (3x3 forward/dgrad convs, fp32 operands split into scaled
                   fp16 pairs, 3 products per MAC on v_mfma_f32_32x32x16_f16), timed live with HIP events on its
-                  launch stream; achieved = ISSUED 16-bit matrix FLOP/s (3 x algorithmic), peak = 2.5 PFLOP/s dense
-                  fp16, frac <= 1; the algorithmic fp32 rate is reported beside it
+                  launch stream; achieved = ALGORITHMIC fp32 FLOP/s, peak = 2.5 PFLOP/s dense fp16 (SURVEY 8 D3);
+                  `issued_frac` (= 3 x frac, what the matrix pipe executes) beside it; `traffic` = HBM-side bytes per
+                  launch from the committed PMC passes (profiles/rNN_pmc.json)
   `roofline_hbm`  the trilinear warp (grid_sample) forward / backward at 160x192x224, algorithmic bytes / HIP-event time
-                  against 8 TB/s, measured in the same process
+                  against 8 TB/s, measured in the same process, on a smooth and on a rough field
   `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (conv3d_split_k forward / dgrad and
-                  conv3d_wgrad_tr_k, both scaled fp16x2 on the 16-bit matrix pipe, issued FLOP/s against 2.5 PFLOP/s)
+                  conv3d_wgrad_tr_k, both scaled fp16x2 on the 16-bit matrix pipe)
+  `also_3d_128`   configs[3]: the 3-D step at 128^3 with the plugin's 6-level U-Net features
   `cpu_baseline`  (N = 1) the CPU oracle = a port of the reference's PyTorch-CPU path, timed on the host cores on a
-                  bounded sample.
+                  bounded sample: the 2-D step at 256^2 batch 1 and (`also_3d_128`) the 3-D step at 128^3.
 """
 import argparse
 import json
@@ -33,7 +35,39 @@ if REPO not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16), 2.4 GHz
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E
-CS_TRAFFIC_BYTES = 480.5e6      # FETCH_SIZE 346.3 MB + WRITE_SIZE 134.2 MB (profiles/r01_conv3x3s_pmc.md)
+G_FULL_GF, G_ENC_GF = 126.61, 68.06   # ResnetGenerator conv GFLOP per image: full pass / encoder-only pass
+STEP_GF_REFERENCE = 1581.0            # per pair, the reference's step
+PLUGIN_FEATS = [[16, 32, 32, 64, 64, 64], [64, 64, 64, 32, 32, 32, 16]]   # registration_model.py:93-96
+
+
+def load_pmc():
+    """HBM-side bytes per launch of the priced kernels: the newest profiles/rNN_pmc.json (written by
+    scripts/pmc_json.py from the rocprofv3 --pmc passes of scripts/collect_profiles.sh; FETCH_SIZE x2 gfx950
+    correction, KiB -> bytes).  Counters cannot be read from inside the process, so `traffic` is the committed
+    measurement of the same kernels on the same shapes; {} when no file is there (traffic: null)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc.json")))
+    if not files:
+        return {}, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], REPO)
+    except Exception:
+        return {}, None
+
+
+def pmc_traffic(pmc, key):
+    e = pmc.get(key) or {}
+    return e.get("traffic_bytes")
+
+
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.lower().startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def synth_pairs(B, H, W, device, seed):
@@ -114,10 +148,10 @@ def pick_cpu_threads():
     return best
 
 
-def cpu_baseline(size, max_steps=3):
+def cpu_baseline(size, max_steps=3, cores=None):
     """The oracle (CPU port of the reference path) at the same 256x256 geometry, batch 1."""
     from oracle import dfmir_oracle as O
-    cores = pick_cpu_threads()
+    cores = cores or pick_cpu_threads()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     st = O.RegistrationStep(size, 1, ngf=64)
@@ -132,34 +166,66 @@ def cpu_baseline(size, max_steps=3):
         if time.time() - t0 > 30.0:
             break
     dt = time.time() - t0
-    return dict(value=n / dt, unit="image-pairs/s", cores=cores, kind="port",
+    return dict(value=n / dt, unit="image-pairs/s", cores=cores, kind="port", cpu_model=cpu_model(),
                 sample="%d train steps of the CPU oracle (PyTorch fp32, %d threads) at 2-D %dx%d batch 1, ngf 64, "
                        "after 1 warm-up fwd+bwd" % (n, cores, size, size))
 
 
-def bench_3d(dev, steps=5, warmup=2):
-    """Auxiliary line: the 3-D step of BASELINE configs[4] geometry on ONE GPU -- 160x192x224, batch 1,
-    VxmDense(default features, int_steps 7, bidir) + NCC[9,9,9] + Grad l2, fwd+bwd+Adam.
-    Its roofline: conv3d_mfma16_k (every stride-1 3x3x3 forward / dgrad conv), fp32 MFMA, timed with HIP events."""
+def cpu_baseline_3d(cores, shape=(128, 128, 128), budget_s=45.0):
+    """The 3-D half of the metric on the host cores: the oracle's Registration3DStep (VxmDense with the plugin's
+    6-level features + NCC_Loss[9,9,9] + Grad_Loss l2 + Adam; SURVEY section 8 A13 / BASELINE.md section 4) at
+    BASELINE configs[3] geometry, 128^3, batch 1.  Bounded: one warm-up step, then steps until `budget_s`."""
+    from oracle import dfmir_oracle as O
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    st = O.Registration3DStep(shape, PLUGIN_FEATS)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1)
+    A = torch.rand(1, 1, *shape, generator=g) * 2 - 1
+    B = 0.5 * A + 0.5 * (torch.rand(1, 1, *shape, generator=g) * 2 - 1)
+    tw = time.time()
+    st.step(A, B)                            # warm-up
+    tw = time.time() - tw
+    t0 = time.time()
+    n = 0
+    while n < 3:
+        st.step(A, B)
+        n += 1
+        if time.time() - t0 + tw > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=n / dt, unit="image-pairs/s", cores=cores, kind="port", cpu_model=cpu_model(),
+                sample="%d train steps of the CPU oracle's Registration3DStep (PyTorch fp32, %d threads) at 3-D %dx%dx%d "
+                       "batch 1, plugin 6-level features, NCC[9,9,9] + Grad-l2 + Adam, after 1 warm-up step"
+                       % ((n, cores) + tuple(shape)))
+
+
+def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, label="BASELINE configs[4] geometry, one GPU",
+             pmc_key="conv3d_split_k_34_32", steps=5, warmup=3, capture=False, roofline_steps=2):
+    """Auxiliary line: the 3-D step on ONE GPU -- batch 1, VxmDense(int_steps 7, bidir) + NCC[9,9,9] + Grad l2,
+    fwd+bwd+Adam: 160x192x224 with the default U-Net features (configs[4]'s per-GPU shard) or
+    128^3 with the plugin's 6-level features (configs[3]).  Its roofline: conv3d_split_k (every stride-1 3x3x3 forward /
+    dgrad conv) and conv3d_wgrad_tr_k, timed with HIP events on the launch stream -- inside the timed region when the
+    step is enqueued eagerly, over `roofline_steps` eager steps right after it when it is one hipGraph replay."""
     from dfmir_amd import ops
     from dfmir_amd.registration3d import Registration3DModel
-    shape = (160, 192, 224)
     torch.manual_seed(0)
-    m = Registration3DModel(shape, None, device=dev)
+    m = Registration3DModel(shape, feats, device=dev, capture_step=capture)
     A = torch.rand(1, 1, *shape, device=dev) * 2 - 1
     B = 0.5 * A + 0.5 * (torch.rand(1, 1, *shape, device=dev) * 2 - 1)
     sizes = ("small", "S", "M", "L")
     sp_kinds = ["conv3ds_" + z for z in sizes]          # split fp16x2 kernel (csrc/conv3ds.hip)
-    fw_kinds = ["conv3d_" + z for z in sizes]           # fp32-MFMA kernel (csrc/conv3d.hip): Cout < 8 layers, or A/B env
-    wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]      # fp32-MFMA wgrad (Cout < 8 / Cin > 48 layers)
+    fw_kinds = ["conv3d_" + z for z in sizes]           # fp32-MFMA kernel (csrc/conv3d.hip): A/B env only
+    wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]      # fp32-MFMA wgrad (Cin > 128 layers)
     wgs_kinds = ["wgrad3ds_" + z for z in ("S", "M", "L")]    # split fp16x2 wgrad
     timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds)
     ops.set_conv_profiler(timer)
-    for _ in range(warmup):
+    for _ in range(max(warmup, 3) if capture else warmup):
         m.set_input({"A": A, "B": B})
         m.optimize_parameters()
     torch.cuda.synchronize()
-    timer.enabled = True
+    graphed = bool(capture and m._graph['graph'] is not None)
+    timer.enabled = not graphed
     t0 = time.perf_counter()
     for _ in range(steps):
         m.set_input({"A": A, "B": B})
@@ -167,6 +233,15 @@ def bench_3d(dev, steps=5, warmup=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     timer.enabled = False
+    if graphed:
+        m._graph['force_eager'] = True
+        timer.enabled = True
+        for _ in range(roofline_steps):
+            m.set_input({"A": A, "B": B})
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        m._graph['force_eager'] = False
     ops.set_conv_profiler(None)
     losses = m.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
@@ -181,37 +256,44 @@ def bench_3d(dev, steps=5, warmup=2):
     fw_tf, fw_n, fw_ms = agg(fw_kinds)
     wg_tf, wg_n, wg_ms = agg(wg_kinds)
     wgs_tf, wgs_n, wgs_ms = agg(wgs_kinds)
+    timed_over = ("%d eager steps right after the timed region (one hipGraph replay per step)" % roofline_steps) if graphed \
+        else "the timed region"
     if sp_n:
-        roof = {"bound": "mfma", "achieved": 3.0 * sp_tf, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": 3.0 * sp_tf / FP16_MFMA_PEAK_TFLOPS, "traffic": None,
-                "achieved_note": "issued 16-bit matrix FLOP/s = 3 x the algorithmic fp32 FLOP/s (scaled fp16x2 split, 3 "
-                                 "products per MAC); algorithmic FLOPs = 2*N*Cout*D*H*W*Cin*27 of the timed launches",
-                "algorithmic_tflops": sp_tf, "products_per_mac": 3.0,
+        roof = {"bound": "mfma", "achieved": sp_tf, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": sp_tf / FP16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(pmc, pmc_key),
+                "traffic_note": "HBM-side bytes of one launch of %s (PMC FETCH_SIZE x2 + WRITE_SIZE)" % pmc_key
+                                if pmc_traffic(pmc, pmc_key) else None,
+                "achieved_note": "achieved = ALGORITHMIC fp32 FLOP/s (2*N*Cout*D*H*W*Cin*27 of the timed launches / their HIP-event "
+                                 "time) over the dense fp16 MFMA peak; the kernel issues 3 fp16 products per fp32 MAC (scaled "
+                                 "fp16x2 split), so the matrix pipe sees issued_frac = 3 x frac",
+                "issued_tflops": 3.0 * sp_tf, "issued_frac": 3.0 * sp_tf / FP16_MFMA_PEAK_TFLOPS, "products_per_mac": 3.0,
+                "frac_of_fp32_mfma_peak": sp_tf / FP32_MFMA_PEAK_TFLOPS,
                 "kernel": "conv3d_split_k (v_mfma_f32_32x32x16_f16, 4x8x16-voxel x 32-cout tiles, LDS halo patch split into "
                           "fp16 pairs per 8-channel chunk): forward + dgrad of every stride-1 3x3x3 conv",
-                "launches_timed": sp_n, "avg_launch_ms": sp_ms / max(sp_n, 1)}
+                "launches_timed": sp_n, "avg_launch_ms": sp_ms / max(sp_n, 1), "timed_over": timed_over}
     else:
         roof = {"bound": "mfma", "achieved": fw_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": fw_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "kernel": "conv3d_mfma16_k (v_mfma_f32_16x16x4_f32): forward + dgrad of every stride-1 3x3x3 conv",
-                "launches_timed": fw_n, "avg_launch_ms": fw_ms / max(fw_n, 1)}
+                "launches_timed": fw_n, "avg_launch_ms": fw_ms / max(fw_n, 1), "timed_over": timed_over}
     if wgs_n:
         roof.update({"wgrad_kernel": "conv3d_wgrad_tr_k (voxels as the matrix K; operands read with ds_read_b64_tr_b16 from "
                                      "channel-major fp16-pair LDS images of the patch and of dY; plane-pair columns for "
                                      "<= 16 output channels)",
-                     "wgrad_achieved": 3.0 * wgs_tf, "wgrad_frac": 3.0 * wgs_tf / FP16_MFMA_PEAK_TFLOPS,
-                     "wgrad_algorithmic_tflops": wgs_tf, "wgrad_launches_timed": wgs_n})
+                     "wgrad_achieved": wgs_tf, "wgrad_frac": wgs_tf / FP16_MFMA_PEAK_TFLOPS,
+                     "wgrad_issued_frac": 3.0 * wgs_tf / FP16_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wgs_n})
     else:
-        roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_kernel_tflops": wg_tf,
+        roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_achieved": wg_tf,
                      "wgrad_frac_of_fp32_peak": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n})
-    return {"workload": "3-D 160x192x224 volume pair, batch 1, VxmDense default features + NCC[9,9,9] + Grad-l2, "
-                        "fwd+bwd+Adam (BASELINE configs[4] geometry, one GPU)",
+    return {"workload": "3-D %dx%dx%d volume pair, batch 1, VxmDense %s features + NCC[9,9,9] + Grad-l2, fwd+bwd+Adam (%s)"
+                        % (tuple(shape) + ("default" if feats is None else "plugin 6-level", label)),
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
-            "conv_tflops": 2393.0 / dt / 1e3, "dtype": "f32",
+            "step_submission": "hipGraph replay + eager Adam" if graphed else "eager",
+            "conv_tflops": gflop_step / dt / 1e3, "conv_gflop_per_step": gflop_step, "dtype": "f32",
             "losses": {k: round(v, 6) for k, v in losses.items()}, "roofline": roof}
 
 
-def bench_warp_hbm(dev, reps=20):
+def bench_warp_hbm(dev, pmc, reps=20):
     """roofline_hbm: the trilinear displacement-field warp (SpatialTransformer = grid_sample, reference
     models/voxelmorph/torchvoxelmorph/layers.py:30-48) at 160x192x224, C = 1, on a registration-like smooth field
     (control points every 32 voxels, ~1 voxel rms).  Algorithmic bytes: fwd 4*(C+nd+C)*N_vox,
@@ -242,7 +324,7 @@ def bench_warp_hbm(dev, reps=20):
     def bwd():
         ops._warp_bwd_dsrc(dout, src, flow, dflow, 0, 0)
 
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pmc_traffic(pmc, "warp_win_fwd_k"),
            "workload": "160x192x224, C=1, smooth field", "kernel": "warp_win_fwd_k<3>"}
     b_f = 4 * (C + nd + C) * nv
     ms = timeit(lambda: ops._warp_fwd(src, flow, 0, 0))
@@ -251,11 +333,21 @@ def bench_warp_hbm(dev, reps=20):
     ms = timeit(bwd)
     out["bwd"] = {"kernel": "warp_win_bwd_own_k<3> + warp_win_gather_k<3> (+ the empty slow-voxel pass): d(src) + d(flow) "
                             "without device-scope atomics, bit-reproducible", "achieved": b_b / ms / 1e6,
-                  "frac": b_b / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_b, "avg_launch_ms": ms}
+                  "frac": b_b / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_b, "avg_launch_ms": ms,
+                  "traffic": pmc_traffic(pmc, "warp_bwd_dsrc_dflow")}
     b_bf = 4 * (C + C + 2 * nd) * nv
     ms = timeit(lambda: ops._warp_bwd(dout, src, flow, None, dflow, 0, 0))
     out["bwd_dflow_only"] = {"achieved": b_bf / ms / 1e6, "frac": b_bf / ms / 1e6 / HBM_PEAK_GBS, "bytes": b_bf,
                              "avg_launch_ms": ms}
+    # the same three launches on a ROUGH field (control points every 16 voxels, 3 voxels rms: many taps leave their
+    # tile's window) -- the worst case of the windowed kernels; a field under a smoothness loss is of the first kind
+    coarse = torch.randn(1, nd, *[s // 16 for s in sp], generator=g).to(dev) * 3.0
+    flow = torch.nn.functional.interpolate(coarse, size=sp, mode='trilinear', align_corners=True).contiguous()
+    ms_f = timeit(lambda: ops._warp_fwd(src, flow, 0, 0))
+    ms_b = timeit(bwd)
+    out["rough_field"] = {"workload": "160x192x224, C=1, control points every 16 voxels, 3 voxels rms",
+                          "fwd": {"achieved": b_f / ms_f / 1e6, "frac": b_f / ms_f / 1e6 / HBM_PEAK_GBS, "avg_launch_ms": ms_f},
+                          "bwd": {"achieved": b_b / ms_b / 1e6, "frac": b_b / ms_b / 1e6 / HBM_PEAK_GBS, "avg_launch_ms": ms_b}}
     return out
 
 
@@ -315,9 +407,12 @@ def main():
         dfdist.barrier()
         torch.cuda.synchronize()
 
-    graphed = bool(opt.capture_step)
-    if graphed:
-        assert model._graph['graph'] is not None
+    graphed = bool(opt.capture_step) and model._graph['graph'] is not None
+    if opt.capture_step and not graphed:
+        print("bench: the step was not captured (%s); timing the eager step" % model._graph.get('capture_error', 'n/a'),
+              file=sys.stderr)
+    if world > 1:
+        model._collective_timing = []             # event pairs around every wait for a gradient exchange
     fence()
     timer.enabled = not graphed                   # HIP events cannot be recorded inside a graph replay
     t0 = time.perf_counter()
@@ -328,6 +423,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    coll_pairs = getattr(model, '_collective_timing', None)
+    model._collective_timing = None
     losses = model.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
     if graphed:
@@ -343,6 +440,16 @@ def main():
         model._graph['force_eager'] = False
 
     dt = dfdist.allreduce_max(dt, dev)            # the slowest rank's clock
+    collective = None
+    if world > 1:
+        exposed = sum(s_.elapsed_time(e_) for s_, e_ in (coll_pairs or [])) / max(args.steps, 1)
+        collective = {"backend": torch.distributed.get_backend(),
+                      "payload_bytes": 4 * sum(o.flat_g.numel() for o in model.optimizers),
+                      "arenas_bytes": [4 * o.flat_g.numel() for o in model.optimizers],
+                      "exposed_ms_per_step": dfdist.allreduce_max(exposed, dev),
+                      "note": "one all-reduce per network arena (G, R, F) issued back to back after the graph replay; "
+                              "exposed = the compute stream's wait for each arena (HIP event pairs), max over ranks; R's and "
+                              "F's exchange ride under G's Adam launch"}
 
     # PCIe-inclusive rate: the same step when set_input() is handed pinned host tensors (what a DataLoader with
     # pin_memory delivers, dfmir_amd/data.py): never the headline value, reported as `value_host_inputs`
@@ -366,17 +473,21 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         wg = ks.get("wgrad3x3_L", dict(launches=0, ms=0.0, flops=0.0))
         wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
-        # conv FLOPs per pair: 1581 G in the reference's step; 3 of its 6 NCE encoder
-        # passes recompute activations the forward pass already holds and are not re-executed here (349 G)
-        step_tflop = (1581e9 - 349e9) * B / 1e12
+        # conv FLOPs per pair: 1581 G in the reference's step; its 3 key-side NCE encoder passes
+        # (forward only, 3 x 68.06 G: SURVEY 3.3 / section 8 A4) recompute activations forward() already holds and are
+        # not re-executed here
+        step_gf = STEP_GF_REFERENCE - 3.0 * G_ENC_GF
+        step_tflop = step_gf * B / 1e3
         split = os.environ.get("DFMIR_CONV_FP32") is None
         nprod = 6.0 if os.environ.get("DFMIR_CONV_SPLIT", "f").startswith("b") else 3.0   # bf16x3 / fp16x2 (default)
         form = "bf16x3 (6 products)" if nprod == 6.0 else "scaled fp16x2 (3 products)"
         # The split kernels issue `nprod` 16-bit MFMA products per algorithmic fp32 MAC, with no padded k-step
         # (conv3x3_split_cs_k: 9 taps x 16 channels = 9 k-steps of K = 16 per chunk): issued = nprod x algorithmic.
+        # achieved = ALGORITHMIC FLOP/s, peak = that of the pipe the kernel issues on.
         peak = FP16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        issued = ach * nprod if split else ach
-        wg_issued = wg_tf * nprod if split else wg_tf
+        npm = nprod if split else 1.0
+        pmc, pmc_file = load_pmc()
+        traffic = pmc_traffic(pmc, "conv3x3_split_cs_k") if split and nprod == 3.0 else None
         result = {
             "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -388,18 +499,20 @@ def main():
                                    "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
                                    "VoxelMorph + bilinear warps, fwd+bwd+Adam), BASELINE configs[1]" % (S, S, B, args.ngf),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
-                         "frac": issued / peak,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak,
+                         "issued_tflops": ach * npm, "issued_frac": ach * npm / peak, "products_per_mac": npm,
+                         "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                          # HBM-side bytes of ONE launch of the dominant shape (256->256 3x3 @64^2, n = 32: 154.6 GFLOP,
-                         # 272 MB algorithmic), rocprofv3 PMC passes of scripts/prof_conv.sh (profiles/*_conv3x3s_pmc.md):
-                         # FETCH_SIZE + WRITE_SIZE
-                         "traffic": CS_TRAFFIC_BYTES if split and nprod == 3.0 else None,
-                         "traffic_note": "bytes per launch of the 154.6-GFLOP shape, PMC (FETCH_SIZE + WRITE_SIZE); "
-                                         "algorithmic 272 MB",
-                         "achieved_note": ("achieved = issued 16-bit matrix FLOP/s = %d x the algorithmic fp32 FLOP/s of the "
-                                           "timed launches (%s); peak = dense fp16 MFMA" % (int(nprod), form)) if split else
+                         # 272 MB algorithmic), rocprofv3 PMC passes of scripts/prof_conv.sh -> profiles/rNN_pmc.json
+                         "traffic": traffic,
+                         "traffic_note": ("bytes per launch of the 154.6-GFLOP shape, PMC FETCH_SIZE x2 (gfx950 correction) + "
+                                          "WRITE_SIZE, from %s; algorithmic 272 MB" % pmc_file) if traffic else None,
+                         "achieved_note": ("achieved = ALGORITHMIC fp32 FLOP/s of the timed launches (2*N*Cout*H*W*Cin*9 / "
+                                           "HIP-event time); peak = dense fp16 MFMA.  The kernel computes in fp32-grade "
+                                           "precision by issuing %d 16-bit products per MAC (%s): the matrix pipe runs at "
+                                           "issued_frac = %d x frac" % (int(nprod), form, int(nprod))) if split else
                                           "achieved = algorithmic fp32 FLOP/s; peak = dense fp32 MFMA",
-                         "algorithmic_tflops": ach, "products_per_mac": nprod if split else 1.0,
                          "kernel": ("conv3x3_split_cs_k<true,64,8> (fp32 operands split into 16-bit terms, %s on "
                                     "v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate; 128 couts x 8x32-pixel tile shared by "
                                     "two ping-pong wave groups; reflect dgrads = zero-padded form + ring kernel)" % form if split else
@@ -409,15 +522,21 @@ def main():
                                        "(profiles/r01_power_clock.md), i.e. a 1.84 PFLOP/s 16-bit roof at that clock",
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "timed_over": ("%d eager steps right after the timed region (which replays one hipGraph per step; "
-                                        "events cannot be recorded inside a replay)" % args.roofline_steps) if graphed else
-                                       "the timed region",
+                                        "events cannot be recorded inside a replay); the rocprofv3 kernel trace of the "
+                                        "replays themselves is profiles/*_bench_b16_kernel_stats.csv and agrees to ~3 %%"
+                                        % args.roofline_steps) if graphed else "the timed region",
                          "wgrad_kernel": ("conv3x3_wgrad_split2_k (same split; 64 ci x 128 co x 9 taps per workgroup, runs of "
                                           "2 rows x 16 px, double-buffered LDS, staggered wave groups)" if split else "conv3x3_wgrad_k<1,4> (v_mfma_f32_32x32x2_f32)"),
-                         "wgrad_achieved": wg_issued, "wgrad_frac": wg_issued / peak,
-                         "wgrad_algorithmic_tflops": wg_tf, "wgrad_launches_timed": wg["launches"],
-                         "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None},
+                         "wgrad_achieved": wg_tf, "wgrad_frac": wg_tf / peak, "wgrad_issued_frac": wg_tf * npm / peak,
+                         "wgrad_traffic": pmc_traffic(pmc, "conv3x3_wgrad_split2_k") if split and nprod == 3.0 else None,
+                         "wgrad_launches_timed": wg["launches"],
+                         "whole_step_tflops": step_tflop * args.steps / dt if S == 256 and args.ngf == 64 else None,
+                         "whole_step_note": "(%.0f - 3 x %.2f) = %.1f conv GFLOP per pair executed (key-side encoder passes "
+                                            "reused from forward()), x batch / step time" % (STEP_GF_REFERENCE, G_ENC_GF, step_gf)},
             "losses": {k: round(v, 6) for k, v in losses.items()},
         }
+        if collective is not None:
+            result["collective"] = collective
     dfdist.barrier()
     if rank == 0:
         ops.set_conv_profiler(None)
@@ -425,11 +544,18 @@ def main():
             model = None
             batches.clear()
             torch.cuda.empty_cache()
-            result["roofline_hbm"] = bench_warp_hbm(dev)
+            result["roofline_hbm"] = bench_warp_hbm(dev, pmc)
             torch.cuda.empty_cache()
-            result["also_3d"] = bench_3d(dev)
+            result["also_3d"] = bench_3d(dev, pmc)
+            torch.cuda.empty_cache()
+            # BASELINE configs[3]: 128^3, the plugin's 6-level features (SURVEY section 8 D2 "state which"), one hipGraph
+            # replay per step (eager, this size is host-bound: 3.7 ms of enqueue per 5.3 ms step)
+            result["also_3d_128"] = bench_3d(dev, pmc, shape=(128, 128, 128), feats=PLUGIN_FEATS, gflop_step=285.0,
+                                             label="BASELINE configs[3]", pmc_key="conv3d_split_k_34_16_128", steps=20,
+                                             warmup=3, capture=True)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(S)
+            result["cpu_baseline"]["also_3d_128"] = cpu_baseline_3d(result["cpu_baseline"]["cores"])
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

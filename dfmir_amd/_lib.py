@@ -40,6 +40,7 @@ _SIGS = {
     "dfmir_instnorm_bwd_pmax_ok": [c_longlong],
     "dfmir_instnorm_bwd_pmax": [P, P, P, P, P, c_int, c_longlong, c_int, P, P, c_int, P, P],
     "dfmir_patch_gather_bwd_gp": [P, P, P, c_int, c_int, c_longlong, c_int, c_int, P, P, P],
+    "dfmir_patch_gather_bwd_any": [P, P, P, c_int, c_int, c_longlong, c_int, c_int, P, P, P],
     "dfmir_absmax": [P, c_longlong, P, P],
     "dfmir_conv3d_split_ok": [_GP],
     "dfmir_conv3d_split_ws_floats": [c_int, c_int],

@@ -74,7 +74,7 @@ class BaseModel(object):
         """One LR scheduler per optimizer (training); weights from disk for inference / --continue_train."""
         if self.isTrain:
             self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
-        if opt.continue_train or not self.isTrain:
+        if not self.isTrain or opt.continue_train:      # reference order (base_model.py:97): TestOptions has no continue_train
             self.load_networks(opt.epoch)
         self.print_networks(opt.verbose)
 

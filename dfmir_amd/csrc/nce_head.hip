@@ -148,7 +148,7 @@ extern "C" int dfmir_patch_ids_draw(unsigned long long* state, const long long* 
   DF_ARG_CHECK(state && sizes && out && n_layers > 0 && n_layers <= 8 && n_sets > 0 && P > 0 && P <= DF_IDS_MAXP);
   DfIdSizes sz{};
   for (int l = 0; l < n_layers; ++l) {
-    DF_ARG_CHECK(sizes[l] >= P && sizes[l] < (1LL << 40));
+    DF_ARG_CHECK(sizes[l] >= P && sizes[l] < (1LL << 32));
     DF_ARG_CHECK(sizes[l] >= 2LL * P || sizes[l] <= DF_IDS_MAXPERM);   // rejection sampling needs S >= 2P; else sort S keys
     sz.S[l] = sizes[l];
   }

@@ -439,6 +439,15 @@ extern "C" int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids
   DF_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int dfmir_patch_gather_bwd_any(const float* dout, const long long* ids, float* dfeat, int B, int C,
+                                          long long S, int P, int G, float* dfeat_amax, float* dfeat_pmax, void* stream) {
+  DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0 && G > 0 && B % G == 0);
+  DF_ARG_CHECK(dfeat_amax || !dfeat_pmax);
+  patch_gather_bwd_k<false><<<df_grid((long long)B * C * P, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      dout, ids, dfeat, B, C, S, P, B / G, reinterpret_cast<unsigned*>(dfeat_amax), reinterpret_cast<unsigned*>(dfeat_pmax));
+  DF_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int dfmir_patch_gather_bwd(const float* dout, const long long* ids, float* dfeat, int B, int C,
                                       long long S, int P, void* stream) {
   DF_ARG_CHECK(dout && ids && dfeat && B > 0 && C > 0 && S > 0 && P > 0);

@@ -444,7 +444,7 @@ class PatchSampleF(nn.Module):
                 patch_id = patch_ids[feat_id]
             else:
                 patch_id = torch.randperm(S, device=feats[0].device)
-                patch_id = patch_id[:int(min(num_patches, patch_id.shape[0]))]
+                patch_id = ops.mark_distinct(patch_id[:int(min(num_patches, patch_id.shape[0]))])
             groups = patch_id.shape[0] if patch_id.dim() == 2 else 1
             x = ops.patch_gather(feat, patch_id, groups)      # [C, B*P]
             return_ids.append(patch_id)

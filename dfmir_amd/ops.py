@@ -121,6 +121,36 @@ def amax_of(t):
 
 _NO_SPLIT3D = bool(os.environ.get("DFMIR_CONV3D_FP32") or os.environ.get("DFMIR_CONV_FP32"))
 
+# Probe audit (DFMIR_PROBE_AUDIT=1 or set_probe_audit(True); debugging / test mode, one device sync per conv launch).
+# The fp16x2 split scales a tensor by its range PROBE, and probes are inherited (blur outputs, nearest_up2 + cat,
+# sampled-feature scatters, dgrad epilogues); a probe below the true maximum would overflow fp16 silently.  In audit
+# mode every split launch first measures the true max |t| of each operand with dfmir_absmax and raises if the probe
+# it was handed is smaller (per-plane dY maxima of the weight gradient included).
+_PROBE_AUDIT = {"on": bool(os.environ.get("DFMIR_PROBE_AUDIT")), "log": []}
+
+
+def set_probe_audit(on):
+    _PROBE_AUDIT["on"] = bool(on)
+    _PROBE_AUDIT["log"] = []
+    return _PROBE_AUDIT["log"]
+
+
+def _audit_probe(t, probe, what, plane_max=None):
+    true = torch.zeros(1, device=t.device, dtype=torch.float32)
+    tc = _c(t)
+    check(lib().dfmir_absmax(_p(tc), tc.numel(), _p(true), _st()))
+    pv, tv = float(probe.max()), float(true)
+    _PROBE_AUDIT["log"].append((what, pv, tv))
+    if tv == tv and not pv >= tv:
+        raise DfmirHipError("probe audit: %s has max|t| = %.6g but its range probe says %.6g" % (what, tv, pv))
+    if plane_max is not None:                 # per-(n, c) maxima of dY (split weight gradient)
+        pm = tc.reshape(plane_max.numel(), -1).abs().amax(dim=1)
+        bad = (plane_max.reshape(-1) < pm)
+        if bool(bad.any()):
+            i = int(bad.nonzero()[0])
+            raise DfmirHipError("probe audit: %s plane %d has max %.6g but its per-plane probe says %.6g"
+                                % (what, i, float(pm[i]), float(plane_max.reshape(-1)[i])))
+
 
 def _wants_amax(K, stride, dil, Di, Cin, Cout):
     """Shapes the split kernels take (the C side decides; this only avoids useless probes): 2-D 3x3 with more than
@@ -148,6 +178,8 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     if act_src is not None and not (split3d and act == 0 and tuple(act_src.shape) == tuple(y.shape) and act_src.is_contiguous()):
         act_src = None                                       # ... and only its epilogue applies an activation derivative
     _LAST_ACTGRAD[0] = act_src is not None
+    if _PROBE_AUDIT["on"] and x_amax is not None:
+        _audit_probe(x5, x_amax, "conv input %s -> %d ch, k=%s" % (tuple(x5.shape), Cout, tuple(K)))
 
     def launch():
         if split3d:
@@ -225,6 +257,12 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
                    pad[2], pad_mode, 0, 0.0)
     split3d = (x_amax is not None and dy_amax is not None and tuple(K) == (3, 3, 3)
                and bool(lib().dfmir_conv3d_split_wgrad_ok(ctypes.byref(g))))
+    if _PROBE_AUDIT["on"]:
+        if x_amax is not None:
+            _audit_probe(x5, x_amax, "wgrad x %s" % (tuple(x5.shape),))
+        if dy_amax is not None:
+            pm_ = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and not split3d) else None
+            _audit_probe(dy5, dy_amax, "wgrad dY %s" % (tuple(dy5.shape),), plane_max=pm_)
 
     def launch():
         if split3d:
@@ -1199,13 +1237,17 @@ class TapForkFn(Function):
             ptag = getattr(g, "_df_pmax", None)
             if ptag is not None and not (ptag[1] == g._version and ptag[2] == g.data_ptr()):
                 ptag = None
-            for dout, ids, (shape, B, C, S, Pn, G) in stash:
+            for dout, ids, (shape, B, C, S, Pn, G, distinct) in stash:
                 if atag is not None and atag[0].numel() != PROBE_SLOTS:
                     atag = None
                 if ptag is not None and (atag is None or ptag[0].numel() != B * C):
                     ptag = None
                 # with a probe: keep g's range probes (from the InstanceNorm backward that produced it) valid
-                if ptag is not None:
+                if not distinct:          # caller-supplied ids with repeats: accumulate with atomics
+                    check(lib().dfmir_patch_gather_bwd_any(_p(dout), _p(ids), _p(g), B, C, S, Pn, G,
+                                                           _p(atag[0]) if atag is not None else None,
+                                                           _p(ptag[0]) if ptag is not None else None, _st()))
+                elif ptag is not None:
                     check(lib().dfmir_patch_gather_bwd_gp(_p(dout), _p(ids), _p(g), B, C, S, Pn, G, _p(atag[0]),
                                                           _p(ptag[0]), _st()))
                 else:
@@ -1244,7 +1286,7 @@ class PatchGatherFn(Function):
     """feat [B,C,*sp], ids int64 [P] (or [G,P]: image b uses row b // (B/G)) -> channel-major rows [C, B*P]."""
 
     @staticmethod
-    def forward(ctx, feat, ids, groups=1):
+    def forward(ctx, feat, ids, groups=1, distinct=True):
         _need(feat, ids)
         ctx.stash = getattr(feat, "_df_tap_stash", None) if feat.is_contiguous() else None
         feat = _c(feat)
@@ -1258,25 +1300,59 @@ class PatchGatherFn(Function):
         out = torch.empty((C, B * Pn), device=feat.device, dtype=torch.float32)
         check(lib().dfmir_patch_gather_fwd_g(_p(feat), _p(ids), _p(out), B, C, S, Pn, G, _st()))
         ctx.save_for_backward(ids)
-        ctx.meta = (feat.shape, B, C, S, Pn, G)
+        ctx.meta = (feat.shape, B, C, S, Pn, G, bool(distinct))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        shape, B, C, S, Pn, G = ctx.meta
+        shape, B, C, S, Pn, G, distinct = ctx.meta
         dout = _c(dout)
         if ctx.stash is not None:                # collected by TapForkFn.backward, which runs after this node
             ctx.stash.append((dout, ids, ctx.meta))
-            return None, None, None
+            return None, None, None, None
         dfeat = zeros(shape, dout.device)
-        check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, G, None, _st()))
-        return dfeat, None, None
+        if distinct:
+            check(lib().dfmir_patch_gather_bwd_g(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, G, None, _st()))
+        else:
+            check(lib().dfmir_patch_gather_bwd_any(_p(dout), _p(ids), _p(dfeat), B, C, S, Pn, G, None, None, _st()))
+        return dfeat, None, None, None
+
+
+_DISTINCT_CHECKED = {}
+
+
+def mark_distinct(ids):
+    """Tag an id tensor as a P-subset per group (what torch.randperm / dfmir_patch_ids_draw yield)."""
+    ids._df_distinct = (ids._version, ids.data_ptr())
+    return ids
+
+
+def ids_distinct(ids, groups=1):
+    """Are the ids of every group pairwise distinct?  Generated ids carry the tag of mark_distinct; a caller-supplied
+    tensor (PatchSampleF.forward(patch_ids=...), model.patch_id_source) is checked on the host ONCE per tensor state
+    (one device sync).  The non-atomic scatter of patch_gather's backward is a data race on repeated ids, so those go
+    through the accumulating kernel instead."""
+    tag = getattr(ids, "_df_distinct", None)
+    if tag is not None and tag == (ids._version, ids.data_ptr()):
+        return True
+    key = (ids.data_ptr(), ids._version, tuple(ids.shape), int(groups))
+    hit = _DISTINCT_CHECKED.get(key)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False                      # no host round trip inside a capture: take the safe (atomic) form
+        srt = torch.sort(ids.reshape(int(groups), -1), dim=1).values
+        hit = bool((srt[:, 1:] != srt[:, :-1]).all()) if srt.shape[1] > 1 else True
+        if len(_DISTINCT_CHECKED) > 256:
+            _DISTINCT_CHECKED.clear()
+        _DISTINCT_CHECKED[key] = hit
+    return hit
 
 
 def patch_gather(feat, ids, groups=1):
-    return PatchGatherFn.apply(feat, ids, groups)
+    distinct = ids_distinct(ids, groups) if (torch.is_grad_enabled() and feat.requires_grad) else True
+    return PatchGatherFn.apply(feat, ids, groups, distinct)
 
 
 class L2NormFn(Function):
@@ -1464,7 +1540,7 @@ def draw_patch_ids(sizes, n_sets, P, device):
     out = torch.empty((L, n_sets, P), device=device, dtype=torch.int64)
     sz = (ctypes.c_longlong * L)(*[int(s) for s in sizes])
     check(lib().dfmir_patch_ids_draw(_p(st), sz, L, int(n_sets), int(P), _p(out), _st()))
-    return out
+    return mark_distinct(out)
 
 
 def patch_gather_multi(srcs, ids):
@@ -1491,6 +1567,9 @@ def patch_gather_multi(srcs, ids):
 # ------------------------------------------------------------------------------------------------
 # scalar losses
 # ------------------------------------------------------------------------------------------------
+_LAST_L1_WS = [None]
+
+
 class MaskedL1Fn(Function):
     @staticmethod
     def forward(ctx, a, b, mask, thr):
@@ -1504,6 +1583,7 @@ class MaskedL1Fn(Function):
         ws = torch.empty(8, device=a.device, dtype=torch.float32)
         out = torch.empty((), device=a.device, dtype=torch.float32)
         check(lib().dfmir_masked_l1_fwd(_p(a), _p(b), _p(m), float(thr), _p(ws), _p(out), a.numel(), _st()))
+        _LAST_L1_WS[0] = ws
         ctx.save_for_backward(a, b, m, ws)
         ctx.thr = float(thr)
         return out
@@ -1522,8 +1602,11 @@ class MaskedL1Fn(Function):
 
 
 def masked_l1(a, b, mask=None, thr=-0.95):
-    """sum(|a-b|*m)/sum(m); m = mask if given else (a>thr)|(b>thr)."""
-    return MaskedL1Fn.apply(a, b, mask, thr)
+    """sum(|a-b|*m)/sum(m); m = mask if given else (a>thr)|(b>thr).  The result carries `_df_mask_sum` = sum(m) (a
+    0-dim view of the kernel's workspace) for the global-batch normalisation of the data-parallel form."""
+    out = MaskedL1Fn.apply(a, b, mask, thr)
+    out._df_mask_sum = _LAST_L1_WS[0][1]
+    return out
 
 
 class FlowSmoothFn(Function):

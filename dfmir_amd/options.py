@@ -21,6 +21,8 @@ def default_options(**overrides):
         dvf_image='synthetic',     # build-defined: None = ./deform256.jpg as in the reference (raises when absent)
         reuse_key_features=True,   # build-defined: tap NCE key features in forward() (exact, see registration_model.forward)
         batch_query_passes=True,   # build-defined: one encoder pass for the three NCE terms' query batches
+        nce_sequential_keys=False,  # build-defined: key side of the NCE terms one netF call per term (reference order, host ids)
+        global_mask_norm=False,    # build-defined, DDP: masked-L1 normalised by the GLOBAL batch's mask sums (DataParallel semantics)
         capture_step=False)        # build-defined: replay the steady-state step as one hipGraph (REGISTRATIONModel)
     for k, v in overrides.items():
         setattr(opt, k, v)

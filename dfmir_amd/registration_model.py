@@ -181,9 +181,19 @@ class REGISTRATIONModel(BaseModel):
         only for its own: R's and F's exchange overlaps G's optimizer pass instead of following it."""
         opts = [self.optimizer_G, self.optimizer_R] + ([self.optimizer_F] if self.opt.netF == 'mlp_sample' else [])
         works = self.sync_gradients(async_op=True)
+        timing = getattr(self, '_collective_timing', None) if works else None     # bench.py: exposed collective time
         for i, o in enumerate(opts):
             if works and i < len(works) and works[i] is not None:
-                works[i].wait()
+                if timing is not None:
+                    # the compute stream's idle time while it waits for this arena's exchange: event pair around the wait
+                    s_ = torch.cuda.Event(enable_timing=True)
+                    e_ = torch.cuda.Event(enable_timing=True)
+                    s_.record()
+                    works[i].wait()
+                    e_.record()
+                    timing.append((s_, e_))
+                else:
+                    works[i].wait()
             o.step()
 
     def _optimize_parameters_graphed(self):
@@ -214,7 +224,16 @@ class REGISTRATIONModel(BaseModel):
 
         # capture needs two eager steps behind it (caches built) and a step whose random draws live on the device
         # (the batched NCE path; a wrapped netF / small feature maps / pinned ids go through the host generator)
-        if st['force_eager'] or (st['graph'] is None and (st['eager_steps'] < 2 or not getattr(self, '_nce_on_device', False))):
+        blocked = not getattr(self, '_nce_on_device', False) or (
+            getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False))   # a collective inside forward
+        if st['force_eager'] or (st['graph'] is None and (st['eager_steps'] < 2 or blocked)):
+            if st['eager_steps'] == 2 and not st['force_eager'] and not st.get('warned'):
+                st['warned'] = True
+                import warnings
+                warnings.warn("opt.capture_step is set but this step cannot be captured (patch ids come from the host: "
+                              "batch_query_passes=False / nce_sequential_keys / a patch_id_source that is not graph_safe / "
+                              "feature maps outside the device draw's sizes -- or opt.global_mask_norm puts a collective "
+                              "on the forward path); it stays eager")
             st['eager_steps'] += 1
             return eager_step()
         if st['graph'] is None:
@@ -227,9 +246,21 @@ class REGISTRATIONModel(BaseModel):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             ops.begin_graph_capture()
+            # Under a process group other threads of this process (RCCL's watchdog) may touch the HIP runtime while the
+            # capture is open: "thread_local" keeps their calls legal; single-process runs keep the strict default.
+            mode = "thread_local" if getattr(self, '_ddp', False) else "global"
             try:
-                with torch.cuda.graph(graph, stream=side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
                     self._forward_backward()
+            except Exception as exc:                                   # noqa: BLE001 -- keep training, eagerly
+                # nothing of a failed capture has executed: weights, moments and the id counter are where the last
+                # eager step left them; this step and every later one are enqueued eagerly
+                ops.end_graph_capture()
+                import warnings
+                warnings.warn("capturing the train step failed (%s: %s); the step stays eager" % (type(exc).__name__, exc))
+                st.update(graph=None, force_eager=True, capture_error="%s: %s" % (type(exc).__name__, exc))
+                torch.cuda.synchronize()
+                return eager_step()
             finally:
                 ops.end_graph_capture()
             st['outputs'] = {k: v for k, v in vars(self).items()
@@ -286,6 +317,8 @@ class REGISTRATIONModel(BaseModel):
         # mask = (real_B > -0.95) | (registered > -0.95);  mask2 = (idt_B > -0.95) | (registered > -0.95)
         l1_reg = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold')
         l1_idt = self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold')
+        if getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False):
+            l1_reg, l1_idt = self._global_mask_norm(l1_reg, l1_idt)
         smooth = smooothing_loss(y_pred[1])
         self._loss_inputs = (l1_reg, l1_idt, smooth)
         if stacked:
@@ -304,6 +337,26 @@ class REGISTRATIONModel(BaseModel):
             all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
         with ops.deferred_weight_grads():
             all_G_loss.backward()
+
+    def _global_mask_norm(self, *terms):
+        """opt.global_mask_norm (build-defined, data-parallel runs only): the reference's DataParallel evaluates
+        calculate_L1_loss on the gathered GLOBAL batch, i.e. sum_ranks(S_r) / sum_ranks(M_r) with S = sum |a-b| m and
+        M = sum m (registration_model.py:160-166,262); per-rank losses averaged by the gradient all-reduce give
+        mean_ranks(S_r / M_r) instead.  With this option each rank's term is rescaled by world * M_r / M_total (one
+        all-reduce of the two mask sums), so that the averaged gradient is exactly the global-batch one.  A collective
+        on the forward path: the step is then not captured into a hipGraph."""
+        import torch.distributed as dist
+        from . import distributed as dfdist
+        m = torch.stack([t._df_mask_sum for t in terms])
+        tot = m.clone()
+        if dfdist._staged(tot):
+            h = tot.cpu()
+            dist.all_reduce(h)
+            tot = h.to(m.device)
+        else:
+            dist.all_reduce(tot)
+        f = torch.where(tot > 0, m * float(dfdist.world_size()) / tot.clamp_min(1e-30), torch.ones_like(m))
+        return tuple(t * f[i] for i, t in enumerate(terms))
 
     # -- registration_model.py:174-183
     def set_input(self, input):
@@ -362,7 +415,11 @@ class REGISTRATIONModel(BaseModel):
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
         with torch.no_grad():  # feat_k is detached inside PatchNCELoss (patchnce.py:17): forward only
             feat_k = self._encode_keys(src)
-            feat_k_pool, sample_ids = self.netF(feat_k, self.opt.num_patches, None)
+            pinned = None
+            if getattr(self, 'patch_id_source', None) is not None:      # ids pinned by the caller (tests, replays of a log)
+                sets = self._patch_id_sets([f.shape[2] * f.shape[3] for f in feat_k], 1, self.opt.num_patches, feat_k[0].device)
+                pinned = [sets[l][0] for l in range(len(feat_k))]
+            feat_k_pool, sample_ids = self.netF(feat_k, self.opt.num_patches, pinned)
         feat_q_pool, _ = self.netF(feat_q, self.opt.num_patches, sample_ids)
         total_nce_loss = 0.0
         for f_q, f_k, crit, nce_layer in zip(feat_q_pool, feat_k_pool, self.criterionNCE, self.nce_layers):
@@ -388,10 +445,17 @@ class REGISTRATIONModel(BaseModel):
         sizes = [f.shape[2] * f.shape[3] for f in feat_q]
         P = self.opt.num_patches
         per_term_groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size
-        wrapped = 'forward' in vars(self.netF) or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS')
-        if not wrapped and self.opt.netF == 'mlp_sample' and all(S >= 2 * P or P <= S <= 4096 for S in sizes):
-            self._nce_on_device = getattr(self, 'patch_id_source', None) is None
-            ids = self._patch_id_sets(sizes, T, P, feat_q[0].device)          # [L, T, P]
+        # opt.nce_sequential_keys (build-defined, default False): the key side term by term through netF.forward, in the
+        # reference's call order with host-drawn ids (torch.randperm).  A netF.forward replaced on the instance (how older
+        # tests pin ids) implies it; `model.patch_id_source` is the hook that pins ids on the default path.
+        sequential = (getattr(self.opt, 'nce_sequential_keys', False) or 'forward' in vars(self.netF)
+                      or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS'))
+        if not sequential and self.opt.netF == 'mlp_sample' and all(S >= 2 * P or P <= S <= 4096 for S in sizes):
+            id_src = getattr(self, 'patch_id_source', None)
+            # a captured step may hold the ids only by device address: the device generator, or a source that declares
+            # `graph_safe` (same tensor every call, refreshed by its owner between steps)
+            self._nce_on_device = id_src is None or bool(getattr(id_src, 'graph_safe', False))
+            ids = self._patch_id_sets(sizes, T, P, feat_q[0].device)           # L x [T, P]
             with torch.no_grad():
                 keys = {}
                 for src, _ in terms:
@@ -411,6 +475,9 @@ class REGISTRATIONModel(BaseModel):
                 pools_k.append(pool)
                 ids_t.append(ids)
         ids_stacked = [torch.stack([ids_t[t][l] for t in range(T)]) for l in range(n_layers)]
+        for l in range(n_layers):
+            if all(getattr(ids_t[t][l], "_df_distinct", None) is not None for t in range(T)):
+                ops.mark_distinct(ids_stacked[l])
         fq_pool, _ = self.netF(feat_q, self.opt.num_patches, ids_stacked)   # [T,P] ids: grouped sampling
         losses = []
         for t in range(T):
@@ -423,12 +490,20 @@ class REGISTRATIONModel(BaseModel):
         return losses
 
     def _patch_id_sets(self, sizes, n_sets, P, device):
-        """[L, n_sets, P] patch positions; `self.patch_id_source(sizes, n_sets, P)` overrides the device draw
-        (tests pin ids with it)."""
+        """Per layer l a [n_sets, P] tensor of patch positions in [0, sizes[l]).  Default: one device launch draws
+        them all (ops.draw_patch_ids; seeded by ops.seed_patch_ids, NOT by torch.manual_seed after first use).
+        `self.patch_id_source(sizes, n_sets, P)` -> [L, n_sets, P] (or a list of L tensors) overrides the draw: tests
+        and replays of a recorded run pin ids with it.  Attributes of the source: `distinct` (every set is a P-subset:
+        the scatter of the backward may skip atomics; otherwise checked / accumulated safely), `graph_safe`."""
         src = getattr(self, 'patch_id_source', None)
-        if src is not None:
-            return src(sizes, n_sets, P).to(device)
-        return ops.draw_patch_ids(sizes, n_sets, P, device)
+        if src is None:
+            ids = ops.draw_patch_ids(sizes, n_sets, P, device)                # P-subsets by construction
+            return [ops.mark_distinct(ids[l]) for l in range(len(sizes))]
+        ids = src(sizes, n_sets, P)
+        out = [ids[l].to(device) for l in range(len(sizes))]
+        if getattr(src, 'distinct', False):
+            out = [ops.mark_distinct(t) for t in out]
+        return out
 
     # -- registration_model.py:255-263
     def calculate_L1_loss(self, src, tgt, mask):

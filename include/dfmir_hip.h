@@ -338,6 +338,11 @@ int dfmir_patch_gather_bwd_g(const float* dout, const long long* ids, float* dfe
 /* bwd_g that also keeps the per-plane maxima dfeat_pmax[B*C] (see dfmir_instnorm_bwd_pmax) valid.  accumulates */
 int dfmir_patch_gather_bwd_gp(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
                               int G, float* dfeat_amax, float* dfeat_pmax, void* stream); /* accumulates */
+/* The grouped scatter for ARBITRARY ids (repeats allowed within a group: a caller-supplied `patch_ids` list,
+ * models/networks.py:602-608): accumulates with atomics, as torch's index backward does.  dfeat_amax / dfeat_pmax
+ * optional (NULL), kept valid as above. */
+int dfmir_patch_gather_bwd_any(const float* dout, const long long* ids, float* dfeat, int B, int C, long long S, int P,
+                               int G, float* dfeat_amax, float* dfeat_pmax, void* stream); /* accumulates */
 /* Key side of several NCE terms in one launch: group g gathers its Bper images from srcs[g] ([Bper,C,S]; srcs is a HOST
  * array of G <= 8 device pointers, copied by value into the launch) at ids[g][0..P) -> out[c][(g*Bper+b)*P+p].
  * Replaces `feat_k_pool, sample_ids = self.netF(feat_k, num_patches, None)` called once per term

@@ -26,9 +26,9 @@ def _free_port():
     return p
 
 
-def _worker_2d(rank, world, port, q, capture):
+def _worker_2d(rank, world, port, q, capture, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, REPO)
     from dfmir_amd import distributed as D
     from dfmir_amd import ops
@@ -38,7 +38,7 @@ def _worker_2d(rank, world, port, q, capture):
     D.init_from_env()
     try:
         size, B = 64, 2
-        opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=8, gpu_ids=[0],
+        opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=8, gpu_ids=[torch.cuda.current_device()],
                               checkpoints_dir="/tmp/dfmir_ddp", name="r%d" % rank, capture_step=capture)
         torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights
         model = REGISTRATIONModel(opt)
@@ -60,9 +60,10 @@ def _worker_2d(rank, world, port, q, capture):
         summed = [o.flat_g.cpu() for o in model.optimizers]
         gathered = []
         for t in local:
-            parts = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            gathered.append(sum(parts))
+            t_ = t.cuda() if backend == "nccl" else t
+            parts = [torch.zeros_like(t_) for _ in range(world)]
+            dist.all_gather(parts, t_)
+            gathered.append(sum(parts).cpu())
         for o in model.optimizers:
             o.step()
         # then the public entry point for a few more steps (graph capture included when asked for)
@@ -80,17 +81,7 @@ def _worker_2d(rank, world, port, q, capture):
 
 @pytest.mark.parametrize("capture", [False, True], ids=["eager", "graph"])
 def test_registration_model_two_ranks(capture):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    r0, r1 = res
+    r0, r1 = _run_two_ranks_2d(capture, "gloo")
     for a, b in zip(r0[1], r1[1]):
         assert np.array_equal(a, b), "weights must be identical after the rank-0 broadcast in parallelize()"
     for s0, s1, g0 in zip(r0[2], r1[2], r0[3]):
@@ -102,6 +93,52 @@ def test_registration_model_two_ranks(capture):
     assert all(np.isfinite(v) for v in r0[5].values()) and all(np.isfinite(v) for v in r1[5].values())
     assert r0[5] != r1[5]                                   # different shards: per-rank losses differ
     assert r0[6] == r1[6] == capture
+
+
+def _run_two_ranks_2d(capture, backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (auto-runs on a >= 2-GPU box)")
+@pytest.mark.parametrize("capture", [False, True], ids=["eager", "graph"])
+def test_registration_model_two_gpus_rccl(capture):
+    """The same protocol over the REAL backend: init_process_group("nccl", device_id=...), weight broadcast, local
+    backward (eager, then captured + replayed), async per-arena all-reduce, Adam -- one rank per GPU."""
+    r0, r1 = _run_two_ranks_2d(capture, "nccl")
+    for a, b in zip(r0[1], r1[1]):
+        assert np.array_equal(a, b)
+    for s0, s1, g0 in zip(r0[2], r1[2], r0[3]):
+        assert np.array_equal(s0, s1)
+        assert np.allclose(s0, g0, rtol=1e-5, atol=1e-10)
+    for a, b in zip(r0[4], r1[4]):
+        assert np.array_equal(a, b), "replicas stay bit-identical through the optimizer steps"
+    assert r0[5] != r1[5] and r0[6] == r1[6] == capture
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (auto-runs on a >= 2-GPU box)")
+def test_bench_two_gpus_rccl():
+    """bench.py at the driver's N = 2 command line over RCCL, full geometry: the all-reduce payload is the 49.1 MB of
+    BASELINE.md section 3 and the exposed collective time is reported."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DFMIR_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "4"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 32
+    assert abs(r["collective"]["payload_bytes"] - 49.1e6) < 0.2e6
+    assert r["collective"]["backend"] == "nccl" and r["collective"]["exposed_ms_per_step"] >= 0.0
 
 
 def _worker_3d(rank, world, port, q):
@@ -163,3 +200,89 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert r["value"] > 0 and r["scaling"] == "weak" and r["step_submission"].startswith("hipGraph")
     assert abs(r["value"] - 4 * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-6 * r["value"]
     assert all(np.isfinite(v) for v in r["losses"].values())
+
+
+def _gmn_data():
+    """Four pairs whose mask sums differ strongly between the two halves of the batch (images 2, 3: top 60 % background)."""
+    from tests.golden import common as C
+    A, B = C.image_pair(300, 4, 64, 64)
+    A[2:, :, :38], B[2:, :, :38] = -1.0, -1.0
+    return A, B
+
+
+def _gmn_model(B, rank_tag, capture=False, gmn=False):
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    from tests.test_gpu_models import PinnedIds
+    opt = default_options(batch_size=B, crop_size=64, load_size=64, ngf=8, gpu_ids=[torch.cuda.current_device()],
+                          checkpoints_dir="/tmp/dfmir_ddp", name="gmn%s" % rank_tag, capture_step=capture,
+                          global_mask_norm=gmn)
+    torch.manual_seed(321)
+    model = REGISTRATIONModel(opt)
+    with torch.no_grad():
+        model.netR.flow.weight.mul_(1e4)
+    model.patch_id_source = PinnedIds("cuda")
+    return model, opt
+
+
+def _worker_gmn(rank, world, port, q, gmn):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, REPO)
+    from dfmir_amd import distributed as D
+    D.init_from_env()
+    try:
+        A, B = _gmn_data()
+        model, opt = _gmn_model(2, "r%d" % rank, gmn=gmn)
+        # the data-dependent init on the SAME pair everywhere (it only creates netF; rank 0's weights are broadcast)
+        init = {"A": A[:2].cuda(), "B": B[:2].cuda(), "A_paths": [""] * 2, "B_paths": [""] * 2}
+        model.data_dependent_initialize(init)
+        model.setup(opt)
+        model.parallelize()
+        sl = slice(2 * rank, 2 * rank + 2)
+        model.set_input({"A": A[sl].cuda(), "B": B[sl].cuda(), "A_paths": [""] * 2, "B_paths": [""] * 2})
+        model._forward_backward()
+        model.sync_gradients()
+        q.put((rank, [(o.flat_g * o.grad_scale).cpu().numpy() for o in model.optimizers],
+               [o.flat_p.cpu().numpy() for o in model.optimizers]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_mask_norm_equals_global_batch():
+    """opt.global_mask_norm: two ranks x batch 2 give, after the gradient average, the gradient of ONE process on the
+    global batch of 4 (the reference's DataParallel semantics, registration_model.py:160-166,262); without the option the
+    per-rank 1/sum(mask) normalisation gives a measurably different gradient on shards with unequal masks."""
+    A, B = _gmn_data()
+    res = {}
+    for gmn in (True, False):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_gmn, args=(r, 2, port, q, gmn)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        res[gmn] = out[0]
+    # the single-process run on the global batch, from the ranks' (broadcast) weights
+    model, opt = _gmn_model(4, "single")
+    model.data_dependent_initialize({"A": A[:2].cuda().repeat(2, 1, 1, 1), "B": B[:2].cuda().repeat(2, 1, 1, 1),
+                                     "A_paths": [""] * 4, "B_paths": [""] * 4})
+    model.setup(opt)
+    for o, w in zip(model.optimizers, res[True][2]):
+        o.flat_p.copy_(torch.from_numpy(w))
+    from dfmir_amd import ops
+    ops.bump_weights_epoch()
+    model.patch_id_source.call = 2          # as on the ranks: two init calls, then the step's three sets
+    model.set_input({"A": A.cuda(), "B": B.cuda(), "A_paths": [""] * 4, "B_paths": [""] * 4})
+    model._forward_backward()
+    ref = [o.flat_g.cpu().numpy() for o in model.optimizers]
+
+    def dist_to_ref(gs):
+        return max(float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(gs, ref))
+    d_on, d_off = dist_to_ref(res[True][1]), dist_to_ref(res[False][1])
+    assert d_on <= 2e-4, d_on
+    assert d_off >= 20 * d_on and d_off >= 2e-3, (d_on, d_off)

@@ -140,6 +140,89 @@ def _hip_model_from_oracle(st, size, B, ngf):
     return model, opt
 
 
+class PinnedIds(object):
+    """model.patch_id_source for the DEFAULT (batched, device-side) NCE path with the fixture's ids: set t of a call
+    with n_sets sets = C.patch_ids(call + t, layer, S, P), `call` advancing as the reference's netF calls do (0, 1 =
+    data-dependent init; 2, 3, 4 = step 0; ...).  graph_safe: one static device buffer per (sizes, n_sets, P), filled in
+    place; inside a capture nothing is copied -- the owner calls prefill() before every step that may replay."""
+    graph_safe = True
+    distinct = True          # randperm prefixes
+
+    def __init__(self, device=None):
+        self.call = 0
+        self.bufs = {}
+        self.device = device or DEV
+        self.filled = False
+
+    def _ids(self, sizes, n_sets, P):
+        ids = torch.stack([torch.stack([C.patch_ids(self.call + t, l, S, P) for t in range(n_sets)])
+                           for l, S in enumerate(sizes)])
+        self.call += n_sets
+        return ids
+
+    def prefill(self, sizes, n_sets, P):
+        key = (tuple(int(s) for s in sizes), int(n_sets), int(P))
+        ids = self._ids(sizes, n_sets, P)
+        if key not in self.bufs:
+            self.bufs[key] = ids.to(self.device)
+        else:
+            self.bufs[key].copy_(ids)
+        self.filled = True
+
+    def __call__(self, sizes, n_sets, P):
+        key = (tuple(int(s) for s in sizes), int(n_sets), int(P))
+        if not self.filled:
+            assert not torch.cuda.is_current_stream_capturing(), "prefill() before a step that is captured"
+            self.prefill(sizes, n_sets, P)
+        self.filled = False
+        return self.bufs[key]
+
+
+def nce_sizes(size):
+    """H*W of the five tapped layers (0, 4, 8, 12, 16) of ResnetGenerator at size x size."""
+    return [(size + 6) ** 2, size ** 2, (size // 2) ** 2, (size // 4) ** 2, (size // 4) ** 2]
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_whole_step_golden_default_path(golden, O, capture):
+    """Fixture S1 (the reference's own three train steps) through the DEFAULT production path -- device-side batched
+    NCE head, stacked query passes, scalar_combine; with capture=True the third step is a hipGraph replay -- ids pinned
+    through model.patch_id_source, no netF.forward wrap, no per-term fallback."""
+    from tests.test_oracle_golden import make_step
+    g = golden("step.npz")
+    st, size, B = make_step()
+    model, opt = _hip_model_from_oracle(st, size, B, 8)
+    opt.capture_step = capture
+    src = model.patch_id_source = PinnedIds()
+    model.set_dvf_image(torch.from_numpy(g["dvf_image"]))
+    A0, B0 = C.image_pair(93, B, size, size)
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    assert src.call == 2
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    for it in range(3):
+        A_, B_ = C.image_pair(100 + 2 * it, B, size, size)
+        src.prefill(nce_sizes(size), 3, opt.num_patches)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        assert model._nce_on_device and 'forward' not in vars(model.netF)
+        ls = model.get_current_losses()
+        got = np.array([ls[k] for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y")])
+        np.testing.assert_allclose(got, g["losses_%d" % it], rtol=3e-4 * (it + 1), atol=1e-6, err_msg="step %d" % it)
+        if it == 0:
+            close(model.fake_B, g["fake_B"], what="fake_B"); close(model.registered, g["registered"], what="registered")
+            close(model.regA, g["regA"], what="regA"); close(model.idt_B, g["idt_B"], what="idt_B")
+            close(model.dvf, g["dvf"], what="dvf")
+            for nm, o_ in (("G", model.optimizer_G), ("F", model.optimizer_F), ("R", model.optimizer_R)):
+                n2 = float(o_.flat_g.double().pow(2).sum().sqrt())
+                ref = float(g["gradnorm_" + nm])
+                assert abs(n2 - ref) <= 2e-3 * ref, (nm, n2, ref)
+    assert src.call == 2 + 9
+    if capture:
+        assert model._graph['graph'] is not None, "the third step must have been a hipGraph replay"
+
+
 def test_whole_step_golden(golden, O):
     """Config 1 geometry (64x64, batch 2): 3 consecutive train steps against the reference's own
     losses / outputs (fixture S1), patch ids pinned."""
@@ -350,8 +433,15 @@ def _full_size_oracle(O, B, double=False):
     return st, size, A0, B0
 
 
-def _full_size_hip(st, size, B, A0, B0):
+def _full_size_hip(st, size, B, A0, B0, default_path=False):
     model, opt = _hip_model_from_oracle(st, size, B, 64)
+    if default_path:       # the production NCE head (batched, device-side), ids pinned through the model's hook
+        model.patch_id_source = PinnedIds()
+        paths = [""] * B
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": paths, "B_paths": paths})
+        _load(model.netF, st.netF)
+        model.setup(opt)
+        return model
     call = [0]
     base_forward = model.netF.forward
 
@@ -369,12 +459,14 @@ def _full_size_hip(st, size, B, A0, B0):
     return model
 
 
-def test_full_size_step_vs_oracle(O):
+@pytest.mark.parametrize("default_path", [False, True], ids=["per-term-keys", "default-batched-head"])
+def test_full_size_step_vs_oracle(O, default_path):
     """256x256, ngf=64 (BASELINE configs[1] geometry) at batch 2: one step of the HIP path against the oracle on
-    identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3."""
+    identical seeded weights -- outputs within 1e-4 relative, losses within 1e-3.  Both NCE-head routes: the per-term
+    key calls a wrapped netF.forward selects, and the default batched device-side head (ids through patch_id_source)."""
     B = 2
     st, size, A0, B0 = _full_size_oracle(O, B)
-    model = _full_size_hip(st, size, B, A0, B0)
+    model = _full_size_hip(st, size, B, A0, B0, default_path)
     A_, B_ = C.image_pair(11, B, size, size)
     ref = st.step(A_, B_)
     model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
@@ -481,6 +573,63 @@ def test_registration3d_step_vs_oracle(O, shape, plugin):
                 close(ph.grad, po.grad, rtol=3e-3, atol=1e-9, what="grad " + k)
         for k in ("ncc", "grad"):
             assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-7), (it, k, got[k], ref[k])
+
+
+def test_probe_audit_full_steps():
+    """DFMIR_PROBE_AUDIT: every fp16x2-split launch of a 256x256 ngf-64 train step and of a 64^3 3-D step is handed a
+    range probe that bounds the true max |t| of its operand (inherited probes included: blur outputs, upcat, sampled-
+    feature scatters, dgrad epilogues, per-plane dY maxima) -- also with a 1e4x outlier pixel in the input, where a stale
+    or under-estimating probe would overflow fp16 to inf."""
+    from dfmir_amd import ops
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration3d import Registration3DModel
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    size, B = 256, 1
+    log = ops.set_probe_audit(True)
+    try:
+        opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=64, gpu_ids=[0],
+                              checkpoints_dir="/tmp/dfmir_ckpt", name="audit", dvf_image="synthetic")
+        torch.manual_seed(5)
+        model = REGISTRATIONModel(opt)
+        with torch.no_grad():
+            model.netR.flow.weight.mul_(1e5)             # a non-identity field: warps produce new values
+        A0, B0 = C.image_pair(9, B, size, size)
+        paths = [""] * B
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": paths, "B_paths": paths})
+        model.setup(opt)
+        for it in range(2):
+            A_, B_ = C.image_pair(11 + it, B, size, size)
+            if it == 1:
+                A_[0, 0, 100, 77] = 1e4                  # one outlier pixel, 1e4 x the data range
+                B_[0, 0, 31, 200] = -1e4
+            model.set_input({"A": A_, "B": B_, "A_paths": paths, "B_paths": paths})
+            model.optimize_parameters()
+            ls = model.get_current_losses()
+            assert all(v == v and abs(v) < 1e30 for v in ls.values()), ls
+            assert bool(torch.isfinite(model.fake_B).all())
+            for o_ in model.optimizers:
+                assert bool(torch.isfinite(o_.flat_g).all())
+        n2d = len(log)
+        assert n2d > 150, n2d                            # ~90 split forward/dgrad launches + wgrads per step, 2 steps
+        shape = (64, 64, 64)
+        torch.manual_seed(6)
+        m3 = Registration3DModel(shape, None, device=DEV)
+        with torch.no_grad():
+            m3.netR.flow.weight.mul_(3e4)
+        for it in range(2):
+            A = C.rand(31 + it, 1, 1, *shape)
+            Bv = 0.5 * A + 0.5 * C.rand(41 + it, 1, 1, *shape)
+            if it == 1:
+                A[0, 0, 10, 20, 30] = 1e4
+            m3.set_input({"A": A, "B": Bv})
+            m3.optimize_parameters()
+            assert bool(torch.isfinite(m3.optimizer_R.flat_g).all())
+        assert len(log) - n2d > 30, len(log) - n2d
+        # the audit really saw inherited probes that are loose upper bounds (probe > true max), never below
+        assert all(pv >= tv for _, pv, tv in log if tv == tv)
+        assert any(pv > tv * 1.0001 for _, pv, tv in log)
+    finally:
+        ops.set_probe_audit(False)
 
 
 # ------------------------------------------------------------------ full-size, size-independent properties
