@@ -88,6 +88,8 @@ _SIGS = {
     "dfmir_warp_bwd_own": [c_int, P, P, P, P, P] + [c_int] * 7 + [P, P],
     "dfmir_resize_fwd": [P, P] + [c_int] * 7 + [c_float, P],
     "dfmir_resize_bwd": [P, P] + [c_int] * 7 + [c_float, P],
+    "dfmir_resize_bwd_ws_floats": [c_int] * 7,
+    "dfmir_resize_bwd_sep": [P, P] + [c_int] * 7 + [c_float, P, P],
     "dfmir_patch_gather_fwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
     "dfmir_patch_gather_bwd": [P, P, P, c_int, c_int, c_longlong, c_int, P],
     "dfmir_patch_gather_bwd_amax": [P, P, P, c_int, c_int, c_longlong, c_int, P, P],
@@ -138,6 +140,7 @@ def lib():
         h.dfmir_weight_pack_floats.restype = c_longlong
         h.dfmir_conv3d_split_ws_floats.restype = c_longlong
         h.dfmir_warp_bwd_own_ws_floats.restype = c_longlong
+        h.dfmir_resize_bwd_ws_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []
         h.dfmir_last_error.restype = ctypes.c_char_p
         _lib = h

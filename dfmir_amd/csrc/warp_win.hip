@@ -274,8 +274,23 @@ __device__ void voxel_bwd_slow(const float* __restrict__ dout_b, const float* __
   const int S = D * H * W;                                                             \
   const int sp = (z * H + y) * W + x
 
+// WW_OCC (A/B build switch, scripts/build_ko.sh warp_win WW_OCC 1 2 3): bit 0 = the forward kernel at 8 waves per SIMD
+// (64 VGPRs: 4 instead of 3 workgroups per CU), bit 1 = pass 1 of the owner-gather backward at 6 waves per SIMD
+#ifndef WW_OCC
+#define WW_OCC 1     // measured (r03): forward 28.4 -> 28.2 us; bit 1 made pass 1 37 % slower (32 spilled registers)
+#endif
+#if (WW_OCC & 1)
+#define WW_FWD_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define WW_FWD_ATTR
+#endif
+#if (WW_OCC & 2)
+#define WW_OWN_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define WW_OWN_ATTR
+#endif
 template <int ND>
-__global__ __launch_bounds__(WNT) void warp_win_fwd_k(const float* __restrict__ src, const float* __restrict__ flow,
+__global__ __launch_bounds__(WNT) WW_FWD_ATTR void warp_win_fwd_k(const float* __restrict__ src, const float* __restrict__ flow,
                                                       float* __restrict__ out, int B, int C, int D, int H, int W,
                                                       int add_identity, int ntx, int nty, int ntz) {
   __shared__ float win[WinGeom<ND>::EZ * WinGeom<ND>::EY * WRS];
@@ -443,41 +458,81 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_k(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Backward without device-scope atomics on d(src), bit-reproducible ("owner gathers"):
-//   pass 1  warp_win_bwd_own_k   as warp_win_bwd_k, but the privatised d(src) window is accumulated in 64-bit FIXED
-//           POINT (LDS integer atomics are associative: the sum does not depend on the order the lanes arrive in),
-//           scaled by 2^40 / 2^ceil(log2 max|contribution| of the workgroup), converted back and written DENSELY to a
-//           scratch slot of its tile together with the window origin.  The origin is clamped so that the window stays
-//           inside the 3 x 3 (x 3) tiles around its own; voxels whose taps leave it go to a list.
-//   pass 2  warp_win_gather_k    every d(src) cell sums, in fixed tile order, the windows of its 27 (9) neighbour tiles
-//           that cover it and writes the result (no pre-zeroed d(src) needed).
+//   pass 1  warp_win_bwd_own_k   as warp_win_bwd_k, but the privatised d(src) window is accumulated in 32-bit FIXED
+//           POINT (LDS integer atomics are associative: the sum does not depend on the order the lanes arrive in).
+//           Scale: 2^(30 - be) with 2^be >= SUM over the workgroup's contributions of |g| -- every voxel spreads its g
+//           with weights that sum to 1, so no cell can exceed that sum and the accumulation cannot overflow, whatever
+//           the field (collapsing fields included).  Absolute error per contribution <= 2^(be - 31), i.e. <= 2^-19 x
+//           the workgroup's MEAN |g| for a 2048-voxel tile (tests bound it against the fp32-atomic path).  The window
+//           is converted back and only its TOUCHED SUB-BOX [0,ez) x [0,ey) x [0,ex) (ex a multiple of 4) is written to
+//           the tile's scratch slot; origin and extents go to the tile's metadata.  The origin is clamped so that the
+//           window stays inside the 3 x 3 (x 3) tiles around its own; voxels whose taps leave it go to the tile's own
+//           list (no global counter: nothing has to be zeroed before the launch).  A non-finite contribution makes the
+//           whole sub-box of that channel NaN (the reference's grid_sample backward propagates NaN / inf as well).
+//   pass 2  warp_win_gather_k    every d(src) cell sums, in fixed tile order, the sub-boxes of its 27 (9) neighbour
+//           tiles that cover it and writes the result (no pre-zeroed d(src) needed).
 //   pass 3  warp_win_slow_k      the listed voxels (none on registration-like fields), scalar routine + atomics.
 // ------------------------------------------------------------------------------------------------
-template <int ND> struct WinOwn { static constexpr int CELLS = WinGeom<ND>::EZ * WinGeom<ND>::EY * WEX; };
+template <int ND> struct WinOwn {
+  static constexpr int CELLS = WinGeom<ND>::EZ * WinGeom<ND>::EY * WEX;
+  static constexpr int TILE_VOX = WinGeom<ND>::TZ * WinGeom<ND>::TY * WTX;     // 2048: slow-list capacity of a tile
+};
+static constexpr int WMETA = 8;      // ints of metadata per tile: oz, oy, ox, (ez << 16 | ey << 8 | ex), nslow, -, -, -
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum_x(float v) {       // xor butterfly: every lane ends with the same bits
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 
 template <int ND>
-__global__ __launch_bounds__(WNT) void warp_win_bwd_own_k(const float* __restrict__ dout, const float* __restrict__ src,
+__global__ __launch_bounds__(WNT) WW_OWN_ATTR void warp_win_bwd_own_k(const float* __restrict__ dout, const float* __restrict__ src,
                                                           const float* __restrict__ flow, float* __restrict__ dflow,
                                                           int B, int C, int D, int H, int W, int add_identity,
                                                           int flow_into_src, int ntx, int nty, int ntz,
-                                                          float* __restrict__ scratch, int* __restrict__ origins,
-                                                          unsigned* __restrict__ slow) {
+                                                          float* __restrict__ scratch, int* __restrict__ meta,
+                                                          unsigned* __restrict__ slowlist) {
   using GG = WinGeom<ND>;
-  __shared__ long long winq[GG::EZ * GG::EY * WRS];       // phase A: the src window (as floats); phase B: fixed point
+  constexpr int NW = GG::EZ * GG::EY * WRS;
+  __shared__ float win[NW];                                // phase A: the src window; phase B: int32 fixed point
   __shared__ int red[3 * WNT / 64];
   __shared__ float redf[WNT / 64];
-  float* win = reinterpret_cast<float*>(winq);
+  __shared__ int s_ext[3];
+  __shared__ int s_nslow, s_bad;
+  int* wini = reinterpret_cast<int*>(win);
   WIN_THREAD_COORDS();
   // linear tile id as win_tile decodes it
   const int tileL = ((b * ntz + tzb_) * nty + tyb_) * ntx + tx_;
   WinThread<ND> th;
   int oz, oy, ox;
   const bool need_own = add_identity || flow_into_src;
+  if (t == 0) { s_ext[0] = 0; s_ext[1] = 0; s_ext[2] = 0; s_nslow = 0; }
   win_prologue<ND>(flow, b, S, H, W, D, z, y, x, active, need_own, th, red, oz, oy, ox, true, tzb_ * G::TZ, tyb_ * G::TY,
                    tx_ * WTX);
-  if (t == 0) { origins[tileL * 4] = oz; origins[tileL * 4 + 1] = oy; origins[tileL * 4 + 2] = ox; }
   float fm[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) fm[e] = ((th.fast >> e) & 1u) ? 1.f : 0.f;
+  // touched sub-box of the window: upper corner of every fast voxel's taps (and its own cell), workgroup maximum
+  {
+    int uz = -1, uy = -1, ux = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((th.fast >> e) & 1u) {
+        const int bse = th.base[e];
+        const int lx = bse % WRS, r = bse / WRS;
+        uz = max(uz, (ND == 3) ? r / GG::EY + 1 : 0);
+        uy = max(uy, r % GG::EY + 1);
+        ux = max(ux, lx + 1);
+        if (need_own) { uz = max(uz, z - oz); uy = max(uy, y - oy); ux = max(ux, x + e - ox); }
+      }
+    uz = wave_max_i(uz); uy = wave_max_i(uy); ux = wave_max_i(ux);
+    if ((t & 63) == 0 && ux >= 0) { atomicMax(&s_ext[0], uz + 1); atomicMax(&s_ext[1], uy + 1); atomicMax(&s_ext[2], ux + 1); }
+  }
   // ---- phase A: d(flow) (identical to warp_win_bwd_k)
   float gz[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gx[4] = {0.f, 0.f, 0.f, 0.f};
   if (dflow || flow_into_src) {
@@ -519,12 +574,13 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_own_k(const float* __restric
       *reinterpret_cast<float4*>(fb + (long long)(ND - 1) * S) = make_float4(gx[0], gx[1], gx[2], gx[3]);
     }
   }
-  // ---- phase B: d(src) of the fast voxels, fixed point in LDS, dense store of the window
-  constexpr int NW = GG::EZ * GG::EY * WRS;
+  // ---- phase B: d(src) of the fast voxels, fixed point in LDS, store of the touched sub-box
   const int own = ((z - oz) * G::EY + (y - oy)) * WRS + (x - ox);
+  int ez = 0, ey = 0, ex4 = 0;
   for (int c = 0; c < C; ++c) {
     float gg[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
     float m = 0.f;
+    bool bad = false;
     if (active && th.fast) {
       const float4 g4 = *reinterpret_cast<const float4*>(dout + ((long long)b * C + c) * S + sp);
       gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
@@ -533,33 +589,37 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_own_k(const float* __restric
         gg[e] *= fm[e];
         ov[e] = add_identity ? gg[e] : 0.f;
         if (flow_into_src) ov[e] += fm[e] * ((ND == 3) ? (c == 0 ? gz[e] : (c == 1 ? gy[e] : gx[e])) : (c == 0 ? gy[e] : gx[e]));
-        m = fmaxf(m, fmaxf(fabsf(gg[e]), fabsf(ov[e])));
+        const float am = fabsf(gg[e]) + fabsf(ov[e]);
+        bad = bad || !(am < 3.0e38f);                       // NaN or inf
+        m += am;
       }
     }
-    // workgroup maximum of |contribution| -> power-of-two scale (NaN / inf propagate as a saturated scale)
-    m = wave_max(m);
+    // workgroup SUM of |contribution| -> power-of-two scale; fixed reduction order (bit-reproducible)
+    m = wave_sum_x(bad ? 0.f : m);
     __syncthreads();                                        // phase A / previous channel is done with the window
     if ((t & 63) == 0) redf[t >> 6] = m;
-    for (int u = t; u < NW; u += WNT) winq[u] = 0;
+    if (t == 0) s_bad = 0;
+    for (int u = t; u < NW; u += WNT) wini[u] = 0;
     __syncthreads();
+    if (bad) s_bad = 1;
     float bm = redf[0];
 #pragma unroll
-    for (int q = 1; q < WNT / 64; ++q) bm = fmaxf(bm, redf[q]);
-    int be = (int)((__float_as_uint(bm) >> 23) & 0xffu) - 127;          // |v| < 2^(be+1)
-    be = bm > 0.f ? (be > 60 ? 60 : (be < -60 ? -60 : be)) : 0;
-    const float up = __uint_as_float((unsigned)(40 - be - 1 + 127) << 23);   // 2^(39-be): |v * up| < 2^40
-    const float dn = __uint_as_float((unsigned)(be + 1 - 40 + 127) << 23);
-    if (active && th.fast) {
+    for (int q = 1; q < WNT / 64; ++q) bm += redf[q];
+    int be = (int)((__float_as_uint(bm) >> 23) & 0xffu) - 127 + 1;      // sum < 2^be
+    be = bm > 0.f ? (be > 90 ? 90 : (be < -90 ? -90 : be)) : 0;
+    const float up = __uint_as_float((unsigned)(30 - be + 127) << 23);        // |cell * up| <= 2^30
+    const float dn = __uint_as_float((unsigned)(be - 30 + 127) << 23);
+    if (active && th.fast && !bad) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (!((th.fast >> e) & 1u)) continue;
-        long long* p = winq + th.base[e];
+        int* p = wini + th.base[e];
         const float g = gg[e] * up;
         const float wx1 = th.wx1[e], wy1 = th.wy1[e], wz1 = th.wz1[e];
         const float wx0 = 1.f - wx1, wy0 = 1.f - wy1, wz0 = 1.f - wz1;
-#define OWN_ADD(ptr_, val_) atomicAdd(reinterpret_cast<unsigned long long*>(ptr_), (unsigned long long)__float2ll_rn(val_))
+#define OWN_ADD(ptr_, val_) atomicAdd(reinterpret_cast<unsigned*>(ptr_), (unsigned)__float2int_rn(val_))
         if (ND == 3) {
-          long long* q = p + G::EY * WRS;
+          int* q = p + G::EY * WRS;
           OWN_ADD(p, g * wz0 * wy0 * wx0);
           OWN_ADD(p + 1, g * wz0 * wy0 * wx1);
           OWN_ADD(p + WRS, g * wz0 * wy1 * wx0);
@@ -574,48 +634,72 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_own_k(const float* __restric
           OWN_ADD(p + WRS, g * wy1 * wx0);
           OWN_ADD(p + WRS + 1, g * wy1 * wx1);
         }
-        if (need_own) OWN_ADD(winq + own + e, ov[e] * up);
+        if (need_own) OWN_ADD(wini + own + e, ov[e] * up);
 #undef OWN_ADD
       }
     }
     __syncthreads();
+    ez = s_ext[0]; ey = s_ext[1]; ex4 = (s_ext[2] + 3) & ~3;
+    if (ND == 2) ez = ey > 0 ? 1 : 0;
+    const bool anybad = s_bad != 0;
     float* slot = scratch + ((long long)tileL * C + c) * WinOwn<ND>::CELLS;
-    for (int u = t; u < WinOwn<ND>::CELLS; u += WNT) {
-      const int lx = u % WEX, r = u / WEX;
-      slot[u] = (float)winq[r * WRS + lx] * dn;
+    const int qx = ex4 >> 2, nq = ez * ey * qx;
+    for (int u = t; u < nq; u += WNT) {
+      const int q = u % qx, r = u / qx;                    // r = lz * ey + ly within the sub-box
+      const int ly = r % ey, lz = r / ey;
+      const int* wp = wini + (lz * GG::EY + ly) * WRS + 4 * q;
+      float4 v;
+      if (anybad) {
+        v.x = v.y = v.z = v.w = __uint_as_float(0x7fc00000u);
+      } else {
+        v.x = (float)wp[0] * dn; v.y = (float)wp[1] * dn; v.z = (float)wp[2] * dn; v.w = (float)wp[3] * dn;
+      }
+      *reinterpret_cast<float4*>(slot + (lz * GG::EY + ly) * WEX + 4 * q) = v;
     }
   }
-  // ---- the voxels whose taps leave the window: listed for pass 3
+  // ---- the voxels whose taps leave the window: listed (per tile) for pass 3
   if (active && th.fast != 15u) {
     const unsigned sl = ~th.fast & 15u;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if ((sl >> e) & 1u) {
-        const unsigned i = atomicAdd(slow, 1u);
-        slow[1 + i] = (unsigned)(b * S + sp + e);
+        const int i = atomicAdd(&s_nslow, 1);
+        slowlist[(long long)tileL * WinOwn<ND>::TILE_VOX + i] = (unsigned)(b * S + sp + e);
       }
+  }
+  __syncthreads();
+  if (t == 0) {
+    int* mt = meta + (long long)tileL * WMETA;
+    mt[0] = oz; mt[1] = oy; mt[2] = ox;
+    mt[3] = (s_ext[0] << 16) | (s_ext[1] << 8) | ((s_ext[2] + 3) & ~3);
+    mt[4] = s_nslow;
   }
 }
 
 template <int ND>
-__global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict__ scratch, const int* __restrict__ origins,
+__global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict__ scratch, const int* __restrict__ meta,
                                                          float* __restrict__ dsrc, int B, int C, int D, int H, int W,
                                                          int ntx, int nty, int ntz) {
-  // one workgroup per tile, the thread <-> voxel-quad map of pass 1: the 27 (9) neighbour origins are workgroup-uniform
-  // (scalar loads), the per-quad coverage test is a few integer compares, only covering windows are read
+  // one workgroup per tile, the thread <-> voxel-quad map of pass 1: the 27 (9) neighbour origins / extents are
+  // workgroup-uniform, the per-quad coverage test is a few integer compares, only covering sub-boxes are read
   WIN_THREAD_COORDS();
   constexpr int NZ = (ND == 3) ? 3 : 1, NN = NZ * 9;
-  // the neighbour tiles' window origins, fetched once per workgroup (one lane each) and kept in LDS; -1 = no such tile
-  __shared__ int org[NN][4];
+  // the neighbour tiles' window origins and extents, fetched once per workgroup (one lane each); -1 = no such tile
+  __shared__ int org[NN][8];
   if (t < NN) {
     const int iz = t / 9, iy = (t / 3) % 3, ix = t % 3;
     const int nz = tzb_ + (ND == 3 ? iz - 1 : 0), ny = tyb_ + iy - 1, nx = tx_ + ix - 1;
     const bool ok = (unsigned)nz < (unsigned)ntz && (unsigned)ny < (unsigned)nty && (unsigned)nx < (unsigned)ntx;
     const int tl = ok ? ((b * ntz + nz) * nty + ny) * ntx + nx : -1;
-    org[t][0] = ok ? origins[tl * 4] : 0;
-    org[t][1] = ok ? origins[tl * 4 + 1] : 0;
-    org[t][2] = ok ? origins[tl * 4 + 2] : 0;
+    const int* mt = meta + (long long)(ok ? tl : 0) * WMETA;
+    const int ext = ok ? mt[3] : 0;
+    org[t][0] = ok ? mt[0] : 0;
+    org[t][1] = ok ? mt[1] : 0;
+    org[t][2] = ok ? mt[2] : 0;
     org[t][3] = tl;
+    org[t][4] = (ND == 3) ? (ext >> 16) & 0xff : (ext ? 1 : 0);
+    org[t][5] = (ext >> 8) & 0xff;
+    org[t][6] = ext & 0xff;
   }
   __syncthreads();
   if (!active) return;
@@ -627,8 +711,8 @@ __global__ __launch_bounds__(WNT) void warp_win_gather_k(const float* __restrict
 #pragma unroll
   for (int i = 0; i < NN; ++i) {
     const int lz = z - org[i][0], ly = y - org[i][1], lx = x - org[i][2];     // ox is a multiple of 4: whole quad or none
-    const bool cov = org[i][3] >= 0 && (unsigned)lz < (unsigned)G::EZ && (unsigned)ly < (unsigned)G::EY &&
-                     (unsigned)lx <= (unsigned)(WEX - 4);
+    const bool cov = org[i][3] >= 0 && (unsigned)lz < (unsigned)org[i][4] && (unsigned)ly < (unsigned)org[i][5] &&
+                     lx >= 0 && lx + 4 <= org[i][6];
     off[i] = cov ? (unsigned)(((lz * G::EY + ly) * WEX + lx) * 4) : OOBG;
   }
   for (int c = 0; c < C; ++c) {
@@ -656,11 +740,15 @@ template <int ND>
 __global__ __launch_bounds__(256) void warp_win_slow_k(const float* __restrict__ dout, const float* __restrict__ src,
                                                        const float* __restrict__ flow, float* __restrict__ dsrc,
                                                        float* __restrict__ dflow, int B, int C, int D, int H, int W,
-                                                       int add_identity, int flow_into_src, const unsigned* __restrict__ slow) {
-  const unsigned n = slow[0];
+                                                       int add_identity, int flow_into_src, const int* __restrict__ meta,
+                                                       const unsigned* __restrict__ slowlist, int T) {
+  // 4 tiles per workgroup (one wave each): a tile's count is a wave-uniform load, empty tiles cost nothing else
+  const int tile = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (tile >= T) return;
+  const int n = meta[(long long)tile * WMETA + 4];
   const int S = D * H * W;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const unsigned v = slow[1 + i];
+  for (int i = threadIdx.x & 63; i < n; i += 64) {
+    const unsigned v = slowlist[(long long)tile * WinOwn<ND>::TILE_VOX + i];
     const int b = (int)(v / (unsigned)S), sp = (int)(v - (unsigned)b * (unsigned)S);
     const int x = sp % W, y = (sp / W) % H, z = sp / (W * H);
     voxel_bwd_slow<ND>(dout + (long long)b * C * S, src + (long long)b * C * S, flow + (long long)b * ND * S,
@@ -713,13 +801,13 @@ int df_warp_win_bwd_try(int nd, const float* dout, const float* src, const float
   return 1;
 }
 
-// owner-gather backward: scratch = [origins: 4 ints per tile][slow: 1 + B*S uints][windows: tiles * C * CELLS floats]
+// owner-gather backward: scratch = [metadata: WMETA ints per tile][slow lists: TILE_VOX uints per tile][windows: tiles * C * CELLS floats]
 template <int ND>
 static long long own_ws_floats(int B, int C, int D, int H, int W) {
   int ntx, nty, ntz; long long grid;
   if (!win_eligible<ND>(B, C, D, H, W, ntx, nty, ntz, grid)) return 0;
-  const long long T = (long long)ntx * nty * ntz * B, S = (long long)D * H * W;
-  long long n = 4 * T + 1 + (long long)B * S;
+  const long long T = (long long)ntx * nty * ntz * B;
+  long long n = WMETA * T + T * WinOwn<ND>::TILE_VOX;
   n = (n + 3) & ~3LL;
   return n + T * C * WinOwn<ND>::CELLS;
 }
@@ -732,17 +820,17 @@ static int own_launch(const float* dout, const float* src, const float* flow, fl
                       int H, int W, int add_identity, int flow_into_src, float* ws, hipStream_t st) {
   int ntx, nty, ntz; long long grid;
   if (!win_eligible<ND>(B, C, D, H, W, ntx, nty, ntz, grid)) return 0;
-  const long long T = (long long)ntx * nty * ntz * B, S = (long long)D * H * W;
-  int* origins = reinterpret_cast<int*>(ws);
-  unsigned* slow = reinterpret_cast<unsigned*>(ws) + 4 * T;
-  long long off = 4 * T + 1 + (long long)B * S;
+  const long long T = (long long)ntx * nty * ntz * B;
+  int* meta = reinterpret_cast<int*>(ws);
+  unsigned* slow = reinterpret_cast<unsigned*>(ws) + WMETA * T;
+  long long off = WMETA * T + T * WinOwn<ND>::TILE_VOX;
   off = (off + 3) & ~3LL;
   float* windows = ws + off;
-  if (df_zero_async(reinterpret_cast<float*>(slow), 1, st) != hipSuccess) return -1;
   warp_win_bwd_own_k<ND><<<(unsigned)grid, WNT, 0, st>>>(dout, src, flow, dflow, B, C, D, H, W, add_identity, flow_into_src,
-                                                         ntx, nty, ntz, windows, origins, slow);
-  warp_win_gather_k<ND><<<(unsigned)grid, WNT, 0, st>>>(windows, origins, dsrc, B, C, D, H, W, ntx, nty, ntz);
-  warp_win_slow_k<ND><<<64, 256, 0, st>>>(dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity, flow_into_src, slow);
+                                                         ntx, nty, ntz, windows, meta, slow);
+  warp_win_gather_k<ND><<<(unsigned)grid, WNT, 0, st>>>(windows, meta, dsrc, B, C, D, H, W, ntx, nty, ntz);
+  warp_win_slow_k<ND><<<(unsigned)((T + 3) / 4), 256, 0, st>>>(dout, src, flow, dsrc, dflow, B, C, D, H, W, add_identity,
+                                                              flow_into_src, meta, slow, (int)T);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
 int df_warp_win_bwd_own_try(int nd, const float* dout, const float* src, const float* flow, float* dsrc, float* dflow,

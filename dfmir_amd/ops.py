@@ -1174,6 +1174,9 @@ def vecint_step(v):
     return VecIntStepFn.apply(v)
 
 
+_RESIZE_ONEPASS = bool(os.environ.get("DFMIR_RESIZE_ONEPASS"))     # A/B switch: the one-pass gather adjoint
+
+
 class ResizeFn(Function):
     @staticmethod
     def forward(ctx, x, out_sp, mult):
@@ -1195,8 +1198,14 @@ class ResizeFn(Function):
         xs, planes, isp, osp, mult = ctx.meta
         dy = _c(dy)
         dx = torch.empty(xs, device=dy.device, dtype=torch.float32)
-        check(lib().dfmir_resize_bwd(_p(dy), _p(dx), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
-                                     mult, _st()))
+        n = lib().dfmir_resize_bwd_ws_floats(planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2])
+        if n > 0 and not _RESIZE_ONEPASS:
+            ws = torch.empty(n + 4, device=dy.device, dtype=torch.float32)
+            check(lib().dfmir_resize_bwd_sep(_p(dy), _p(dx), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
+                                             mult, _p(ws), _st()))
+        else:
+            check(lib().dfmir_resize_bwd(_p(dy), _p(dx), planes, isp[0], isp[1], isp[2], osp[0], osp[1], osp[2],
+                                         mult, _st()))
         return dx, None, None
 
 

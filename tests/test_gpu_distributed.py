@@ -221,6 +221,9 @@ def _gmn_model(B, rank_tag, capture=False, gmn=False):
     model = REGISTRATIONModel(opt)
     with torch.no_grad():
         model.netR.flow.weight.mul_(1e4)
+        # a random-init G outputs ~0 everywhere (> -0.95: every mask pixel set, equal mask sums on all shards); push its
+        # output to tanh(-3) = -0.995 so that the masks follow the data: (real_B > -0.95) | (registered > -0.95)
+        dict(model.netG.named_parameters())['model.30.bias'].fill_(-3.0)
     model.patch_id_source = PinnedIds("cuda")
     return model, opt
 

@@ -171,9 +171,9 @@ class PinnedIds(object):
 
     def __call__(self, sizes, n_sets, P):
         key = (tuple(int(s) for s in sizes), int(n_sets), int(P))
-        if not self.filled:
+        if not self.filled:       # not prefilled: fresh tensors (an earlier call's ids may be saved for its backward)
             assert not torch.cuda.is_current_stream_capturing(), "prefill() before a step that is captured"
-            self.prefill(sizes, n_sets, P)
+            return self._ids(sizes, n_sets, P).to(self.device)
         self.filled = False
         return self.bufs[key]
 
