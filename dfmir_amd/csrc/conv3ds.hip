@@ -66,12 +66,17 @@ __device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
 // reduces the maximum itself (L2-resident) and packs its share of the units.
 // ------------------------------------------------------------------------------------------------
 // pair != 0 (M <= 16): 36 taps' per chunk, row (p, co) = p * 16 + co holds W[dz' - p] (see the PAIR form above).
+// Ktot / koff: the layer's reduction channels are rows koff .. koff + K - 1 of a packing with Ktot rows per tap (the skip
+// channels of a concatenated input, conv3d_up_phase_k below); Ktot == K, koff == 0 for a whole layer.
 __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
-                                                        int M, float* __restrict__ trailer, int pair) {
+                                                        int M, float* __restrict__ trailer, int pair, int Ktot, int koff) {
   __shared__ float sm[17];
   float m = 0.f;
   const int total = 27 * K * M;
-  for (int i = threadIdx.x; i < total; i += 1024) m = fmaxf(m, fabsf(w[i]));
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    const int tapi = i / (K * M), rem = i - tapi * (K * M);
+    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot + koff) * M + rem]));
+  }
   m = block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int kk = ch * 8 + c;
-      v[c] = (tok && kk < K && mo < M) ? w[((long long)tap * K + kk) * M + mo] : 0.f;
+      v[c] = (tok && kk < K && mo < M) ? w[((long long)tap * Ktot + koff + kk) * M + mo] : 0.f;
     }
     u32x4 h, r;
 #pragma unroll
@@ -128,6 +133,9 @@ struct C3sP {
   // and the separate act_bwd pass over the tensor (read dy, read y, write: 3 transfers of up to 0.9 GB) disappears
   const float* act_src;
   float act_slope;
+  // av_mode 2: act_src is an ADDEND of the output's shape (may be y itself): y = act(conv + bias + addend) -- the skip
+  // channels' share of a convolution over cat(nearest_up2(a), b) whose up-sampled share conv3d_up_phase_k left in y
+  int av_mode;                   // 0 none, 1 activation derivative of act_src, 2 addend
 };
 
 // TT > 1 (multi-tile form): a workgroup computes TT tiles stacked along y with ONE staging of each chunk's weights -- the
@@ -487,9 +495,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
       const int pz = PAIR ? (rowu >> 4) : 0;
       const bool ok = vok && (cou + hi * 4) < k.cout_used && (cz0 + wz + pz) < k.D;
       float v = acc[tt][j][r] * osc + bv[r];
+      if (k.av_mode == 2) v += av[j & 1][r];
       if (k.act == 1) v = v > 0.f ? v : v * k.slope;
       else if (k.act == 2) v = tanhf(v);
-      if (k.act_src) v = av[j & 1][r] > 0.f ? v : v * k.act_slope;
+      if (k.av_mode == 1) v = av[j & 1][r] > 0.f ? v : v * k.act_slope;
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo + (unsigned)pz * plane4 : OOB,
                                             (unsigned)cou * s4, 0);
       pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
@@ -538,12 +547,13 @@ extern "C" long long dfmir_conv3d_split_ws_floats(int Cin, int Cout) {
 }
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
-                                 int cout_used, void* stream, const float* act_src = nullptr, float act_slope = 0.f);
+                                 int cout_used, void* stream, const float* act_src = nullptr, float act_slope = 0.f,
+                                 int av_mode = 0, int w_ktot = 0, int w_koff = 0);
 extern "C" int dfmir_conv3d_split_fwd_actgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                               const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
                                               int cout_used, const float* act_src, float act_slope, void* stream) {
   DF_ARG_CHECK(g && cout_used > 0 && cout_used <= g->Cout && act_src && g->act == 0);
-  return conv3d_split_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, ws, bias, y, y_amax, cout_used, stream, act_src, act_slope);
+  return conv3d_split_fwd_impl(g, x, x_amax, x_amax_n, w_tcc, ws, bias, y, y_amax, cout_used, stream, act_src, act_slope, 1);
 }
 extern "C" int dfmir_conv3d_split_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                       const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
@@ -558,7 +568,8 @@ extern "C" int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, c
 }
 static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                  const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
-                                 int cout_used, void* stream, const float* act_src, float act_slope) {
+                                 int cout_used, void* stream, const float* act_src, float act_slope, int av_mode,
+                                 int w_ktot, int w_koff) {
   // w_tcc == NULL: ws already holds the split of this layer's weights for this cout_used (a host that keeps ws per
   // (layer, mode) and re-splits only after an optimizer step saves the conv3d_wsplit_k launch of every call)
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && ws && y);
@@ -575,11 +586,12 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
     long long nwg = (units + 1023) / 1024;
     if (nwg > ws_wgs) nwg = ws_wgs;
     if (nwg < 1) nwg = 1;
-    conv3d_wsplit_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer, pair ? 1 : 0);
+    conv3d_wsplit_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer,
+                                                    pair ? 1 : 0, w_ktot > 0 ? w_ktot : g->Cin, w_koff);
     DF_LAUNCH_CHECK();
   }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
-         nchunk, x_amax_n, cout_used, 0, act_src, act_slope};
+         nchunk, x_amax_n, cout_used, 0, act_src, act_slope, act_src ? av_mode : 0};
   const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
   // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
   static const bool multi_off = getenv("DFMIR_CONV3D_NO_MULTI") != nullptr;
@@ -604,6 +616,528 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   else conv3d_split_k<false, false, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   DF_LAUNCH_CHECK();
   return 0;
+}
+
+// ================================================================================================
+// conv(cat(nearest_up2(a), b)) WITHOUT the up-sampled tensor and without multiplying by duplicated values
+// (torchvoxelmorph/networks.py:64,97-100: nn.Upsample(scale 2, nearest) + torch.cat feeding the next ConvBlock).
+//
+// A 3x3x3 tap of an output voxel 2V + p (p = its parity per axis) over nearest_up2(a) reads a[V + o] with
+// o = floor((p + d - 1) / 2) in {p - 1, p}: the 27 taps fall on 2 x 2 x 2 low-resolution voxels, so the up-sampled
+// share of the convolution is, per parity class p, an 8-tap convolution of `a` with the SUMMED weights
+//     Weff[p][t] = sum of w[d] over the d that land on low-resolution offset p - 1 + t      (t in {0, 1} per axis)
+//     p = 0:  t = 0 <- {d = 0},     t = 1 <- {d = 1, 2};      p = 1:  t = 0 <- {d = 0, 1},  t = 1 <- {d = 2}
+// -- 8 / 27 of the products (the same sums in a different order: fp32 round-off only).  conv3d_up_phase_k computes
+// that share: workgroup = one 4 x 8 x 16 tile of LOW-resolution voxels x 32 output channels x one (pz, py) pair
+// (grid.z), both px classes (two accumulator sets, 8 k-steps of K = 2 x-taps x 8 channels per chunk); the halo patch
+// of `a` is staged exactly as conv3d_split_k stages its input (same geometry: offsets -1 .. +1), the output voxels
+// (2z + pz, 2y + py, 2x .. 2x + 1) leave as 8-byte stores (a half-wave row = 128 contiguous bytes).  The result is the
+// PARTIAL sum; the skip channels b follow as an ordinary conv3d_split_k launch whose epilogue adds it (av_mode 2),
+// the bias, the activation and the range probe.
+// ================================================================================================
+// w_tcc [27][Ktot][M] (forward packing); the up-sampled channels are rows 0 .. Ka - 1.
+// ws[pzy 4][mtile][chunk][split 2][16 units u = px*8 + tz*4 + ty*2 + tx][32] x (8 channels x fp16); trailer[0] = ew.
+__device__ __forceinline__ float up_weff(const float* __restrict__ w, int Ktot, int M, int kk, int mo, int pz, int py,
+                                         int px, int tz, int ty, int tx) {
+  // taps d of axis with parity p that land on slot t:  lo = (p == 0) ? t : 2 t,  n = (t == p) ? 1 : 2 ... spelled out:
+  const int z0 = pz ? (tz ? 2 : 0) : (tz ? 1 : 0), zn = (pz == tz) ? 1 : 2;
+  const int y0 = py ? (ty ? 2 : 0) : (ty ? 1 : 0), yn = (py == ty) ? 1 : 2;
+  const int x0 = px ? (tx ? 2 : 0) : (tx ? 1 : 0), xn = (px == tx) ? 1 : 2;
+  float s = 0.f;
+  for (int a = 0; a < zn; ++a)
+    for (int b = 0; b < yn; ++b)
+      for (int c = 0; c < xn; ++c)
+        s += w[((long long)(((z0 + a) * 3 + (y0 + b)) * 3 + (x0 + c)) * Ktot + kk) * M + mo];
+  return s;
+}
+// Cb in {1, 2} skip channels (the network's input images at the top level): a second section after the phase units,
+// [mtile][split 2][10 tap rows t = dz*3 + dy (9 = padding)][32] x (4 x-taps (3 = padding) x 2 channels x fp16) with its own
+// scale trailer[1] -- the skip share then runs INSIDE conv3d_up_phase_k (one MFMA k-step = 2 tap rows x 4 x 2).
+__global__ __launch_bounds__(1024) void conv3d_up_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
+                                                           int Ktot, int M, float* __restrict__ trailer, int Cb) {
+  __shared__ float sm[17];
+  float m = 0.f;
+  const int total = 64 * Ka * M;                           // (8 phases x 8 slots) x Ka x M effective weights
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    const int mo = i % M;
+    int t = i / M;
+    const int kk = t % Ka; t /= Ka;
+    m = fmaxf(m, fabsf(up_weff(w, Ktot, M, kk, mo, (t >> 5) & 1, (t >> 4) & 1, (t >> 3) & 1, (t >> 2) & 1, (t >> 1) & 1, t & 1)));
+  }
+  m = block_max(m, sm);
+  if (!(m == m)) m = __uint_as_float(0x7f800000u);
+  const int ew = scale_exp3(m);
+  const float s = pow2f3(ew);
+  if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
+  const int nchunk = (Ka + 7) / 8, nmt = (M + 31) / 32;
+  const int units = 4 * nmt * nchunk * 16 * 32;
+  for (int u = blockIdx.x * 1024 + threadIdx.x; u < units; u += gridDim.x * 1024) {
+    const int co = u & 31;
+    int t = u >> 5;
+    const int slot = t & 15; t >>= 4;
+    const int ch = t % nchunk; t /= nchunk;
+    const int mt = t % nmt, pzy = t / nmt;
+    const int mo = mt * 32 + co;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int kk = ch * 8 + c;
+      v[c] = (kk < Ka && mo < M) ? up_weff(w, Ktot, M, kk, mo, pzy >> 1, pzy & 1, slot >> 3, (slot >> 2) & 1, (slot >> 1) & 1, slot & 1)
+                                 : 0.f;
+    }
+    u32x4 h, r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hh, rr;
+      split_pair3(v[2 * q], v[2 * q + 1], s, hh, rr);
+      h[q] = hh; r[q] = rr;
+    }
+    const long long base = ((((long long)pzy * nmt + mt) * nchunk + ch) * 2) * 512;
+    ws[base + slot * 32 + co] = h;
+    ws[base + 512 + slot * 32 + co] = r;
+  }
+  if (Cb <= 0) return;
+  __syncthreads();
+  float ms = 0.f;
+  for (int i = threadIdx.x; i < 27 * Cb * M; i += 1024) {
+    const int mo = i % M, c = (i / M) % Cb, tap = i / (M * Cb);
+    ms = fmaxf(ms, fabsf(w[((long long)tap * Ktot + Ka + c) * M + mo]));
+  }
+  ms = block_max(ms, sm);
+  if (!(ms == ms)) ms = __uint_as_float(0x7f800000u);
+  const int es = scale_exp3(ms);
+  const float ss = pow2f3(es);
+  if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[1] = es;
+  u32x4* wsk = ws + 2LL * units;                          // after the phase units (h and r of every (slot, cout))
+  for (int u = blockIdx.x * 1024 + threadIdx.x; u < nmt * 10 * 32; u += gridDim.x * 1024) {
+    const int co = u & 31, t = (u >> 5) % 10, mt = (u >> 5) / 10;
+    const int mo = mt * 32 + co;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int dx = i >> 1, c = i & 1;
+      v[i] = (t < 9 && dx < 3 && c < Cb && mo < M) ? w[((long long)(t * 3 + dx) * Ktot + Ka + c) * M + mo] : 0.f;
+    }
+    u32x4 h, r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hh, rr;
+      split_pair3(v[2 * q], v[2 * q + 1], ss, hh, rr);
+      h[q] = hh; r[q] = rr;
+    }
+    wsk[(long long)mt * 640 + t * 32 + co] = h;
+    wsk[(long long)mt * 640 + 320 + t * 32 + co] = r;
+  }
+}
+
+struct C3uP {
+  int N, Ca, Cout, D, H, W;      // D, H, W: the LOW-resolution volume (a); y is [N, Cout, 2D, 2H, 2W]
+  int nz, ny, nx, nchunk, x_n;
+  long long ntile;
+  // SKIP2 form: the <= 2 skip channels b [N, Cb, 2D, 2H, 2W] inside the same launch, then bias, activation, range probe
+  const float* b;
+  const float* b_amax;
+  int b_n, Cb;
+  const float* bias;
+  int act;
+  float slope;
+  float* y_amax;
+};
+
+// SKIP2 (Cb <= 2: the two input images of the top level): after the up-sampled channels the workgroup stages the skip
+// patch it needs -- full-resolution planes 2 z0 + pz - 1 .. + 8, rows 2 y0 + py - 1 .. + 16, columns 2 x0 - 1 .. 2 x0 + 33
+// as [split][9][17][40] x (2 channels x fp16) -- and runs 2 px x 5 k-steps with K = 2 tap rows (dz, dy) x 4 x-taps x 2
+// channels (operand = 4 consecutive 4-byte LDS words); the accumulators are first moved to the skip products' scale by
+// an exact power of two.  No partial sum ever goes to memory.
+template <bool SKIP2>
+__global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                         const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
+                                                         float* __restrict__ y, C3uP k) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
+  constexpr int XP = (TZ + 2) * HY * HX;                  // 1080 positions
+  constexpr int WU = 2 * 16 * 32;                         // 1024 16-B units of one chunk's weights (2 px x 8 slots)
+  constexpr int NW = WU / 256;                            // 4
+  constexpr int NJ = 4;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int SRS = 40, SROWS = 9 * 17, SPW = SROWS * SRS;       // skip patch: row stride (words), rows, words per split
+  constexpr int XSU = SKIP2 ? ((2 * SPW + 3) / 4 > 2 * XP ? (2 * SPW + 3) / 4 : 2 * XP) : 2 * XP;
+  __shared__ u32x4 Xs[XSU];
+  __shared__ u32x4 Ws[WU];
+  __shared__ float red[17];
+  __shared__ unsigned smax;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long S = (long long)k.D * k.H * k.W;
+  // tiles: XCD-contiguous eighths, x fastest, then z, then y (as conv3d_split_k); one tile per workgroup
+  const long long per_xcd = (k.ntile + 7) / 8;
+  const long long tile = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((long long)(blockIdx.x >> 3) >= per_xcd || tile >= k.ntile) return;
+  int n, z0, y0, x0;
+  {
+    long long pid = tile;
+    const int bx = (int)(pid % k.nx); pid /= k.nx;
+    const int bz = (int)(pid % k.nz); pid /= k.nz;
+    const int by = (int)(pid % k.ny);
+    n = (int)(pid / k.ny);
+    z0 = bz * TZ; y0 = by * TY; x0 = bx * TX;
+  }
+  const int mt = blockIdx.y, pzy = blockIdx.z, pz = pzy >> 1, py = pzy & 1;
+
+  const float amax = reduce_absmax(x_amax, k.x_n, red);
+  const int ex = scale_exp3(amax);
+  const int ew = reinterpret_cast<const int*>(w_trailer)[0];
+  const float xscale = pow2f3(ex), osc = pow2f3(-ex) * pow2f3(-ew);
+
+  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (long long)n * k.Ca * S), 0, (unsigned)((long long)k.Ca * S * 4), 0x00020000);
+  const unsigned s4 = (unsigned)S * 4u;
+  // patch loads (the VEC form of conv3d_split_k): thread t < 240 owns quad q = t & 3 of halo row t >> 2 in all 8 channels
+  // of the chunk, thread t < 120 additionally the left / right halo column of row t >> 1
+  unsigned gq = OOB, gh = OOB;
+  int posq = -1, posh = -1;
+  if (tid < 240) {
+    const int row = tid >> 2, q = tid & 3;
+    const int hz = row / HY, hy = row % HY;
+    const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 + 4 * q;
+    posq = row * HX + 1 + 4 * q;
+    if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && gx < k.W)
+      gq = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+  }
+  if (tid < 120) {
+    const int row = tid >> 1, side = tid & 1;
+    const int hz = row / HY, hy = row % HY;
+    const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = side ? x0 + TX : x0 - 1;
+    posh = row * HX + (side ? HX - 1 : 0);
+    if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
+      gh = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;
+  }
+  const __amdgpu_buffer_rsrc_t w_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(wsp + ((long long)pzy * gridDim.y + mt) * k.nchunk * WU), 0, (unsigned)(k.nchunk * WU * 16), 0x00020000);
+
+  // B positions of this lane: column tile j = rows 2j, 2j + 1 of plane wid (see conv3d_split_k for the lane rotation);
+  // tap slot (tz, ty, tx) of parity (pz, py, px) sits at patch offset ((pz + tz) HY + (py + ty)) HX + (px + tx)
+  const int lx = (l31 - 2 * (l31 >> 4)) & 15;
+  int pbase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) pbase[j] = ((wid + pz) * HY + 2 * j + (l31 >> 4) + py) * HX + lx + hi;   // + tx = hi
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
+
+  float rh[8];
+  u32x4 rq[8];
+  u32x4 rw[NW];
+#define C3U_GLOAD_X(ch_, s_)                                                                      \
+  {                                                                                               \
+    const unsigned co_ = (unsigned)((ch_) * 8 + (s_)) * s4;                                       \
+    rq[s_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + co_, 0, 0);      \
+    rh[s_] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_src, gh == OOB ? OOB : gh + co_, 0, 0)); \
+  }
+#define C3U_GLOAD_W(ch_)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NW; ++j)                                                  \
+    rw[j] = __builtin_amdgcn_raw_buffer_load_b128(w_src, (unsigned)(((ch_) * WU + tid + 256 * j) * 16), 0, 0);
+#define C3U_SPLIT8(v_, h_, r_)                                                                    \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+    unsigned hh, rr;                                                                              \
+    split_pair3(v_[2 * q], v_[2 * q + 1], xscale, hh, rr);                                        \
+    h_[q] = hh; r_[q] = rr;                                                                       \
+  }
+#define C3U_LSTORE()                                                                              \
+  {                                                                                               \
+    if (posq >= 0) {                                                                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+        float v[8];                                                                               \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rq[c][e]);           \
+        u32x4 h, r;                                                                               \
+        C3U_SPLIT8(v, h, r)                                                                       \
+        Xs[posq + e] = h;                                                                         \
+        Xs[XP + posq + e] = r;                                                                    \
+      }                                                                                           \
+    }                                                                                             \
+    if (posh >= 0) {                                                                              \
+      u32x4 h, r;                                                                                 \
+      C3U_SPLIT8(rh, h, r)                                                                        \
+      Xs[posh] = h;                                                                               \
+      Xs[XP + posh] = r;                                                                          \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) Ws[tid + 256 * j] = rw[j];                     \
+  }
+  // operands of k-step tp_ = px * 4 + tz * 2 + ty (tx = this half-wave): unit u = 2 tp_ + hi
+#define C3U_OPLOAD(b_, tp_)                                                                       \
+  {                                                                                               \
+    const int toff = ((((tp_) >> 1) & 1) * HY + ((tp_) & 1)) * HX + ((tp_) >> 2);                 \
+    const int u = 2 * (tp_) + hi;                                                                 \
+    A0[b_] = Ws[u * 32 + l31];                                                                    \
+    A1[b_] = Ws[512 + u * 32 + l31];                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                              \
+      B0[b_][j] = Xs[pbase[j] + toff];                                                            \
+      B1[b_][j] = Xs[XP + pbase[j] + toff];                                                       \
+    }                                                                                             \
+  }
+  u32x4 A0[2], A1[2], B0[2][NJ], B1[2][NJ];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) C3U_GLOAD_X(0, s);
+  C3U_GLOAD_W(0);
+  C3U_LSTORE();
+  __syncthreads();
+
+  for (int ch = 0; ch < k.nchunk; ++ch) {
+    const bool more = ch + 1 < k.nchunk;
+    C3U_OPLOAD(0, 0);
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {
+      const int cur = tp & 1;
+      if (more) {                                             // next chunk's loads, one channel per k-step (uniform branch)
+        C3U_GLOAD_X(ch + 1, tp);
+        if (tp == 7) C3U_GLOAD_W(ch + 1);
+      }
+      if (tp + 1 < 8) C3U_OPLOAD(cur ^ 1, tp + 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[tp >> 2][j] = mma3(A1[cur], B0[cur][j], acc[tp >> 2][j]);
+        acc[tp >> 2][j] = mma3(A0[cur], B1[cur][j], acc[tp >> 2][j]);
+        acc[tp >> 2][j] = mma3(A0[cur], B0[cur][j], acc[tp >> 2][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3 * NJ; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
+    }
+    if (more) {
+      __syncthreads();
+      C3U_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef C3U_GLOAD_X
+#undef C3U_GLOAD_W
+#undef C3U_SPLIT8
+#undef C3U_LSTORE
+#undef C3U_OPLOAD
+
+  float osc_f = osc;
+  if constexpr (SKIP2) {
+    // ---- the skip channels: accumulators to the skip products' scale, stage the patch + weights, 2 x 5 k-steps
+    __syncthreads();                                       // every wave is done with Xs / Ws
+    const float bmax = reduce_absmax(k.b_amax, k.b_n, red);
+    const int eb = scale_exp3(bmax);
+    const int es = reinterpret_cast<const int*>(w_trailer)[1];
+    const float bscale = pow2f3(eb);
+    {
+      int d = (eb + es) - (ex + ew);
+      d = d > 120 ? 120 : (d < -120 ? -120 : d);
+      const float rs = pow2f3(d);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[p][j][r] *= rs;
+      osc_f = pow2f3(-eb) * pow2f3(-es);
+    }
+    const int Df = 2 * k.D, Hf = 2 * k.H, Wf = 2 * k.W;
+    const long long Sfl = (long long)Df * Hf * Wf;
+    const __amdgpu_buffer_rsrc_t b_src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(k.b + (long long)n * k.Cb * Sfl), 0, (unsigned)((long long)k.Cb * Sfl * 4), 0x00020000);
+    const unsigned sb4 = (unsigned)Sfl * 4u;
+    unsigned* Xw = reinterpret_cast<unsigned*>(Xs);
+    const int bz0 = 2 * z0 + pz - 1, by0 = 2 * y0 + py - 1, bx0 = 2 * x0;      // patch word 4 + i of a row = column bx0 + i
+    // (row, quad) tasks: 153 rows x 9 aligned quads (columns bx0 .. bx0 + 35), both channels per task
+    constexpr int NTASK = SROWS * 9, NIT = (NTASK + 255) / 256;
+    u32x4 q0[NIT], q1[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int task = tid + 256 * i;
+      const int row = task / 9, q = task - 9 * row;
+      const int gz = bz0 + row / 17, gy = by0 + row % 17, gx = bx0 + 4 * q;
+      const bool ok = task < NTASK && (unsigned)gz < (unsigned)Df && (unsigned)gy < (unsigned)Hf && gx < Wf;
+      const unsigned off = ok ? (unsigned)((gz * Hf + gy) * Wf + gx) * 4u : OOB;
+      q0[i] = __builtin_amdgcn_raw_buffer_load_b128(b_src, off, 0, 0);
+      q1[i] = __builtin_amdgcn_raw_buffer_load_b128(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0);
+    }
+    float h0 = 0.f, h1 = 0.f;                              // left halo column bx0 - 1: one row per thread < 153
+    if (tid < SROWS) {
+      const int gz = bz0 + tid / 17, gy = by0 + tid % 17, gx = bx0 - 1;
+      const bool ok = (unsigned)gz < (unsigned)Df && (unsigned)gy < (unsigned)Hf && gx >= 0;
+      const unsigned off = ok ? (unsigned)((gz * Hf + gy) * Wf + gx) * 4u : OOB;
+      h0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, off, 0, 0));
+      h1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0));
+    }
+    // skip weights of this cout tile: 640 units after the phase section
+    const u32x4* wsk = wsp + 4LL * gridDim.y * k.nchunk * WU + (long long)mt * 640;
+    u32x4 rws[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rws[j] = (tid + 256 * j < 640) ? wsk[tid + 256 * j] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int task = tid + 256 * i;
+      if (task < NTASK) {
+        const int row = task / 9, q = task - 9 * row;
+        u32x4 h, r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned hh, rr;
+          split_pair3(__uint_as_float(q0[i][e]), __uint_as_float(q1[i][e]), bscale, hh, rr);
+          h[e] = hh; r[e] = rr;
+        }
+        *reinterpret_cast<u32x4*>(Xw + row * SRS + 4 + 4 * q) = h;
+        *reinterpret_cast<u32x4*>(Xw + SPW + row * SRS + 4 + 4 * q) = r;
+      }
+    }
+    if (tid < SROWS) {
+      unsigned hh, rr;
+      split_pair3(h0, h1, bscale, hh, rr);
+      Xw[tid * SRS + 3] = hh;
+      Xw[SPW + tid * SRS + 3] = rr;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (tid + 256 * j < 640) Ws[tid + 256 * j] = rws[j];
+    __syncthreads();
+    // lane's word offset of (plane 2 vz, row 2 vy, column word 3 + 2 vx): + (dz * 17 + dy) * SRS + px
+    int sbase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sbase[j] = ((2 * wid) * 17 + 2 * (2 * j + (l31 >> 4))) * SRS + 3 + 2 * lx;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int t = (2 * ks + hi) < 9 ? 2 * ks + hi : 8;            // tap row 9 is padding (zero weights): any valid address
+      const int toff = ((t / 3) * 17 + t % 3) * SRS;
+      const u32x4 a0 = Ws[(2 * ks + hi) * 32 + l31], a1 = Ws[320 + (2 * ks + hi) * 32 + l31];
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const unsigned* p0 = Xw + sbase[j] + toff + px;
+          const u32x4 b0{p0[0], p0[1], p0[2], p0[3]};
+          const u32x4 b1{p0[SPW], p0[SPW + 1], p0[SPW + 2], p0[SPW + 3]};
+          acc[px][j] = mma3(a1, b0, acc[px][j]);
+          acc[px][j] = mma3(a0, b1, acc[px][j]);
+          acc[px][j] = mma3(a0, b0, acc[px][j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: acc[px][j][r] <-> cout row (r>>2)*8 + hi*4 + (r&3), low-resolution voxel (wid, 2j + (l31>>4), lx)
+  // -> output voxels (2 z + pz, 2 y + py, 2 x + {0, 1}): one 8-byte store per (j, r)
+  const int Dfo = 2 * k.D, Hfo = 2 * k.H, Wfo = 2 * k.W;
+  const long long Sf = (long long)Dfo * Hfo * Wfo;
+  const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
+      y + (long long)n * k.Cout * Sf, 0, (unsigned)((long long)k.Cout * Sf * 4), 0x00020000);
+  const unsigned sf4 = (unsigned)Sf * 4u;
+  const int gz = z0 + wid;
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = mt * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+    bv[r] = (SKIP2 && k.bias && co < k.Cout) ? k.bias[co] : 0.f;
+  }
+  float pm = 0.f;
+  if (SKIP2 && tid == 0) smax = 0u;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int gy = y0 + 2 * j + (l31 >> 4), gx = x0 + lx;
+    const bool vok = gz < k.D && gy < k.H && gx < k.W;
+    const unsigned vo = (unsigned)(((2 * gz + pz) * Hfo + 2 * gy + py) * Wfo + 2 * gx) * 4u + (unsigned)(hi * 4) * sf4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rowu = (r >> 2) * 8 + (r & 3);
+      const int cou = mt * 32 + rowu;
+      const bool ok = vok && (cou + hi * 4) < k.Cout;
+      float v0 = acc[0][j][r] * osc_f + bv[r], v1 = acc[1][j][r] * osc_f + bv[r];
+      if (SKIP2) {
+        if (k.act == 1) { v0 = v0 > 0.f ? v0 : v0 * k.slope; v1 = v1 > 0.f ? v1 : v1 * k.slope; }
+        pm = fmaxf(pm, ok ? fmaxf(fabsf(v0), fabsf(v1)) : 0.f);
+      }
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      u32x2_ v2;
+      v2[0] = __float_as_uint(v0);
+      v2[1] = __float_as_uint(v1);
+      __builtin_amdgcn_raw_buffer_store_b64(v2, y_dst, ok ? vo : OOB, (unsigned)cou * sf4, 0);
+    }
+  }
+  if (SKIP2 && k.y_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, k.y_amax);
+  }
+}
+
+extern "C" long long dfmir_conv3d_up_ws_floats(int Ca, int Cout) {
+  if (Ca <= 0 || Cout <= 0) return -1;
+  return 4LL * ((Cout + 31) / 32) * ((Ca + 7) / 8) * 1024 * 4 + (long long)((Cout + 31) / 32) * 640 * 4 + 4;
+}
+extern "C" int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W) {
+  // D, H, W: the low-resolution volume.  W % 4: 16-B patch loads; sizes: 32-bit buffer offsets on both tensors
+  if (split3d_off() || getenv("DFMIR_CONV3D_NO_UPPHASE")) return 0;
+  if (N <= 0 || Ca < 8 || (Ca & 7) || Cout < 8 || D < 2 || H < 2 || W < 4 || (W & 3)) return 0;
+  if ((long long)Ca * D * H * W * 4 >= 0x7FFFFFFFLL || (long long)Cout * D * H * W * 8 * 4 >= 0x7FFFFFFFLL) return 0;
+  return 1;
+}
+static int conv3d_up_launch(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
+                            float* y, int N, int Ca, int Cout, int D, int H, int W, const float* b, const float* b_amax,
+                            int b_n, int Cb, const float* bias, int act, float slope, float* y_amax, hipStream_t st) {
+  const int nchunk = (Ca + 7) / 8, nmt = (Cout + 31) / 32;
+  float* trailer = ws + dfmir_conv3d_up_ws_floats(Ca, Cout) - 4;
+  if (w_tcc) {
+    const long long units = 4LL * nmt * nchunk * 512;
+    long long nwg = (units + 1023) / 1024;
+    if (nwg > 32) nwg = 32;
+    conv3d_up_wsplit_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), Ca, Ktot, Cout, trailer, Cb);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  C3uP k{N, Ca, Cout, D, H, W, (D + 3) / 4, (H + 7) / 8, (W + 15) / 16, nchunk, a_amax_n, 0,
+         b, b_amax, b_n, Cb, bias, act, slope, y_amax};
+  k.ntile = (long long)N * k.nz * k.ny * k.nx;
+  const dim3 grid((unsigned)(8 * ((k.ntile + 7) / 8)), (unsigned)nmt, 4);
+  if (Cb > 0) conv3d_up_phase_k<true><<<grid, 256, 0, st>>>(a, a_amax, reinterpret_cast<const u32x4*>(ws), trailer, y, k);
+  else conv3d_up_phase_k<false><<<grid, 256, 0, st>>>(a, a_amax, reinterpret_cast<const u32x4*>(ws), trailer, y, k);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// y [N, Cout, 2D, 2H, 2W] <- the up-sampled channels' share of conv3x3x3(cat(nearest_up2(a), b)); a [N, Ca, D, H, W].
+// w_tcc: the layer's forward packing [27][Ktot][Cout] (channels 0 .. Ca - 1 are a's), or NULL when ws already holds
+// the phase split of the current weights.
+extern "C" int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot,
+                                   float* ws, float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream) {
+  DF_ARG_CHECK(a && a_amax && a_amax_n > 0 && ws && y && dfmir_conv3d_up_ok(N, Ca, Cout, D, H, W));
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (!w_tcc || Ktot >= Ca));
+  if (conv3d_up_launch(a, a_amax, a_amax_n, w_tcc, Ktot, ws, y, N, Ca, Cout, D, H, W, nullptr, nullptr, 0, 0, nullptr, 0,
+                       0.f, nullptr, (hipStream_t)stream) != 0)
+    return df_set_error((int)hipErrorLaunchFailure, __FILE__, __LINE__);
+  return 0;
+}
+// The whole layer in ONE launch when the skip tensor b [N, Cb, 2D, 2H, 2W] has Cb <= 2 channels (the network's input
+// images at the top of the U-Net): y = act(conv3x3x3(cat(nearest_up2(a), b)) + bias), y_amax = its range probe.
+// Ktot == Ca + Cb.  act: 0 none, 1 LeakyReLU(slope).
+extern "C" int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, int a_amax_n, const float* b,
+                                         const float* b_amax, int b_amax_n, int Cb, const float* w_tcc, float* ws,
+                                         const float* bias, float* y, float* y_amax, int N, int Ca, int Cout, int D, int H,
+                                         int W, int act, float slope, void* stream) {
+  DF_ARG_CHECK(a && a_amax && a_amax_n > 0 && b && b_amax && b_amax_n > 0 && ws && y && Cb >= 1 && Cb <= 2 && act >= 0 && act <= 1);
+  DF_ARG_CHECK(dfmir_conv3d_up_ok(N, Ca, Cout, D, H, W) && (long long)Cb * D * H * W * 8 * 4 < 0x7FFFFFFFLL);
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0);
+  if (conv3d_up_launch(a, a_amax, a_amax_n, w_tcc, Ca + Cb, ws, y, N, Ca, Cout, D, H, W, b, b_amax, b_amax_n, Cb, bias, act,
+                       slope, y_amax, (hipStream_t)stream) != 0)
+    return df_set_error((int)hipErrorLaunchFailure, __FILE__, __LINE__);
+  return 0;
+}
+// The skip channels' share, added to the partial sum already in y: y = act(conv3x3x3(b; rows koff .. koff + Cb - 1 of the
+// layer's [27][Ktot][Cout] packing) + bias + y), range probe of y in y_amax.  g describes the conv over b alone
+// (Cin = Cb).  w_tcc NULL: ws holds the split of the current weights.
+extern "C" int dfmir_conv3d_split_fwd_add(const DfConvGeom* g, const float* b, const float* b_amax, int b_amax_n,
+                                          const float* w_tcc, int Ktot, int koff, float* ws, const float* bias, float* y,
+                                          float* y_amax, void* stream) {
+  DF_ARG_CHECK(g && y && (!w_tcc || (Ktot >= koff + g->Cin && koff >= 0)));
+  return conv3d_split_fwd_impl(g, b, b_amax, b_amax_n, w_tcc, ws, bias, y, y_amax, g->Cout, stream, y, 0.f, 2, Ktot, koff);
 }
 
 // ================================================================================================

@@ -53,6 +53,14 @@ class _ConvNd(nn.Module):
         return ops.conv(x, self.weight, self.bias, self, self.stride, self.padding,
                         1 if reflect else 0, act, slope, sole=sole)
 
+    def forward_upcat(self, a, b, act=0, slope=0.0, sole=False):
+        """This conv applied to cat([nearest_up2(a), b], 1) (torchvoxelmorph/networks.py:97-100 + the next ConvBlock):
+        3-D 3x3x3 layers take the form that never builds the concatenation (ops.upcat_conv3d), the rest materialise it."""
+        if (self.nd == 3 and self.kernel_size == 3 and self.stride == 1 and self.padding == 1
+                and ops.upcat_conv3d_ok(a, b, self.weight)):
+            return ops.upcat_conv3d(a, b, self.weight, self.bias, self, act, slope, sole=sole)
+        return self.forward(ops.upcat(a, b), act, slope, sole=sole)
+
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d, padding=%d" % (
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)

@@ -504,10 +504,18 @@ class ConvFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, dskip=None):
-        nd, K, stride, p3, pad_mode, act, slope, owner = ctx.cfg
         if dy is None:              # only the skip output was used downstream
             return (dskip,) + (None,) * 9
         x5, weight, y5 = ctx.saved_tensors
+        dx, dw, db = _conv_backward_impl(ctx, dy, dskip, x5, weight, y5)
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _conv_backward_impl(ctx, dy, dskip, x5, weight, y5):
+    """Backward of y = act(conv(x5, weight) + bias) for a ctx-like object carrying cfg, x_amax, dead_tail, in_act,
+    has_bias, needs_input_grad (x, weight, bias); returns (dx, dw, db).  Shared by ConvFn and UpCatConv3dFn."""
+    if True:
+        nd, K, stride, p3, pad_mode, act, slope, owner = ctx.cfg
         dy5 = _c(dy) if nd == 3 else _c(dy).unsqueeze(2)
         Cout, Cin = weight.shape[0], weight.shape[1]
         want_probe = _wants_amax(K, stride, 1, dy5.shape[2], Cout, Cin) or ctx.x_amax is not None
@@ -609,7 +617,7 @@ class ConvFn(Function):
         elif db_buf is not None:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
             check(lib().dfmir_bias_grad(_p(dy5), _p(db_buf), dy5.shape[0], Cout, S, _st()))   # accumulates
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db
 
 
 _LAST_CONV_AMAX = [None]
@@ -981,6 +989,146 @@ def upcat(a, b):
         check(lib().dfmir_probe_merge(_p(pa), _p(pb), _p(slot), _st()))
         tag_amax(y, slot)
     return y
+
+
+_NO_UPSKIP2 = bool(os.environ.get("DFMIR_CONV3D_NO_UPSKIP2"))     # A/B switch: <= 2 skip channels as a second launch
+_NO_UPPHASE = bool(os.environ.get("DFMIR_CONV3D_NO_UPPHASE"))     # A/B switch: materialise nearest_up2 + cat, one conv
+
+
+def _ws_cached(w_tcc, key, floats, device):
+    """(ws, needs_split): a per-(packed-weight buffer, key) workspace for split weights, re-made only when the packed
+    buffer was re-packed (its generation changed).  A temporary packing (no generation) gets a fresh workspace."""
+    gen = getattr(w_tcc, "_df_gen", None)
+    cache = getattr(w_tcc, "_df_ws3d", None) if gen is not None else None
+    ent = cache.get(key) if cache is not None else None
+    if ent is not None and ent[0] == gen:
+        return ent[1], False
+    ws = ent[1] if ent is not None else torch.empty(floats, device=device, dtype=torch.float32)   # in place: graphs hold it
+    if gen is not None:
+        if cache is None:
+            cache = w_tcc._df_ws3d = {}
+        cache[key] = (gen, ws)
+    return ws, True
+
+
+class _Ctx(object):
+    pass
+
+
+class UpCatConv3dFn(Function):
+    """y = act(conv3x3x3(cat([nearest_up2(a), b], 1), weight) + bias)  (torchvoxelmorph/networks.py:64,97-100 + the next
+    ConvBlock, :1506-1521) without the up-sampled / concatenated tensor in the forward pass: the up-sampled channels
+    through the parity-class form (8 of the 27 products, csrc/conv3ds.hip conv3d_up_phase_k), the skip channels
+    through the split kernel whose epilogue adds both, the bias and the activation.  Backward: the concatenation is
+    materialised there (for the weight gradient's operand) and the existing dgrad / wgrad / pooling kernels run."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, owner, act, slope):
+        _need(a, b, weight, bias)
+        a, b = _c(a), _c(b)
+        N, Ca, D, H, W = a.shape
+        Cb = b.shape[1]
+        Cout = weight.shape[0]
+        if tuple(b.shape[2:]) != (2 * D, 2 * H, 2 * W) or weight.shape[1] != Ca + Cb:
+            raise DfmirHipError("upcat_conv3d: a %s, b %s, weight %s do not fit" % (tuple(a.shape), tuple(b.shape), tuple(weight.shape)))
+        w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
+        pa = _valid_amax(a)
+        pa = _probe64(a) if pa is None else pa
+        pb = _valid_amax(b)
+        pb = _probe64(b) if pb is None else pb
+        y = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), device=a.device, dtype=torch.float32)
+        g = DfConvGeom(N, Cb, Cout, 2 * D, 2 * H, 2 * W, 2 * D, 2 * H, 2 * W, 3, 3, 3, 1, 1, 1, 1, 1, 0, act, float(slope))
+        ws_up, split_up = _ws_cached(w_tcc, ("up", Ca, Cout), lib().dfmir_conv3d_up_ws_floats(Ca, Cout), a.device)
+        ws_sk, split_sk = (None, False) if (Cb <= 2 and act in (0, 1) and not _NO_UPSKIP2) else \
+            _ws_cached(w_tcc, ("skip", Ca, Cb, Cout), lib().dfmir_conv3d_split_ws_floats(Cb, Cout), a.device)
+        slot = amax_slot(a.device, PROBE_SLOTS)
+        if _PROBE_AUDIT["on"]:
+            _audit_probe(a, pa, "upcat conv a %s" % (tuple(a.shape),))
+            _audit_probe(b, pb, "upcat conv b %s" % (tuple(b.shape),))
+
+        fused = Cb <= 2 and act in (0, 1) and not _NO_UPSKIP2
+
+        def launch_fused():
+            check(lib().dfmir_conv3d_up_skip2_fwd(_p(a), _p(pa), pa.numel(), _p(b), _p(pb), pb.numel(), Cb,
+                                                  _p(w_tcc) if split_up else None, _p(ws_up), _p(bias), _p(y), _p(slot),
+                                                  N, Ca, Cout, D, H, W, act, float(slope), _st()))
+
+        def launch_up():
+            check(lib().dfmir_conv3d_up_fwd(_p(a), _p(pa), pa.numel(), _p(w_tcc) if split_up else None, Ca + Cb, _p(ws_up),
+                                            _p(y), N, Ca, Cout, D, H, W, _st()))
+
+        def launch_skip():
+            check(lib().dfmir_conv3d_split_fwd_add(ctypes.byref(g), _p(b), _p(pb), pb.numel(), _p(w_tcc) if split_sk else None,
+                                                   Ca + Cb, Ca, _p(ws_sk), _p(bias), _p(y), _p(slot), _st()))
+
+        prof = _CONV_PROFILER[0]
+        vox = 8.0 * N * D * H * W
+        size = "L" if Cout > 64 else ("M" if Cout > 32 else ("S" if Cout > 4 else "small"))
+        if fused:
+            if prof is None:
+                launch_fused()
+            else:
+                prof("conv3dup_" + size, 2.0 * vox * Cout * (Ca + Cb) * 27, launch_fused)   # reference-equivalent FLOPs
+        elif prof is None:
+            launch_up()
+            launch_skip()
+        else:
+            prof("conv3dup_" + size, 2.0 * vox * Cout * Ca * 27, launch_up)        # reference-equivalent FLOPs (27 taps)
+            prof("conv3ds_" + size, 2.0 * vox * Cout * Cb * 27, launch_skip)
+        _LAST_CONV_AMAX[0] = slot
+        ctx.save_for_backward(a, b, weight, y if act else None)
+        ctx.probes = (pa, pb)
+        ctx.cfg = (3, (3, 3, 3), 1, (1, 1, 1), 0, act, slope, owner)
+        ctx.has_bias = bias is not None
+        ctx.b_needs = bool(b.requires_grad)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        a, b, weight, y = ctx.saved_tensors
+        N, Ca, D, H, W = a.shape
+        Cb = b.shape[1]
+        # the concatenation, for the weight gradient's operand (and its range probe from the parts')
+        x = torch.empty((N, Ca + Cb) + tuple(b.shape[2:]), device=a.device, dtype=torch.float32)
+        check(lib().dfmir_upcat_fwd(_p(a), _p(b), _p(x), N, Ca, Cb, D, H, W, 2, _st()))
+        xp = amax_slot(a.device, PROBE_SLOTS)
+        check(lib().dfmir_probe_merge(_p(ctx.probes[0]), _p(ctx.probes[1]), _p(xp), _st()))
+        c = _Ctx()
+        c.cfg, c.x_amax, c.has_bias = ctx.cfg, xp, ctx.has_bias
+        need_b = ctx.needs_input_grad[1]
+        c.dead_tail = 0 if need_b else Cb
+        c.in_act = None
+        c.needs_input_grad = (ctx.needs_input_grad[0] or need_b, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dx, dw, dbias = _conv_backward_impl(c, dy, None, x, weight, y)
+        da = db = None
+        if dx is not None:
+            dx = _c(dx)
+            da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            db = torch.empty_like(b) if need_b else None
+            if da is not None or db is not None:
+                check(lib().dfmir_upcat_bwd(_p(dx), _p(da), _p(db), N, Ca, Cb, D, H, W, 2, _st()))
+        return da, db, dw, dbias, None, None, None
+
+
+def upcat_conv3d_ok(a, b, weight):
+    if _NO_UPPHASE or _NO_SPLIT3D or a.dim() != 5 or not (a.is_cuda and b.is_cuda):
+        return False
+    N, Ca, D, H, W = a.shape
+    return (tuple(weight.shape[2:]) == (3, 3, 3) and tuple(b.shape[2:]) == (2 * D, 2 * H, 2 * W)
+            and bool(lib().dfmir_conv3d_up_ok(N, Ca, int(weight.shape[0]), D, H, W)))
+
+
+def upcat_conv3d(a, b, weight, bias, owner, act=0, slope=0.0, sole=False):
+    """The next ConvBlock applied to cat([nearest_up2(a), b], 1); see UpCatConv3dFn."""
+    _LAST_CONV_AMAX[0] = None
+    out = UpCatConv3dFn.apply(a, b, weight, bias, owner, act, slope)
+    if _LAST_CONV_AMAX[0] is not None:
+        tag_amax(out, _LAST_CONV_AMAX[0])
+        _LAST_CONV_AMAX[0] = None
+    if sole and act == 1:
+        out._df_act_sole = (act, float(slope), out._version, out.data_ptr())
+    return out
 
 
 class CatChannelsFn(Function):

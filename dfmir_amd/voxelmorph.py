@@ -81,6 +81,8 @@ class ConvBlock(nn.Module):
 
     def forward(self, x, sole=False):
         # sole=True: the result feeds exactly one consumer (the next conv): see ops.conv
+        if isinstance(x, tuple):        # (a, b): this block consumes cat([nearest_up2(a), b], 1) -- see Unet.forward
+            return self.main.forward_upcat(x[0], x[1], act=1, slope=0.2, sole=sole)
         return self.main(x, act=1, slope=0.2, sole=sole)
 
 
@@ -131,9 +133,13 @@ class Unet(nn.Module):
         x = x_enc.pop()
         for layer in self.uparm:
             x = layer(x)
-            x = ops.upcat(x, x_enc.pop())
-        for layer in self.extras:
+            # nn.Upsample(nearest, x2) + torch.cat with the mirrored encoder level (networks.py:97-100) are consumed by the
+            # NEXT ConvBlock: handed over as the pair (a, b), so that the 3-D layers never build the concatenation
+            x = (x, x_enc.pop())
+        for i, layer in enumerate(self.extras):
             x = layer(x, sole=True)     # a chain: each output feeds the next ConvBlock (the last one the flow head) only
+        if isinstance(x, tuple):        # no extras (not a configuration of the path): the concatenation itself
+            x = ops.upcat(x[0], x[1])
         return x
 
 

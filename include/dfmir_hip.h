@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 6
+#define DFMIR_ABI_VERSION 7
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -101,6 +101,29 @@ int dfmir_conv3d_split_fwd_sub(const DfConvGeom* g, const float* x, const float*
 int dfmir_conv3d_split_fwd_actgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                    const float* w_tcc, float* ws, const float* bias, float* y, float* y_amax,
                                    int cout_used, const float* act_src, float act_slope, void* stream);
+/* conv3x3x3(cat(nearest_up2(a), b)) WITHOUT the up-sampled / concatenated tensor -- nn.Upsample(scale_factor=2,
+ * mode='nearest') + torch.cat feeding the next ConvBlock (models/voxelmorph/torchvoxelmorph/networks.py:64,97-100).
+ * Per output parity class the 27 taps over nearest_up2(a) fall on 2x2x2 voxels of `a`: dfmir_conv3d_up_fwd computes the
+ * up-sampled channels' share as eight 8-tap convolutions of `a` with summed weights (8/27 of the products) and leaves
+ * the PARTIAL sum in y [N, Cout, 2D, 2H, 2W]; dfmir_conv3d_split_fwd_add then runs the skip channels b (g: the conv
+ * over b alone, Cin = Cb; its weights are rows koff .. koff + Cb - 1 of the layer's [27][Ktot][Cout] forward packing)
+ * and its epilogue adds the partial sum, the bias, the activation of g and writes y and its range probe.
+ * a [N, Ca, D, H, W] with Ca % 8 == 0, W % 4 == 0 (dfmir_conv3d_up_ok); ws: dfmir_conv3d_up_ws_floats /
+ * dfmir_conv3d_split_ws_floats(Cb, Cout) floats; w_tcc NULL = ws already holds the split of the current weights. */
+int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W);
+long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);
+int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
+                        float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream);
+/* Cb <= 2 (the two input images at the top of the U-Net, networks.py:1105 `x = torch.cat([source, target], dim=1)`): the
+ * whole layer in ONE launch -- after the up-sampled channels the same workgroup runs the skip channels from its own
+ * full-resolution patch (one MFMA k-step = 2 tap rows x 4 x-taps x 2 channels), then bias, LeakyReLU (act 1) and the
+ * range probe.  Ktot of w_tcc == Ca + Cb; ws as dfmir_conv3d_up_ws_floats. */
+int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, int a_amax_n, const float* b, const float* b_amax,
+                              int b_amax_n, int Cb, const float* w_tcc, float* ws, const float* bias, float* y,
+                              float* y_amax, int N, int Ca, int Cout, int D, int H, int W, int act, float slope,
+                              void* stream);
+int dfmir_conv3d_split_fwd_add(const DfConvGeom* g, const float* b, const float* b_amax, int b_amax_n, const float* w_tcc,
+                               int Ktot, int koff, float* ws, const float* bias, float* y, float* y_amax, void* stream);
 int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
 int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
                              const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);

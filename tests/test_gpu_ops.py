@@ -244,6 +244,41 @@ def test_conv3d(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
 
 
+@pytest.mark.parametrize("cfg", [(16, 2, 32, 1, 6, 10, 12, 1), (32, 16, 32, 1, 5, 9, 20, 1), (8, 3, 16, 2, 4, 8, 8, 0),
+                                 (64, 64, 64, 1, 3, 5, 8, 1), (32, 2, 32, 1, 9, 17, 36, 1)],
+                         ids=["16+2->32", "32+16->32", "8+3->16-pair-batch2", "64+64->64", "32+2->32-ragged"])
+def test_upcat_conv3d_parity_class_form(ops, cfg):
+    """ConvBlock over cat([nearest_up2(a), b], 1) (torchvoxelmorph/networks.py:64,97-100,1506-1521) in the form that
+    never builds the concatenation -- up-sampled channels as eight 8-tap parity-class convolutions of `a` with summed
+    weights + skip channels with the partial sum added in the epilogue -- against torch fp64 on the materialised tensor:
+    output, d(a), d(b), dW, db; and against the materialising path of this library."""
+    Ca, Cb, Cout, N, D, H, W, act = cfg
+    a = C.randn(201, N, Ca, D, H, W)
+    b = C.randn(202, N, Cb, 2 * D, 2 * H, 2 * W)
+    w = C.randn(203, Cout, Ca + Cb, 3, 3, 3) / ((Ca + Cb) * 27) ** 0.5
+    bias = C.randn(204, Cout) * 0.1
+    cot = C.randn(205, N, Cout, 2 * D, 2 * H, 2 * W)
+    ar, br, wr, biasr = (t.double().clone().requires_grad_() for t in (a, b, w, bias))
+    xr = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), br], 1)
+    yr = F.conv3d(xr, wr, biasr, padding=1)
+    if act:
+        yr = F.leaky_relu(yr, 0.2)
+    (yr * cot.double()).sum().backward()
+    assert ops.upcat_conv3d_ok(a.to(DEV), b.to(DEV), w.to(DEV))
+    ag, bg, wg, biasg = (t.clone().to(DEV).requires_grad_() for t in (a, b, w, bias))
+    yg = ops.upcat_conv3d(ag, bg, wg, biasg, None, act, 0.2)
+    (yg * cot.to(DEV)).sum().backward()
+    close(yg, yr, what="y")
+    close(ag.grad, ar.grad, rtol=3e-4, what="da")
+    close(bg.grad, br.grad, rtol=3e-4, what="db")
+    close(wg.grad, wr.grad, rtol=1e-3, what="dw")
+    close(biasg.grad, biasr.grad, rtol=1e-3, what="dbias")
+    # the materialising path (one conv over the concatenation): same numbers up to the order of the weight sums
+    a2, b2 = a.clone().to(DEV), b.clone().to(DEV)
+    y2 = ops.conv(ops.upcat(a2, b2), wg.detach(), biasg.detach(), None, 1, 1, 0, act, 0.2)
+    close(yg, y2, rtol=2e-5, what="y vs materialised")
+
+
 def test_conv3d_chain_folds_leaky_relu_backward(ops):
     """A chain of LeakyReLU ConvBlocks whose outputs feed only the next conv (conv(sole=True)): the consumer's dgrad
     epilogue applies the activation's derivative (dfmir_conv3d_split_fwd_actgrad), so no act_bwd pass runs between
