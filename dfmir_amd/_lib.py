@@ -51,9 +51,12 @@ _SIGS = {
     "dfmir_conv3d_up_ws_floats": [c_int, c_int],
     "dfmir_conv3d_up_fwd": [P, P, c_int, P, c_int, P, P] + [c_int] * 6 + [P],
     "dfmir_conv3d_up_skip2_fwd": [P, P, c_int, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 7 + [c_float, P],
+    "dfmir_conv3d_up_dgrad_ws_floats": [c_int, c_int],
+    "dfmir_conv3d_up_dgrad": [P, P, c_int, P, c_int, P, P, P, P, c_float] + [c_int] * 6 + [P],
     "dfmir_conv3d_split_fwd_add": [_GP, P, P, c_int, P, c_int, c_int, P, P, P, P, P],
     "dfmir_conv3d_split_wgrad_ok": [_GP],
     "dfmir_conv3d_split_wgrad": [_GP, P, P, c_int, P, P, c_int, P, P],
+    "dfmir_conv3d_split_wgrad_upcat": [_GP, P, P, c_int, P, c_int, P, P, c_int, P, P, P],
     "dfmir_conv3d_split_wgrad_db": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_probe_merge": [P, P, P, P],
     "dfmir_act_bwd_amax": [P, P, P, c_longlong, c_int, c_float, P, P],
@@ -145,6 +148,7 @@ def lib():
         h.dfmir_weight_pack_floats.restype = c_longlong
         h.dfmir_conv3d_split_ws_floats.restype = c_longlong
         h.dfmir_conv3d_up_ws_floats.restype = c_longlong
+        h.dfmir_conv3d_up_dgrad_ws_floats.restype = c_longlong
         h.dfmir_warp_bwd_own_ws_floats.restype = c_longlong
         h.dfmir_resize_bwd_ws_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []

@@ -1130,6 +1130,274 @@ extern "C" int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, in
     return df_set_error((int)hipErrorLaunchFailure, __FILE__, __LINE__);
   return 0;
 }
+// ================================================================================================
+// d(a) of the same layer, directly at LOW resolution: the adjoint of nearest_up2 (a 2x2x2 sum pool) composed with the
+// conv's dgrad is a 4x4x4 stride-2 convolution of dy -- 64 taps per low-resolution voxel instead of 8 x 27.  In parity
+// classes: with Yp[co, U] = dy[co, 2U + p],
+//     d(a)[ci, V] = sum_p sum_{s in {0,1}^3} sum_co Weff[p][1 - s][ci, co] * Yp[co, V + s - p]
+// conv3d_up_dgrad_k: workgroup = 2 x 8 x 16 low-resolution voxels x 32 input channels; for each (pz, py) and chunk of
+// 8 output channels it reads the rows 2 (z0 - 1 + hz) + pz, 2 (y0 - 1 + hy) + py of dy ONCE (aligned quads), splits
+// them into the two px sub-lattices' patches ([px][split][4 x 10 x 18 positions] x 16 B) and runs 2 x 4 k-steps
+// (K = 2 x-slots x 8 channels).  No up-sampled gradient tensor (0.9 GB at 160x192x224), no pooling pass.
+// ================================================================================================
+// ws[pzy 4][mtile (ci)][chunk (co / 8)][split 2][16 units u = px*8 + sz*4 + sy*2 + sx][32 ci] x (8 co x fp16)
+__global__ __launch_bounds__(1024) void conv3d_up_wsplit_t_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
+                                                             int Ktot, int M, float* __restrict__ trailer) {
+  __shared__ float sm[17];
+  float m = 0.f;
+  const int total = 64 * Ka * M;
+  for (int i = threadIdx.x; i < total; i += 1024) {
+    const int mo = i % M;
+    int t = i / M;
+    const int kk = t % Ka; t /= Ka;
+    m = fmaxf(m, fabsf(up_weff(w, Ktot, M, kk, mo, (t >> 5) & 1, (t >> 4) & 1, (t >> 3) & 1, (t >> 2) & 1, (t >> 1) & 1, t & 1)));
+  }
+  m = block_max(m, sm);
+  if (!(m == m)) m = __uint_as_float(0x7f800000u);
+  const int ew = scale_exp3(m);
+  const float s = pow2f3(ew);
+  if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
+  const int nchunk = (M + 7) / 8, nmt = (Ka + 31) / 32;     // reduction = output channels, rows = a's channels
+  const int units = 4 * nmt * nchunk * 16 * 32;
+  for (int u = blockIdx.x * 1024 + threadIdx.x; u < units; u += gridDim.x * 1024) {
+    const int ci_l = u & 31;
+    int t = u >> 5;
+    const int slot = t & 15; t >>= 4;
+    const int ch = t % nchunk; t /= nchunk;
+    const int mt = t % nmt, pzy = t / nmt;
+    const int ci = mt * 32 + ci_l;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int co = ch * 8 + c;
+      v[c] = (ci < Ka && co < M) ? up_weff(w, Ktot, M, ci, co, pzy >> 1, pzy & 1, slot >> 3, 1 - ((slot >> 2) & 1),
+                                           1 - ((slot >> 1) & 1), 1 - (slot & 1))
+                                 : 0.f;
+    }
+    u32x4 h, r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hh, rr;
+      split_pair3(v[2 * q], v[2 * q + 1], s, hh, rr);
+      h[q] = hh; r[q] = rr;
+    }
+    const long long base = ((((long long)pzy * nmt + mt) * nchunk + ch) * 2) * 512;
+    ws[base + slot * 32 + ci_l] = h;
+    ws[base + 512 + slot * 32 + ci_l] = r;
+  }
+}
+
+struct C3dP {
+  int N, Ca, Cout, D, H, W;      // D, H, W: the LOW-resolution volume (d(a)); dy is [N, Cout, 2D, 2H, 2W]
+  int nz, ny, nx, nchunk, dy_n;
+  long long ntile;
+  const float* act_src;          // optional: a itself when it is the output of a LeakyReLU feeding only this layer
+  float act_slope;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_up_dgrad_k(const float* __restrict__ dy, const float* __restrict__ dy_amax,
+                                                         const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
+                                                         float* __restrict__ da, float* __restrict__ da_amax, C3dP k) {
+  constexpr int TZ = 2, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  constexpr int XP = HZ * HY * HX;                        // 720 positions per px sub-lattice and split
+  constexpr int WU = 2 * 16 * 32;                         // 1024 units of one (pzy, chunk)'s weights
+  constexpr int NJ = 2;
+  constexpr int NTASK = HZ * HY * 10, NIT = (NTASK + 255) / 256;   // (row, aligned quad) tasks: 400 -> 2 per thread
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ u32x4 Xs[2 * 2 * XP];                        // [px][split][position]
+  __shared__ u32x4 Ws[WU];
+  __shared__ float red[17];
+  __shared__ unsigned smax;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long S = (long long)k.D * k.H * k.W;
+  const int Df = 2 * k.D, Hf = 2 * k.H, Wf = 2 * k.W;
+  const long long Sf = (long long)Df * Hf * Wf;
+  const long long per_xcd = (k.ntile + 7) / 8;
+  const long long tile = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((long long)(blockIdx.x >> 3) >= per_xcd || tile >= k.ntile) return;
+  int n, z0, y0, x0;
+  {
+    long long pid = tile;
+    const int bx = (int)(pid % k.nx); pid /= k.nx;
+    const int bz = (int)(pid % k.nz); pid /= k.nz;
+    const int by = (int)(pid % k.ny);
+    n = (int)(pid / k.ny);
+    z0 = bz * TZ; y0 = by * TY; x0 = bx * TX;
+  }
+  const int mt = blockIdx.y;
+  const float amax = reduce_absmax(dy_amax, k.dy_n, red);
+  const int ex = scale_exp3(amax);
+  const int ew = reinterpret_cast<const int*>(w_trailer)[0];
+  const float xscale = pow2f3(ex), osc = pow2f3(-ex) * pow2f3(-ew);
+  if (tid == 0) smax = 0u;
+
+  const __amdgpu_buffer_rsrc_t y_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dy + (long long)n * k.Cout * Sf), 0, (unsigned)((long long)k.Cout * Sf * 4), 0x00020000);
+  const unsigned sf4 = (unsigned)Sf * 4u;
+  // staging tasks of this thread: task = row * 10 + q, row = hz * HY + hy; the quad starts at column 2 x0 - 4 + 4 q
+  int trow[NIT], tq[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int task = tid + 256 * i;
+    trow[i] = task < NTASK ? task / 10 : -1;
+    tq[i] = task - 10 * (task / 10);
+  }
+  // this lane's output voxels: plane wz, rows wy + 2 j + (l31 >> 4), column lx (lane rotation as conv3d_split_k)
+  const int wz = wid & 1, wy = 4 * (wid >> 1);
+  const int lx = (l31 - 2 * (l31 >> 4)) & 15;
+  int pbase[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) pbase[j] = (wz * HY + wy + 2 * j + (l31 >> 4)) * HX + lx + hi;      // + sx = hi
+
+  f32x16 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  u32x4 rq[NIT][8];
+  u32x4 rw[4];
+  const int nmt = gridDim.y;
+  // loads of sub-phase sp = pzy * nchunk + chunk
+#define C3D_GLOAD(sp_)                                                                            \
+  {                                                                                               \
+    const int pzy_ = (sp_) / k.nchunk, ch_ = (sp_) - pzy_ * k.nchunk;                             \
+    const int pz_ = pzy_ >> 1, py_ = pzy_ & 1;                                                    \
+    _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                             \
+      const int hz = trow[i] / HY, hy = trow[i] - HY * (trow[i] / HY);                            \
+      const int fz = 2 * (z0 - 1 + hz) + pz_, fy = 2 * (y0 - 1 + hy) + py_, fx = 2 * x0 - 4 + 4 * tq[i];   \
+      const bool ok = trow[i] >= 0 && (unsigned)fz < (unsigned)Df && (unsigned)fy < (unsigned)Hf && (unsigned)fx < (unsigned)Wf; \
+      const unsigned off = ok ? (unsigned)((fz * Hf + fy) * Wf + fx) * 4u : OOB;                  \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                               \
+        rq[i][c] = __builtin_amdgcn_raw_buffer_load_b128(y_src, ok ? off + (unsigned)(ch_ * 8 + c) * sf4 : OOB, 0, 0); \
+    }                                                                                             \
+    const u32x4* wp_ = wsp + (((long long)pzy_ * nmt + mt) * k.nchunk + ch_) * WU;                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) rw[j] = wp_[tid + 256 * j];                     \
+  }
+#define C3D_LSTORE()                                                                              \
+  {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                             \
+      if (trow[i] >= 0) {                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+          const int hx = 2 * tq[i] - 1 + (e >> 1);                                                \
+          if ((unsigned)hx < (unsigned)HX) {                                                      \
+            u32x4 h, r;                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
+              unsigned hh, rr;                                                                    \
+              split_pair3(__uint_as_float(rq[i][2 * q][e]), __uint_as_float(rq[i][2 * q + 1][e]), xscale, hh, rr); \
+              h[q] = hh; r[q] = rr;                                                               \
+            }                                                                                     \
+            const int pos = (e & 1) * 2 * XP + trow[i] * HX + hx;                                 \
+            Xs[pos] = h;                                                                          \
+            Xs[XP + pos] = r;                                                                     \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) Ws[tid + 256 * j] = rw[j];                      \
+  }
+  const int nsp = 4 * k.nchunk;
+  C3D_GLOAD(0);
+  C3D_LSTORE();
+  __syncthreads();
+  for (int sp = 0; sp < nsp; ++sp) {
+    const bool more = sp + 1 < nsp;
+    const int pzy = sp / k.nchunk, pz = pzy >> 1, py = pzy & 1;
+    if (more) C3D_GLOAD(sp + 1);
+    // patch offset of slot (sz, sy) for this (pz, py): ((sz + 1 - pz) HY + (sy + 1 - py)) HX + (1 - px)   [+ sx in pbase]
+    const int pofs = ((1 - pz) * HY + (1 - py)) * HX;
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {
+      const int px = tp >> 2, sz = (tp >> 1) & 1, sy = tp & 1;
+      const int toff = px * 2 * XP + pofs + (sz * HY + sy) * HX + (1 - px);
+      const int u = 2 * tp + hi;
+      const u32x4 a0 = Ws[u * 32 + l31], a1 = Ws[512 + u * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const u32x4 b0 = Xs[pbase[j] + toff], b1 = Xs[XP + pbase[j] + toff];
+        acc[j] = mma3(a1, b0, acc[j]);
+        acc[j] = mma3(a0, b1, acc[j]);
+        acc[j] = mma3(a0, b0, acc[j]);
+      }
+    }
+    if (more) {
+      __syncthreads();
+      C3D_LSTORE();
+      __syncthreads();
+    }
+  }
+#undef C3D_GLOAD
+#undef C3D_LSTORE
+  // ---- epilogue: acc[j][r] <-> channel row (r>>2)*8 + hi*4 + (r&3) of tile mt, voxel (z0 + wz, y0 + wy + 2j + (l31>>4), x0 + lx)
+  const __amdgpu_buffer_rsrc_t a_dst = __builtin_amdgcn_make_buffer_rsrc(
+      da + (long long)n * k.Ca * S, 0, (unsigned)((long long)k.Ca * S * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((k.act_src ? k.act_src : da) + (long long)n * k.Ca * S), 0, (unsigned)((long long)k.Ca * S * 4), 0x00020000);
+  const unsigned s4 = (unsigned)S * 4u;
+  float pm = 0.f;
+  const int gz = z0 + wz;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int gy = y0 + wy + 2 * j + (l31 >> 4), gx = x0 + lx;
+    const bool vok = gz < k.D && gy < k.H && gx < k.W;
+    const unsigned vo = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u + (unsigned)(hi * 4) * s4;
+    float av[16];
+    if (k.act_src) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = mt * 32 + (r >> 2) * 8 + (r & 3);
+        av[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s_src, (vok && (ci + hi * 4) < k.Ca) ? vo : OOB, (unsigned)ci * s4, 0));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = mt * 32 + (r >> 2) * 8 + (r & 3);
+      const bool ok = vok && (ci + hi * 4) < k.Ca;
+      float v = acc[j][r] * osc;
+      if (k.act_src) v = av[r] > 0.f ? v : v * k.act_slope;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), a_dst, ok ? vo : OOB, (unsigned)ci * s4, 0);
+      pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
+    }
+  }
+  if (da_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, da_amax);
+  }
+}
+
+extern "C" long long dfmir_conv3d_up_dgrad_ws_floats(int Ca, int Cout) {
+  if (Ca <= 0 || Cout <= 0) return -1;
+  return 4LL * ((Ca + 31) / 32) * ((Cout + 7) / 8) * 1024 * 4 + 4;
+}
+// da [N, Ca, D, H, W] <- d(a) of y = conv3x3x3(cat(nearest_up2(a), b)) given dy [N, Cout, 2D, 2H, 2W] (the gradient
+// w.r.t. the conv's result, i.e. after the activation's backward).  w_tcc: the FORWARD packing [27][Ktot][Cout] or NULL
+// (ws holds the current split).  act_src (optional): a, when a is the output of a LeakyReLU(act_slope) that feeds only
+// this layer -- da then is the gradient w.r.t. that activation's input.  da_amax (optional): range probe of da.
+extern "C" int dfmir_conv3d_up_dgrad(const float* dy, const float* dy_amax, int dy_amax_n, const float* w_tcc, int Ktot,
+                                     float* ws, float* da, float* da_amax, const float* act_src, float act_slope, int N,
+                                     int Ca, int Cout, int D, int H, int W, void* stream) {
+  DF_ARG_CHECK(dy && dy_amax && dy_amax_n > 0 && ws && da && dfmir_conv3d_up_ok(N, Ca, Cout, D, H, W) && (Cout & 7) == 0);
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (!w_tcc || Ktot >= Ca));
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (Cout + 7) / 8, nmt = (Ca + 31) / 32;
+  float* trailer = ws + dfmir_conv3d_up_dgrad_ws_floats(Ca, Cout) - 4;
+  if (w_tcc) {
+    const long long units = 4LL * nmt * nchunk * 512;
+    long long nwg = (units + 1023) / 1024;
+    if (nwg > 32) nwg = 32;
+    conv3d_up_wsplit_t_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), Ca, Ktot, Cout, trailer);
+    DF_LAUNCH_CHECK();
+  }
+  C3dP k{N, Ca, Cout, D, H, W, (D + 1) / 2, (H + 7) / 8, (W + 15) / 16, nchunk, dy_amax_n, 0, act_src, act_slope};
+  k.ntile = (long long)N * k.nz * k.ny * k.nx;
+  const dim3 grid((unsigned)(8 * ((k.ntile + 7) / 8)), (unsigned)nmt);
+  conv3d_up_dgrad_k<<<grid, 256, 0, st>>>(dy, dy_amax, reinterpret_cast<const u32x4*>(ws), trailer, da, da_amax, k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
 // The skip channels' share, added to the partial sum already in y: y = act(conv3x3x3(b; rows koff .. koff + Cb - 1 of the
 // layer's [27][Ktot][Cout] packing) + bias + y), range probe of y in y_amax.  g describes the conv over b alone
 // (Cin = Cb).  w_tcc NULL: ws holds the split of the current weights.
@@ -1164,6 +1432,10 @@ struct W3sP {
   int flip;
   float* db;                     // optional bias gradient: db[.] += sum over voxels of the layer's output gradient
   int db_from_x;                 // 0: db indexed by co, summed from the dY operand;  1: by ci, from the X operand (swapped roles)
+  // X = cat(nearest_up2(xa), x) never materialised (tr kernel): channels 0 .. Ca - 1 are read from the HALF-resolution
+  // tensor xa [N, Ca, D/2, H/2, W/2] at (z >> 1, y >> 1, x >> 1), the remaining Cin - Ca from x [N, Cin - Ca, D, H, W]
+  const float* xa;
+  int Ca;
 };
 
 template <int NCH>
@@ -1409,7 +1681,10 @@ struct W3T {
 // row (dz', .) x column (p, .) is a term of dW[dz' - p] (dropped where dz' - p is outside 0..2): 9 row tiles x 8
 // k-steps instead of 7 x 16.  A wave owns tiles w and w + 4 and k-steps 2w, 2w + 1 of tile 8 (the partial sums meet
 // in the atomics of the epilogue): 18 tile-steps per wave and phase instead of 32.
-template <int NCH, bool PAIR>
+// UPCAT: X = cat(nearest_up2(xa), x) read in place (see W3sP::xa).  A compile-time variant: a branch around the operand
+// prefetch splits the k-loop's basic block and with it the MFMA / LDS / VMEM interleave (measured: +35 % on every shape),
+// so both sources are loaded branch-free -- the inactive one with an out-of-range offset (returns 0, no memory access).
+template <int NCH, bool PAIR, bool UPCAT>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restrict__ x, const float* __restrict__ x_amax,
                                                          const float* __restrict__ dy, const float* __restrict__ dy_amax,
                                                          float* __restrict__ dwt, W3sP k) {
@@ -1502,19 +1777,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
     ty = 2 * (b_ / nzb) + ((u_ >> 1) & 1);                                                        \
   }
   W3T_DECODE(t_first)
-  unsigned gq = OOB, gy_ = OOB;
-  __amdgpu_buffer_rsrc_t x_src, y_src;
+  unsigned gq = OOB, gy_ = OOB, gqa = OOB;
+  __amdgpu_buffer_rsrc_t x_src, y_src, xa_src;
+  const int Cup = UPCAT ? k.Ca : 0;                         // channels taken from the half-resolution tensor
+  const int Dh = k.D >> 1, Hh = k.H >> 1, Wh = k.W >> 1;
+  const unsigned sa4 = (unsigned)((long long)Dh * Hh * Wh) * 4u;
 #define W3T_TILE_ADDR()                                                                           \
   {                                                                                               \
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;                                           \
-    x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)tn * k.Cin * S), 0,   \
-                                              (unsigned)((long long)k.Cin * S * 4), 0x00020000);  \
+    x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)tn * (k.Cin - Cup) * S), 0,   \
+                                              (unsigned)((long long)(k.Cin - Cup) * S * 4), 0x00020000);  \
+    if (UPCAT) xa_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k.xa + (long long)tn * Cup * (sa4 >> 2)), 0,   \
+                                                        (unsigned)((long long)Cup * sa4), 0x00020000);  \
     y_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (long long)tn * k.Cout * S), 0, \
                                               (unsigned)((long long)k.Cout * S * 4), 0x00020000); \
     {                                                                                             \
       const int gz = z0 - 1 + xhz, gyy = y0 - 1 + xhy, gx = x0 - 4 + 4 * xqq;                     \
       gq = (xt && tz < k.nz && ty < k.ny && (unsigned)gz < (unsigned)k.D && (unsigned)gyy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
                ? (unsigned)((gz * k.H + gyy) * k.W + gx) * 4u : OOB;                              \
+      gqa = (UPCAT && gq != OOB) ? (unsigned)(((gz >> 1) * Hh + (gyy >> 1)) * Wh + (gx >> 1)) * 4u : OOB;   \
     }                                                                                             \
     {                                                                                             \
       const int gz = z0 + (yrow >> 3), gyy = y0 + (yrow & 7), gx = x0 + 4 * yq;                   \
@@ -1522,7 +1803,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
     }                                                                                             \
   }
 #define W3T_GLOAD_X1(ca_, c_)                                                                     \
-  rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + (unsigned)((ca_) * 8 + (c_)) * s4, 0, 0);
+  if constexpr (UPCAT) {     /* a chunk lies entirely in one of the two tensors (Ca % 8 == 0): wave-uniform selects */ \
+    typedef unsigned u32x2w_ __attribute__((ext_vector_type(2)));                                 \
+    const bool up_ = (ca_) * 8 < Cup;                                                             \
+    const u32x2w_ v2_ = __builtin_amdgcn_raw_buffer_load_b64(                                     \
+        xa_src, (up_ && gqa != OOB) ? gqa + (unsigned)((ca_) * 8 + (c_)) * sa4 : OOB, 0, 0);      \
+    const u32x4 v4_ = __builtin_amdgcn_raw_buffer_load_b128(                                      \
+        x_src, (!up_ && gq != OOB) ? gq + (unsigned)((ca_) * 8 + (c_) - Cup) * s4 : OOB, 0, 0);   \
+    rq[c_] = u32x4{v2_[0] | v4_[0], v2_[0] | v4_[1], v2_[1] | v4_[2], v2_[1] | v4_[3]};           \
+  } else {                                                                                        \
+    rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + (unsigned)((ca_) * 8 + (c_)) * s4, 0, 0); \
+  }
 #define W3T_GLOAD_Y1(c_)                                                                          \
   ry[c_] = __builtin_amdgcn_raw_buffer_load_b128(y_src, gy_ == OOB ? OOB : gy_ + (unsigned)(wid * 8 + (c_)) * s4, 0, 0);
 #define W3T_STORE_X()                                                                             \
@@ -1752,7 +2043,17 @@ extern "C" int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g) {
 }
 static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                    const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
-                                   void* stream);
+                                   void* stream, const float* xa = nullptr, int Ca = 0);
+// The weight gradient of conv3x3x3 over X = cat(nearest_up2(a), b) without building X: a [N, Ca, D/2, H/2, W/2] is read
+// at (z >> 1, y >> 1, x >> 1) while the operand patch is staged.  g: the full layer (Cin = Ca + Cb); Ca % 8 == 0; even
+// D, H, W; x_amax: a range probe valid for both parts.
+extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* a, const float* b, int Ca,
+                                              const float* x_amax, int x_amax_n, const float* dy, const float* dy_amax,
+                                              int dy_amax_n, float* dw_tcc, float* db, void* stream) {
+  DF_ARG_CHECK(g && a && b && Ca > 0 && (Ca & 7) == 0 && Ca < g->Cin && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7));
+  DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !getenv("DFMIR_CONV3D_WGRAD_COPIES") && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
+  return conv3d_split_wgrad_impl(g, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream, a, Ca);
+}
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                         const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                         void* stream) {
@@ -1765,13 +2066,14 @@ extern "C" int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, 
 }
 static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                    const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
-                                   void* stream) {
+                                   void* stream, const float* xa, int Ca) {
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
   DF_ARG_CHECK(!split3d_off() && (split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
   hipStream_t st = (hipStream_t)stream;
   const bool swapped = !split3d_wgrad_geom_ok(g);
   W3sP k{};
   k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
+  k.xa = xa; k.Ca = xa ? Ca : 0;
   if (swapped) {
     k.Cin = g->Cout; k.Cout = g->Cin;                        // kernel roles
     k.s_tap = (long long)g->Cin * g->Cout; k.s_row = 1; k.s_col = g->Cout; k.flip = 1;
@@ -1816,10 +2118,13 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
 #define W3S_LAUNCH(N_)                                                                            \
   {                                                                                               \
     if (tr_off) conv3d_wgrad_split_k<N_><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
-    else conv3d_wgrad_tr_k<N_, false><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
+    else if (xa) conv3d_wgrad_tr_k<N_, false, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
+    else conv3d_wgrad_tr_k<N_, false, false><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);   \
   }
-  if (pairw && per_wg == 1) conv3d_wgrad_tr_k<1, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
-  else if (pairw) conv3d_wgrad_tr_k<2, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  if (pairw && per_wg == 1 && xa) conv3d_wgrad_tr_k<1, true, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  else if (pairw && xa) conv3d_wgrad_tr_k<2, true, true><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  else if (pairw && per_wg == 1) conv3d_wgrad_tr_k<1, true, false><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
+  else if (pairw) conv3d_wgrad_tr_k<2, true, false><<<dim3(nbx, gy), 256, 0, st>>>(kx, kxa, kdy, kda, dw_tcc, k);
   else if (per_wg == 1) W3S_LAUNCH(1)
   else if (per_wg == 2) W3S_LAUNCH(2)
   else W3S_LAUNCH(3)

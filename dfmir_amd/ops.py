@@ -247,9 +247,17 @@ def _tag_ok(t, tag):
     return tag is not None and tag[-2] == t._version and tag[-1] == t.data_ptr()
 
 
-def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None):
-    """dW in the tap-major packing; `out` (same packing) is accumulated into when given."""
-    N, Cin, Di, Hi, Wi = x5.shape
+def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None,
+                   parts=None):
+    """dW in the tap-major packing; `out` (same packing) is accumulated into when given.  parts = (a, b): the operand is
+    cat(nearest_up2(a), b), never built (x5 is None; the caller checked upcat_wgrad_ok)."""
+    if parts is not None:
+        a_, b_ = parts
+        N, Cin = b_.shape[0], a_.shape[1] + b_.shape[1]
+        Di, Hi, Wi = b_.shape[2:]
+        x5 = b_
+    else:
+        N, Cin, Di, Hi, Wi = x5.shape
     _, Cout, Do, Ho, Wo = dy5.shape
     T = K[0] * K[1] * K[2]
     dw = zeros((T, Cin, Cout), x5.device) if out is None else out
@@ -257,14 +265,22 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
                    pad[2], pad_mode, 0, 0.0)
     split3d = (x_amax is not None and dy_amax is not None and tuple(K) == (3, 3, 3)
                and bool(lib().dfmir_conv3d_split_wgrad_ok(ctypes.byref(g))))
+    if parts is not None and not split3d:
+        raise DfmirHipError("conv_wgrad_raw(parts=...) needs the split 3-D weight-gradient kernel")
     if _PROBE_AUDIT["on"]:
         if x_amax is not None:
-            _audit_probe(x5, x_amax, "wgrad x %s" % (tuple(x5.shape),))
+            for t_ in (parts if parts is not None else (x5,)):
+                _audit_probe(t_, x_amax, "wgrad x %s" % (tuple(t_.shape),))
         if dy_amax is not None:
             pm_ = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and not split3d) else None
             _audit_probe(dy5, dy_amax, "wgrad dY %s" % (tuple(dy5.shape),), plane_max=pm_)
 
     def launch():
+        if parts is not None:
+            check(lib().dfmir_conv3d_split_wgrad_upcat(ctypes.byref(g), _p(parts[0]), _p(parts[1]), parts[0].shape[1],
+                                                       _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax), dy_amax.numel(),
+                                                       _p(dw), _p(db), _st()))
+            return
         if split3d:
             check(lib().dfmir_conv3d_split_wgrad_db(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(dy5),
                                                     _p(dy_amax), dy_amax.numel(), _p(dw), _p(db), _st()))   # db fused
@@ -605,14 +621,15 @@ def _conv_backward_impl(ctx, dy, dskip, x5, weight, y5):
             ptag = getattr(dy, "_df_pmax", None) if not act else None     # per-plane maxima of dY (InstanceNorm backward)
             dy_pmax = ptag[0] if (ptag is not None and ptag[1] == dy._version and ptag[2] == dy.data_ptr()
                                   and dy.is_contiguous() and not _NO_CH_SCALE) else None
+            parts = getattr(ctx, "x_parts", None)
             if defer:
                 T = K[0] * K[1] * K[2]
                 conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode,
                                out=_deferred_buffer(owner, T, Cin, Cout, tuple(weight.shape), dy5.device),
-                               x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf, dy_pmax=dy_pmax)
+                               x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf, dy_pmax=dy_pmax, parts=parts)
             else:
                 dwt = conv_wgrad_raw(x5, dy5, K, stride, p3, pad_mode, x_amax=ctx.x_amax, dy_amax=dy_amax, db=db_buf,
-                                     dy_pmax=dy_pmax)
+                                     dy_pmax=dy_pmax, parts=parts)
                 dw = weight_unpack(dwt, tuple(weight.shape))
         elif db_buf is not None:
             S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
@@ -991,6 +1008,8 @@ def upcat(a, b):
     return y
 
 
+_NO_UPWGRAD = bool(os.environ.get("DFMIR_CONV3D_NO_UPWGRAD"))     # A/B switch: weight gradient from the materialised cat
+_NO_UPDGRAD = bool(os.environ.get("DFMIR_CONV3D_NO_UPDGRAD"))     # A/B switch: d(a) through the full-resolution dgrad + pool
 _NO_UPSKIP2 = bool(os.environ.get("DFMIR_CONV3D_NO_UPSKIP2"))     # A/B switch: <= 2 skip channels as a second launch
 _NO_UPPHASE = bool(os.environ.get("DFMIR_CONV3D_NO_UPPHASE"))     # A/B switch: materialise nearest_up2 + cat, one conv
 
@@ -1080,7 +1099,8 @@ class UpCatConv3dFn(Function):
         ctx.probes = (pa, pb)
         ctx.cfg = (3, (3, 3, 3), 1, (1, 1, 1), 0, act, slope, owner)
         ctx.has_bias = bias is not None
-        ctx.b_needs = bool(b.requires_grad)
+        ta = getattr(a, "_df_act_sole", None)          # a = the output of a LeakyReLU ConvBlock feeding only this layer
+        ctx.a_act = (ta[0], ta[1]) if (_tag_ok(a, ta) and not _NO_ACTGRAD) else None
         return y
 
     @staticmethod
@@ -1089,22 +1109,69 @@ class UpCatConv3dFn(Function):
         a, b, weight, y = ctx.saved_tensors
         N, Ca, D, H, W = a.shape
         Cb = b.shape[1]
-        # the concatenation, for the weight gradient's operand (and its range probe from the parts')
-        x = torch.empty((N, Ca + Cb) + tuple(b.shape[2:]), device=a.device, dtype=torch.float32)
-        check(lib().dfmir_upcat_fwd(_p(a), _p(b), _p(x), N, Ca, Cb, D, H, W, 2, _st()))
+        Cout = weight.shape[0]
+        nd, K, stride, p3, pad_mode, act, slope, owner = ctx.cfg
+        dy = _c(dy)
+        # gradient w.r.t. the conv's result (LeakyReLU backward, unless the consumer's dgrad epilogue already applied it)
+        if act and not _tag_ok(dy, getattr(dy, "_df_premasked", None)):
+            dpre = torch.empty_like(dy)
+            if not ((dy.data_ptr() | y.data_ptr() | dpre.data_ptr()) & 15):
+                slot = amax_slot(dy.device, PROBE_SLOTS)
+                check(lib().dfmir_act_bwd_amax(_p(dy), _p(y), _p(dpre), dy.numel(), act, float(slope), _p(slot), _st()))
+                tag_amax(dpre, slot)
+            else:
+                check(lib().dfmir_act_bwd(_p(dy), _p(y), _p(dpre), dy.numel(), act, float(slope), _st()))
+            dy = dpre
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        up_dgrad = need_a and not need_b and Cout % 8 == 0 and not _NO_UPDGRAD
         xp = amax_slot(a.device, PROBE_SLOTS)
         check(lib().dfmir_probe_merge(_p(ctx.probes[0]), _p(ctx.probes[1]), _p(xp), _st()))
         c = _Ctx()
-        c.cfg, c.x_amax, c.has_bias = ctx.cfg, xp, ctx.has_bias
-        need_b = ctx.needs_input_grad[1]
+        gfull = DfConvGeom(N, Ca + Cb, Cout, 2 * D, 2 * H, 2 * W, 2 * D, 2 * H, 2 * W, 3, 3, 3, 1, 1, 1, 1, 1, 0, 0, 0.0)
+        gather = (up_dgrad and not _NO_UPWGRAD and W % 4 == 0 and ctx.needs_input_grad[2]
+                  and bool(lib().dfmir_conv3d_split_wgrad_ok(ctypes.byref(gfull))) and Cout >= 8)
+        if gather:
+            # the weight gradient stages its operand patch from a (at half the coordinates) and b: no concatenation
+            x = None
+            c.x_parts = (a, b)
+        else:
+            # the concatenation, for the weight gradient's operand (and the dgrad's reference shape)
+            x = torch.empty((N, Ca + Cb) + tuple(b.shape[2:]), device=a.device, dtype=torch.float32)
+            check(lib().dfmir_upcat_fwd(_p(a), _p(b), _p(x), N, Ca, Cb, D, H, W, 2, _st()))
+        c.cfg, c.x_amax, c.has_bias = (nd, K, stride, p3, pad_mode, 0, 0.0, owner), xp, ctx.has_bias
         c.dead_tail = 0 if need_b else Cb
         c.in_act = None
-        c.needs_input_grad = (ctx.needs_input_grad[0] or need_b, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
-        dx, dw, dbias = _conv_backward_impl(c, dy, None, x, weight, y)
+        c.needs_input_grad = ((need_a or need_b) and not up_dgrad, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dx, dw, dbias = _conv_backward_impl(c, dy, None, x, weight, None)
         da = db = None
-        if dx is not None:
+        if up_dgrad:
+            # d(a) directly at low resolution: the sum pool of nearest_up2's adjoint composed with the dgrad is a 4x4x4
+            # stride-2 conv of dy, run in parity classes (csrc/conv3ds.hip conv3d_up_dgrad_k)
+            w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
+            ws, split = _ws_cached(w_tcc, ("updgrad", Ca, Cout), lib().dfmir_conv3d_up_dgrad_ws_floats(Ca, Cout), a.device)
+            dya = amax_of(dy)
+            if _PROBE_AUDIT["on"]:
+                _audit_probe(dy, dya, "upcat conv dY %s" % (tuple(dy.shape),))
+            da = torch.empty_like(a)
+            slot = amax_slot(a.device, PROBE_SLOTS)
+            ia = ctx.a_act
+
+            def launch():
+                check(lib().dfmir_conv3d_up_dgrad(_p(dy), _p(dya), dya.numel(), _p(w_tcc) if split else None, Ca + Cb, _p(ws),
+                                                  _p(da), _p(slot), _p(a) if ia else None, float(ia[1]) if ia else 0.0,
+                                                  N, Ca, Cout, D, H, W, _st()))
+            prof = _CONV_PROFILER[0]
+            if prof is None:
+                launch()
+            else:
+                size = "L" if Ca > 64 else ("M" if Ca > 32 else ("S" if Ca > 4 else "small"))
+                prof("conv3dup_" + size, 2.0 * 8.0 * N * D * H * W * Cout * Ca * 27, launch)     # reference-equivalent FLOPs
+            tag_amax(da, slot)
+            if ia:
+                da._df_premasked = (da._version, da.data_ptr())
+        elif dx is not None:
             dx = _c(dx)
-            da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            da = torch.empty_like(a) if need_a else None
             db = torch.empty_like(b) if need_b else None
             if da is not None or db is not None:
                 check(lib().dfmir_upcat_bwd(_p(dx), _p(da), _p(db), N, Ca, Cb, D, H, W, 2, _st()))

@@ -132,7 +132,7 @@ class Unet(nn.Module):
             x_enc.append(layer(x_enc[-1]))
         x = x_enc.pop()
         for layer in self.uparm:
-            x = layer(x)
+            x = layer(x, sole=True)     # feeds only the next block (through the pair below)
             # nn.Upsample(nearest, x2) + torch.cat with the mirrored encoder level (networks.py:97-100) are consumed by the
             # NEXT ConvBlock: handed over as the pair (a, b), so that the 3-D layers never build the concatenation
             x = (x, x_enc.pop())

@@ -122,11 +122,28 @@ int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, int a_amax_n,
                               int b_amax_n, int Cb, const float* w_tcc, float* ws, const float* bias, float* y,
                               float* y_amax, int N, int Ca, int Cout, int D, int H, int W, int act, float slope,
                               void* stream);
+/* d(a) of that layer, directly at low resolution (autograd of nn.Upsample(nearest) + Conv3d: a 2x2x2 sum pool of the
+ * conv's input gradient = a 4x4x4 stride-2 convolution of dy, run in parity classes: 64 instead of 216 taps per
+ * low-resolution voxel, no up-sampled gradient tensor, no pooling pass).  dy [N, Cout, 2D, 2H, 2W] = gradient w.r.t. the
+ * conv's result (after the activation's backward), Cout % 8 == 0; w_tcc = the FORWARD packing [27][Ktot][Cout] or NULL (ws
+ * current); act_src (optional) = a when a is the output of a LeakyReLU(act_slope) feeding only this layer: da then is the
+ * gradient w.r.t. that activation's input; da_amax (optional) = range probe of da. */
+long long dfmir_conv3d_up_dgrad_ws_floats(int Ca, int Cout);
+int dfmir_conv3d_up_dgrad(const float* dy, const float* dy_amax, int dy_amax_n, const float* w_tcc, int Ktot, float* ws,
+                          float* da, float* da_amax, const float* act_src, float act_slope, int N, int Ca, int Cout, int D,
+                          int H, int W, void* stream);
 int dfmir_conv3d_split_fwd_add(const DfConvGeom* g, const float* b, const float* b_amax, int b_amax_n, const float* w_tcc,
                                int Ktot, int koff, float* ws, const float* bias, float* y, float* y_amax, void* stream);
 int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g);
 int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
                              const float* dy_amax, int dy_amax_n, float* dw_tcc, void* stream);
+/* The weight (and bias) gradient of conv3x3x3 over X = cat(nearest_up2(a), b) without building X (autograd of
+ * nn.Upsample + torch.cat + Conv3d, networks.py:64,97-100): a [N, Ca, D/2, H/2, W/2] is read at (z>>1, y>>1, x>>1) while
+ * the operand patch is staged.  g = the whole layer (Cin = Ca + Cb); Ca % 8 == 0; D, H even, W % 8 == 0; x_amax = a range
+ * probe valid for both parts; db may be NULL. */
+int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax,
+                                   int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
+                                   float* db, void* stream);
 /* The same, also accumulating the bias gradient db[Cout] += sum dy from the units it stages anyway (db may be NULL).
  * Layers with fewer than 8 output channels (the 16 -> 3 flow conv, networks.py:1077) are taken with the operand roles
  * swapped: rows = (tap, co) from shifted dy, columns = ci. */

@@ -273,6 +273,15 @@ def test_upcat_conv3d_parity_class_form(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
     close(wg.grad, wr.grad, rtol=1e-3, what="dw")
     close(biasg.grad, biasr.grad, rtol=1e-3, what="dbias")
+    # b without a gradient (the network's input images at the top level): d(a) comes from the parity-class dgrad kernel
+    # (4x4x4 stride-2 conv of dy at low resolution) instead of full-resolution dgrad + 2x2x2 sum pool
+    if Cout % 8 == 0:
+        a3, w3, bias3 = (t.clone().to(DEV).requires_grad_() for t in (a, w, bias))
+        y3 = ops.upcat_conv3d(a3, b.clone().to(DEV), w3, bias3, None, act, 0.2)
+        (y3 * cot.to(DEV)).sum().backward()
+        close(y3, yr, what="y (b no grad)")
+        close(a3.grad, ar.grad, rtol=3e-4, what="da (parity-class dgrad)")
+        close(w3.grad, wr.grad, rtol=1e-3, what="dw (b no grad)")
     # the materialising path (one conv over the concatenation): same numbers up to the order of the weight sums
     a2, b2 = a.clone().to(DEV), b.clone().to(DEV)
     y2 = ops.conv(ops.upcat(a2, b2), wg.detach(), biasg.detach(), None, 1, 1, 0, act, 0.2)
