@@ -218,7 +218,8 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     fw_kinds = ["conv3d_" + z for z in sizes]           # fp32-MFMA kernel (csrc/conv3d.hip): A/B env only
     wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]      # fp32-MFMA wgrad (Cin > 128 layers)
     wgs_kinds = ["wgrad3ds_" + z for z in ("S", "M", "L")]    # split fp16x2 wgrad
-    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds)
+    up_kinds = ["conv3dup_" + z for z in sizes]         # parity-class kernels of the nearest_up2 + cat layers
+    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds + up_kinds)
     ops.set_conv_profiler(timer)
     for _ in range(max(warmup, 3) if capture else warmup):
         m.set_input({"A": A, "B": B})
@@ -256,6 +257,7 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     fw_tf, fw_n, fw_ms = agg(fw_kinds)
     wg_tf, wg_n, wg_ms = agg(wg_kinds)
     wgs_tf, wgs_n, wgs_ms = agg(wgs_kinds)
+    up_tf, up_n, up_ms = agg(up_kinds)
     timed_over = ("%d eager steps right after the timed region (one hipGraph replay per step)" % roofline_steps) if graphed \
         else "the timed region"
     if sp_n:
@@ -285,6 +287,14 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     else:
         roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_achieved": wg_tf,
                      "wgrad_frac_of_fp32_peak": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n})
+    if up_n:
+        roof["up_phase"] = {
+            "kernel": "conv3d_up_phase_k / conv3d_up_dgrad_k: forward and d(a) of the ConvBlocks that consume "
+                      "cat(nearest_up2(a), b) in parity classes (the 27 taps over the up-sampled tensor fall on 2x2x2 "
+                      "low-resolution voxels: 8/27 of the reference's products, no up-sampled / concatenated tensor)",
+            "reference_equivalent_tflops": up_tf, "executed_fraction_of_reference_flops": 8.0 / 27.0,
+            "executed_tflops": up_tf * 8.0 / 27.0, "issued_frac": 3.0 * up_tf * 8.0 / 27.0 / FP16_MFMA_PEAK_TFLOPS,
+            "launches_timed": up_n, "ms": up_ms}
     return {"workload": "3-D %dx%dx%d volume pair, batch 1, VxmDense %s features + NCC[9,9,9] + Grad-l2, fwd+bwd+Adam (%s)"
                         % (tuple(shape) + ("default" if feats is None else "plugin 6-level", label)),
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,

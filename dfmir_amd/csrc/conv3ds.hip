@@ -68,9 +68,8 @@ __device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
 // pair != 0 (M <= 16): 36 taps' per chunk, row (p, co) = p * 16 + co holds W[dz' - p] (see the PAIR form above).
 // Ktot / koff: the layer's reduction channels are rows koff .. koff + K - 1 of a packing with Ktot rows per tap (the skip
 // channels of a concatenated input, conv3d_up_phase_k below); Ktot == K, koff == 0 for a whole layer.
-__global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
-                                                        int M, float* __restrict__ trailer, int pair, int Ktot, int koff) {
-  __shared__ float sm[17];
+__device__ __forceinline__ void conv3d_wsplit_body(const float* __restrict__ w, u32x4* __restrict__ ws, int K, int M,
+                                                   float* __restrict__ trailer, int pair, int Ktot, int koff, float* sm) {
   float m = 0.f;
   const int total = 27 * K * M;
   for (int i = threadIdx.x; i < total; i += 1024) {
@@ -116,6 +115,11 @@ __global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict_
     ws[base + tu * 32 + co] = h;
     ws[base + NT * 32 + tu * 32 + co] = r;
   }
+}
+__global__ __launch_bounds__(1024) void conv3d_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int K,
+                                                        int M, float* __restrict__ trailer, int pair, int Ktot, int koff) {
+  __shared__ float sm[17];
+  conv3d_wsplit_body(w, ws, K, M, trailer, pair, Ktot, koff, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -653,18 +657,17 @@ __device__ __forceinline__ float up_weff(const float* __restrict__ w, int Ktot, 
 // Cb in {1, 2} skip channels (the network's input images at the top level): a second section after the phase units,
 // [mtile][split 2][10 tap rows t = dz*3 + dy (9 = padding)][32] x (4 x-taps (3 = padding) x 2 channels x fp16) with its own
 // scale trailer[1] -- the skip share then runs INSIDE conv3d_up_phase_k (one MFMA k-step = 2 tap rows x 4 x 2).
-__global__ __launch_bounds__(1024) void conv3d_up_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
-                                                           int Ktot, int M, float* __restrict__ trailer, int Cb) {
-  __shared__ float sm[17];
+__device__ __forceinline__ void conv3d_up_wsplit_body(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka, int Ktot,
+                                                      int M, float* __restrict__ trailer, int Cb, float* sm) {
+  // scale from a BOUND of the effective weights: an effective weight sums <= 8 taps, so |Weff| <= 8 max|w| (evaluating
+  // all 64 Ka M sums in every workgroup just for their maximum cost 0.2 ms on the 64-channel levels).  A loose scale
+  // only moves the fp16 pairs' exponent window: elements above 2^-14 of the bound keep their 22 bits
   float m = 0.f;
-  const int total = 64 * Ka * M;                           // (8 phases x 8 slots) x Ka x M effective weights
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int mo = i % M;
-    int t = i / M;
-    const int kk = t % Ka; t /= Ka;
-    m = fmaxf(m, fabsf(up_weff(w, Ktot, M, kk, mo, (t >> 5) & 1, (t >> 4) & 1, (t >> 3) & 1, (t >> 2) & 1, (t >> 1) & 1, t & 1)));
+  for (int i = threadIdx.x; i < 27 * Ka * M; i += 1024) {
+    const int tapi = i / (Ka * M), rem = i - tapi * (Ka * M);
+    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot) * M + rem]));
   }
-  m = block_max(m, sm);
+  m = 8.f * block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
   const float s = pow2f3(ew);
@@ -728,6 +731,11 @@ __global__ __launch_bounds__(1024) void conv3d_up_wsplit_k(const float* __restri
     wsk[(long long)mt * 640 + t * 32 + co] = h;
     wsk[(long long)mt * 640 + 320 + t * 32 + co] = r;
   }
+}
+__global__ __launch_bounds__(1024) void conv3d_up_wsplit_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
+                                                           int Ktot, int M, float* __restrict__ trailer, int Cb) {
+  __shared__ float sm[17];
+  conv3d_up_wsplit_body(w, ws, Ka, Ktot, M, trailer, Cb, sm);
 }
 
 struct C3uP {
@@ -1141,18 +1149,15 @@ extern "C" int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, in
 // (K = 2 x-slots x 8 channels).  No up-sampled gradient tensor (0.9 GB at 160x192x224), no pooling pass.
 // ================================================================================================
 // ws[pzy 4][mtile (ci)][chunk (co / 8)][split 2][16 units u = px*8 + sz*4 + sy*2 + sx][32 ci] x (8 co x fp16)
-__global__ __launch_bounds__(1024) void conv3d_up_wsplit_t_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
-                                                             int Ktot, int M, float* __restrict__ trailer) {
-  __shared__ float sm[17];
+__device__ __forceinline__ void conv3d_up_wsplit_t_body(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka, int Ktot,
+                                                        int M, float* __restrict__ trailer, float* sm) {
+  // scale from the same BOUND as conv3d_up_wsplit_body: |Weff| <= 8 max|w| (see there)
   float m = 0.f;
-  const int total = 64 * Ka * M;
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int mo = i % M;
-    int t = i / M;
-    const int kk = t % Ka; t /= Ka;
-    m = fmaxf(m, fabsf(up_weff(w, Ktot, M, kk, mo, (t >> 5) & 1, (t >> 4) & 1, (t >> 3) & 1, (t >> 2) & 1, (t >> 1) & 1, t & 1)));
+  for (int i = threadIdx.x; i < 27 * Ka * M; i += 1024) {
+    const int tapi = i / (Ka * M), rem = i - tapi * (Ka * M);
+    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot) * M + rem]));
   }
-  m = block_max(m, sm);
+  m = 8.f * block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
   const float s = pow2f3(ew);
@@ -1186,6 +1191,35 @@ __global__ __launch_bounds__(1024) void conv3d_up_wsplit_t_k(const float* __rest
     ws[base + 512 + slot * 32 + ci_l] = r;
   }
 }
+__global__ __launch_bounds__(1024) void conv3d_up_wsplit_t_k(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka,
+                                                             int Ktot, int M, float* __restrict__ trailer) {
+  __shared__ float sm[17];
+  conv3d_up_wsplit_t_body(w, ws, Ka, Ktot, M, trailer, sm);
+}
+// Every split of a network's 3-D conv weights in ONE launch (they all change together, at the optimizer step): 16
+// launches of ~20 us each were 7 % of the 128^3 train step.  grid = (32, jobs).
+struct DfWsplitJob {
+  const float* w;
+  u32x4* ws;
+  float* trailer;
+  int kind;                      // 0: conv3d_wsplit_k, 1: conv3d_up_wsplit_k, 2: conv3d_up_wsplit_t_k
+  int K, M, pair, Ktot, koff, Cb, pad_;
+};
+static_assert(sizeof(DfWsplitJob) == 56, "job table layout (7 x int64 on the host side)");
+__global__ __launch_bounds__(1024) void conv3d_wsplit_batch_k(const DfWsplitJob* __restrict__ jobs) {
+  __shared__ float sm[17];
+  const DfWsplitJob j = jobs[blockIdx.y];
+  if (j.kind == 0) conv3d_wsplit_body(j.w, j.ws, j.K, j.M, j.trailer, j.pair, j.Ktot, j.koff, sm);
+  else if (j.kind == 1) conv3d_up_wsplit_body(j.w, j.ws, j.K, j.Ktot, j.M, j.trailer, j.Cb, sm);
+  else conv3d_up_wsplit_t_body(j.w, j.ws, j.K, j.Ktot, j.M, j.trailer, sm);
+}
+extern "C" int dfmir_conv3d_wsplit_batch(const void* jobs_dev, int njobs, void* stream) {
+  DF_ARG_CHECK(jobs_dev && njobs > 0 && njobs < 65536);
+  conv3d_wsplit_batch_k<<<dim3(32, (unsigned)njobs), 1024, 0, (hipStream_t)stream>>>(reinterpret_cast<const DfWsplitJob*>(jobs_dev));
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_conv3d_split_is_pair(int cout_used) { return (cout_used <= 16 && !pair3d_off()) ? 1 : 0; }
 
 struct C3dP {
   int N, Ca, Cout, D, H, W;      // D, H, W: the LOW-resolution volume (d(a)); dy is [N, Cout, 2D, 2H, 2W]

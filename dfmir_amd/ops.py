@@ -188,19 +188,10 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
             cu = Cout if cout_used is None else cout_used
             # (the generation and the cache live ON the persistent packed buffer's tensor object: a temporary packing
             # has neither, and an address recycled by the allocator cannot alias a stale entry)
-            wkey = (Cin, Cout, cu)
-            gen = getattr(w_tcc, "_df_gen", None)
-            cache = getattr(w_tcc, "_df_ws3d", None) if gen is not None else None
-            ent = cache.get(wkey) if cache is not None else None
-            if ent is not None and ent[0] == gen:
-                ws, w_arg = ent[1], None
-            else:
-                ws = torch.empty(lib().dfmir_conv3d_split_ws_floats(Cin, Cout), device=x5.device, dtype=torch.float32)
-                w_arg = w_tcc
-                if gen is not None:
-                    if cache is None:
-                        cache = w_tcc._df_ws3d = {}
-                    cache[wkey] = (gen, ws)
+            pair_ = lib().dfmir_conv3d_split_is_pair(cu)
+            ws, need_ = _ws_cached(w_tcc, (Cin, Cout, cu), lib().dfmir_conv3d_split_ws_floats(Cin, Cout), x5.device,
+                                   job=(0, Cin, cu if pair_ else Cout, pair_, Cin, 0, 0))
+            w_arg = w_tcc if need_ else None
             slot = amax_slot(x5.device, PROBE_SLOTS)
             if act_src is not None:
                 # dgrad into the output of a LeakyReLU: the epilogue applies the activation's derivative (csrc/conv3ds.hip)
@@ -389,6 +380,7 @@ def _repack_all(ep):
         e["epoch"] = ep
         e["version"] = e["w"]._version
         _bump_gen(e["buf"])
+    _resplit_all_3d(dev)
 
 
 def weight_unpack(g_tcc, shape):
@@ -1014,7 +1006,51 @@ _NO_UPSKIP2 = bool(os.environ.get("DFMIR_CONV3D_NO_UPSKIP2"))     # A/B switch: 
 _NO_UPPHASE = bool(os.environ.get("DFMIR_CONV3D_NO_UPPHASE"))     # A/B switch: materialise nearest_up2 + cat, one conv
 
 
-def _ws_cached(w_tcc, key, floats, device):
+# Registry of the split-weight workspaces of persistent packed buffers: after the batched re-pack of an optimizer step
+# (_repack_all) every registered split is re-made by ONE launch (dfmir_conv3d_wsplit_batch) instead of one launch per
+# layer and mode at its first use.
+_WS3D = {"entries": {}, "key": None, "dev": None}
+_NO_WS_BATCH = bool(os.environ.get("DFMIR_NO_WSPLIT_BATCH"))
+
+
+def _ws3d_register(w_tcc, key, ws, job):
+    """job = (kind, K, M, pair, Ktot, koff, Cb) as dfmir_conv3d_wsplit_batch reads them."""
+    import weakref
+    _WS3D["entries"][(id(w_tcc), key)] = {"ref": weakref.ref(w_tcc), "key": key, "ws": ws, "job": job}
+    _WS3D["key"] = None
+
+
+def _resplit_all_3d(dev):
+    import numpy as np
+    ents = _WS3D["entries"]
+    for k_ in [k_ for k_, e in ents.items() if e["ref"]() is None]:
+        del ents[k_]
+        _WS3D["key"] = None
+    live = [e for e in ents.values() if e["ws"].device == dev and getattr(e["ref"](), "_df_gen", None) is not None]
+    if not live or _NO_WS_BATCH:
+        return
+    key = tuple((e["ref"]().data_ptr(), e["ws"].data_ptr()) + tuple(e["job"]) for e in live)
+    if _WS3D["key"] != key:
+        tab = np.zeros((len(live), 7), dtype=np.int64)
+        for i, e in enumerate(live):
+            kind, K, M, pair, Ktot, koff, Cb = e["job"]
+            tab[i, 0] = e["ref"]().data_ptr()
+            tab[i, 1] = e["ws"].data_ptr()
+            tab[i, 2] = e["ws"].data_ptr() + 4 * (e["ws"].numel() - 4)
+            tab[i, 3] = kind | (K << 32)
+            tab[i, 4] = M | (pair << 32)
+            tab[i, 5] = Ktot | (koff << 32)
+            tab[i, 6] = Cb
+        _WS3D["dev"] = torch.from_numpy(tab).to(dev)
+        _KEEP_TABLES.append(_WS3D["dev"])
+        _WS3D["key"] = key
+    check(lib().dfmir_conv3d_wsplit_batch(_p(_WS3D["dev"]), len(live), _st()))
+    for e in live:
+        w_tcc = e["ref"]()
+        w_tcc._df_ws3d[e["key"]] = (w_tcc._df_gen, e["ws"])
+
+
+def _ws_cached(w_tcc, key, floats, device, job=None):
     """(ws, needs_split): a per-(packed-weight buffer, key) workspace for split weights, re-made only when the packed
     buffer was re-packed (its generation changed).  A temporary packing (no generation) gets a fresh workspace."""
     gen = getattr(w_tcc, "_df_gen", None)
@@ -1027,6 +1063,8 @@ def _ws_cached(w_tcc, key, floats, device):
         if cache is None:
             cache = w_tcc._df_ws3d = {}
         cache[key] = (gen, ws)
+        if ent is None and job is not None:
+            _ws3d_register(w_tcc, key, ws, job)
     return ws, True
 
 
@@ -1057,9 +1095,12 @@ class UpCatConv3dFn(Function):
         pb = _probe64(b) if pb is None else pb
         y = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), device=a.device, dtype=torch.float32)
         g = DfConvGeom(N, Cb, Cout, 2 * D, 2 * H, 2 * W, 2 * D, 2 * H, 2 * W, 3, 3, 3, 1, 1, 1, 1, 1, 0, act, float(slope))
-        ws_up, split_up = _ws_cached(w_tcc, ("up", Ca, Cout), lib().dfmir_conv3d_up_ws_floats(Ca, Cout), a.device)
+        fused_ = Cb <= 2 and act in (0, 1) and not _NO_UPSKIP2
+        ws_up, split_up = _ws_cached(w_tcc, ("up", Ca, Cout, Cb if fused_ else 0), lib().dfmir_conv3d_up_ws_floats(Ca, Cout),
+                                     a.device, job=(1, Ca, Cout, 0, Ca + Cb, 0, Cb if fused_ else 0))
         ws_sk, split_sk = (None, False) if (Cb <= 2 and act in (0, 1) and not _NO_UPSKIP2) else \
-            _ws_cached(w_tcc, ("skip", Ca, Cb, Cout), lib().dfmir_conv3d_split_ws_floats(Cb, Cout), a.device)
+            _ws_cached(w_tcc, ("skip", Ca, Cb, Cout), lib().dfmir_conv3d_split_ws_floats(Cb, Cout), a.device,
+                       job=(0, Cb, Cout, lib().dfmir_conv3d_split_is_pair(Cout), Ca + Cb, Ca, 0))
         slot = amax_slot(a.device, PROBE_SLOTS)
         if _PROBE_AUDIT["on"]:
             _audit_probe(a, pa, "upcat conv a %s" % (tuple(a.shape),))
@@ -1148,7 +1189,8 @@ class UpCatConv3dFn(Function):
             # d(a) directly at low resolution: the sum pool of nearest_up2's adjoint composed with the dgrad is a 4x4x4
             # stride-2 conv of dy, run in parity classes (csrc/conv3ds.hip conv3d_up_dgrad_k)
             w_tcc = owner.packed(0) if owner is not None else weight_pack(weight, 0)
-            ws, split = _ws_cached(w_tcc, ("updgrad", Ca, Cout), lib().dfmir_conv3d_up_dgrad_ws_floats(Ca, Cout), a.device)
+            ws, split = _ws_cached(w_tcc, ("updgrad", Ca, Cout), lib().dfmir_conv3d_up_dgrad_ws_floats(Ca, Cout), a.device,
+                                   job=(2, Ca, Cout, 0, Ca + Cb, 0, 0))
             dya = amax_of(dy)
             if _PROBE_AUDIT["on"]:
                 _audit_probe(dy, dya, "upcat conv dY %s" % (tuple(dy.shape),))

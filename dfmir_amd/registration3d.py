@@ -24,6 +24,7 @@ class Registration3DModel(object):
         Small volumes are host-bound otherwise (128^3: 3.7 ms of Python / autograd / ctypes per 5.2 ms step)."""
         self.device = torch.device(device)
         self.netR = VxmDense(tuple(shape), features, int_steps=7, bidir=True).to(self.device)
+        self.netR.skip_unused_target = True      # the step reads (y_source, flow) only
         self.optimizer_R = FlatAdam(self.netR.parameters(), lr=lr, betas=betas)
         self.criterionNCC = NCC_Loss(self.device, kernel_var=[win] * len(shape), kernel_type='mean')
         self.criterionGrad = Grad_Loss(dim=len(shape), penalty='l2')

@@ -102,6 +102,8 @@ class REGISTRATIONModel(BaseModel):
         vol_shape = (opt.crop_size, opt.crop_size)
         self.netR = vxm.networks.VxmDense(vol_shape, nb_features, int_steps=7, bidir=True).to(self.device)
         self.netR.train()
+        # registration_model.py:143-147 read y_output[0] and [2] only: the discarded warp(real_B, -flow) branch is not computed
+        self.netR.skip_unused_target = bool(getattr(opt, 'skip_unused_target', True))
         self.spatialTransformer = SpatialTransformer(vol_shape).to(self.device)
         self._dvf_image = None
 

@@ -171,6 +171,10 @@ class VxmDense(nn.Module):
         self.fullsize = ResizeTransform(1 / int_downsize, nd) if half else None
         self.integrate = VecInt([int(d / int_downsize) for d in inshape], int_steps) if int_steps > 0 else None
         self.transformer = SpatialTransformer(inshape)
+        # build-defined: the bidir branch's warp(target, neg_flow) (networks.py:1125-1139) is computed by the reference on
+        # every step and read by nobody in REGISTRATIONModel (registration_model.py:143-147 use [0] and [2]).
+        # A model that never reads it sets this and gets None in its place: 7 VecInt warps, a resize and a warp less.
+        self.skip_unused_target = False
 
     def forward(self, source, target, registration=False):
         x = ops.upcat_channels(source, target)
@@ -184,18 +188,19 @@ class VxmDense(nn.Module):
         if self.integrate:
             sc = self.integrate.scale
             # negate + 2^-n scale folded into one launch per direction
-            if self.bidir:
+            want_neg = self.bidir and not (self.skip_unused_target and not registration)
+            if want_neg:
                 neg_flow = ops.scale(pos_flow, -sc)
                 neg_flow = self.integrate(neg_flow, scale_folded=True)
             pos_flow = ops.scale(pos_flow, sc)
             pos_flow = self.integrate(pos_flow, scale_folded=True)
             if self.fullsize:
                 pos_flow = self.fullsize(pos_flow)
-                neg_flow = self.fullsize(neg_flow) if self.bidir else None
-        elif self.bidir:
+                neg_flow = self.fullsize(neg_flow) if neg_flow is not None else None
+        elif self.bidir and not (self.skip_unused_target and not registration):
             neg_flow = ops.scale(pos_flow, -1.0)
         y_source = self.transformer(source, pos_flow)
-        y_target = self.transformer(target, neg_flow) if self.bidir else None
+        y_target = self.transformer(target, neg_flow) if (self.bidir and neg_flow is not None) else None
         if not registration:
             return (y_source, y_target, pos_flow) if self.bidir else (y_source, preint_flow)
         return y_source, pos_flow

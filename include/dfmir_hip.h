@@ -111,6 +111,13 @@ int dfmir_conv3d_split_fwd_actgrad(const DfConvGeom* g, const float* x, const fl
  * a [N, Ca, D, H, W] with Ca % 8 == 0, W % 4 == 0 (dfmir_conv3d_up_ok); ws: dfmir_conv3d_up_ws_floats /
  * dfmir_conv3d_split_ws_floats(Cb, Cout) floats; w_tcc NULL = ws already holds the split of the current weights. */
 int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W);
+/* Every weight split of a network's 3-D convs in ONE launch (all weights change together at the optimizer step;
+ * torch.optim.Adam.step, registration_model.py:168-171).  jobs_dev: device array of njobs records of 7 x int64 --
+ * {w_tcc, ws, trailer (= ws + its ws_floats - 4), kind | K << 32, M | pair << 32, Ktot | koff << 32, Cb}; kind 0 = the
+ * split dfmir_conv3d_split_fwd* makes (K = Cin, M = Cout or cout_used in the plane-pair form), 1 = dfmir_conv3d_up_fwd /
+ * _up_skip2_fwd's (K = Ca, Cb = skip channels or 0), 2 = dfmir_conv3d_up_dgrad's.  The entry points then take w_tcc = NULL. */
+int dfmir_conv3d_wsplit_batch(const void* jobs_dev, int njobs, void* stream);
+int dfmir_conv3d_split_is_pair(int cout_used);
 long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);
 int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
                         float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream);

@@ -575,6 +575,33 @@ def test_registration3d_step_vs_oracle(O, shape, plugin):
             assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-7), (it, k, got[k], ref[k])
 
 
+def test_skipping_the_unused_target_branch_changes_nothing(O):
+    """VxmDense.skip_unused_target (build-defined): without the discarded warp(target, -flow) output the
+    outputs the step reads (y_source, flow) and every parameter gradient are bit-identical."""
+    from dfmir_amd.voxelmorph import VxmDense
+    shape = (16, 16, 24)
+    torch.manual_seed(3)
+    net = VxmDense(shape, None, int_steps=7, bidir=True).to(DEV)
+    with torch.no_grad():
+        net.flow.weight.mul_(3e4)
+    A = C.rand(31, 1, 1, *shape).to(DEV)
+    B = C.rand(41, 1, 1, *shape).to(DEV)
+    res = []
+    for skip in (False, True):
+        net.skip_unused_target = skip
+        net.zero_grad()
+        ys, yt, fl = net(A, B)
+        (ys.sum() + (fl * fl).sum()).backward()
+        assert (yt is None) == skip
+        res.append((ys.detach().clone(), fl.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for g0, g1 in zip(res[0][2], res[1][2]):
+        assert torch.equal(g0, g1)
+    net.skip_unused_target = True
+    y2, f2 = net(A, B, registration=True)            # the inference form is untouched
+    assert y2.shape == A.shape and f2.shape[1] == 3
+
+
 def test_probe_audit_full_steps():
     """DFMIR_PROBE_AUDIT: every fp16x2-split launch of a 256x256 ngf-64 train step and of a 64^3 3-D step is handed a
     range probe that bounds the true max |t| of its operand (inherited probes included: blur outputs, upcat, sampled-
