@@ -579,7 +579,7 @@ def test_skipping_the_unused_target_branch_changes_nothing(O):
     """VxmDense.skip_unused_target (build-defined): without the discarded warp(target, -flow) output the
     outputs the step reads (y_source, flow) and every parameter gradient are bit-identical."""
     from dfmir_amd.voxelmorph import VxmDense
-    shape = (16, 16, 24)
+    shape = (16, 16, 32)
     torch.manual_seed(3)
     net = VxmDense(shape, None, int_steps=7, bidir=True).to(DEV)
     with torch.no_grad():
