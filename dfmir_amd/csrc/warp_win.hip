@@ -279,6 +279,9 @@ __device__ void voxel_bwd_slow(const float* __restrict__ dout_b, const float* __
 #ifndef WW_OCC
 #define WW_OCC 1     // measured (r03): forward 28.4 -> 28.2 us; bit 1 made pass 1 37 % slower (32 spilled registers)
 #endif
+#ifndef WW_KO
+#define WW_KO 0      // knock-out builds of pass 1 (timing only): 1 no LDS atomics, 2 no sub-box store, 4 no d(flow) phase, 8 no LDS zero
+#endif
 #if (WW_OCC & 1)
 #define WW_FWD_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #else
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(WNT) void warp_win_bwd_k(const float* __restrict__ 
   for (int e = 0; e < 4; ++e) fm[e] = ((th.fast >> e) & 1u) ? 1.f : 0.f;
   // ---- phase A: d(flow) = sum_c dout_c * d(interp)/d(position), corner values from the src window
   float gz[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gx[4] = {0.f, 0.f, 0.f, 0.f};
-  if (dflow || flow_into_src) {
+  if ((dflow || flow_into_src) && !(WW_KO & 4)) {
     for (int c = 0; c < C; ++c) {
       const float* sc = src + ((long long)b * C + c) * S;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc), 0, (unsigned)S * 4u, 0x00020000);
@@ -512,6 +515,10 @@ __global__ __launch_bounds__(WNT) WW_OWN_ATTR void warp_win_bwd_own_k(const floa
   int oz, oy, ox;
   const bool need_own = add_identity || flow_into_src;
   if (t == 0) { s_ext[0] = 0; s_ext[1] = 0; s_ext[2] = 0; s_nslow = 0; }
+  // (fetching channel 0's gradient quad here, together with the flow, was measured: 138 -> 152 us -- four more live
+  // registers cost more than the round trip saves; knock-outs: without atomics, stores, the d(flow) phase and the LDS
+  // zeroing the three passes still take 119 of 138 us: the chain of dependent loads and barriers at 2 workgroups per
+  // CU bounds pass 1, not its arithmetic)
   win_prologue<ND>(flow, b, S, H, W, D, z, y, x, active, need_own, th, red, oz, oy, ox, true, tzb_ * G::TZ, tyb_ * G::TY,
                    tx_ * WTX);
   float fm[4];
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(WNT) WW_OWN_ATTR void warp_win_bwd_own_k(const floa
     __syncthreads();                                        // phase A / previous channel is done with the window
     if ((t & 63) == 0) redf[t >> 6] = m;
     if (t == 0) s_bad = 0;
-    for (int u = t; u < NW; u += WNT) wini[u] = 0;
+    if (!(WW_KO & 8)) for (int u = t; u < NW; u += WNT) wini[u] = 0;
     __syncthreads();
     if (bad) s_bad = 1;
     float bm = redf[0];
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(WNT) WW_OWN_ATTR void warp_win_bwd_own_k(const floa
     be = bm > 0.f ? (be > 90 ? 90 : (be < -90 ? -90 : be)) : 0;
     const float up = __uint_as_float((unsigned)(30 - be + 127) << 23);        // |cell * up| <= 2^30
     const float dn = __uint_as_float((unsigned)(be - 30 + 127) << 23);
-    if (active && th.fast && !bad) {
+    if (active && th.fast && !bad && !(WW_KO & 1)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (!((th.fast >> e) & 1u)) continue;
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(WNT) WW_OWN_ATTR void warp_win_bwd_own_k(const floa
     if (ND == 2) ez = ey > 0 ? 1 : 0;
     const bool anybad = s_bad != 0;
     float* slot = scratch + ((long long)tileL * C + c) * WinOwn<ND>::CELLS;
-    const int qx = ex4 >> 2, nq = ez * ey * qx;
+    const int qx = ex4 >> 2, nq = (WW_KO & 2) ? 0 : ez * ey * qx;
     for (int u = t; u < nq; u += WNT) {
       const int q = u % qx, r = u / qx;                    // r = lz * ey + ly within the sub-box
       const int ly = r % ey, lz = r / ey;
