@@ -733,6 +733,9 @@ struct ConvCsP {
   const float* res;       // optional [N][Cout][Ho][Wo]: y = act(conv + bias) + res (a second gradient / residual)
   const float* ring;      // optional [N][4][Cout][ring_rl]: the reflect ring of a dgrad (conv3x3_reflect_ring_k)
   int ring_rl;
+  // 1-D grid of 2 x tiles workgroups, the two cout halves of a pixel tile on the SAME XCD, 8 dispatch slots apart:
+  // id = 16 g + 8 h + r  ->  tile 8 g + r, half h (workgroup ids go round-robin over the 8 XCDs, one L2 each)
+  int xcd_pair;
 };
 
 #ifdef CS_TRACE
@@ -772,12 +775,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
-  int bt = blockIdx.x;
+  int bt = blockIdx.x, bm = blockIdx.y;
+  if (k.xcd_pair == 1) { bm = (bt >> 3) & 1; bt = ((bt >> 4) << 3) + (bt & 7); }
+  else if (k.xcd_pair >= 2) {   // XCD e = id & 7 walks a contiguous eighth of the tiles; xcd_pair - 1 cout slices of a tile back to back
+    const int ny = k.xcd_pair - 1, per = (int)(gridDim.x >> 3) / ny, j = bt >> 3;
+    bm = j % ny;
+    bt = (bt & 7) * per + j / ny;
+  }
   const int tx = bt % k.tiles_x; bt /= k.tiles_x;
   const int ty = bt % k.tiles_y;
   const int n = bt / k.tiles_y;
   const int oy0 = ty * CS_TH, ox0 = tx * CS_TW;
-  const int m0 = blockIdx.y * (2 * CPG), m0g = m0 + CPG * grp;
+  const int m0 = bm * (2 * CPG), m0g = m0 + CPG * grp;
 
   const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, bs));     // bs: scratch here, bias below
   __syncthreads();
@@ -1024,13 +1033,24 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
     // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces (those go through the
     // zero-padded form + ring kernel instead; what still arrives here unfilled stays on the flat-run kernel below)
     ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, tlx, tly, res,
-               ring, ring_rl};
+               ring, ring_rl, 0};
     const long long nb = (long long)g->N * tlx * tly;
     if (g->Cout > 64) {
       dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
+      // the two cout halves of a pixel tile on the same XCD (one L2): measured 83.5 -> 83.0 ms per 2-D step, issued
+      // fraction 0.432 -> 0.438 (DFMIR_CS_XCD_PAIR=0 restores the 2-D grid; =2: contiguous tile runs per XCD)
+      // =2 (default): every XCD walks a contiguous run of tiles (neighbouring tiles share their halo rows in that L2 too):
+      // 83.8 -> 82.3 ms, issued 0.432 -> 0.447
+      static const int xcd_pair = getenv("DFMIR_CS_XCD_PAIR") ? atoi(getenv("DFMIR_CS_XCD_PAIR")) : 2;
+      if (xcd_pair && grid.y <= 2 && (nb & 7) == 0) {
+        kc.xcd_pair = xcd_pair == 1 ? (grid.y == 2 ? 1 : 0) : (int)grid.y + 1;
+        if (kc.xcd_pair) grid = dim3((unsigned)(grid.y * nb), 1u);
+      }
       if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
       else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
     } else {
+      static const int xcd1 = getenv("DFMIR_CS_XCD_PAIR") ? atoi(getenv("DFMIR_CS_XCD_PAIR")) : 2;
+      if (xcd1 >= 2 && (nb & 7) == 0) kc.xcd_pair = 2;          // one cout slice: contiguous tile runs per XCD
       conv3x3_split_cs_k<true, 32, 16><<<dim3((unsigned)nb, 1u), 512, 0, st>>>(x, ws, bias, y, kc, sc);
     }
     hipError_t e = hipGetLastError();
