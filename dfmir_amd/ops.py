@@ -226,7 +226,20 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                  and pad[1] in (1, 2) and Cout > 4)
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
-        prof(("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size, flops, launch)
+        kind = ("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size
+        if split3d:
+            # 16-bit products the kernel ISSUES per algorithmic MAC: 3 (a0b0 + a0b1 + a1b0) x the padding of its tiling --
+            # taps 27 -> 28 (plane-pair rows: 27 -> 36 taps'), input channels to whole chunks of 8, output channels to 32 rows
+            cu = Cout if cout_used is None else cout_used
+            pair_ = bool(lib().dfmir_conv3d_split_is_pair(cu))
+            pad_k = (36.0 if pair_ else 28.0) / 27.0 * (8.0 * ((Cin + 7) // 8)) / Cin
+            pad_m = (16.0 / cu) if pair_ else (32.0 * ((cu + 31) // 32)) / cu
+            if getattr(prof, "accepts_issued", False):
+                prof(kind, flops * cu / Cout, launch, 3.0 * pad_k * pad_m * flops * cu / Cout)
+            else:
+                prof(kind, flops * cu / Cout, launch)
+        else:
+            prof(kind, flops, launch)
     return y
 
 

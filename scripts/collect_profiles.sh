@@ -9,6 +9,8 @@ python scripts/bench_conv.py 32 > $O/bench_conv.txt 2>&1
 python scripts/bench_conv3d.py > $O/bench_conv3d.txt 2>&1
 DFMIR_CONV3D_FP32=1 python scripts/bench_conv3d.py > $O/bench_conv3d_fp32.txt 2>&1
 python scripts/bench_warp_roofline.py > $O/bench_warp_roofline.json 2>&1
+python scripts/bench_upconv3d.py > $O/bench_upconv3d.txt 2>&1
+DFMIR_CONV3D_NO_UPPHASE=1 python scripts/bench_upconv3d.py >> $O/bench_upconv3d.txt 2>&1
 python scripts/bench_wgrad3d.py > $O/bench_wgrad3d.txt 2>&1
 DFMIR_CONV3D_WGRAD_COPIES=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
 DFMIR_CONV3D_WGRAD_NO_PAIR=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
@@ -32,4 +34,8 @@ CELL=32 AMP=1.0 bash scripts/prof_warp.sh > $O/pmc_warp.txt 2>&1
 bash scripts/prof_conv3d.sh 34-32 > $O/pmc_conv3d_34_32.txt 2>&1
 bash scripts/prof_conv3d.sh 32-16 > $O/pmc_conv3d_32_16.txt 2>&1
 bash scripts/prof_3d_step.sh 60 > $O/step_trace_3d.txt 2>&1
-rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d
+bash scripts/prof_step.sh scripts/bench_3d_128.py 3d128 50 > $O/step_trace_3d_128.txt 2>&1
+bash scripts/prof_upconv3d.sh > $O/pmc_upconv3d.txt 2>&1
+for v in 0 2; do DFMIR_CS_XCD_PAIR=$v python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('DFMIR_CS_XCD_PAIR=$v', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step issued_frac', round(r['roofline']['issued_frac'],4))"; done > $O/ab_xcd_order.txt 2>&1
+rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d $R/gpurun_out/upconv_prof
+python scripts/pmc_json.py r03 > $O/pmc_json.log 2>&1; cp profiles/r03_pmc.json $O/

@@ -97,6 +97,17 @@ def main():
                 out["conv3d_split_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
             if 'wgrad_tr' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_wgrad_tr_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
+    if not from_prof and os.path.exists(C + "pmc_upconv3d.txt"):
+        d, c = parse(open(C + "pmc_upconv3d.txt").read())
+        lo = 80 * 96 * 112
+        for k in c:
+            if 'conv3d_up_phase_k<true>' in k and 'FETCH_SIZE' in c[k]:
+                out["conv3d_up_phase_k"] = entry(k, d, c[k], 4.0 * (32 * lo + 2 * nv + 32 * nv),
+                                                 "32 (half res) + 2 -> 32 @160x192x224, one launch (404 GFLOP reference-equivalent)")
+            if 'conv3d_up_dgrad_k' in k and 'FETCH_SIZE' in c[k]:
+                out["conv3d_up_dgrad_k"] = entry(k, d, c[k], 4.0 * (32 * nv + 32 * lo), "d(a): 32 @160x192x224 -> 32 @80x96x112")
+            if 'wgrad_tr_k<3, false, true>' in k and 'FETCH_SIZE' in c[k]:
+                out["conv3d_wgrad_tr_k_upcat"] = entry(k, d, c[k], 4.0 * (32 * lo + 2 * nv + 32 * nv), "34 -> 32 weight gradient, operand cat(up2(a), b) read in place")
     json.dump(out, open(P + tag + "_pmc.json", "w"), indent=1, sort_keys=True)
     print("wrote", P + tag + "_pmc.json", sorted(k for k in out if not k.startswith("_")))
 
