@@ -425,7 +425,8 @@ def main():
     if opt.capture_step and not graphed:
         print("bench: the step was not captured (%s); timing the eager step" % model._graph.get('capture_error', 'n/a'),
               file=sys.stderr)
-    if world > 1:
+    distributed = dfdist.is_distributed()         # world > 1 (or a forced single-rank group: tests)
+    if distributed:
         model._collective_timing = []             # event pairs around every wait for a gradient exchange
     fence()
     timer.enabled = not graphed                   # HIP events cannot be recorded inside a graph replay
@@ -455,7 +456,7 @@ def main():
 
     dt = dfdist.allreduce_max(dt, dev)            # the slowest rank's clock
     collective = None
-    if world > 1:
+    if distributed:
         exposed = sum(s_.elapsed_time(e_) for s_, e_ in (coll_pairs or [])) / max(args.steps, 1)
         collective = {"backend": torch.distributed.get_backend(),
                       "payload_bytes": 4 * sum(o.flat_g.numel() for o in model.optimizers),
@@ -571,7 +572,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(S)
             result["cpu_baseline"]["also_3d_128"] = cpu_baseline_3d(result["cpu_baseline"]["cores"])
         print(json.dumps(result))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

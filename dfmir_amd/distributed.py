@@ -22,7 +22,7 @@ def init_from_env(default_backend="nccl"):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(index)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DFMIR_DIST_BACKEND", default_backend)
         if backend == "nccl":
@@ -32,8 +32,14 @@ def init_from_env(default_backend="nccl"):
     return rank, world, index
 
 
+# DFMIR_FORCE_DIST=1: treat a world of ONE rank as distributed (process group created, weights broadcast, every arena
+# all-reduced through the backend).  On a 1-GPU box this is the only way to run the RCCL code path itself -- communicator
+# creation with device_id, the watchdog thread next to a hipGraph capture, async work handles -- before an 8-GPU node does.
+_FORCE = bool(os.environ.get("DFMIR_FORCE_DIST"))
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():

@@ -141,6 +141,24 @@ def test_bench_two_gpus_rccl():
     assert r["collective"]["backend"] == "nccl" and r["collective"]["exposed_ms_per_step"] >= 0.0
 
 
+def test_bench_single_rank_over_rccl():
+    """bench.py with a process group of ONE rank over the real backend (DFMIR_FORCE_DIST=1): RCCL communicator created
+    with device_id, weights broadcast, the step captured into a hipGraph (thread-local capture mode, RCCL's watchdog
+    thread alive), the three arena all-reduces issued asynchronously through RCCL after every replay, exposure timed.
+    Everything the 8-GPU launch does except talking to a second GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DFMIR_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("DFMIR_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "4", "--batch", "2",
+           "--size", "64", "--ngf", "8", "--no-3d", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["step_submission"].startswith("hipGraph"), r["step_submission"]
+    assert r["collective"]["backend"] == "nccl" and r["collective"]["exposed_ms_per_step"] >= 0.0
+    assert r["collective"]["payload_bytes"] > 0 and all(np.isfinite(v) for v in r["losses"].values())
+
+
 def _worker_3d(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND="gloo")
