@@ -839,8 +839,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
       for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
 
   float rh[8];
-  u32x4 rq[8];
-  u32x4 rw[NW];
+  u32x4 stg[8 + NW];                                       // rq = stg[0..7] (the patch quads), rw = stg[8..]; the skip phase reuses them
+#define rq stg
+#define rw (stg + 8)
 #define C3U_GLOAD_X(ch_, s_)                                                                      \
   {                                                                                               \
     const unsigned co_ = (unsigned)((ch_) * 8 + (s_)) * s4;                                       \
@@ -888,6 +889,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
       B1[b_][j] = Xs[XP + pbase[j] + toff];                                                       \
     }                                                                                             \
   }
+  // SKIP2: the skip patch's global loads ride in the k-steps of the LAST up-sampled chunk (the patch registers of the
+  // chunk pipeline are free by then); its conversion + LDS stores follow the barrier after that chunk
+  constexpr int SNTASK = SROWS * 9, SNIT = (SNTASK + 255) / 256;
+  static_assert(2 * SNIT <= 8 + NW, "the skip patch's quads live in the chunk pipeline's staging registers");
+  u32x4 srw[SKIP2 ? 3 : 1];
+  const int Dfs = 2 * k.D, Hfs = 2 * k.H, Wfs = 2 * k.W;
+  const long long Sfs = (long long)Dfs * Hfs * Wfs;
+  const __amdgpu_buffer_rsrc_t b_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((SKIP2 ? k.b : x) + (SKIP2 ? (long long)n * k.Cb * Sfs : 0)), 0,
+      SKIP2 ? (unsigned)((long long)k.Cb * Sfs * 4) : 0u, 0x00020000);
+  const unsigned sb4 = (unsigned)Sfs * 4u;
+  const int bz0 = 2 * z0 + pz - 1, by0 = 2 * y0 + py - 1, bx0 = 2 * x0;      // patch word 4 + i of a row = column bx0 + i
+  const u32x4* wsk = wsp + 4LL * gridDim.y * k.nchunk * WU + (long long)mt * 640;
+#define C3U_SKIP_GLOAD(i_)                                                                        \
+  if constexpr (SKIP2) {                                                                          \
+    if ((i_) < SNIT) {                                                                            \
+      const int task = tid + 256 * (i_);                                                          \
+      const int row = task / 9, q = task - 9 * row;                                               \
+      const int gz = bz0 + row / 17, gy = by0 + row % 17, gx = bx0 + 4 * q;                       \
+      const bool ok = task < SNTASK && (unsigned)gz < (unsigned)Dfs && (unsigned)gy < (unsigned)Hfs && gx < Wfs; \
+      const unsigned off = ok ? (unsigned)((gz * Hfs + gy) * Wfs + gx) * 4u : OOB;                \
+      stg[(i_) < SNIT ? (i_) : 0] = __builtin_amdgcn_raw_buffer_load_b128(b_src, off, 0, 0);      \
+      stg[(i_) < SNIT ? SNIT + (i_) : 0] = __builtin_amdgcn_raw_buffer_load_b128(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0); \
+    } else if ((i_) == SNIT) {                                                                    \
+      if (tid < SROWS) {                                                                          \
+        const int gz = bz0 + tid / 17, gy = by0 + tid % 17, gx = bx0 - 1;                         \
+        const bool ok = (unsigned)gz < (unsigned)Dfs && (unsigned)gy < (unsigned)Hfs && gx >= 0;  \
+        const unsigned off = ok ? (unsigned)((gz * Hfs + gy) * Wfs + gx) * 4u : OOB;              \
+        rh[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, off, 0, 0));          \
+        rh[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0)); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#ifndef C3U_SKIP_PREFETCH
+#define C3U_SKIP_PREFETCH 0   // 1: the skip patch's loads ride in the last chunk's k-steps -- measured SLOWER (0.74 -> 0.82 ms:
+#endif                        //    22 registers spill although the staging registers are shared); 0: loaded after that chunk
+#ifndef C3U_SB
+#define C3U_SB 1     // 1: operands of a k-step are read at its start (single register set: no scratch spills; the other
+#endif               //    wave of the SIMD covers the LDS latency); 0: one step ahead (31 spilled registers)
   u32x4 A0[2], A1[2], B0[2][NJ], B1[2][NJ];
 #pragma unroll
   for (int s = 0; s < 8; ++s) C3U_GLOAD_X(0, s);
@@ -897,15 +937,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
 
   for (int ch = 0; ch < k.nchunk; ++ch) {
     const bool more = ch + 1 < k.nchunk;
-    C3U_OPLOAD(0, 0);
+    if (!C3U_SB) C3U_OPLOAD(0, 0);
 #pragma unroll
     for (int tp = 0; tp < 8; ++tp) {
-      const int cur = tp & 1;
+      const int cur = C3U_SB ? 0 : (tp & 1);
+      if (C3U_SB) C3U_OPLOAD(0, tp);
       if (more) {                                             // next chunk's loads, one channel per k-step (uniform branch)
         C3U_GLOAD_X(ch + 1, tp);
         if (tp == 7) C3U_GLOAD_W(ch + 1);
+      } else if (C3U_SKIP_PREFETCH) {
+        C3U_SKIP_GLOAD(tp)                                    // (SNIT = 6 task slots, then the halo column)
       }
-      if (tp + 1 < 8) C3U_OPLOAD(cur ^ 1, tp + 1);
+      if (!C3U_SB && tp + 1 < 8) C3U_OPLOAD(cur ^ 1, tp + 1);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         acc[tp >> 2][j] = mma3(A1[cur], B0[cur][j], acc[tp >> 2][j]);
@@ -927,6 +970,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
   }
 #undef C3U_GLOAD_X
 #undef C3U_GLOAD_W
+#undef rq
+#undef rw
 #undef C3U_SPLIT8
 #undef C3U_LSTORE
 #undef C3U_OPLOAD
@@ -951,39 +996,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
           for (int r = 0; r < 16; ++r) acc[p][j][r] *= rs;
       osc_f = pow2f3(-eb) * pow2f3(-es);
     }
-    const int Df = 2 * k.D, Hf = 2 * k.H, Wf = 2 * k.W;
-    const long long Sfl = (long long)Df * Hf * Wf;
-    const __amdgpu_buffer_rsrc_t b_src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(k.b + (long long)n * k.Cb * Sfl), 0, (unsigned)((long long)k.Cb * Sfl * 4), 0x00020000);
-    const unsigned sb4 = (unsigned)Sfl * 4u;
     unsigned* Xw = reinterpret_cast<unsigned*>(Xs);
-    const int bz0 = 2 * z0 + pz - 1, by0 = 2 * y0 + py - 1, bx0 = 2 * x0;      // patch word 4 + i of a row = column bx0 + i
-    // (row, quad) tasks: 153 rows x 9 aligned quads (columns bx0 .. bx0 + 35), both channels per task
-    constexpr int NTASK = SROWS * 9, NIT = (NTASK + 255) / 256;
-    u32x4 q0[NIT], q1[NIT];
+    constexpr int NTASK = SNTASK, NIT = SNIT;
+    if (!C3U_SKIP_PREFETCH) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int task = tid + 256 * i;
-      const int row = task / 9, q = task - 9 * row;
-      const int gz = bz0 + row / 17, gy = by0 + row % 17, gx = bx0 + 4 * q;
-      const bool ok = task < NTASK && (unsigned)gz < (unsigned)Df && (unsigned)gy < (unsigned)Hf && gx < Wf;
-      const unsigned off = ok ? (unsigned)((gz * Hf + gy) * Wf + gx) * 4u : OOB;
-      q0[i] = __builtin_amdgcn_raw_buffer_load_b128(b_src, off, 0, 0);
-      q1[i] = __builtin_amdgcn_raw_buffer_load_b128(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0);
+      for (int i = 0; i <= SNIT; ++i) C3U_SKIP_GLOAD(i)
     }
-    float h0 = 0.f, h1 = 0.f;                              // left halo column bx0 - 1: one row per thread < 153
-    if (tid < SROWS) {
-      const int gz = bz0 + tid / 17, gy = by0 + tid % 17, gx = bx0 - 1;
-      const bool ok = (unsigned)gz < (unsigned)Df && (unsigned)gy < (unsigned)Hf && gx >= 0;
-      const unsigned off = ok ? (unsigned)((gz * Hf + gy) * Wf + gx) * 4u : OOB;
-      h0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, off, 0, 0));
-      h1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_src, (ok && k.Cb > 1) ? off + sb4 : OOB, 0, 0));
-    }
-    // skip weights of this cout tile: 640 units after the phase section
-    const u32x4* wsk = wsp + 4LL * gridDim.y * k.nchunk * WU + (long long)mt * 640;
-    u32x4 rws[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) rws[j] = (tid + 256 * j < 640) ? wsk[tid + 256 * j] : u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < 3; ++j) srw[j] = (tid + 256 * j < 640) ? wsk[tid + 256 * j] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int task = tid + 256 * i;
@@ -993,7 +1013,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned hh, rr;
-          split_pair3(__uint_as_float(q0[i][e]), __uint_as_float(q1[i][e]), bscale, hh, rr);
+          split_pair3(__uint_as_float(stg[i][e]), __uint_as_float(stg[SNIT + i][e]), bscale, hh, rr);
           h[e] = hh; r[e] = rr;
         }
         *reinterpret_cast<u32x4*>(Xw + row * SRS + 4 + 4 * q) = h;
@@ -1002,13 +1022,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
     }
     if (tid < SROWS) {
       unsigned hh, rr;
-      split_pair3(h0, h1, bscale, hh, rr);
+      split_pair3(rh[0], rh[1], bscale, hh, rr);
       Xw[tid * SRS + 3] = hh;
       Xw[SPW + tid * SRS + 3] = rr;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      if (tid + 256 * j < 640) Ws[tid + 256 * j] = rws[j];
+      if (tid + 256 * j < 640) Ws[tid + 256 * j] = srw[j];
     __syncthreads();
     // lane's word offset of (plane 2 vz, row 2 vy, column word 3 + 2 vx): + (dz * 17 + dy) * SRS + px
     int sbase[NJ];
@@ -1034,6 +1054,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
     }
   }
 
+#undef C3U_SKIP_GLOAD
   // ---- epilogue: acc[px][j][r] <-> cout row (r>>2)*8 + hi*4 + (r&3), low-resolution voxel (wid, 2j + (l31>>4), lx)
   // -> output voxels (2 z + pz, 2 y + py, 2 x + {0, 1}): one 8-byte store per (j, r)
   const int Dfo = 2 * k.D, Hfo = 2 * k.H, Wfo = 2 * k.W;
@@ -1342,20 +1363,38 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_dgrad_k(const float* __restr
     if (more) C3D_GLOAD(sp + 1);
     // patch offset of slot (sz, sy) for this (pz, py): ((sz + 1 - pz) HY + (sy + 1 - py)) HX + (1 - px)   [+ sx in pbase]
     const int pofs = ((1 - pz) * HY + (1 - py)) * HX;
+    // operands one k-step ahead (two register sets), reads pinned between the MFMAs
+#define C3D_OPLOAD(b_, tp_)                                                                       \
+    {                                                                                             \
+      const int px_ = (tp_) >> 2, sz_ = ((tp_) >> 1) & 1, sy_ = (tp_) & 1;                        \
+      const int toff_ = px_ * 2 * XP + pofs + (sz_ * HY + sy_) * HX + (1 - px_);                  \
+      const int u_ = 2 * (tp_) + hi;                                                              \
+      A0[b_] = Ws[u_ * 32 + l31];                                                                 \
+      A1[b_] = Ws[512 + u_ * 32 + l31];                                                           \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                            \
+        B0[b_][j] = Xs[pbase[j] + toff_];                                                         \
+        B1[b_][j] = Xs[XP + pbase[j] + toff_];                                                    \
+      }                                                                                           \
+    }
+    u32x4 A0[2], A1[2], B0[2][NJ], B1[2][NJ];
+    C3D_OPLOAD(0, 0)
 #pragma unroll
     for (int tp = 0; tp < 8; ++tp) {
-      const int px = tp >> 2, sz = (tp >> 1) & 1, sy = tp & 1;
-      const int toff = px * 2 * XP + pofs + (sz * HY + sy) * HX + (1 - px);
-      const int u = 2 * tp + hi;
-      const u32x4 a0 = Ws[u * 32 + l31], a1 = Ws[512 + u * 32 + l31];
+      const int cur = tp & 1;
+      if (tp + 1 < 8) C3D_OPLOAD(cur ^ 1, tp + 1)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const u32x4 b0 = Xs[pbase[j] + toff], b1 = Xs[XP + pbase[j] + toff];
-        acc[j] = mma3(a1, b0, acc[j]);
-        acc[j] = mma3(a0, b1, acc[j]);
-        acc[j] = mma3(a0, b0, acc[j]);
+        acc[j] = mma3(A1[cur], B0[cur][j], acc[j]);
+        acc[j] = mma3(A0[cur], B1[cur][j], acc[j]);
+        acc[j] = mma3(A0[cur], B0[cur][j], acc[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3 * NJ; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
       }
     }
+#undef C3D_OPLOAD
     if (more) {
       __syncthreads();
       C3D_LSTORE();
