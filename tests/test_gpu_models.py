@@ -577,7 +577,7 @@ def test_registration3d_step_vs_oracle(O, shape, plugin):
 
 def test_skipping_the_unused_target_branch_changes_nothing(O):
     """VxmDense.skip_unused_target (build-defined): without the discarded warp(target, -flow) output the
-    outputs the step reads (y_source, flow) and every parameter gradient are bit-identical."""
+    outputs the step reads (y_source, flow) are bit-identical and the parameter gradients equal to atomic-order round-off."""
     from dfmir_amd.voxelmorph import VxmDense
     shape = (16, 16, 32)
     torch.manual_seed(3)
@@ -595,8 +595,8 @@ def test_skipping_the_unused_target_branch_changes_nothing(O):
         assert (yt is None) == skip
         res.append((ys.detach().clone(), fl.detach().clone(), [p.grad.clone() for p in net.parameters()]))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    for g0, g1 in zip(res[0][2], res[1][2]):
-        assert torch.equal(g0, g1)
+    for g0, g1 in zip(res[0][2], res[1][2]):          # (weight gradients sum through float atomics: equal to round-off)
+        close(g0, g1, rtol=1e-5, atol=1e-9, what="parameter gradient")
     net.skip_unused_target = True
     y2, f2 = net(A, B, registration=True)            # the inference form is untouched
     assert y2.shape == A.shape and f2.shape[1] == 3
