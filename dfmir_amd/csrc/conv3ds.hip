@@ -82,6 +82,28 @@ __device__ __forceinline__ void conv3d_wsplit_body(const float* __restrict__ w, 
   const float s = pow2f3(ew);
   if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<int*>(trailer)[0] = ew;
   const int nchunk = (K + 7) / 8, nmt = pair ? 1 : (M + 31) / 32;
+  if (pair == 2) {
+    // M16 form (conv3d_split_m16_k): [chunk][split][28 taps][16 couts] x (8 channels x fp16), no padding rows
+    for (int u = blockIdx.x * 1024 + threadIdx.x; u < nchunk * 28 * 16; u += gridDim.x * 1024) {
+      const int co = u & 15, tap = (u >> 4) % 28, ch = (u >> 4) / 28;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int kk = ch * 8 + c;
+        v[c] = (tap < 27 && kk < K && co < M) ? w[((long long)tap * Ktot + koff + kk) * M + co] : 0.f;
+      }
+      u32x4 h, r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hh, rr;
+        split_pair3(v[2 * q], v[2 * q + 1], s, hh, rr);
+        h[q] = hh; r[q] = rr;
+      }
+      ws[(long long)ch * 896 + tap * 16 + co] = h;
+      ws[(long long)ch * 896 + 448 + tap * 16 + co] = r;
+    }
+    return;
+  }
   const int NT = pair ? 36 : 28;
   const int units = nmt * nchunk * NT * 32;                 // one unit = both splits of (mtile, chunk, tap, row)
   for (int u = blockIdx.x * 1024 + threadIdx.x; u < units; u += gridDim.x * 1024) {
@@ -529,6 +551,308 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_k(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// M16 form (<= 16 output channels): the same tiling and staging, products on v_mfma_f32_16x16x32_f16 -- 16 rows =
+// the output channels, 16 columns = one x-row of the tile, K = 32 = 4 taps x 8 channels (7 k-steps per chunk, tap 27
+// padding).  No padding ROWS: the plane-pair form issues 36/27 of the useful products (rows (plane, cout) against 4
+// input planes), this form 28/27 -- on a package that sits on its power cap, fewer issued products is time.
+// Wave w = z-plane w of the tile; column tile j = tile row j (8 per wave); lane = (kg = lane >> 4, x = lane & 15):
+// A = Ws[(4 ks + kg) * 16 + x-as-cout], B = patch position of (plane, row j, x) + offset of tap 4 ks + kg.
+typedef float f32x4_3 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_3 mma16(u32x4 a, u32x4 b, f32x4_3 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_3, a), __builtin_bit_cast(f16x8_3, b), c, 0, 0, 0);
+}
+template <bool VEC, int TT>
+__global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                          const u32x4* __restrict__ wsp, const float* __restrict__ w_trailer,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ y_amax, C3sP k) {
+  constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
+  constexpr int XP = (TZ + 2) * HY * HX;                  // 1080 positions
+  constexpr int NS = (XP + 255) / 256;
+  constexpr int WU = 2 * 28 * 16;                         // 896 16-B units of one chunk's weights
+  constexpr int NW = (WU + 255) / 256;                    // 4 (the last partly)
+  constexpr int NJ = 8;                                   // column tiles (tile rows) per wave
+  constexpr int NKS = 7;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ u32x4 Xs[2 * XP];
+  __shared__ u32x4 Ws[WU];
+  __shared__ float red[17];
+  __shared__ unsigned smax;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const long long S = (long long)k.D * k.H * k.W;
+  const long long per_xcd = (k.ntile + 7) / 8;
+  const int J = (int)(gridDim.x >> 3);
+  const long long t_first = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  long long t_lim = (long long)((blockIdx.x & 7) + 1) * per_xcd;
+  if (t_lim > k.ntile) t_lim = k.ntile;
+  if (t_first >= t_lim) return;
+  const int niter = (int)((t_lim - t_first + J - 1) / J);
+  int n, z0, y0, x0;
+#define C3M_DECODE(t_)                                                                            \
+  {                                                                                               \
+    long long pid_ = (t_);                                                                        \
+    const int bx_ = (int)(pid_ % k.nx); pid_ /= k.nx;                                             \
+    const int bz_ = (int)(pid_ % k.nz); pid_ /= k.nz;                                             \
+    const int by_ = (int)(pid_ % k.ny);                                                           \
+    n = (int)(pid_ / k.ny);                                                                       \
+    z0 = bz_ * TZ; y0 = by_ * TY * TT; x0 = bx_ * TX;                                             \
+  }
+  C3M_DECODE(t_first)
+
+  const float amax = reduce_absmax(x_amax, k.x_n, red);
+  const int ex = scale_exp3(amax);
+  const int ew = reinterpret_cast<const int*>(w_trailer)[0];
+  const float xscale = pow2f3(ex), osc = pow2f3(-ex) * pow2f3(-ew);
+  if (tid == 0) smax = 0u;
+
+  __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (long long)n * k.Cin * S), 0, (unsigned)((long long)k.Cin * S * 4), 0x00020000);
+  const unsigned s4 = (unsigned)S * 4u;
+  constexpr int NPART = VEC ? 8 : NS;
+  unsigned gbyte[NS];
+  unsigned gq = OOB, gh = OOB;
+  int posq = -1, posh = -1;
+#define C3M_OFFS(t_)                                                                              \
+  {                                                                                               \
+    const int yt0_ = y0 + (t_) * TY;                                                              \
+    if constexpr (VEC) {                                                                          \
+      gq = OOB; gh = OOB;                                                                         \
+      if (tid < 240) {                                                                            \
+        const int row = tid >> 2, q = tid & 3;                                                    \
+        const int hz = row / HY, hy = row % HY;                                                   \
+        const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = x0 + 4 * q;                          \
+        posq = row * HX + 1 + 4 * q;                                                              \
+        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && gx < k.W)             \
+          gq = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                       \
+      }                                                                                           \
+      if (tid < 120) {                                                                            \
+        const int row = tid >> 1, side = tid & 1;                                                 \
+        const int hz = row / HY, hy = row % HY;                                                   \
+        const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = side ? x0 + TX : x0 - 1;             \
+        posh = row * HX + (side ? HX - 1 : 0);                                                    \
+        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+          gh = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                       \
+      }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                            \
+        const int pos = tid + 256 * s;                                                            \
+        unsigned off = OOB;                                                                       \
+        if (pos < XP) {                                                                           \
+          const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;                        \
+          const int gz = z0 - 1 + hz, gy = yt0_ - 1 + hy, gx = x0 - 1 + hx;                       \
+          if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+            off = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                                    \
+        }                                                                                         \
+        gbyte[s] = off;                                                                           \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  C3M_OFFS(0)
+
+  // this lane's B positions (plane wid, row j, column l15) and the patch offsets of its taps 4 ks + kg
+  int pbase[NJ], toffs[NKS];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) pbase[j] = (wid * HY + j) * HX + l15;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int t = (4 * ks + kg) < 27 ? 4 * ks + kg : 26;     // tap 27: zero weights, any valid offset
+    toffs[ks] = ((t / 9) * HY + (t / 3) % 3) * HX + t % 3;
+  }
+
+  f32x4_3 acc[TT][NJ];
+  float rx[NS][8];
+  u32x4 rq[8];
+  u32x4 rw[NW];
+  const __amdgpu_buffer_rsrc_t w_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(wsp), 0, (unsigned)(k.nchunk * WU * 16), 0x00020000);
+#define C3M_GLOAD_X(ch_, s_)                                                                      \
+  {                                                                                               \
+    const unsigned cbase = (unsigned)((ch_) * 8) * s4;                                            \
+    if constexpr (VEC) {                                                                          \
+      const unsigned co_ = cbase + (unsigned)(s_) * s4;                                           \
+      rq[s_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, gq == OOB ? OOB : gq + co_, 0, 0);    \
+      rx[0][s_] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(x_src, gh == OOB ? OOB : gh + co_, 0, 0)); \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int c = 0; c < 8; ++c)                                               \
+        rx[s_][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                         \
+            x_src, gbyte[s_] == OOB ? OOB : gbyte[s_] + cbase + (unsigned)c * s4, 0, 0));         \
+    }                                                                                             \
+  }
+#define C3M_GLOAD_W(ch_)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NW; ++j)                                                  \
+    rw[j] = __builtin_amdgcn_raw_buffer_load_b128(w_src, (tid + 256 * j) < WU ? (unsigned)(((ch_) * WU + tid + 256 * j) * 16) : OOB, 0, 0);
+#define C3M_SPLIT8(v_, h_, r_)                                                                    \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+    unsigned hh, rr;                                                                              \
+    split_pair3(v_[2 * q], v_[2 * q + 1], xscale, hh, rr);                                        \
+    h_[q] = hh; r_[q] = rr;                                                                       \
+  }
+#define C3M_LSTORE()                                                                              \
+  {                                                                                               \
+    if constexpr (VEC) {                                                                          \
+      if (posq >= 0) {                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+          float v[8];                                                                             \
+          _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rq[c][e]);         \
+          u32x4 h, r;                                                                             \
+          C3M_SPLIT8(v, h, r)                                                                     \
+          Xs[posq + e] = h;                                                                       \
+          Xs[XP + posq + e] = r;                                                                  \
+        }                                                                                         \
+      }                                                                                           \
+      if (posh >= 0) {                                                                            \
+        u32x4 h, r;                                                                               \
+        C3M_SPLIT8(rx[0], h, r)                                                                   \
+        Xs[posh] = h;                                                                             \
+        Xs[XP + posh] = r;                                                                        \
+      }                                                                                           \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                            \
+        const int pos = tid + 256 * s;                                                            \
+        if (pos < XP) {                                                                           \
+          u32x4 h, r;                                                                             \
+          C3M_SPLIT8(rx[s], h, r)                                                                 \
+          Xs[pos] = h;                                                                            \
+          Xs[XP + pos] = r;                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#define C3M_LSTORE_W() _Pragma("unroll") for (int j = 0; j < NW; ++j) if (tid + 256 * j < WU) Ws[tid + 256 * j] = rw[j];
+  // operands of a k-step are read at its start (ONE register set: 2 + 16 units; a second set spilled 176 registers in the
+  // three-tile form); the MFMAs start as the reads return in order, the other wave of the SIMD covers the rest
+#define C3M_OPLOAD(ks_)                                                                           \
+  {                                                                                               \
+    const int tap = 4 * (ks_) + kg;                                                               \
+    A0 = Ws[tap * 16 + l15];                                                                      \
+    A1 = Ws[448 + tap * 16 + l15];                                                                \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                              \
+      B0[j] = Xs[pbase[j] + toffs[ks_]];                                                          \
+      B1[j] = Xs[XP + pbase[j] + toffs[ks_]];                                                     \
+    }                                                                                             \
+  }
+  u32x4 A0, A1, B0[NJ], B1[NJ];
+#pragma unroll
+  for (int s = 0; s < NPART; ++s) C3M_GLOAD_X(0, s);
+  C3M_GLOAD_W(0);
+  C3M_LSTORE();
+  C3M_LSTORE_W();
+  __syncthreads();
+
+  float pm = 0.f;
+  int cn = n, cz0 = z0, cy0 = y0, cx0 = x0;
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4_3{0.f, 0.f, 0.f, 0.f};
+  int it = 0, ch = 0;
+  for (int q = 0; q < niter * k.nchunk; ++q) {
+#pragma unroll
+   for (int tt = 0; tt < TT; ++tt) {
+    const bool tile_end = (ch + 1 == k.nchunk) && (tt + 1 == TT);
+    const bool more = !tile_end || (it + 1 < niter);
+    const int nch = tile_end ? 0 : ((tt + 1 < TT) ? ch : ch + 1);
+    const int wch = tile_end ? 0 : ch + 1;
+    if (tile_end && more) {
+      C3M_DECODE(t_first + (long long)(it + 1) * J)
+      x_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)n * k.Cin * S), 0,
+                                                (unsigned)((long long)k.Cin * S * 4), 0x00020000);
+    }
+    if (TT > 1 || tile_end) C3M_OFFS((tt + 1) % TT)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      C3M_OPLOAD(ks);
+      if (ks < NPART) C3M_GLOAD_X(nch, ks);
+      if (NPART > NKS && ks == NKS - 1) {                     // VEC: 8 parts over 7 k-steps
+#pragma unroll
+        for (int s2 = NKS; s2 < NPART; ++s2) C3M_GLOAD_X(nch, s2);
+      }
+      if (ks == NKS - 1 && tt + 1 == TT) C3M_GLOAD_W(wch);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[tt][j] = mma16(A1, B0[j], acc[tt][j]);
+        acc[tt][j] = mma16(A0, B1[j], acc[tt][j]);
+        acc[tt][j] = mma16(A0, B0[j], acc[tt][j]);
+      }
+    }
+    if (more) {
+      __syncthreads();
+      C3M_LSTORE();
+      if (tt + 1 == TT) { C3M_LSTORE_W(); }
+      __syncthreads();
+    }
+   }
+   const bool tile_done = (ch + 1 == k.nchunk);
+   if (!tile_done) { ++ch; continue; }
+   // ---- epilogue: acc[tt][j][i] <-> cout 4 kg + i, voxel (cz0 + wid, yt0 + j, cx0 + l15)
+   __builtin_amdgcn_sched_barrier(0);
+   float bv[4];
+#pragma unroll
+   for (int i = 0; i < 4; ++i) bv[i] = (bias && 4 * kg + i < k.cout_used) ? bias[4 * kg + i] : 0.f;
+   const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
+       y + (long long)cn * k.Cout * S, 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+   const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
+       const_cast<float*>((k.act_src ? k.act_src : y) + (long long)cn * k.Cout * S), 0,
+       (unsigned)((long long)k.Cout * S * 4), 0x00020000);
+#pragma unroll
+   for (int tt = 0; tt < TT; ++tt) {
+     const int yt0 = cy0 + tt * TY;
+     const int gz = cz0 + wid, gx = cx0 + l15;
+     float av[2][4];
+#define C3M_AVLOAD(set_, j_)                                                                      \
+     if (k.act_src) {                                                                             \
+       const int gy_ = yt0 + (j_);                                                                \
+       const bool vok_ = gz < k.D && gy_ < k.H && gx < k.W;                                       \
+       const unsigned vo_ = (unsigned)((gz * k.H + gy_) * k.W + gx) * 4u + (unsigned)(4 * kg) * s4; \
+       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+         av[set_][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                      \
+             a_src, (vok_ && 4 * kg + i < k.cout_used) ? vo_ : OOB, (unsigned)i * s4, 0));        \
+     }
+     C3M_AVLOAD(0, 0)
+#pragma unroll
+     for (int j = 0; j < NJ; ++j) {
+       if (j + 1 < NJ) C3M_AVLOAD((j + 1) & 1, j + 1)
+       const int gy = yt0 + j;
+       const bool vok = gz < k.D && gy < k.H && gx < k.W;
+       const unsigned vo = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u + (unsigned)(4 * kg) * s4;
+#pragma unroll
+       for (int i = 0; i < 4; ++i) {
+         const bool ok = vok && 4 * kg + i < k.cout_used;
+         float v = acc[tt][j][i] * osc + bv[i];
+         if (k.av_mode == 2) v += av[j & 1][i];
+         if (k.act == 1) v = v > 0.f ? v : v * k.slope;
+         else if (k.act == 2) v = tanhf(v);
+         if (k.av_mode == 1) v = av[j & 1][i] > 0.f ? v : v * k.act_slope;
+         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo : OOB, (unsigned)i * s4, 0);
+         pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
+       }
+     }
+#undef C3M_AVLOAD
+   }
+#pragma unroll
+   for (int t = 0; t < TT; ++t)
+#pragma unroll
+     for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4_3{0.f, 0.f, 0.f, 0.f};
+   cn = n; cz0 = z0; cy0 = y0; cx0 = x0;
+   ch = 0; ++it;
+  }
+#undef C3M_DECODE
+#undef C3M_OFFS
+#undef C3M_GLOAD_X
+#undef C3M_GLOAD_W
+#undef C3M_SPLIT8
+#undef C3M_LSTORE
+#undef C3M_LSTORE_W
+#undef C3M_OPLOAD
+  if (y_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, y_amax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 static bool split3d_off() {
   static int v = -1;
   if (v < 0) v = (getenv("DFMIR_CONV3D_FP32") || getenv("DFMIR_CONV_FP32")) ? 1 : 0;
@@ -537,6 +861,11 @@ static bool split3d_off() {
 static bool pair3d_off() {
   static int v = -1;
   if (v < 0) v = getenv("DFMIR_CONV3D_NO_PAIR") ? 1 : 0;
+  return v == 1;
+}
+static bool m16_off() {       // A/B switch: <= 16 output channels through the plane-pair form instead of the 16-row MFMA form
+  static int v = -1;
+  if (v < 0) v = getenv("DFMIR_CONV3D_NO_M16") ? 1 : 0;
   return v == 1;
 }
 static bool split3d_geom_ok(const DfConvGeom* g) {
@@ -582,6 +911,7 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   const int nchunk = (g->Cin + 7) / 8, nmt = (g->Cout + 31) / 32;
   float* trailer = ws + dfmir_conv3d_split_ws_floats(g->Cin, g->Cout) - 4;          // after the largest unit layout
   const bool pair = cout_used <= 16 && !pair3d_off();
+  const bool m16 = pair && !m16_off();
   if (w_tcc) {
     // one unit per thread where possible: every workgroup re-reduces max|w| itself (L2-resident), the packing is what
     // parallelises (8 workgroups took 25 us on the 64 -> 64 layers, a latency chain of strided loads)
@@ -591,7 +921,7 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
     if (nwg > ws_wgs) nwg = ws_wgs;
     if (nwg < 1) nwg = 1;
     conv3d_wsplit_k<<<(unsigned)nwg, 1024, 0, st>>>(w_tcc, reinterpret_cast<u32x4*>(ws), g->Cin, pair ? cout_used : g->Cout, trailer,
-                                                    pair ? 1 : 0, w_ktot > 0 ? w_ktot : g->Cin, w_koff);
+                                                    m16 ? 2 : (pair ? 1 : 0), w_ktot > 0 ? w_ktot : g->Cin, w_koff);
     DF_LAUNCH_CHECK();
   }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
@@ -599,7 +929,9 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
   // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
   static const bool multi_off = getenv("DFMIR_CONV3D_NO_MULTI") != nullptr;
-  const int tt = (pair && vec && !multi_off && k.ny >= 3) ? 3 : 1;
+  // (the 16-row form runs one tile per workgroup: 143 registers = three workgroups per CU beat the shared weight staging
+  // of the three-tile form, 32->16: 0.85 -> 0.80 ms, 16->16: 0.55 -> 0.48 ms)
+  const int tt = (pair && !m16 && vec && !multi_off && k.ny >= 3) ? 3 : 1;
   k.ny = (k.ny + tt - 1) / tt;
   k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
   // One tile (group) per workgroup by default.  DFMIR_CONV3D_WGS=<n> caps the workgroups (512 = two per CU = fully
@@ -613,7 +945,9 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   if (nb > cap) nb = cap;
   const dim3 grid((unsigned)nb, gy);
   const u32x4* wsu = reinterpret_cast<const u32x4*>(ws);
-  if (pair && vec && tt == 3) conv3d_split_k<true, true, 3><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  if (m16 && vec) conv3d_split_m16_k<true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (m16) conv3d_split_m16_k<false, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
+  else if (pair && vec && tt == 3) conv3d_split_k<true, true, 3><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   else if (pair && vec) conv3d_split_k<true, true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   else if (pair) conv3d_split_k<true, false, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
   else if (vec) conv3d_split_k<false, true, 1><<<grid, 256, 0, st>>>(x, x_amax, wsu, trailer, bias, y, y_amax, k);
@@ -1240,7 +1574,10 @@ extern "C" int dfmir_conv3d_wsplit_batch(const void* jobs_dev, int njobs, void* 
   DF_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int dfmir_conv3d_split_is_pair(int cout_used) { return (cout_used <= 16 && !pair3d_off()) ? 1 : 0; }
+// 0: 32-row form, 1: plane-pair form, 2: 16-row (M16) form -- the `pair` field of a dfmir_conv3d_wsplit_batch job
+extern "C" int dfmir_conv3d_split_is_pair(int cout_used) {
+  return (cout_used <= 16 && !pair3d_off()) ? (m16_off() ? 1 : 2) : 0;
+}
 
 struct C3dP {
   int N, Ca, Cout, D, H, W;      // D, H, W: the LOW-resolution volume (d(a)); dy is [N, Cout, 2D, 2H, 2W]

@@ -231,9 +231,9 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
             # 16-bit products the kernel ISSUES per algorithmic MAC: 3 (a0b0 + a0b1 + a1b0) x the padding of its tiling --
             # taps 27 -> 28 (plane-pair rows: 27 -> 36 taps'), input channels to whole chunks of 8, output channels to 32 rows
             cu = Cout if cout_used is None else cout_used
-            pair_ = bool(lib().dfmir_conv3d_split_is_pair(cu))
-            pad_k = (36.0 if pair_ else 28.0) / 27.0 * (8.0 * ((Cin + 7) // 8)) / Cin
-            pad_m = (16.0 / cu) if pair_ else (32.0 * ((cu + 31) // 32)) / cu
+            form_ = lib().dfmir_conv3d_split_is_pair(cu)      # 0: 32 rows, 1: plane pairs (36 taps'), 2: 16 rows
+            pad_k = (36.0 if form_ == 1 else 28.0) / 27.0 * (8.0 * ((Cin + 7) // 8)) / Cin
+            pad_m = (16.0 / cu) if form_ else (32.0 * ((cu + 31) // 32)) / cu
             if getattr(prof, "accepts_issued", False):
                 prof(kind, flops * cu / Cout, launch, 3.0 * pad_k * pad_m * flops * cu / Cout)
             else:
