@@ -724,7 +724,8 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
       conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
     } else if (g->Cout > 64) {
       const long long big = ((Ps + 127) / 128) * ((g->Cout + 127) / 128);
-      if (big < 256) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
+      static const int big_min = getenv("DFMIR_GEMM_BIG_MIN") ? atoi(getenv("DFMIR_GEMM_BIG_MIN")) : 256;
+      if (big < big_min) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
         dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));
         conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
       } else {
