@@ -116,6 +116,7 @@ _SIGS = {
     "dfmir_ncc_fwd": [P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_ncc_bwd": [P, P, P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_patch_gather_fwd_multi": [P, c_int, P, P, c_int, c_int, c_longlong, c_int, P],
+    "dfmir_nce_head_fwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_longlong, c_int, c_float, P],
     "dfmir_patch_ids_draw": [P, P, c_int, c_int, c_int, P, P],
     "dfmir_segment_means_fwd": [P, P, c_int, c_int, c_longlong, c_float, P],
     "dfmir_segment_means_bwd": [P, P, c_int, c_int, c_longlong, c_float, P],

@@ -198,6 +198,170 @@ extern "C" int dfmir_patch_gather_fwd_multi(const float* const* srcs, int G, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// The PatchNCE head of one layer in ONE launch: sample the patches, Linear(C, 256) + ReLU, Linear(256, 256), L2-normalise
+// (PatchSampleF.forward, models/networks.py:602-619: feat.permute(0,2,3,1).flatten(1,2)[:, patch_id, :] -> mlp -> l2norm),
+// for the rows of G groups (NCE terms) at once.  Replaces gather + two 1x1-conv launches + l2norm (4 launches per layer
+// and side, the GEMMs at 44 TF on the generic kernel).
+// Workgroup = 32 rows (patches) x all 256 output channels, 4 waves (wave w: channels 64 w .. 64 w + 63 = two 32-row MFMA
+// tiles); products on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: the arithmetic of the unfused path).
+//   phase 0  gather x[C][32] into LDS (and to `xs` when the backward needs it)
+//   phase 1  h = relu(W1^T x + b1): A = W1[k][m] straight from global / L2 (consecutive lanes = consecutive m), B = x from LDS
+//   phase 2  y = W2^T h + b2 likewise with h in LDS
+//   phase 3  row norms (shuffle across the half-waves, LDS across the waves), out = y / (norm + eps)
+// Saved for the backward on request: xs [C][rows], hs [256][rows], ypre [256][rows], nrm [rows].
+// ------------------------------------------------------------------------------------------------
+typedef float nh_f32x16 __attribute__((ext_vector_type(16)));
+struct NceHeadP {
+  DfGatherSrcs srcs;
+  const long long* ids;
+  const float *w1, *b1, *w2, *b2;
+  float *out, *nrm, *xs, *hs, *ypre;
+  int G, Bper, C, P;
+  long long S, rows;
+  float eps;
+};
+constexpr int NH_R = 32, NH_M = 256, NH_CMAX = 256, NH_KB = 8;
+__global__ __launch_bounds__(256, 2) void nce_head_fwd_k(NceHeadP k) {
+  __shared__ float Xs[NH_CMAX * NH_R];
+  __shared__ float Hs[NH_M * NH_R];
+  __shared__ float red[4][NH_R];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long r0 = (long long)blockIdx.x * NH_R;
+  // ---- phase 0: thread (c0 = tid >> 5, r = tid & 31) gathers channels c0, c0 + 8, ... of row r0 + r
+  {
+    const int r = tid & 31;
+    const long long rr = r0 + r;
+    const bool rok = rr < k.rows;
+    const long long gb = rok ? rr / k.P : 0;
+    const int pp = rok ? (int)(rr - gb * k.P) : 0;
+    const int g = (int)(gb / k.Bper), b = (int)(gb - (long long)g * k.Bper);
+    const long long id = rok ? k.ids[(long long)g * k.P + pp] : 0;
+    const float* src = k.srcs.p[g] + (long long)b * k.C * k.S + id;
+    const int Cp = (k.C + 2 * NH_KB - 1) / (2 * NH_KB) * (2 * NH_KB);   // the K loop runs in batches of NH_KB row pairs: zero rows up to there
+    // 8 scattered loads in flight per thread (each one its own cache line): issued one at a time in front of its LDS
+    // store this phase alone cost more than the two GEMMs
+    for (int cb = tid >> 5; cb < Cp; cb += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = cb + 8 * u;
+        v[u] = (rok && c < k.C) ? src[(long long)c * k.S] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = cb + 8 * u;
+        if (c < Cp) {
+          Xs[c * NH_R + r] = v[u];
+          if (k.xs && rok && c < k.C) k.xs[(long long)c * k.rows + rr] = v[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int m0 = 64 * wid;
+  nh_f32x16 acc[2];
+  // ---- phase 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // K loop in batches of NH_KB pairs: the weights of batch j + 1 are fetched (global / L2, one dword per lane and MFMA)
+  // while the MFMAs of batch j run -- fetched at the point of use the loop was bound by that latency (107 us per launch)
+#define NH_GEMM(W_, KTOT_, SRC_)                                                                  \
+  {                                                                                               \
+    const float* wp = (W_) + m0 + l31;                                                            \
+    const int K2 = ((KTOT_) + 1) >> 1, nb = (K2 + NH_KB - 1) / NH_KB;                             \
+    float ca0[NH_KB], ca1[NH_KB], na0[NH_KB], na1[NH_KB];                                         \
+    _Pragma("unroll") for (int u = 0; u < NH_KB; ++u) {                                           \
+      const int kr = 2 * u + hi;                                                                  \
+      const bool ok = kr < (KTOT_);                                                               \
+      ca0[u] = ok ? wp[(long long)kr * NH_M] : 0.f;                                               \
+      ca1[u] = ok ? wp[(long long)kr * NH_M + 32] : 0.f;                                          \
+    }                                                                                             \
+    for (int j = 0; j < nb; ++j) {                                                                \
+      if (j + 1 < nb) {                                                                           \
+        _Pragma("unroll") for (int u = 0; u < NH_KB; ++u) {                                       \
+          const int kr = 2 * ((j + 1) * NH_KB + u) + hi;                                          \
+          const bool ok = kr < (KTOT_);                                                           \
+          na0[u] = ok ? wp[(long long)kr * NH_M] : 0.f;                                           \
+          na1[u] = ok ? wp[(long long)kr * NH_M + 32] : 0.f;                                      \
+        }                                                                                         \
+      }                                                                                           \
+      _Pragma("unroll") for (int u = 0; u < NH_KB; ++u) {                                         \
+        const int kr = 2 * (j * NH_KB + u) + hi;                                                  \
+        const float bv = (SRC_)[kr * NH_R + l31];                                                 \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[u], bv, acc[0], 0, 0, 0);               \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[u], bv, acc[1], 0, 0, 0);               \
+      }                                                                                           \
+      _Pragma("unroll") for (int u = 0; u < NH_KB; ++u) { ca0[u] = na0[u]; ca1[u] = na1[u]; }     \
+    }                                                                                             \
+  }
+  NH_GEMM(k.w1, k.C, Xs)
+  // D layout: acc[i][e] <-> channel m0 + 32 i + (e >> 2) * 8 + hi * 4 + (e & 3), row l31
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + 32 * i + (e >> 2) * 8 + hi * 4 + (e & 3);
+      float v = acc[i][e] + k.b1[m];
+      v = v > 0.f ? v : 0.f;
+      Hs[m * NH_R + l31] = v;
+      if (k.hs && r0 + l31 < k.rows) k.hs[(long long)m * k.rows + r0 + l31] = v;
+      acc[i][e] = 0.f;
+    }
+  __syncthreads();
+  // ---- phase 2
+  NH_GEMM(k.w2, NH_M, Hs)
+#undef NH_GEMM
+  // ---- phase 3: bias, row norms, normalise
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + 32 * i + (e >> 2) * 8 + hi * 4 + (e & 3);
+      acc[i][e] += k.b2[m];
+      ss += acc[i][e] * acc[i][e];
+    }
+  ss += __shfl_xor(ss, 32);
+  if (hi == 0) red[wid][l31] = ss;
+  __syncthreads();
+  const float nr = sqrtf((red[0][l31] + red[1][l31]) + (red[2][l31] + red[3][l31]));
+  const float inv = 1.f / (nr + k.eps);
+  const long long rr = r0 + l31;
+  if (rr < k.rows) {
+    if (k.nrm && wid == 0 && hi == 0) k.nrm[rr] = nr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + 32 * i + (e >> 2) * 8 + hi * 4 + (e & 3);
+        k.out[(long long)m * k.rows + rr] = acc[i][e] * inv;
+        if (k.ypre) k.ypre[(long long)m * k.rows + rr] = acc[i][e];
+      }
+  }
+}
+// srcs: HOST array of G <= 8 device pointers (group g's images [Bper, C, S]); ids [G][P]; w1 [C][256], w2 [256][256] in
+// the forward packing of dfmir_weight_pack ([Cin][Cout]); out [256][G*Bper*P].  xs / hs / ypre / nrm may be NULL.
+extern "C" int dfmir_nce_head_fwd(const float* const* srcs, int G, const long long* ids, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, float* out, float* nrm, float* xs, float* hs,
+                                  float* ypre, int Bper, int C, long long S, int P, float eps, void* stream) {
+  DF_ARG_CHECK(srcs && ids && w1 && b1 && w2 && b2 && out && G > 0 && G <= 8 && Bper > 0 && C > 0 && C <= NH_CMAX && S > 0 && P > 0);
+  NceHeadP k{};
+  for (int g = 0; g < G; ++g) {
+    DF_ARG_CHECK(srcs[g] != nullptr);
+    k.srcs.p[g] = srcs[g];
+  }
+  k.ids = ids; k.w1 = w1; k.b1 = b1; k.w2 = w2; k.b2 = b2;
+  k.out = out; k.nrm = nrm; k.xs = xs; k.hs = hs; k.ypre = ypre;
+  k.G = G; k.Bper = Bper; k.C = C; k.P = P; k.S = S; k.rows = (long long)G * Bper * P; k.eps = eps;
+  nce_head_fwd_k<<<(unsigned)((k.rows + NH_R - 1) / NH_R), 256, 0, (hipStream_t)stream>>>(k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // out[t] = scale * sum_l mean(rows[l][t*seg .. (t+1)*seg))  for rows [L][T*seg]: the per-term NCE losses
 // `total_nce_loss += loss.mean() * lambda_NCE ... / n_layers` (models/registration_model.py:247-253), all terms and
 // layers in one launch (deterministic: one workgroup per term, fixed reduction order).

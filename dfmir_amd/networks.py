@@ -459,6 +459,22 @@ class PatchSampleF(nn.Module):
             return_feats.append(self.project(feat_id, x).t())  # [B*P, nc] view
         return return_feats, return_ids
 
+    def sample_project(self, feat_id, feat, ids, groups=1):
+        """Layer `feat_id`: sample `ids` ([G, P]: image b of the batch uses row b // (B / G)) from feat [B, C, H, W] and
+        project -> L2-normalised [nc, B*P] (channel-major; models/networks.py:604-619).  One fused launch where the
+        library has one (MLP head, nc = 256, C <= 256), else gather + project."""
+        if ops.nce_head_ok(feat.shape[1], self.nc, self.use_mlp):
+            mlp = getattr(self, 'mlp_%d' % feat_id)
+            return ops.nce_head(feat, ids, mlp[0], mlp[2])
+        return self.project(feat_id, ops.patch_gather(feat, ids, groups))
+
+    def sample_project_multi(self, feat_id, srcs, ids):
+        """The same for G source tensors (no gradient: the detached key side), group g sampled at ids[g]."""
+        if ops.nce_head_ok(srcs[0].shape[1], self.nc, self.use_mlp):
+            mlp = getattr(self, 'mlp_%d' % feat_id)
+            return ops.nce_head_multi(srcs, ids, mlp[0], mlp[2])
+        return self.project(feat_id, ops.patch_gather_multi(srcs, ids))
+
     def project(self, feat_id, x_cm):
         """Sampled rows of layer `feat_id`, channel-major [C, rows] -> MLP (Linear, ReLU, Linear) -> L2-normalised
         [nc, rows] (models/networks.py:613-619); the transposed view of the result is what forward() returns."""

@@ -1843,6 +1843,112 @@ def patch_gather_multi(srcs, ids):
     return out
 
 
+_NO_NCE_FUSED = bool(os.environ.get("DFMIR_NO_NCE_FUSED"))     # A/B switch: gather, two 1x1 convs and l2norm as 4 launches
+
+
+def nce_head_ok(C, nc, use_mlp):
+    return use_mlp and not _NO_NCE_FUSED and nc == 256 and 1 <= C <= 256
+
+
+def _nce_head_launch(ptrs, G, ids, mlp0, mlp2, Bper, C, S, Pn, eps, device, save):
+    rows = G * Bper * Pn
+    out = torch.empty((256, rows), device=device, dtype=torch.float32)
+    nrm = xs = hs = ypre = None
+    if save:
+        nrm = torch.empty(rows, device=device, dtype=torch.float32)
+        xs = torch.empty((C, rows), device=device, dtype=torch.float32)
+        hs = torch.empty((256, rows), device=device, dtype=torch.float32)
+        ypre = torch.empty((256, rows), device=device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * G)(*ptrs)
+    check(lib().dfmir_nce_head_fwd(arr, G, _p(ids), _p(mlp0.packed(0)), _p(mlp0.bias), _p(mlp2.packed(0)), _p(mlp2.bias),
+                                   _p(out), _p(nrm), _p(xs), _p(hs), _p(ypre), Bper, C, S, Pn, float(eps), _st()))
+    return out, nrm, xs, hs, ypre
+
+
+def nce_head_multi(srcs, ids, mlp0, mlp2, eps=1e-7):
+    """Key side (no gradient): G source tensors [Bper, C, *sp], ids [G, P] -> L2-normalised projections [256, G*Bper*P]."""
+    _need(*srcs)
+    srcs = [_c(s_) for s_ in srcs]
+    Bper, C = srcs[0].shape[0], srcs[0].shape[1]
+    S = srcs[0].numel() // (Bper * C)
+    ids = _c(ids.to(torch.int64))
+    out, _, _, _, _ = _nce_head_launch([s_.data_ptr() for s_ in srcs], len(srcs), ids, mlp0, mlp2, Bper, C, S, ids.shape[1], eps,
+                                       srcs[0].device, False)
+    return out
+
+
+class NceHeadFn(Function):
+    """Query side: feat [B, C, *sp] (the G terms' images stacked along the batch), ids [G, P] -> [256, B*P]; the backward
+    runs the chain the unfused modules would run (l2norm, the two Linear layers' dgrad / wgrad / bias gradients, the
+    sampled-feature scatter) on the intermediates the fused forward saved."""
+
+    @staticmethod
+    def forward(ctx, feat, ids, w1, b1, w2, b2, mlp0, mlp2, eps, distinct):
+        _need(feat, ids)
+        ctx.stash = getattr(feat, "_df_tap_stash", None) if feat.is_contiguous() else None
+        feat = _c(feat)
+        ids = _c(ids.to(torch.int64))
+        G, Pn = ids.shape
+        B, C = feat.shape[0], feat.shape[1]
+        if B % G:
+            raise DfmirHipError("nce_head: ids [G,P] with G dividing the batch")
+        Bper = B // G
+        S = feat.numel() // (B * C)
+        base = feat.data_ptr()
+        ptrs = [base + 4 * g * Bper * C * S for g in range(G)]
+        out, nrm, xs, hs, ypre = _nce_head_launch(ptrs, G, ids, mlp0, mlp2, Bper, C, S, Pn, eps, feat.device, True)
+        ctx.save_for_backward(ids, nrm, xs, hs, ypre, w1, w2)
+        ctx.meta = (tuple(feat.shape), B, C, S, Pn, G, bool(distinct), float(eps))
+        ctx.mods = (mlp0, mlp2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        ids, nrm, xs, hs, ypre, w1, w2 = ctx.saved_tensors
+        shape, B, C, S, Pn, G, distinct, eps = ctx.meta
+        mlp0, mlp2 = ctx.mods
+        rows = B * Pn
+        dout = _c(dout)
+        dy = torch.empty_like(ypre)
+        check(lib().dfmir_l2norm_bwd(_p(dout), _p(ypre), _p(nrm), _p(dy), 256, rows, eps, _st()))
+        # Linear(256, 256): y = W2 h + b2
+        c2 = _Ctx()
+        c2.cfg, c2.x_amax, c2.dead_tail, c2.in_act, c2.has_bias = (2, (1, 1, 1), 1, (0, 0, 0), 0, 0, 0.0, mlp2), None, 0, None, True
+        c2.needs_input_grad = (True, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        dh, dw2, db2 = _conv_backward_impl(c2, dy.view(1, 256, 1, rows), None, hs.view(1, 256, 1, 1, rows),
+                                           w2.view(256, 256, 1, 1), None)
+        # Linear(C, 256) + ReLU: h = relu(W1 x + b1)
+        c1 = _Ctx()
+        c1.cfg, c1.x_amax, c1.dead_tail, c1.in_act, c1.has_bias = (2, (1, 1, 1), 1, (0, 0, 0), 0, 1, 0.0, mlp0), None, 0, None, True
+        c1.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dx, dw1, db1 = _conv_backward_impl(c1, dh, None, xs.view(1, C, 1, 1, rows), w1.view(256, C, 1, 1),
+                                           hs.view(1, 256, 1, 1, rows))
+        dfeat = None
+        if dx is not None:
+            dxr = _c(dx).view(C, rows)
+            meta = (shape, B, C, S, Pn, G, distinct)
+            if ctx.stash is not None:
+                ctx.stash.append((dxr, ids, meta))
+            else:
+                dfeat = zeros(shape, dxr.device)
+                if distinct:
+                    check(lib().dfmir_patch_gather_bwd_g(_p(dxr), _p(ids), _p(dfeat), B, C, S, Pn, G, None, _st()))
+                else:
+                    check(lib().dfmir_patch_gather_bwd_any(_p(dxr), _p(ids), _p(dfeat), B, C, S, Pn, G, None, None, _st()))
+        dw1 = dw1.view(256, C) if dw1 is not None else None          # the Linear parameters are [out, in]
+        dw2 = dw2.view(256, 256) if dw2 is not None else None
+        return dfeat, None, dw1, db1, dw2, db2, None, None, None, None
+
+
+def nce_head(feat, ids, mlp0, mlp2, eps=1e-7):
+    """Query side with gradient; see NceHeadFn."""
+    groups = ids.shape[0] if ids.dim() == 2 else 1
+    ids2 = ids if ids.dim() == 2 else ids.view(1, -1)
+    distinct = ids_distinct(ids, groups) if (torch.is_grad_enabled() and feat.requires_grad) else True
+    return NceHeadFn.apply(feat, ids2, mlp0.weight, mlp0.bias, mlp2.weight, mlp2.bias, mlp0, mlp2, eps, distinct)
+
+
 # ------------------------------------------------------------------------------------------------
 # scalar losses
 # ------------------------------------------------------------------------------------------------

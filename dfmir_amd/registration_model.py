@@ -463,9 +463,9 @@ class REGISTRATIONModel(BaseModel):
                 for src, _ in terms:
                     if id(src) not in keys:
                         keys[id(src)] = self._encode_keys(src)
-                k_cm = [self.netF.project(l, ops.patch_gather_multi([keys[id(src)][l] for src, _ in terms], ids[l]))
+                k_cm = [self.netF.sample_project_multi(l, [keys[id(src)][l] for src, _ in terms], ids[l])
                         for l in range(n_layers)]
-            q_cm = [self.netF.project(l, ops.patch_gather(feat_q[l], ids[l], T)) for l in range(n_layers)]
+            q_cm = [self.netF.sample_project(l, feat_q[l], ids[l], T) for l in range(n_layers)]
             losses = ops.nce_terms(q_cm, k_cm, T * per_term_groups, self.opt.nce_T,
                                    self.opt.lambda_NCE / n_layers, T)
             return list(losses.unbind(0))

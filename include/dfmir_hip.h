@@ -401,6 +401,14 @@ int dfmir_patch_gather_bwd_any(const float* dout, const long long* ids, float* d
  * (models/registration_model.py:244-245; gather = models/networks.py:604-611). */
 int dfmir_patch_gather_fwd_multi(const float* const* srcs, int G, const long long* ids, float* out, int Bper, int C,
                                  long long S, int P, void* stream);
+/* The PatchNCE head of one layer in one launch (PatchSampleF.forward, models/networks.py:602-619): sample ids[g][0..P) from
+ * group g's images srcs[g] [Bper, C, S], Linear(C, 256) + ReLU, Linear(256, 256), x / (||x||_2 + eps) -> out [256][G*Bper*P]
+ * (channel-major rows, row = (g*Bper + b)*P + p).  w1 [C][256], w2 [256][256]: forward packings of dfmir_weight_pack
+ * (T = 1); C <= 256.  Optional outputs for the backward: nrm [rows], xs [C][rows] (sampled features), hs [256][rows]
+ * (after the ReLU), ypre [256][rows] (before the normalisation).  srcs: HOST array of G <= 8 device pointers. */
+int dfmir_nce_head_fwd(const float* const* srcs, int G, const long long* ids, const float* w1, const float* b1,
+                       const float* w2, const float* b2, float* out, float* nrm, float* xs, float* hs, float* ypre,
+                       int Bper, int C, long long S, int P, float eps, void* stream);
 /* Patch positions drawn on the device: out[layer][set][0..P) = a uniformly random P-subset of [0, sizes[layer]) --
  * what `torch.randperm(H*W)[:num_patches]` (models/networks.py:609-610) yields per layer and per netF call, for
  * n_sets calls at once (the set, not its order, is what PatchNCELoss sees).  sizes: HOST array of n_layers <= 8

@@ -162,3 +162,51 @@ def test_batched_key_path_matches_term_by_term():
     # the batched path reproduces itself to 1e-6).
     a, b = arenas["F"]
     assert float((a - b).norm()) <= 2e-6 * float(arenas["G"][1].norm()), float((a - b).norm())
+
+
+@pytest.mark.parametrize("C_in,hw,G", [(3, 24, 1), (128, 16, 3), (256, 8, 2), (37, 12, 1)])
+def test_fused_head_matches_torch_and_unfused(ops, C_in, hw, G):
+    """dfmir_nce_head_fwd (sample + Linear + ReLU + Linear + L2-normalise in one launch, csrc/nce_head.hip) against the
+    torch restatement of PatchSampleF.forward (models/networks.py:604-619) and against the unfused launches it replaces
+    -- outputs and the gradients of the features and of both Linear layers -- including a channel count that is not a
+    multiple of the K batch, an odd one, and a row count that does not fill the last 32-row tile."""
+    from dfmir_amd import networks as N
+    torch.manual_seed(7 + C_in)
+    Bper, P = 2, 50 if C_in == 37 else 64
+    B = G * Bper
+    S = hw * hw
+    feat0 = torch.randn(B, C_in, hw, hw, device=DEV)
+    ids = torch.stack([torch.randperm(S, device=DEV)[:P] for _ in range(G)])
+    netF = N.PatchSampleF(use_mlp=True, init_type='normal', init_gain=0.5, gpu_ids=[0], nc=256)
+    netF.create_mlp([feat0])
+    mlp = netF.mlp_0
+    dy = torch.randn(256, B * P, device=DEV)
+    got = {}
+    for fused in (True, False):
+        feat = feat0.clone().requires_grad_(True)
+        for p_ in mlp.parameters():
+            p_.grad = None
+        if fused:
+            assert ops.nce_head_ok(C_in, 256, True)
+            y = ops.nce_head(feat, ids, mlp[0], mlp[2])
+        else:
+            y = netF.project(0, ops.patch_gather(feat, ids, G))
+        (y * dy).sum().backward()
+        got[fused] = [y.detach().clone(), feat.grad.clone()] + [p_.grad.clone() for p_ in mlp.parameters()]
+    # torch restatement in fp64
+    w1, b1, w2, b2 = [p_.detach().double() for p_ in (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)]
+    w1, w2 = w1.reshape(256, C_in), w2.reshape(256, 256)
+    f = feat0.double().requires_grad_(True)
+    fr = f.permute(0, 2, 3, 1).flatten(1, 2)                                    # [B, S, C]
+    xs = torch.cat([fr[b, ids[b // Bper]] for b in range(B)], 0)               # [B*P, C]
+    h = torch.relu(xs @ w1.t() + b1)
+    yp = h @ w2.t() + b2
+    yr = yp / (yp.pow(2).sum(1, keepdim=True).sqrt() + 1e-7)
+    (yr.t() * dy.double()).sum().backward()
+    close(got[True][0], yr.t().float(), rtol=2e-5, atol=2e-6, what="fused head vs torch")
+    close(got[True][1], f.grad.float(), rtol=1e-4, atol=1e-5, what="fused head d(feat) vs torch")
+    for a, b, nm in zip(got[True], got[False], ("y", "dfeat", "dw1", "db1", "dw2", "db2")):
+        close(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())), what="fused vs unfused " + nm)
+    # key side: G separate source tensors, no gradient
+    srcs = [feat0[g * Bper:(g + 1) * Bper].contiguous() for g in range(G)]
+    close(ops.nce_head_multi(srcs, ids, mlp[0], mlp[2]), got[True][0], rtol=0, atol=0, what="multi-source head")
