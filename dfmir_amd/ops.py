@@ -171,18 +171,28 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                    stride, dil, pad[0], pad[1], pad[2], pad_mode, act, float(slope))
     fuse_res = (res is not None and not _NO_RES and x_amax is not None and res.is_contiguous() and tuple(res.shape) == tuple(y.shape)
                 and lib().dfmir_conv3x3_res_ok(ctypes.byref(g)))
-    split3d = (x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
+    # the flow head / its data gradient (16 -> 3, 3 -> 16): plain fp32 FMAs (csrc/conv3dt.hip)
+    tiny3d = (tuple(K) == (3, 3, 3) and res is None and ring is None and not _NO_TINY3D
+              and (cout_used is None or cout_used == Cout) and bool(lib().dfmir_conv3d_tiny_ok(ctypes.byref(g))))
+    split3d = (not tiny3d and x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
     if cout_used is not None and not split3d:
         cout_used = None                                     # only the split 3-D kernel computes a channel subset
-    if act_src is not None and not (split3d and act == 0 and tuple(act_src.shape) == tuple(y.shape) and act_src.is_contiguous()):
-        act_src = None                                       # ... and only its epilogue applies an activation derivative
+    if act_src is not None and not ((split3d or tiny3d) and act == 0 and tuple(act_src.shape) == tuple(y.shape)
+                                    and act_src.is_contiguous()):
+        act_src = None                                       # ... and only these epilogues apply an activation derivative
     _LAST_ACTGRAD[0] = act_src is not None
     if _PROBE_AUDIT["on"] and x_amax is not None:
         _audit_probe(x5, x_amax, "conv input %s -> %d ch, k=%s" % (tuple(x5.shape), Cout, tuple(K)))
 
     def launch():
-        if split3d:
+        if tiny3d:
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_tiny_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _p(act_src),
+                                              float(act_slope), _st()))
+            tag_amax(y, slot)
+            _LAST_CONV_AMAX[0] = slot
+        elif split3d:
             # fp16x2 split form on the 16-bit matrix pipe; the kernel leaves the range probe of y for the next layer.
             # The split weights are kept per packed-weight buffer and re-made only when that buffer was re-packed.
             cu = Cout if cout_used is None else cout_used
@@ -227,6 +237,8 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
         kind = ("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size
+        if tiny3d:
+            kind = "conv3dt_" + size
         if split3d:
             # 16-bit products the kernel ISSUES per algorithmic MAC: 3 (a0b0 + a0b1 + a1b0) x the padding of its tiling --
             # taps 27 -> 28 (plane-pair rows: 27 -> 36 taps'), input channels to whole chunks of 8, output channels to 32 rows
@@ -244,6 +256,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
 
 _LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
+_NO_TINY3D = bool(os.environ.get("DFMIR_CONV3D_NO_TINY"))  # A/B switch: the flow head on the split kernels
 _NO_ACTGRAD = bool(os.environ.get("DFMIR_NO_ACTGRAD"))     # A/B switch: LeakyReLU backward always as its own pass
 
 

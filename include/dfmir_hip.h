@@ -118,6 +118,14 @@ int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W);
  * _up_skip2_fwd's (K = Ca, Cb = skip channels or 0), 2 = dfmir_conv3d_up_dgrad's.  The entry points then take w_tcc = NULL. */
 int dfmir_conv3d_wsplit_batch(const void* jobs_dev, int njobs, void* stream);
 int dfmir_conv3d_split_is_pair(int cout_used);
+/* The flow head (models/voxelmorph/torchvoxelmorph/networks.py:1076-1080: Conv3d(16, 3, 3, padding=1)) and its data
+ * gradient (3 -> 16) as plain fp32 FMAs -- neither side fills a matrix-core tile (3 of 16 rows / 3 of 8 K channels).
+ * w_tcc: the fp32 tap-major packing [27][Cin][Cout] of dfmir_weight_pack (mode 0 forward, mode 1 data gradient);
+ * y = act(conv + bias), times the derivative of the LeakyReLU whose OUTPUT is act_src when act_src != NULL (g->act == 0);
+ * y_amax: NULL or the 64 accumulating range-probe slots of y. */
+int dfmir_conv3d_tiny_ok(const DfConvGeom* g);
+int dfmir_conv3d_tiny_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
+                          float* y_amax, const float* act_src, float act_slope, void* stream);
 long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);
 int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
                         float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream);

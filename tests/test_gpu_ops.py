@@ -220,6 +220,9 @@ CONV3D = [
     # one with two phantom tiles; the flow-head shape (Cout 3) with 5 tile rows
     (16, 16, 3, 1, 1, 1, 5, 26, 16),
     (16, 3, 3, 1, 1, 1, 6, 40, 8),
+    # the flow head on the fp32-FMA kernel (conv3dt.hip; W % 4 == 0): ragged tiles in every axis with batch 2, several x tiles
+    (16, 3, 3, 1, 1, 2, 5, 9, 36),
+    (16, 3, 3, 1, 1, 1, 9, 17, 68),
 ]
 
 
