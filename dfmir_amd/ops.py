@@ -90,6 +90,21 @@ def amax_slot(device, n=1):
     return pool["buf"][i:i + n]
 
 
+def prepare_step(device):
+    """What a step triggers lazily on first use and every stream of the step then relies on -- the batched re-pack of all
+    weights after an optimizer step, a probe pool with room for a whole step -- done NOW, on the current stream: a step
+    that forks work onto a second stream (registration_model._forward_backward) calls this before the fork."""
+    ep = weights_epoch()
+    if _PACKS["epoch"] != ep and _PACKS["entries"]:
+        _repack_all(ep)
+    pool = _AMAX_POOL
+    if pool["buf"] is None or pool["buf"].device != device:
+        amax_slot(device, 0)
+    elif pool["next"] + (1 << 16) > pool["buf"].numel() and not pool.get("capturing"):
+        pool["buf"] = zeros(1 << 18, device)
+        pool["next"] = 0
+
+
 def begin_graph_capture():
     """Called right before a hipGraph capture of the step: probe slots handed out during the capture must be zeroed by
     the graph itself at every replay, so the pool is re-created (allocation + zero fill) inside the capture."""

@@ -278,14 +278,34 @@ class REGISTRATIONModel(BaseModel):
         st['graph'].replay()
         self._apply_updates()
 
+    def _overlap_registration(self):
+        return (self.isTrain and self.device.type == 'cuda' and getattr(self.opt, 'overlap_registration', True)
+                and not os.environ.get('DFMIR_NO_OVERLAP_R'))
+
     def _graph_state(self):
         return self.__dict__.setdefault('_graph', {'eager_steps': 0, 'graph': None, 'shape': None, 'force_eager': False,
                                                    'stream': torch.cuda.Stream(device=self.device)})
 
     def _forward_backward(self):
-        self.forward()
-
-        y_output = self.netR(self.real_A, self.real_B)
+        if self._overlap_registration():
+            # netR reads only the two input images (registration_model.py:146): its forward runs on a second stream beside
+            # the generator's, and autograd then runs its backward there as well, beside the generator's backward -- a
+            # few hundred small-grid launches under the big convolutions instead of in front of them.  Captured, the
+            # fork / join become parallel branches of the hipGraph.
+            cur, rs = torch.cuda.current_stream(), self._graph_state().setdefault('r_stream', torch.cuda.Stream(device=self.device))
+            ops.prepare_step(self.device)
+            rs.wait_stream(cur)
+            with torch.cuda.stream(rs):
+                y_output = self.netR(self.real_A, self.real_B)
+            self.forward()
+            cur.wait_stream(rs)
+            if not torch.cuda.is_current_stream_capturing():
+                for t in y_output:
+                    if torch.is_tensor(t):
+                        t.record_stream(cur)
+        else:
+            self.forward()
+            y_output = self.netR(self.real_A, self.real_B)
         y_pred = [self.spatialTransformer(self.fake_B, y_output[2]), y_output[2]]
         self.registered = y_pred[0]
         self.regA = y_output[0]

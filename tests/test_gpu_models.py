@@ -522,6 +522,44 @@ def test_full_size_gradients_vs_fp64_oracle(O, capsys):
         assert e_hip <= (3.5e-2 if k.startswith("F.") else 8e-3), "%s: HIP %.3e vs fp64" % (k, e_hip)
 
 
+def test_registration_net_on_a_second_stream_changes_nothing(O):
+    """opt.overlap_registration (build-defined, default on): netR's forward and backward run on a second HIP stream beside
+    the generator's.  Two steps with and without it from identical states: same losses, outputs and gradient arenas (up to
+    the summation order of the weight gradients' float atomics)."""
+    from tests.test_oracle_golden import make_step
+    res = []
+    for overlap in (True, False):
+        st, size, B = make_step()
+        model, opt = _hip_model_from_oracle(st, size, B, 8)
+        opt.overlap_registration = overlap
+        model.patch_id_source = PinnedIds()
+        A0, B0 = C.image_pair(93, B, size, size)
+        model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+        _load(model.netF, st.netF)
+        model.setup(opt)
+        assert model._overlap_registration() == overlap
+        out = []
+        for it in range(2):
+            A_, B_ = C.image_pair(100 + it, B, size, size)
+            model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            out.append(([v for v in model.get_current_losses().values()], model.fake_B.clone(), model.registered.clone(),
+                        model.regA.clone(), [o_.flat_g.clone() for o_ in model.optimizers]))
+        res.append(out)
+    for it, (a, b) in enumerate(zip(*res)):
+        # step 0 starts from identical weights; step 1 from weights one Adam update apart by at most lr wherever a gradient
+        # element sits at round-off level (Adam's first update is lr * g / |g|)
+        tol = 1e-6 if it == 0 else 2e-4
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5 if it == 0 else 2e-3, atol=1e-9)
+        for x, y in zip(a[1:4], b[1:4]):
+            close(x, y, rtol=tol, what="outputs, step %d" % it)
+        if it == 0:
+            gscale = max(float(g.norm()) for g in b[4])
+            for nm, x, y in zip("GRF", a[4], b[4]):
+                assert float((x - y).norm()) <= 2e-5 * float(y.norm()) + 2e-6 * gscale, nm
+
+
 def test_batch16_step_vs_oracle(O, capsys):
     """BASELINE configs[1] as quoted -- 256x256, ngf 64, batch 16 -- one whole step (forward, losses, backward, Adam)
     against the CPU oracle on identical weights, inputs and patch ids: outputs within 1e-4 relative, losses within 1e-3,
