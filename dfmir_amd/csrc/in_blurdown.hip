@@ -1,0 +1,213 @@
+// InstanceNorm + ReLU + Downsample (models/networks.py:984-996) on the 256 x 256 planes of the generator's first encoder
+// stage -- the ring-free form of norm_resample.hip's in_relu_blurdown_{fwd,bwd}_k.  Its own translation unit because it is
+// built WITHOUT packed-fp32 VALU instructions (csrc/Makefile): paired registers for v_pk_* cost 13 (forward) / 15 (backward)
+// spilled registers next to the 64 that hold the plane.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// The 256 x 256 planes again, with the plane laid over the workgroup so that NO band ring is needed: wave w (16 of them)
+// holds rows 16 w .. 16 w + 15 (register i = row 16 w + i, lane l = columns 4 l .. 4 l + 3; a global load instruction of a
+// wave is still one contiguous 1 KB row).  The horizontal [1 2 1] / 4 stride-2 blur needs one value of the neighbouring lane
+// (a shuffle), the vertical one the rows of the SAME thread -- except row 16 w - 1, which is the previous wave's last
+// horizontally-blurred row: 512 bytes per wave through LDS, one barrier.  (The banded form above pushed the whole
+// normalised plane through a 2 x 16-row LDS ring with two barriers per band: 2.6 TB/s against 4.4 TB/s of the plain
+// InstanceNorm kernel on the same planes.)  Backward likewise: x stays in registers for both passes, each wave reads the 9
+// dz rows its 16 rows touch straight from global memory, the blur's adjoint is evaluated from registers (static tap
+// geometry per register index), no LDS besides the reductions.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned irb_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned irb_u32x2 __attribute__((ext_vector_type(2)));
+// rows through buffer instructions: lane offset in one VGPR, the (wave-uniform) row offset in an SGPR -- with flat pointers
+// the 16 + 9 row addresses of a thread alone took 50 registers next to the 64 of the plane
+__device__ __forceinline__ float4 irb_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const irb_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+__device__ __forceinline__ float2 irb_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const irb_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ void irb_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  irb_u32x4 t;
+  t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+}
+__device__ __forceinline__ void irb_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  irb_u32x2 t;
+  t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+}
+__global__ __launch_bounds__(1024) void in_relu_blurdown_fwd256_k(const float* __restrict__ x, float* __restrict__ z,
+                                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                                  float eps, float* __restrict__ amax) {
+  constexpr int S = 65536;
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  __shared__ float edge[16][128];
+  if (threadIdx.x == 0) smax = 0u;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)blockIdx.x * S), 0,
+                                                                       S * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(z + (long long)blockIdx.x * (S / 4), 0, S, 0x00020000);
+  float4 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = irb_ld4(xr, 16u * l, (unsigned)(16 * w + i) * 1024u);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = block_sum(s, sm) / (float)S;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float var = block_sum(q, sm) / (float)S;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[blockIdx.x] = mean;
+    rstd_o[blockIdx.x] = rstd;
+  }
+  // normalise + ReLU + horizontal blur: output columns 2 l (from columns 4 l - 1, 4 l, 4 l + 1; column -1 reflects to 1)
+  // and 2 l + 1 (columns 4 l + 1 .. 4 l + 3)
+  float am = 0.f;                                        // v[i].x / .y become the two horizontally blurred values of row i
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float ox = fmaxf((v[i].x - mean) * rstd, 0.f), oy = fmaxf((v[i].y - mean) * rstd, 0.f);
+    const float oz = fmaxf((v[i].z - mean) * rstd, 0.f), ow = fmaxf((v[i].w - mean) * rstd, 0.f);
+    am = fmaxf(fmaxf(am, fmaxf(ox, oy)), fmaxf(oz, ow));
+    float left = __shfl_up(ow, 1, 64);
+    if (l == 0) left = oy;
+    v[i].x = 0.25f * left + 0.5f * ox + 0.25f * oy;
+    v[i].y = 0.25f * oy + 0.5f * oz + 0.25f * ow;
+  }
+  *reinterpret_cast<float2*>(&edge[w][2 * l]) = make_float2(v[15].x, v[15].y);
+  __syncthreads();
+  const float2 up = w > 0 ? *reinterpret_cast<const float2*>(&edge[w - 1][2 * l]) : make_float2(v[1].x, v[1].y);   // row -1 -> row 1
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a0 = j == 0 ? up.x : v[2 * j - 1].x, a1 = j == 0 ? up.y : v[2 * j - 1].y;
+    float2 o;
+    // the order of the banded kernel's sums: rows a = 0, 1, 2 with weights 1/4, 1/2, 1/4
+    o.x = 0.25f * a0 + 0.5f * v[2 * j].x + 0.25f * v[2 * j + 1].x;
+    o.y = 0.25f * a1 + 0.5f * v[2 * j].y + 0.25f * v[2 * j + 1].y;
+    irb_st2(o, zr, 8u * l, (unsigned)(8 * w + j) * 512u);
+  }
+  if (amax) publish_block_absmax_acc(am, &smax, amax);     // bounds the blur's output too (convex combination)
+}
+
+__global__ __launch_bounds__(1024) void in_relu_blurdown_bwd256_k(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean_i,
+                                                                  const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                                  float* __restrict__ amax, float* __restrict__ pmax) {
+  constexpr int S = 65536;
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  __shared__ __attribute__((aligned(16))) float dzs[129 * 128];          // the whole dz plane + a zero row 128
+  if (threadIdx.x == 0) smax = 0u;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
+  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)blockIdx.x * S), 0,
+                                                                       S * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz + (long long)blockIdx.x * (S / 4)), 0,
+                                                                       S, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(dx + (long long)blockIdx.x * S, 0, S * 4u, 0x00020000);
+  float4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = irb_ld4(xr, 16u * l, (unsigned)(16 * w + i) * 1024u);
+  // dz (a quarter of the plane) goes through LDS: a wave's 16 rows touch dz rows 8 w .. 8 w + 8 (row 128 = zeros), a lane
+  // its columns 2 l .. 2 l + 2 -- kept in registers next to x they spilled
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(&dzs[4 * (threadIdx.x + 1024 * q)]) = irb_ld4(zr, 16u * (threadIdx.x + 1024 * q), 0u);
+  if (threadIdx.x < 32) *reinterpret_cast<float4*>(&dzs[128 * 128 + 4 * threadIdx.x]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const float* dzw = dzs + (8 * w) * 128 + 2 * l;
+  // column adjoint of dz row k: input columns 4 l .. 4 l + 3 take  1/2 dz[2l] | 1/4 (dz[2l] + dz[2l+1]) (+ 1/4 dz[0] at
+  // column 1: the reflected -1) | 1/2 dz[2l+1] | 1/4 (dz[2l+1] + dz[2l+2]).  Evaluated in both passes, rolling over the
+  // row pairs
+#define IRB2_CA(k_, c_)                                                                           \
+  {                                                                                               \
+    const float2 d_ = *reinterpret_cast<const float2*>(dzw + (k_) * 128);                         \
+    const float nx_ = l == 63 ? 0.f : dzw[(k_) * 128 + 2];                                        \
+    c_.x = 0.5f * d_.x;                                                                           \
+    c_.y = 0.25f * d_.x + 0.25f * d_.y + (l == 0 ? 0.25f * d_.x : 0.f);                           \
+    c_.z = 0.5f * d_.y;                                                                           \
+    c_.w = 0.25f * d_.y + 0.25f * nx_;                                                            \
+  }
+  // row adjoint: row 16 w + 2 j takes 1/2 ca[j]; row 16 w + 2 j + 1 takes 1/4 (ca[j] + ca[j + 1]) (+ 1/4 ca[0] at row 1)
+#define IRB2_ROW(i_, g_, BODY_)                                                                   \
+  {                                                                                               \
+    const float hx = (v[i_].x - MEAN_) * RSTD_, hy = (v[i_].y - MEAN_) * RSTD_, hz = (v[i_].z - MEAN_) * RSTD_, \
+                hw = (v[i_].w - MEAN_) * RSTD_;                                                   \
+    if (!(hx > 0.f)) g_.x = 0.f;                                                                  \
+    if (!(hy > 0.f)) g_.y = 0.f;                                                                  \
+    if (!(hz > 0.f)) g_.z = 0.f;                                                                  \
+    if (!(hw > 0.f)) g_.w = 0.f;                                                                  \
+    BODY_                                                                                         \
+  }
+#define IRB2_PASS(BODY_)                                                                          \
+  {                                                                                               \
+    float4 cur, nxt;                                                                              \
+    IRB2_CA(0, cur)                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                               \
+      IRB2_CA(j + 1, nxt)                                                                         \
+      const float e_ = (j == 0 && w == 0) ? 0.25f : 0.f;                                          \
+      float4 g0, g1;                                                                              \
+      g0.x = 0.5f * cur.x; g0.y = 0.5f * cur.y; g0.z = 0.5f * cur.z; g0.w = 0.5f * cur.w;          \
+      g1.x = 0.25f * cur.x + 0.25f * nxt.x + e_ * cur.x;                                          \
+      g1.y = 0.25f * cur.y + 0.25f * nxt.y + e_ * cur.y;                                          \
+      g1.z = 0.25f * cur.z + 0.25f * nxt.z + e_ * cur.z;                                          \
+      g1.w = 0.25f * cur.w + 0.25f * nxt.w + e_ * cur.w;                                          \
+      { const int i = 2 * j; IRB2_ROW(i, g0, BODY_(g0)) }                                         \
+      { const int i = 2 * j + 1; IRB2_ROW(i, g1, BODY_(g1)) }                                     \
+      cur = nxt;                                                                                  \
+    }                                                                                             \
+  }
+  float s1 = 0.f, s2 = 0.f;
+#define MEAN_ mean
+#define RSTD_ rstd
+#define IRB2_SUMS(g_) s1 += (g_.x + g_.y) + (g_.z + g_.w); s2 += (g_.x * hx + g_.y * hy) + (g_.z * hz + g_.w * hw);
+  IRB2_PASS(IRB2_SUMS)
+  const float m1 = block_sum(s1, sm) / (float)S;
+  const float m2 = block_sum(s2, sm) / (float)S;
+  const float mean_b = mean, rstd_b = rstd;
+  float am = 0.f;
+#define IRB2_OUT(g_)                                                                              \
+  {                                                                                               \
+    float4 o;                                                                                     \
+    o.x = rstd_b * (g_.x - m1 - hx * m2); o.y = rstd_b * (g_.y - m1 - hy * m2);                   \
+    o.z = rstd_b * (g_.z - m1 - hz * m2); o.w = rstd_b * (g_.w - m1 - hw * m2);                   \
+    irb_st4(o, dr, 16u * l, (unsigned)(16 * w + i) * 1024u);                                      \
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));         \
+  }
+#undef MEAN_
+#undef RSTD_
+#define MEAN_ mean_b
+#define RSTD_ rstd_b
+  IRB2_PASS(IRB2_OUT)
+#undef MEAN_
+#undef RSTD_
+#undef IRB2_OUT
+#undef IRB2_SUMS
+#undef IRB2_PASS
+#undef IRB2_ROW
+#undef IRB2_CA
+  if (amax) publish_block_absmax_acc(am, &smax, amax);
+  if (amax && pmax && threadIdx.x == 0) pmax[blockIdx.x] = __uint_as_float(smax);
+}
+
+
+int df_in_relu_blurdown_fwd256_launch(const float* x, float* z, float* mean, float* rstd, int planes, float eps, float* z_amax,
+                                      hipStream_t st) {
+  in_relu_blurdown_fwd256_k<<<planes, 1024, 0, st>>>(x, z, mean, rstd, eps, z_amax);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+int df_in_relu_blurdown_bwd256_launch(const float* dz, const float* x, const float* mean, const float* rstd, float* dx,
+                                      int planes, float* dx_amax, float* dx_pmax, hipStream_t st) {
+  in_relu_blurdown_bwd256_k<<<planes, 1024, 0, st>>>(dz, x, mean, rstd, dx, dx_amax, dx_pmax);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
