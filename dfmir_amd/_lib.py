@@ -52,6 +52,9 @@ _SIGS = {
     "dfmir_conv3d_split_is_pair": [c_int],
     "dfmir_conv3d_tiny_ok": [_GP],
     "dfmir_conv3d_tiny_fwd": [_GP, P, P, P, P, P, P, c_float, P],
+    "dfmir_conv3d_s2c2_ok": [_GP],
+    "dfmir_conv3d_s2c2_fwd": [_GP, P, P, P, P, P, P],
+    "dfmir_conv3d_s2c2_wgrad": [_GP, P, P, P, P],
     "dfmir_conv3d_up_ws_floats": [c_int, c_int],
     "dfmir_conv3d_up_fwd": [P, P, c_int, P, c_int, P, P] + [c_int] * 6 + [P],
     "dfmir_conv3d_up_skip2_fwd": [P, P, c_int, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 7 + [c_float, P],

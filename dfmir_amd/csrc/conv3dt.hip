@@ -235,3 +235,218 @@ extern "C" int dfmir_conv3d_tiny_fwd(const DfConvGeom* g, const float* x, const 
   DF_LAUNCH_CHECK();
   return 0;
 }
+
+// ================================================================================================
+// The first encoder level of the 3-D U-Net: Conv3d(2, 16, kernel_size=3, stride=2, padding=1) + LeakyReLU over
+// cat(source, target) at full resolution (torchvoxelmorph/networks.py:66-86,1105).  The
+// layer is pure memory traffic (55 MB in, 55 MB out at 160 x 192 x 224) but ran on the generic gather kernels (per-element
+// index arithmetic, 4-byte loads): 0.18 ms forward at 8 TFLOP/s, 0.25 ms weight gradient at 6 TFLOP/s.
+//
+// Forward (conv3d_s2c2_fwd_k): workgroup = 2 x 8 x 32 output voxels, 128 threads, thread = 4 consecutive output x, all 16
+// output channels; the (5 x 17 x 65) input patch of both channels is staged once (16-byte rows + the left halo column,
+// interior at LDS column 4: a thread's 9 input columns are one ds_read_b32 + two ds_read_b128); weights by wave-uniform
+// scalar loads ([27][2][16] tap-major packing); epilogue bias + activation + range probe.
+//
+// Weight gradient (conv3d_s2c2_wgrad_k): dW[j][co] += sum_p Xg[j][p] dY[co][p], j = tap * 2 + ci (54 rows), on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products): wave w of a workgroup owns rows 16 w .. 16 w + 15, all 16 output channels;
+// K = output voxels, 4 per MFMA.  Per tile the input patch and the 16 x 512 dY tile are staged in LDS; the A operand is
+// gathered from the patch with a per-lane (tap, channel) base + per-k voxel offset, B is dY[co][voxel].  Persistent
+// workgroups (one per CU), one atomicAdd per result and workgroup at the end.
+// ================================================================================================
+namespace {
+constexpr int S2_TZ = 2, S2_TY = 8, S2_TX = 32, S2_PZ = 2 * S2_TZ + 1, S2_PY = 2 * S2_TY + 1, S2_PITCH = 68;
+struct C3s2P {
+  int N, D, H, W, Do, Ho, Wo, nz, ny, nx, act;
+  float slope;
+  long long ntile;
+};
+// stage the (2 ch x S2_PZ x S2_PY) rows of tile (n, z0, y0, x0) [output coordinates]: LDS row = [c][pz][py], column 3 =
+// input x = 2 x0 - 1, columns 4 .. 67 = input x = 2 x0 .. 2 x0 + 63
+template <int NT>
+__device__ __forceinline__ void s2_stage_patch(const float* __restrict__ xn, float* __restrict__ Xs, const C3s2P& k, int z0,
+                                               int y0, int x0, long long DHW) {
+  constexpr int ROWS = 2 * S2_PZ * S2_PY;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < ROWS * 16; i += NT) {
+    const int row = i >> 4, q = i & 15;
+    const int c = row / (S2_PZ * S2_PY), r = row - c * (S2_PZ * S2_PY), pz = r / S2_PY, py = r - pz * S2_PY;
+    const int z = 2 * z0 - 1 + pz, yy = 2 * y0 - 1 + py, xx = 2 * x0 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (z >= 0 && z < k.D && yy >= 0 && yy < k.H && xx < k.W)
+      v = *reinterpret_cast<const float4*>(xn + c * DHW + ((long long)z * k.H + yy) * k.W + xx);
+    *reinterpret_cast<float4*>(&Xs[row * S2_PITCH + 4 + 4 * q]) = v;
+  }
+  for (int row = threadIdx.x; row < ROWS; row += NT) {
+    const int c = row / (S2_PZ * S2_PY), r = row - c * (S2_PZ * S2_PY), pz = r / S2_PY, py = r - pz * S2_PY;
+    const int z = 2 * z0 - 1 + pz, yy = 2 * y0 - 1 + py, xx = 2 * x0 - 1;
+    float v = 0.f;
+    if (z >= 0 && z < k.D && yy >= 0 && yy < k.H && xx >= 0) v = xn[c * DHW + ((long long)z * k.H + yy) * k.W + xx];
+    Xs[row * S2_PITCH + 3] = v;
+  }
+}
+
+__global__ __launch_bounds__(128) void conv3d_s2c2_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         float* __restrict__ y_amax, C3s2P k) {
+  constexpr int COUT = 16;
+  __shared__ __attribute__((aligned(16))) float Xs[2 * S2_PZ * S2_PY * S2_PITCH];
+  __shared__ unsigned smax;
+  const int tid = threadIdx.x;
+  if (tid == 0) smax = 0u;
+  const long long per = (k.ntile + 7) / 8;
+  long long bt = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const bool live = (long long)(blockIdx.x >> 3) < per && bt < k.ntile;
+  if (!live) bt = 0;
+  const int tx = (int)(bt % k.nx); bt /= k.nx;
+  const int ty = (int)(bt % k.ny); bt /= k.ny;
+  const int tz = (int)(bt % k.nz);
+  const int n = (int)(bt / k.nz);
+  const int z0 = tz * S2_TZ, y0 = ty * S2_TY, x0 = tx * S2_TX;
+  const long long DHW = (long long)k.D * k.H * k.W, DHWo = (long long)k.Do * k.Ho * k.Wo;
+  s2_stage_patch<128>(x + (long long)n * 2 * DHW, Xs, k, z0, y0, x0, DHW);
+  __syncthreads();
+  const int lx = tid & 7, ly = (tid >> 3) & 7, lz = tid >> 6;
+  float acc[COUT][4];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll 1
+    for (int dz = 0; dz < 3; ++dz) {
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* row = &Xs[((c * S2_PZ + 2 * lz + dz) * S2_PY + 2 * ly + dy) * S2_PITCH + 8 * lx + 3];
+        float v[9];
+        v[0] = row[0];
+        const float4 m0 = *reinterpret_cast<const float4*>(row + 1), m1 = *reinterpret_cast<const float4*>(row + 5);
+        v[1] = m0.x; v[2] = m0.y; v[3] = m0.z; v[4] = m0.w; v[5] = m1.x; v[6] = m1.y; v[7] = m1.z; v[8] = m1.w;
+        const float* wt = w + ((dz * 3 + dy) * 3 * 2 + c) * COUT;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) {
+            const float wv = wt[dx * 2 * COUT + co];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, v[2 * p + dx], acc[co][p]);
+          }
+      }
+    }
+  }
+  const int z = z0 + lz, yy = y0 + ly, xx = x0 + 4 * lx;
+  float pm = 0.f;
+  if (live && z < k.Do && yy < k.Ho && xx < k.Wo) {
+    const long long sp = ((long long)z * k.Ho + yy) * k.Wo + xx;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float b = bias ? bias[co] : 0.f;
+      float r[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float t = acc[co][p] + b;
+        if (k.act == 1) t = t > 0.f ? t : t * k.slope;
+        else if (k.act == 2) t = tanhf(t);
+        r[p] = t;
+      }
+      *reinterpret_cast<float4*>(y + ((long long)n * COUT + co) * DHWo + sp) = make_float4(r[0], r[1], r[2], r[3]);
+      pm = fmaxf(fmaxf(pm, fmaxf(fabsf(r[0]), fabsf(r[1]))), fmaxf(fabsf(r[2]), fabsf(r[3])));
+    }
+  }
+  if (y_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, y_amax);
+  }
+}
+
+typedef float s2_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void conv3d_s2c2_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dwt, C3s2P k) {
+  constexpr int COUT = 16, NV = S2_TZ * S2_TY * S2_TX;     // 512 output voxels per tile
+  constexpr int DP = NV + 4;                               // dY row stride: 16 channels x 4 voxels of a B read on 64 banks
+  __shared__ __attribute__((aligned(16))) float Xs[2 * S2_PZ * S2_PY * S2_PITCH];
+  __shared__ __attribute__((aligned(16))) float Ds[COUT * DP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const long long DHW = (long long)k.D * k.H * k.W, DHWo = (long long)k.Do * k.Ho * k.Wo;
+  // A operand: lane (m = lane & 15, kk = lane >> 4): row j = 16 wid + m = tap * 2 + ci -> patch offset of (ci, dz, dy, dx);
+  // voxel 4 s + kk of the tile (x fastest): (vz, vy, vx) -> patch offset 2 vz * PY * PITCH + 2 vy * PITCH + 2 vx
+  const int j = 16 * wid + (lane & 15), kk = lane >> 4;
+  const bool jok = j < 54;
+  const int tap = jok ? j >> 1 : 0, ci = j & 1;
+  const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
+  const int abase = jok ? ((ci * S2_PZ + dz) * S2_PY + dy_) * S2_PITCH + dx + 3 : 0;
+  s2_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long long t = blockIdx.x; t < k.ntile; t += gridDim.x) {
+    long long bt = t;
+    const int tx = (int)(bt % k.nx); bt /= k.nx;
+    const int ty = (int)(bt % k.ny); bt /= k.ny;
+    const int tz = (int)(bt % k.nz);
+    const int n = (int)(bt / k.nz);
+    const int z0 = tz * S2_TZ, y0 = ty * S2_TY, x0 = tx * S2_TX;
+    __syncthreads();                                       // the previous tile's readers are done
+    s2_stage_patch<256>(x + (long long)n * 2 * DHW, Xs, k, z0, y0, x0, DHW);
+    // dY tile [co][vz][vy][vx]: 16 x 2 x 8 rows of 32 floats (8 float4)
+    for (int i = tid; i < COUT * S2_TZ * S2_TY * 8; i += 256) {
+      const int q = i & 7, r = i >> 3, vy = r % S2_TY, r2 = r / S2_TY, vz = r2 % S2_TZ, co = r2 / S2_TZ;
+      const int z = z0 + vz, yy = y0 + vy, xx = x0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z < k.Do && yy < k.Ho && xx < k.Wo)
+        v = *reinterpret_cast<const float4*>(dy + ((long long)n * COUT + co) * DHWo + ((long long)z * k.Ho + yy) * k.Wo + xx);
+      *reinterpret_cast<float4*>(&Ds[co * DP + (vz * S2_TY + vy) * S2_TX + 4 * q]) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < NV / 4; ++s) {
+      const int v = 4 * s + kk, vx = v & 31, vy = (v >> 5) & 7, vz = v >> 8;
+      const float a = jok ? Xs[abase + (2 * vz * S2_PY + 2 * vy) * S2_PITCH + 2 * vx] : 0.f;
+      const float b = Ds[(lane & 15) * DP + v];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // D: register r of lane l = row 4 (l >> 4) + r, column l & 15
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * wid + 4 * (lane >> 4) + r;
+    if (row < 54) atomicAdd(&dwt[row * COUT + (lane & 15)], acc[r]);
+  }
+}
+}  // namespace
+
+extern "C" int dfmir_conv3d_s2c2_ok(const DfConvGeom* g) {
+  if (!g || tiny_off()) return 0;
+  if (!(g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 2 && g->dil == 1 && g->pd == 1 && g->ph == 1 && g->pw == 1 &&
+        g->pad_mode == 0 && g->Cin == 2 && g->Cout == 16))
+    return 0;
+  if (g->Do != (g->Di - 1) / 2 + 1 || g->Ho != (g->Hi - 1) / 2 + 1 || g->Wo != (g->Wi - 1) / 2 + 1) return 0;
+  if ((g->Wi & 3) || (g->Wo & 3) || g->Di < 2) return 0;
+  return (long long)2 * g->Di * g->Hi * g->Wi < 0x7FFFFFFFLL ? 1 : 0;
+}
+static C3s2P s2_params(const DfConvGeom* g) {
+  C3s2P k{g->N, g->Di, g->Hi, g->Wi, g->Do, g->Ho, g->Wo, (g->Do + S2_TZ - 1) / S2_TZ, (g->Ho + S2_TY - 1) / S2_TY,
+          (g->Wo + S2_TX - 1) / S2_TX, g->act, g->slope, 0};
+  k.ntile = (long long)g->N * k.nz * k.ny * k.nx;
+  return k;
+}
+// y = act(conv3x3x3 stride 2 (x [N, 2, D, H, W]) + bias) -> [N, 16, Do, Ho, Wo]; w_tcc [27][2][16] (dfmir_weight_pack mode 0);
+// y_amax: NULL or the accumulating range-probe slots of y
+extern "C" int dfmir_conv3d_s2c2_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
+                                     float* y_amax, void* stream) {
+  DF_ARG_CHECK(g && x && w_tcc && y && dfmir_conv3d_s2c2_ok(g));
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  const C3s2P k = s2_params(g);
+  DF_ARG_CHECK(k.ntile < (1LL << 30));
+  conv3d_s2c2_fwd_k<<<(unsigned)(8 * ((k.ntile + 7) / 8)), 128, 0, (hipStream_t)stream>>>(x, w_tcc, bias, y, y_amax, k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+// dw_tcc [27][2][16] += the weight gradient (accumulates, like dfmir_conv_wgrad)
+extern "C" int dfmir_conv3d_s2c2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream) {
+  DF_ARG_CHECK(g && x && dy && dw_tcc && dfmir_conv3d_s2c2_ok(g));
+  DF_ARG_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+  const C3s2P k = s2_params(g);
+  DF_ARG_CHECK(k.ntile < (1LL << 30));
+  const unsigned grid = (unsigned)(k.ntile < 512 ? k.ntile : 512);
+  conv3d_s2c2_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw_tcc, k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

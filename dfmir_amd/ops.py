@@ -189,7 +189,10 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     # the flow head / its data gradient (16 -> 3, 3 -> 16): plain fp32 FMAs (csrc/conv3dt.hip)
     tiny3d = (tuple(K) == (3, 3, 3) and res is None and ring is None and not _NO_TINY3D
               and (cout_used is None or cout_used == Cout) and bool(lib().dfmir_conv3d_tiny_ok(ctypes.byref(g))))
-    split3d = (not tiny3d and x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
+    # the first encoder level (2 -> 16, stride 2) from an LDS-staged patch (csrc/conv3dt.hip)
+    s2c2 = (not tiny3d and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and res is None and ring is None and not _NO_TINY3D
+            and cout_used is None and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
+    split3d = (not tiny3d and not s2c2 and x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
     if cout_used is not None and not split3d:
         cout_used = None                                     # only the split 3-D kernel computes a channel subset
@@ -205,6 +208,11 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
             slot = amax_slot(x5.device, PROBE_SLOTS)
             check(lib().dfmir_conv3d_tiny_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _p(act_src),
                                               float(act_slope), _st()))
+            tag_amax(y, slot)
+            _LAST_CONV_AMAX[0] = slot
+        elif s2c2:
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_s2c2_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _st()))
             tag_amax(y, slot)
             _LAST_CONV_AMAX[0] = slot
         elif split3d:
@@ -252,7 +260,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
         kind = ("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size
-        if tiny3d:
+        if tiny3d or s2c2:
             kind = "conv3dt_" + size
         if split3d:
             # 16-bit products the kernel ISSUES per algorithmic MAC: 3 (a0b0 + a0b1 + a1b0) x the padding of its tiling --
@@ -307,7 +315,15 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             pm_ = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and not split3d) else None
             _audit_probe(dy5, dy_amax, "wgrad dY %s" % (tuple(dy5.shape),), plane_max=pm_)
 
+    s2c2 = (parts is None and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and not _NO_TINY3D
+            and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
+
     def launch():
+        if s2c2:
+            if db is not None:
+                check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, Do * Ho * Wo, _st()))   # accumulates
+            check(lib().dfmir_conv3d_s2c2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+            return
         if parts is not None:
             check(lib().dfmir_conv3d_split_wgrad_upcat(ctypes.byref(g), _p(parts[0]), _p(parts[1]), parts[0].shape[1],
                                                        _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax), dy_amax.numel(),
@@ -331,7 +347,8 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
         size = "L" if Cout > 64 else ("M" if Cout > 32 else "S")
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0 and Cout <= 32
                 and Wi % 4 == 0)                          # csrc/conv3d.hip::df_conv3d_wgrad_try
-        prof(("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size,
+        prof("wgrad3dt_S" if s2c2 else
+             ("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size,
              2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
     return dw
 

@@ -126,6 +126,13 @@ int dfmir_conv3d_split_is_pair(int cout_used);
 int dfmir_conv3d_tiny_ok(const DfConvGeom* g);
 int dfmir_conv3d_tiny_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y,
                           float* y_amax, const float* act_src, float act_slope, void* stream);
+/* The first encoder level of the 3-D U-Net (torchvoxelmorph/networks.py:66-86: Conv3d(2, 16, 3, stride=2, padding=1) +
+ * LeakyReLU over cat(source, target)): forward as fp32 FMAs from an LDS-staged patch, weight gradient on fp32 MFMA with the
+ * operand gathered from the same patch.  w_tcc / dw_tcc: [27][2][16] tap-major (dfmir_weight_pack mode 0); dw accumulates. */
+int dfmir_conv3d_s2c2_ok(const DfConvGeom* g);
+int dfmir_conv3d_s2c2_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y, float* y_amax,
+                          void* stream);
+int dfmir_conv3d_s2c2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream);
 long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);
 int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
                         float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream);

@@ -223,6 +223,11 @@ CONV3D = [
     # the flow head on the fp32-FMA kernel (conv3dt.hip; W % 4 == 0): ragged tiles in every axis with batch 2, several x tiles
     (16, 3, 3, 1, 1, 2, 5, 9, 36),
     (16, 3, 3, 1, 1, 1, 9, 17, 68),
+    # the first encoder level (2 -> 16, stride 2) from an LDS-staged patch, weight gradient on fp32 MFMA (conv3dt.hip): one
+    # tile, ragged tiles in every axis with batch 2, odd input sizes
+    (2, 16, 3, 2, 1, 1, 12, 10, 16),
+    (2, 16, 3, 2, 1, 2, 9, 17, 72),
+    (2, 16, 3, 2, 1, 1, 7, 33, 136),
 ]
 
 
