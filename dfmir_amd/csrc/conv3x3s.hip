@@ -1101,6 +1101,12 @@ struct WS3P {
   int x_n, dy_n;
   float* db;              // optional: bias gradient db[co] += sum_{n,p} dY, taken from the dY units as they pass
   const float* dy_pmax;   // optional (split2 kernel): max |dY| per (n, co) plane, [N][Cout] -> one scale per output channel
+  // split2 kernel with the operands' ROLES SWAPPED (x := dY, dy := X; zero padding only): dW[t][ci][co] =
+  // sum_q dY[co][q] X[ci][q + t - 1] is what the kernel computes for tap 8 - t with rows = co and columns = ci, so the
+  // epilogue stores tap 8 - t transposed.  Used for 64 output channels under > 64 input channels (the 128 -> 64 decoder
+  // layer at 256^2): its natural tile is 64 x 128 (ci x co), which a 64-channel dY half fills; the other way round the
+  // layer fills it completely.
+  int swap;
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -1681,6 +1687,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     __syncthreads();
     if (tid < BC && co0 + tid < k.Cout) atomicAdd(&k.db[co0 + tid], bsum[tid]);
   }
+  if (k.swap) {
+    // transposed store: the real layout is [8 - t][co][ci] with ci (this kernel's rows) fastest.  Each wave turns its
+    // 32 x 32 tile around through LDS (the operand buffers are free now) so that a half-wave adds to 32 consecutive
+    // floats -- 19 M lane-scattered atomics on 74 K addresses cost 0.4 ms at the 128 -> 64 layer
+    __syncthreads();
+    float* T = reinterpret_cast<float*>(Xc) + wid * (32 * 33);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(4 * lhi + (r & 3) + 8 * (r >> 2)) * 33 + l31] = acc[t][r] * oscale * oscale2;
+      __syncthreads();
+      const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = 4 * lhi + (r & 3) + 8 * (r >> 2);
+        const int co = co0 + wc * 32 + col;
+        const float v = T[l31 * 33 + col];
+        if (ci < k.Cin && co < k.Cout) atomicAdd(&dwt[((long long)(8 - t) * k.Cout + co) * k.Cin + ci], v);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int co = co0 + wc * 32 + l31;
   if (co < k.Cout) {
 #pragma unroll
@@ -1694,6 +1723,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   }
 }
 
+// does df_conv3x3_split_wgrad_try run this geometry with swapped roles (and therefore leave db to the caller)?
+bool df_conv3x3_split_wgrad_swaps(const DfConvGeom* g) {
+  static const bool off = getenv("DFMIR_WGRAD_NO_SWAP") != nullptr || getenv("DFMIR_WGRAD_V1") != nullptr;
+  return !off && df_split_mode() == 2 && g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 &&
+         g->dil == 1 && g->ph == 1 && g->pw == 1 && g->pd == 0 && g->Ho == g->Hi && g->Wo == g->Wi && g->pad_mode == 0 &&
+         g->Cout == 64 && g->Cin > 64;
+}
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc,
                                 const float* dy_pmax) {
@@ -1707,12 +1743,19 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   if ((g->Hi & 1) || (g->Wi & 15) || g->Hi < 2) return false;
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax};
+  const bool swap = mode == 2 && x_amax && dy_amax && df_conv3x3_split_wgrad_swaps(g);
+  if (swap && db) return false;                        // the caller takes db first (conv.hip)
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax, 0};
+  if (swap) {
+    k.Cin = g->Cout; k.Cout = g->Cin;
+    k.x_amax = dy_amax; k.dy_amax = x_amax; k.x_n = dy_n; k.dy_n = x_n;
+    k.db = nullptr; k.dy_pmax = nullptr; k.swap = 1;
+  }
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
   if (total >= (1LL << 30)) return false;
   k.runs_total = (int)total;
-  const unsigned ny = (g->Cin + 63) / 64, nz = wide ? (g->Cout + 127) / 128 : 1;
+  const unsigned ny = (k.Cin + 63) / 64, nz = (wide || swap) ? (k.Cout + 127) / 128 : 1;
   long long want = 256 / ((long long)ny * nz);    // one resident round: 1 workgroup per CU
   if (want < 1) want = 1;
   long long maxs = (k.runs_total + 7) / 8;        // >= 8 runs per block
@@ -1723,7 +1766,8 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const dim3 grid(nx, ny, nz);
   if (mode == 2) {
     static const bool v1 = getenv("DFMIR_WGRAD_V1") != nullptr;      // A/B: the single-buffered kernel
-    if (wide && !v1) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
+    if (swap) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(dy, x, dw_tcc, k);
+    else if (wide && !v1) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
     else if (wide) conv3x3_wgrad_split_k<2, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
     else conv3x3_wgrad_split_k<2, 64><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
   } else {

@@ -55,6 +55,7 @@ CONV2D = [
     (128, 128, 3, 1, 1, True, 0, 2, 64, 64),
     (32, 64, 3, 1, 1, False, 1, 1, 48, 40),
     (128, 64, 3, 1, 1, False, 0, 2, 64, 64),
+    (160, 64, 3, 1, 1, False, 0, 1, 34, 48),      # swapped-role weight gradient (64 couts under > 64 cins), ragged cin tile
     (64, 128, 3, 1, 1, False, 0, 1, 16, 256),
     (36, 132, 3, 1, 1, True, 0, 1, 24, 72),
     (256, 256, 3, 1, 1, True, 0, 2, 64, 64),
