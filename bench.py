@@ -508,6 +508,10 @@ def main():
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
             "step_submission": "hipGraph replay + eager all-reduce/Adam" if graphed else "eager",
+            "host_enqueue_note": ("time the host spends inside the submission calls of a step.  With opt.overlap_registration "
+                                  "(default) the captured graph has two parallel branches and hipGraphLaunch (ROCm 7.2) returns "
+                                  "only when the second branch has been handed to the GPU, ~60 % into the step; "
+                                  "DFMIR_NO_OVERLAP_R=1: one chain, 0.5 ms of host time and a 1.3 ms longer step"),
             "value_host_inputs": host_rate, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "2-D %dx%d T1<->T2-shaped synthetic slice pairs, batch %d per GPU, ngf %d: "
@@ -535,6 +539,10 @@ def main():
                                    ": forward + dgrad of every 3x3 conv with Cout > 64",
                          "clock_note": "these kernels hold the package at its 1400 W cap: sclk ~1.75 GHz sustained "
                                        "(profiles/r01_power_clock.md), i.e. a 1.84 PFLOP/s 16-bit roof at that clock",
+                         "overlap_note": ("since round 3 netR's kernels run on a second stream beside these launches "
+                                          "(opt.overlap_registration): a launch's duration includes the share of the CUs they take -- "
+                                          "with DFMIR_NO_OVERLAP_R=1 the same kernel measures ~371 TF / issued 0.445 "
+                                          "(profiles/README.md) and the step is 1.3 ms longer"),
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "timed_over": ("%d eager steps right after the timed region (which replays one hipGraph per step; "
                                         "events cannot be recorded inside a replay); the rocprofv3 kernel trace of the "

@@ -672,31 +672,36 @@ __global__ __launch_bounds__(256) void blur_down_bwd_v4_k(const float* __restric
   }
   *reinterpret_cast<float4*>(dx + ((long long)blockIdx.y * H + iy) * W + ix) = make_float4(s[0], s[1], s[2], s[3]);
 }
+// thread = 2 input columns of one row -> one float4 of each of the two output rows: every store instruction of a wave
+// writes 1 KB of consecutive bytes (with 4 input columns per thread the two float4 stores of a row interleaved at 32-byte
+// stride).  The neighbouring columns are the neighbouring lanes' values (consecutive lanes = consecutive pairs of a row; at
+// a row's ends the clamp takes the thread's own): lane-strided 4-byte loads made this kernel TA-bound.
 __global__ __launch_bounds__(256) void blur_up_fwd_v4_k(const float* __restrict__ x, float* __restrict__ y,
                                                         int H, int W) {
-  const int G = W >> 2, Wo = 2 * W;
+  const int G = W >> 1, Wo = 2 * W, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * G) return;
-  const int iy = i / G, ix = (i - iy * G) << 2;
+  const int iy = i / G, ix = (i - iy * G) << 1;
   const float* xp = x + (long long)blockIdx.y * H * W;
-  float v[3][6];                                             // rows iy-1, iy, iy+1 (clamped); columns ix-1 .. ix+4 (clamped)
+  float v[3][4];                                             // rows iy-1, iy, iy+1 (clamped); columns ix-1 .. ix+2 (clamped)
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     int r = iy + a - 1;
     r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
     const float* row = xp + r * W + ix;
-    const float4 q = *reinterpret_cast<const float4*>(row);
-    v[a][0] = ix ? row[-1] : q.x;
-    v[a][1] = q.x; v[a][2] = q.y; v[a][3] = q.z; v[a][4] = q.w;
-    v[a][5] = (ix + 4 < W) ? row[4] : q.w;
+    const float2 q = *reinterpret_cast<const float2*>(row);
+    const float lft = __shfl_up(q.y, 1, 64), rgt = __shfl_down(q.x, 1, 64);
+    v[a][0] = ix ? (lane ? lft : row[-1]) : q.x;
+    v[a][1] = q.x; v[a][2] = q.y;
+    v[a][3] = (ix + 2 < W) ? (lane < 63 ? rgt : row[2]) : q.y;
   }
   float* yp = y + ((long long)blockIdx.y * 2 * H + 2 * iy) * Wo + 2 * ix;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {                              // output rows 2iy (neighbour iy-1) and 2iy+1 (neighbour iy+1)
     const int nb = p ? 2 : 0;
-    float o[8];
+    float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {                          // output columns 2(ix+j) (neighbour -1) and +1 (neighbour +1)
         const int xn = q ? j + 2 : j;
@@ -706,13 +711,12 @@ __global__ __launch_bounds__(256) void blur_up_fwd_v4_k(const float* __restrict_
       }
     }
     *reinterpret_cast<float4*>(yp + p * Wo) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<float4*>(yp + p * Wo + 4) = make_float4(o[4], o[5], o[6], o[7]);
   }
 }
 // adjoint: per axis the 4-tap filter (1/4, 3/4, 3/4, 1/4) over dy[2m-1 .. 2m+2] with clamped indices
 __global__ __launch_bounds__(256) void blur_up_bwd_v4_k(const float* __restrict__ dy, float* __restrict__ dx,
                                                         int H, int W) {
-  const int G = W >> 2, Wo = 2 * W, Ho = 2 * H;
+  const int G = W >> 2, Wo = 2 * W, Ho = 2 * H, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= H * G) return;
   const int iy = i / G, ix = (i - iy * G) << 2;
@@ -725,7 +729,8 @@ __global__ __launch_bounds__(256) void blur_up_bwd_v4_k(const float* __restrict_
     r = r < 0 ? 0 : (r > Ho - 1 ? Ho - 1 : r);
     const float* row = gp + r * Wo + 2 * ix;
     const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
-    const float l = ix ? row[-1] : q0.x, rr = (2 * ix + 8 < Wo) ? row[8] : q1.w;
+    const float lft = __shfl_up(q1.w, 1, 64), rgt = __shfl_down(q0.x, 1, 64);      // see blur_up_fwd_v4_k
+    const float l = ix ? (lane ? lft : row[-1]) : q0.x, rr = (2 * ix + 8 < Wo) ? (lane < 63 ? rgt : row[8]) : q1.w;
     const float v[10] = {l, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, rr};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1056,8 +1061,8 @@ extern "C" int dfmir_blur_down_bwd(const float* dy, float* dx, int planes, int H
 }
 extern "C" int dfmir_blur_up_fwd(const float* x, float* y, int planes, int H, int W, void* stream) {
   DF_ARG_CHECK(x && y && planes > 0 && H > 0 && W > 0);
-  if ((W & 3) == 0 && planes <= 65535 && (long long)H * W < (1LL << 28)) {
-    blur_up_fwd_v4_k<<<dim3((unsigned)((H * (W / 4) + 255) / 256), (unsigned)planes), 256, 0,
+  if ((W & 1) == 0 && planes <= 65535 && (long long)H * W < (1LL << 28)) {
+    blur_up_fwd_v4_k<<<dim3((unsigned)((H * (W / 2) + 255) / 256), (unsigned)planes), 256, 0,
                        (hipStream_t)stream>>>(x, y, H, W);
     DF_LAUNCH_CHECK();
     return 0;

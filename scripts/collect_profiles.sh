@@ -15,6 +15,11 @@ python scripts/bench_wgrad3d.py > $O/bench_wgrad3d.txt 2>&1
 DFMIR_CONV3D_WGRAD_COPIES=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
 DFMIR_CONV3D_WGRAD_NO_PAIR=1 python scripts/bench_wgrad3d.py >> $O/bench_wgrad3d.txt 2>&1
 python scripts/launch_census.py capture_step=False > $O/launch_census.txt 2>&1
+python scripts/bench_in_blurdown.py > $O/bench_in_blurdown.txt 2>&1
+DFMIR_IN_BLUR_BANDED=1 python scripts/bench_in_blurdown.py >> $O/bench_in_blurdown.txt 2>&1
+python scripts/conv2d_layer_census.py > $O/conv2d_layer_census.txt 2>&1
+python scripts/conv3d_step_census.py > $O/conv3d_step_census.txt 2>&1
+for sw in DFMIR_NO_OVERLAP_R DFMIR_NO_NCE_FUSED DFMIR_WGRAD_NO_SWAP DFMIR_IN_BLUR_BANDED NONE; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_round3_switches.txt 2>&1
 for u in mfma_peak lds_unaligned valu_under_mfma; do   # built from source on the box (binaries are not tracked)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u scripts/ubench/$u.hip && /tmp/$u > $O/ubench_$u.txt 2>&1
 done
@@ -23,6 +28,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-3d --roofline-steps 0 > $O/kt.log 2>&1
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 python $R/scripts/step_trace.py $(ls $O/kt/*/*kernel_trace.csv | head -1) 70 > $O/step_trace.txt 2>&1
+python $R/scripts/overlap_trace.py $(ls $O/kt/*/*kernel_trace.csv | head -1) > $O/overlap_trace.txt 2>&1
 rm -rf $O/kt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python $R/scripts/bench_3d.py > $O/bench_3d.txt 2>&1
 cp $(ls $O/kt3/*/*kernel_stats.csv | head -1) $O/bench_3d_kernel_stats.csv

@@ -12,7 +12,8 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'bench_warp_roofline.json': TAG + '_bench_warp_roofline.json', 'bench_wgrad3d.txt': TAG + '_bench_wgrad3d.txt',
       'step_trace_3d.txt': TAG + '_step_trace_3d.txt', 'sustain3d.txt': TAG + '_power_clock_3d.txt', 'pmc_warp.txt': TAG + '_warp_pmc_raw.txt',
       'step_trace_3d_128.txt': TAG + '_step_trace_3d_128.txt', 'bench_upconv3d.txt': TAG + '_bench_upconv3d.txt',
-      'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'r03_pmc.json': TAG + '_pmc.json'}
+      'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'overlap_trace.txt': TAG + '_overlap_trace.txt', 'bench_in_blurdown.txt': TAG + '_bench_in_blurdown.txt',
+      'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'r03_pmc.json': TAG + '_pmc.json'}
 def clean(txt):
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
 for a, b in cp.items():
