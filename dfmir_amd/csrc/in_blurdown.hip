@@ -199,15 +199,150 @@ __global__ __launch_bounds__(1024) void in_relu_blurdown_bwd256_k(const float* _
 }
 
 
+// ---- the 128 x 128 planes (second encoder stage): the same lay-out with 8 waves x 16 rows, a lane = 2 columns of a row ----
+__global__ __launch_bounds__(512) void in_relu_blurdown_fwd128_k(const float* __restrict__ x, float* __restrict__ z,
+                                                                 float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                                 float eps, float* __restrict__ amax) {
+  constexpr int S = 16384;
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  __shared__ float edge[8][64];
+  if (threadIdx.x == 0) smax = 0u;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)blockIdx.x * S), 0,
+                                                                       S * 4u, 0x00020000);
+  float2 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = irb_ld2(xr, 8u * l, (unsigned)(16 * w + i) * 512u);
+    s += v[i].x + v[i].y;
+  }
+  const float mean = block_sum(s, sm) / (float)S;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean;
+    q += a * a + b * b;
+  }
+  const float var = block_sum(q, sm) / (float)S;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[blockIdx.x] = mean;
+    rstd_o[blockIdx.x] = rstd;
+  }
+  // normalise + ReLU + horizontal blur: output column l from columns 2 l - 1 (column -1 reflects to 1), 2 l, 2 l + 1
+  float h[16], am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float ox = fmaxf((v[i].x - mean) * rstd, 0.f), oy = fmaxf((v[i].y - mean) * rstd, 0.f);
+    am = fmaxf(am, fmaxf(ox, oy));
+    float left = __shfl_up(oy, 1, 64);
+    if (l == 0) left = oy;
+    h[i] = 0.25f * left + 0.5f * ox + 0.25f * oy;
+  }
+  edge[w][l] = h[15];
+  __syncthreads();
+  const float up = w > 0 ? edge[w - 1][l] : h[1];                               // row -1 -> row 1
+  float* zp = z + (long long)blockIdx.x * (S / 4) + (8 * w) * 64 + l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a0 = j == 0 ? up : h[2 * j - 1];
+    zp[j * 64] = 0.25f * a0 + 0.5f * h[2 * j] + 0.25f * h[2 * j + 1];
+  }
+  if (amax) publish_block_absmax_acc(am, &smax, amax);
+}
+
+__global__ __launch_bounds__(512) void in_relu_blurdown_bwd128_k(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean_i,
+                                                                 const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                                 float* __restrict__ amax, float* __restrict__ pmax) {
+  constexpr int S = 16384;
+  __shared__ float sm[17];
+  __shared__ unsigned smax;
+  __shared__ __attribute__((aligned(16))) float dzs[65 * 64 + 4];          // the dz plane + a zero row 64 (+ the read past a row)
+  if (threadIdx.x == 0) smax = 0u;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
+  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long long)blockIdx.x * S), 0,
+                                                                       S * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz + (long long)blockIdx.x * (S / 4)), 0,
+                                                                       S, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(dx + (long long)blockIdx.x * S, 0, S * 4u, 0x00020000);
+  float2 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = irb_ld2(xr, 8u * l, (unsigned)(16 * w + i) * 512u);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    *reinterpret_cast<float4*>(&dzs[4 * (threadIdx.x + 512 * q)]) = irb_ld4(zr, 16u * (threadIdx.x + 512 * q), 0u);
+  if (threadIdx.x < 17) *reinterpret_cast<float4*>(&dzs[64 * 64 + 4 * threadIdx.x]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const float* dzw = dzs + (8 * w) * 64 + l;
+  // column adjoint of dz row k: input columns 2 l, 2 l + 1 take  1/2 dz[l] | 1/4 (dz[l] + dz[l + 1]) (+ 1/4 dz[0] at column 1)
+#define IRB1_CA(k_, c_)                                                                           \
+  {                                                                                               \
+    const float d_ = dzw[(k_) * 64];                                                              \
+    const float nx_ = l == 63 ? 0.f : dzw[(k_) * 64 + 1];                                         \
+    c_.x = 0.5f * d_;                                                                             \
+    c_.y = 0.25f * d_ + 0.25f * nx_ + (l == 0 ? 0.25f * d_ : 0.f);                                \
+  }
+#define IRB1_ROW(i_, g_, BODY_)                                                                   \
+  {                                                                                               \
+    const float hx = (v[i_].x - mean) * rstd, hy = (v[i_].y - mean) * rstd;                       \
+    if (!(hx > 0.f)) g_.x = 0.f;                                                                  \
+    if (!(hy > 0.f)) g_.y = 0.f;                                                                  \
+    BODY_                                                                                         \
+  }
+#define IRB1_PASS(BODY_)                                                                          \
+  {                                                                                               \
+    float2 cur, nxt;                                                                              \
+    IRB1_CA(0, cur)                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                               \
+      IRB1_CA(j + 1, nxt)                                                                         \
+      const float e_ = (j == 0 && w == 0) ? 0.25f : 0.f;                                          \
+      float2 g0, g1;                                                                              \
+      g0.x = 0.5f * cur.x; g0.y = 0.5f * cur.y;                                                   \
+      g1.x = 0.25f * cur.x + 0.25f * nxt.x + e_ * cur.x;                                          \
+      g1.y = 0.25f * cur.y + 0.25f * nxt.y + e_ * cur.y;                                          \
+      { const int i = 2 * j; IRB1_ROW(i, g0, BODY_(g0)) }                                         \
+      { const int i = 2 * j + 1; IRB1_ROW(i, g1, BODY_(g1)) }                                     \
+      cur = nxt;                                                                                  \
+    }                                                                                             \
+  }
+  float s1 = 0.f, s2 = 0.f;
+#define IRB1_SUMS(g_) s1 += g_.x + g_.y; s2 += g_.x * hx + g_.y * hy;
+  IRB1_PASS(IRB1_SUMS)
+  const float m1 = block_sum(s1, sm) / (float)S;
+  const float m2 = block_sum(s2, sm) / (float)S;
+  float am = 0.f;
+#define IRB1_OUT(g_)                                                                              \
+  {                                                                                               \
+    float2 o;                                                                                     \
+    o.x = rstd * (g_.x - m1 - hx * m2); o.y = rstd * (g_.y - m1 - hy * m2);                       \
+    irb_st2(o, dr, 8u * l, (unsigned)(16 * w + i) * 512u);                                        \
+    am = fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y)));                                                \
+  }
+  IRB1_PASS(IRB1_OUT)
+#undef IRB1_OUT
+#undef IRB1_SUMS
+#undef IRB1_PASS
+#undef IRB1_ROW
+#undef IRB1_CA
+  if (amax) publish_block_absmax_acc(am, &smax, amax);
+  if (amax && pmax && threadIdx.x == 0) pmax[blockIdx.x] = __uint_as_float(smax);
+}
+
 int df_in_relu_blurdown_fwd256_launch(const float* x, float* z, float* mean, float* rstd, int planes, float eps, float* z_amax,
-                                      hipStream_t st) {
-  in_relu_blurdown_fwd256_k<<<planes, 1024, 0, st>>>(x, z, mean, rstd, eps, z_amax);
+                                      hipStream_t st, int W) {
+  if (W == 128) in_relu_blurdown_fwd128_k<<<planes, 512, 0, st>>>(x, z, mean, rstd, eps, z_amax);
+  else in_relu_blurdown_fwd256_k<<<planes, 1024, 0, st>>>(x, z, mean, rstd, eps, z_amax);
   DF_LAUNCH_CHECK();
   return 0;
 }
 int df_in_relu_blurdown_bwd256_launch(const float* dz, const float* x, const float* mean, const float* rstd, float* dx,
-                                      int planes, float* dx_amax, float* dx_pmax, hipStream_t st) {
-  in_relu_blurdown_bwd256_k<<<planes, 1024, 0, st>>>(dz, x, mean, rstd, dx, dx_amax, dx_pmax);
+                                      int planes, float* dx_amax, float* dx_pmax, hipStream_t st, int W) {
+  if (W == 128) in_relu_blurdown_bwd128_k<<<planes, 512, 0, st>>>(dz, x, mean, rstd, dx, dx_amax, dx_pmax);
+  else in_relu_blurdown_bwd256_k<<<planes, 1024, 0, st>>>(dz, x, mean, rstd, dx, dx_amax, dx_pmax);
   DF_LAUNCH_CHECK();
   return 0;
 }

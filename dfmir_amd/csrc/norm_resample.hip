@@ -541,9 +541,9 @@ __global__ __launch_bounds__(NT) void in_relu_blurdown_bwd_k(const float* __rest
 
 // The 256 x 256 planes take the ring-free kernels of in_blurdown.hip (built without packed-fp32 VALU instructions).
 int df_in_relu_blurdown_fwd256_launch(const float* x, float* z, float* mean, float* rstd, int planes, float eps, float* z_amax,
-                                      hipStream_t st);
+                                      hipStream_t st, int W);
 int df_in_relu_blurdown_bwd256_launch(const float* dz, const float* x, const float* mean, const float* rstd, float* dx,
-                                      int planes, float* dx_amax, float* dx_pmax, hipStream_t st);
+                                      int planes, float* dx_amax, float* dx_pmax, hipStream_t st, int W);
 
 // ---------------------------------------------------------------------------------------------
 // Upsample (replicate pad 1 + conv_transpose 4x4 stride 2 pad 2, cropped) == per axis
@@ -999,7 +999,7 @@ extern "C" int dfmir_in_relu_blurdown_fwd(const float* x, float* z, float* mean,
   DF_ARG_CHECK(x && z && mean && rstd && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
   hipStream_t st = (hipStream_t)stream;
   static const bool banded = getenv("DFMIR_IN_BLUR_BANDED") != nullptr;      // A/B: the LDS-ring form on the 256^2 planes
-  if (W == 256 && !banded) return df_in_relu_blurdown_fwd256_launch(x, z, mean, rstd, planes, eps, z_amax, st);
+  if (!banded) return df_in_relu_blurdown_fwd256_launch(x, z, mean, rstd, planes, eps, z_amax, st, W);
   if (W == 256) in_relu_blurdown_fwd_k<1024, 16><<<planes, 1024, 2 * 16 * 256 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
   else in_relu_blurdown_fwd_k<256, 16><<<planes, 256, 2 * 8 * 128 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
   DF_LAUNCH_CHECK();
@@ -1010,7 +1010,7 @@ extern "C" int dfmir_in_relu_blurdown_bwd(const float* dz, const float* x, const
   DF_ARG_CHECK(dz && x && mean && rstd && dx && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
   hipStream_t st = (hipStream_t)stream;
   static const bool banded = getenv("DFMIR_IN_BLUR_BANDED") != nullptr;
-  if (W == 256 && !banded) return df_in_relu_blurdown_bwd256_launch(dz, x, mean, rstd, dx, planes, dx_amax, dx_pmax, st);
+  if (!banded) return df_in_relu_blurdown_bwd256_launch(dz, x, mean, rstd, dx, planes, dx_amax, dx_pmax, st, W);
   if (W == 256) in_relu_blurdown_bwd_k<1024, 16><<<planes, 1024, (8 + 1) * 128 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);
   else in_relu_blurdown_bwd_k<256, 16><<<planes, 256, (4 + 1) * 64 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);
   DF_LAUNCH_CHECK();
