@@ -297,20 +297,47 @@ class REGISTRATIONModel(BaseModel):
             rs.wait_stream(cur)
             with torch.cuda.stream(rs):
                 y_output = self.netR(self.real_A, self.real_B)
+                r_done = torch.cuda.Event()
+                r_done.record(rs)
             self.forward()
-            cur.wait_stream(rs)
+            cur.wait_event(r_done)                         # regA exists: the NCE query pass below reads it
             if not torch.cuda.is_current_stream_capturing():
                 for t in y_output:
                     if torch.is_tensor(t):
                         t.record_stream(cur)
         else:
+            rs = None
             self.forward()
             y_output = self.netR(self.real_A, self.real_B)
-        y_pred = [self.spatialTransformer(self.fake_B, y_output[2]), y_output[2]]
-        self.registered = y_pred[0]
         self.regA = y_output[0]
-        with torch.no_grad():
-            self.dvf = self.spatialTransformer(self._checkerboard(self.real_A.size(0)), y_pred[1].detach())
+
+        def registration_losses():
+            # registration_model.py:147-166: the warp of the translated image, the checkerboard visual, the two masked-L1
+            # terms (masks evaluated inside the fused kernel: mask = (real_B > -0.95) | (registered > -0.95);
+            # mask2 = (idt_B > -0.95) | (registered > -0.95)) and the flow smoothness
+            y_pred = [self.spatialTransformer(self.fake_B, y_output[2]), y_output[2]]
+            self.registered = y_pred[0]
+            with torch.no_grad():
+                self.dvf = self.spatialTransformer(self._checkerboard(self.real_A.size(0)), y_pred[1].detach())
+            l1_reg = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold')
+            l1_idt = self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold')
+            if getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False):
+                l1_reg, l1_idt = self._global_mask_norm(l1_reg, l1_idt)
+            return l1_reg, l1_idt, smooothing_loss(y_pred[1])
+
+        # ... which follow netR on ITS stream, beside the NCE query pass (not when the masked-L1 normalisation is a collective)
+        side_losses = (rs is not None and not os.environ.get('DFMIR_NO_SIDE_LOSSES')
+                       and not (getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False)))
+        if side_losses:
+            rs.wait_stream(cur)                            # fake_B / idt_B exist
+            with torch.cuda.stream(rs):
+                l1_reg, l1_idt, smooth = registration_losses()
+            if not torch.cuda.is_current_stream_capturing():
+                self.fake.record_stream(rs)
+                for t in (l1_reg, l1_idt, smooth, self.registered, self.dvf):
+                    t.record_stream(cur)
+        elif rs is not None:
+            cur.wait_stream(rs)
 
         self.optimizer_G.zero_grad()
         self.optimizer_R.zero_grad()
@@ -335,13 +362,10 @@ class REGISTRATIONModel(BaseModel):
             self.loss_G = self.compute_G_loss()
             nce_local = self.calculate_NCE_loss(self.real_B, y_output[0])
 
-        # masks (registration_model.py:160-161) are evaluated inside the fused masked-L1 kernel:
-        # mask = (real_B > -0.95) | (registered > -0.95);  mask2 = (idt_B > -0.95) | (registered > -0.95)
-        l1_reg = self.calculate_L1_loss(y_pred[0], self.real_B, mask='threshold')
-        l1_idt = self.calculate_L1_loss(self.idt_B, y_pred[0], mask='threshold')
-        if getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False):
-            l1_reg, l1_idt = self._global_mask_norm(l1_reg, l1_idt)
-        smooth = smooothing_loss(y_pred[1])
+        if side_losses:
+            cur.wait_stream(rs)
+        else:
+            l1_reg, l1_idt, smooth = registration_losses()
         self._loss_inputs = (l1_reg, l1_idt, smooth)
         if stacked:
             # registration_model.py:163-166,230-234 as ONE launch (and one for its gradient):
