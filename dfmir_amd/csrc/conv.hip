@@ -600,7 +600,6 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
                               const float* bias, const float* res, const float* ring, int ring_rl, float* y,
                               hipStream_t st, int* rc);
 int df_conv3x3_split_res_ok(const DfConvGeom* g);
-bool df_conv3x3_split_wgrad_swaps(const DfConvGeom* g);
 bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float* x_amax, int x_n, const float* dy,
                                 const float* dy_amax, int dy_n, float* dw_tcc, float* db, hipStream_t st, int* rc,
                                 const float* dy_pmax);
@@ -770,11 +769,6 @@ static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_a
   hipStream_t st = (hipStream_t)stream;
   if (!use_generic_only()) {
     int rc = 0;
-    if (db && x_amax && dy_amax && df_conv3x3_split_wgrad_swaps(g)) {     // swapped roles: the kernel's dY operand is X
-      const int rcb = bias_grad_launch(dy, db, g->N, g->Cout, (long long)g->Do * g->Ho * g->Wo, st);
-      if (rcb) return rcb;
-      db = nullptr;
-    }
     if (df_conv3x3_split_wgrad_try(g, x, x_amax, x_n, dy, dy_amax, dy_n, dw_tcc, db, st, &rc, dy_pmax)) return rc;   // db fused
   }
   if (db) {   // every other kernel: the bias gradient is its own pass over dY

@@ -1107,6 +1107,7 @@ struct WS3P {
   // layer at 256^2): its natural tile is 64 x 128 (ci x co), which a 64-channel dY half fills; the other way round the
   // layer fills it completely.
   int swap;
+  float* dbx;             // swapped roles: the bias gradient is the pixel sum of the kernel's X operand (= dY), interior rows of a run
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool want_db = k.db != nullptr && blockIdx.y == 0;
   if (tid < BC) bsum[tid] = 0.f;
-  float bacc = 0.f;
+  float bacc = 0.f, baccx = 0.f;
   const int wc = wid & 3, wi = wid >> 2;             // wi is also the stagger group
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HW = k.H * k.W;
@@ -1527,6 +1528,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   // loader roles: X group (patch row xr 0..3, half xu, channel xc 0..63), dY group (k-step dk, half du, channel dc)
   const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
   const int dc = tid & (BC - 1), du = (tid >> 7) & 1, dk = tid >> 8;
+  const bool xin = k.dbx != nullptr && blockIdx.z == 0 && (xr == 1 || xr == 2);     // rows of a run that are not halo
   const float xscale = pow2f(ex), dscale = pow2f(edc[dc]), oscale = pow2f(-ex), oscale2 = pow2f(-edc[wc * 32 + l31]);
   const unsigned hw4 = (unsigned)HW * 4u;
   constexpr unsigned OOB = 0x80000000u;
@@ -1578,6 +1580,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     float r[10];                                                                                 \
     r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
+    baccx += xin ? ((r[1] + r[2]) + (r[3] + r[4])) + ((r[5] + r[6]) + (r[7] + r[8])) : 0.f;      \
     unsigned pa[5][NSP], pb[4][NSP];                                                             \
     _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
@@ -1687,6 +1690,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     __syncthreads();
     if (tid < BC && co0 + tid < k.Cout) atomicAdd(&k.db[co0 + tid], bsum[tid]);
   }
+  if (k.dbx != nullptr && blockIdx.z == 0) {
+    atomicAdd(&bsum[xc], baccx);
+    __syncthreads();
+    if (tid < CT && ci0 + tid < k.Cin) atomicAdd(&k.dbx[ci0 + tid], bsum[tid]);
+  }
   if (k.swap) {
     // transposed store: the real layout is [8 - t][co][ci] with ci (this kernel's rows) fastest.  Each wave turns its
     // 32 x 32 tile around through LDS (the operand buffers are free now) so that a half-wave adds to 32 consecutive
@@ -1744,12 +1752,11 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
   const bool swap = mode == 2 && x_amax && dy_amax && df_conv3x3_split_wgrad_swaps(g);
-  if (swap && db) return false;                        // the caller takes db first (conv.hip)
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax, 0};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax, 0, nullptr};
   if (swap) {
     k.Cin = g->Cout; k.Cout = g->Cin;
     k.x_amax = dy_amax; k.dy_amax = x_amax; k.x_n = dy_n; k.dy_n = x_n;
-    k.db = nullptr; k.dy_pmax = nullptr; k.swap = 1;
+    k.db = nullptr; k.dbx = db; k.dy_pmax = nullptr; k.swap = 1;
   }
   k.runs_per_img = (g->Hi / 2) * k.runs_per_row;
   const long long total = (long long)g->N * k.runs_per_img;
