@@ -68,14 +68,30 @@ __device__ __forceinline__ f32x16 mma3(u32x4 a, u32x4 b, f32x16 c) {
 // pair != 0 (M <= 16): 36 taps' per chunk, row (p, co) = p * 16 + co holds W[dz' - p] (see the PAIR form above).
 // Ktot / koff: the layer's reduction channels are rows koff .. koff + K - 1 of a packing with Ktot rows per tap (the skip
 // channels of a concatenated input, conv3d_up_phase_k below); Ktot == K, koff == 0 for a whole layer.
+// max |w| over rows koff .. koff + K - 1 of every tap of a [27][Ktot][M] packing: per tap K * M consecutive floats, read as
+// float4 where the slab is 16-byte aligned (one division per element and 4-byte loads made this reduction -- which every
+// workgroup of a weight-split job repeats -- the longest part of conv3d_wsplit_batch_k)
+__device__ __forceinline__ float wslab_absmax(const float* __restrict__ w, int K, int Ktot, int koff, int M) {
+  float m = 0.f;
+  const int slab = K * M;
+  if ((slab & 3) == 0 && ((Ktot * M) & 3) == 0 && ((koff * M) & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    const int s4 = slab >> 2;
+    for (int i = threadIdx.x; i < 27 * s4; i += 1024) {
+      const int tapi = i / s4, r4 = i - tapi * s4;
+      const float4 v = *reinterpret_cast<const float4*>(w + ((long long)tapi * Ktot + koff) * M + 4 * r4);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  } else {
+    for (int i = threadIdx.x; i < 27 * slab; i += 1024) {
+      const int tapi = i / slab, rem = i - tapi * slab;
+      m = fmaxf(m, fabsf(w[((long long)tapi * Ktot + koff) * M + rem]));
+    }
+  }
+  return m;
+}
 __device__ __forceinline__ void conv3d_wsplit_body(const float* __restrict__ w, u32x4* __restrict__ ws, int K, int M,
                                                    float* __restrict__ trailer, int pair, int Ktot, int koff, float* sm) {
-  float m = 0.f;
-  const int total = 27 * K * M;
-  for (int i = threadIdx.x; i < total; i += 1024) {
-    const int tapi = i / (K * M), rem = i - tapi * (K * M);
-    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot + koff) * M + rem]));
-  }
+  float m = wslab_absmax(w, K, Ktot, koff, M);
   m = block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
@@ -996,11 +1012,7 @@ __device__ __forceinline__ void conv3d_up_wsplit_body(const float* __restrict__ 
   // scale from a BOUND of the effective weights: an effective weight sums <= 8 taps, so |Weff| <= 8 max|w| (evaluating
   // all 64 Ka M sums in every workgroup just for their maximum cost 0.2 ms on the 64-channel levels).  A loose scale
   // only moves the fp16 pairs' exponent window: elements above 2^-14 of the bound keep their 22 bits
-  float m = 0.f;
-  for (int i = threadIdx.x; i < 27 * Ka * M; i += 1024) {
-    const int tapi = i / (Ka * M), rem = i - tapi * (Ka * M);
-    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot) * M + rem]));
-  }
+  float m = wslab_absmax(w, Ka, Ktot, 0, M);
   m = 8.f * block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
@@ -1507,11 +1519,7 @@ extern "C" int dfmir_conv3d_up_skip2_fwd(const float* a, const float* a_amax, in
 __device__ __forceinline__ void conv3d_up_wsplit_t_body(const float* __restrict__ w, u32x4* __restrict__ ws, int Ka, int Ktot,
                                                         int M, float* __restrict__ trailer, float* sm) {
   // scale from the same BOUND as conv3d_up_wsplit_body: |Weff| <= 8 max|w| (see there)
-  float m = 0.f;
-  for (int i = threadIdx.x; i < 27 * Ka * M; i += 1024) {
-    const int tapi = i / (Ka * M), rem = i - tapi * (Ka * M);
-    m = fmaxf(m, fabsf(w[((long long)tapi * Ktot) * M + rem]));
-  }
+  float m = wslab_absmax(w, Ka, Ktot, 0, M);
   m = 8.f * block_max(m, sm);
   if (!(m == m)) m = __uint_as_float(0x7f800000u);
   const int ew = scale_exp3(m);
