@@ -206,6 +206,50 @@ __global__ __launch_bounds__(256) void ncc_prod_boxw_k(const float* __restrict__
   }
   o[i] = s0; o[N + i] = s1; o[2 * N + i] = s2; o[3 * N + i] = s3; o[4 * N + i] = s4;
 }
+// r = 4, W % 4 == 0: 4 consecutive outputs per thread from its own float4 of I / J and the neighbouring lanes' (see
+// box_axis_x4_k); the same sums in the same order
+__global__ __launch_bounds__(256) void ncc_prod_boxw_x4_k(const float* __restrict__ I, const float* __restrict__ J,
+                                                          float* __restrict__ o, long long N, int W) {
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = i4 < (N >> 2);
+  const long long i = live ? i4 << 2 : 0;
+  const int x = (int)(i % W);
+  const bool ha = x >= 4, hb = x + 8 <= W;
+  float va[12], vb[12];
+#define NPB_WINDOW(P_, v_)                                                                        \
+  {                                                                                               \
+    const float* p = (P_) + i;                                                                    \
+    const float4 c = live ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f); \
+    float4 a, b;                                                                                  \
+    a.x = __shfl_up(c.x, 1, 64); a.y = __shfl_up(c.y, 1, 64); a.z = __shfl_up(c.z, 1, 64); a.w = __shfl_up(c.w, 1, 64); \
+    b.x = __shfl_down(c.x, 1, 64); b.y = __shfl_down(c.y, 1, 64); b.z = __shfl_down(c.z, 1, 64); b.w = __shfl_down(c.w, 1, 64); \
+    if (lane == 0 && ha && live) a = *reinterpret_cast<const float4*>(p - 4);                     \
+    if (lane == 63 && hb && live) b = *reinterpret_cast<const float4*>(p + 4);                    \
+    if (!ha) a = make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
+    if (!hb) b = make_float4(0.f, 0.f, 0.f, 0.f);                                                 \
+    v_[0] = a.x; v_[1] = a.y; v_[2] = a.z; v_[3] = a.w; v_[4] = c.x; v_[5] = c.y; v_[6] = c.z; v_[7] = c.w; \
+    v_[8] = b.x; v_[9] = b.y; v_[10] = b.z; v_[11] = b.w;                                         \
+  }
+  NPB_WINDOW(I, va)
+  NPB_WINDOW(J, vb)
+#undef NPB_WINDOW
+  if (!live) return;
+  float s[5][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      const float a = va[j + d], b = vb[j + d];
+      s0 += a; s1 += b; s2 += a * a; s3 += b * b; s4 += a * b;
+    }
+    s[0][j] = s0; s[1][j] = s1; s[2][j] = s2; s[3][j] = s3; s[4][j] = s4;
+  }
+#pragma unroll
+  for (int f = 0; f < 5; ++f) *reinterpret_cast<float4*>(o + (long long)f * N + i) = make_float4(s[f][0], s[f][1], s[f][2], s[f][3]);
+}
+static void ncc_prod_boxw_launch(const float* I, const float* J, float* o, long long N, int W, int r, hipStream_t st);
 // out[f][v] = sum_{d} in[f][v + d*stride] over the axis of length `len` (coordinate = (v/stride)%len)
 __global__ __launch_bounds__(256) void box_axis_k(const float* __restrict__ in, float* __restrict__ out,
                                                   int nf, long long N, long long stride, int len, int r) {
@@ -266,15 +310,59 @@ __global__ __launch_bounds__(256) void box_axis_march_k(const float* __restrict_
     }
   }
 }
+// The contiguous axis (stride 1, r = 4, len % 4 == 0): a thread owns 4 consecutive outputs; the 12 values their windows span
+// are its own float4 and the neighbouring lanes' (shuffles; the first / last lane of a wave loads them), masked by the
+// line's ends -- 1 load instruction per 4 outputs instead of 36 (box_axis_k is bound by the texture path, not by HBM).
+__global__ __launch_bounds__(256) void box_axis_x4_k(const float* __restrict__ in, float* __restrict__ out, int nf,
+                                                     long long N, int len) {
+  const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;      // float4 index inside one field
+  const long long n4 = N >> 2;
+  const int lane = threadIdx.x & 63;
+  const bool live = i4 < n4;
+  const long long i = live ? i4 << 2 : 0;
+  const int x = (int)(i % len);
+  for (int f = 0; f < nf; ++f) {
+    const float* p = in + (long long)f * N + i;
+    const float4 c = live ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a, b;                                               // the float4 before / after
+    a.x = __shfl_up(c.x, 1, 64); a.y = __shfl_up(c.y, 1, 64); a.z = __shfl_up(c.z, 1, 64); a.w = __shfl_up(c.w, 1, 64);
+    b.x = __shfl_down(c.x, 1, 64); b.y = __shfl_down(c.y, 1, 64); b.z = __shfl_down(c.z, 1, 64); b.w = __shfl_down(c.w, 1, 64);
+    const bool ha = x >= 4, hb = x + 8 <= len;                 // the neighbours lie on this line
+    if (lane == 0 && ha && live) a = *reinterpret_cast<const float4*>(p - 4);
+    if (lane == 63 && hb && live) b = *reinterpret_cast<const float4*>(p + 4);
+    if (!ha) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!hb) b = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float v[12] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, b.x, b.y, b.z, b.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                              // output x + j: window v[j] .. v[j + 8], in box_axis_k's order
+      float sacc = 0.f;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) sacc += v[j + d];
+      o[j] = sacc;
+    }
+    if (live) *reinterpret_cast<float4*>(out + (long long)f * N + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
 static void box_axis_launch(const float* in, float* out, int nf, long long N, long long stride, int len, int r,
                             hipStream_t st) {
   if (r == 4 && stride > 1 && N % len == 0) {
     constexpr int SEG = 36;
     const long long thr = (N / len) * ((len + SEG - 1) / SEG) * nf;
     box_axis_march_k<4, SEG><<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(in, out, nf, N, stride, len);
+  } else if (r == 4 && stride == 1 && (len & 3) == 0 && len >= 8 && N % len == 0 &&
+             ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (N & 3) == 0) {
+    box_axis_x4_k<<<(unsigned)(((N >> 2) + 255) / 256), 256, 0, st>>>(in, out, nf, N, len);
   } else {
     box_axis_k<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(in, out, nf, N, stride, len, r);
   }
+}
+static void ncc_prod_boxw_launch(const float* I, const float* J, float* o, long long N, int W, int r, hipStream_t st) {
+  if (r == 4 && (W & 3) == 0 && W >= 8 && (N & 3) == 0 && N % W == 0 &&
+      ((reinterpret_cast<uintptr_t>(I) | reinterpret_cast<uintptr_t>(J) | reinterpret_cast<uintptr_t>(o)) & 15) == 0)
+    ncc_prod_boxw_x4_k<<<(unsigned)(((N >> 2) + 255) / 256), 256, 0, st>>>(I, J, o, N, W);
+  else
+    ncc_prod_boxw_k<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(I, J, o, N, W, r);
 }
 struct NccTerms { float cross, Iv, Jv, uI, uJ, den; };
 __device__ __forceinline__ NccTerms ncc_terms(const float* s, long long N, long long i, float wn, float eps) {
@@ -430,7 +518,7 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   float wn;
   if (D > 1) {
-    ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp, N, W, r);
+    ncc_prod_boxw_launch(I, J, tmp, N, W, r, st);
     DF_LAUNCH_CHECK();
     box_axis_launch(tmp, tmp2, 5, N, W, H, r, st);
     DF_LAUNCH_CHECK();
@@ -438,7 +526,7 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
     DF_LAUNCH_CHECK();
     wn = (float)win * win * win;
   } else {
-    ncc_prod_boxw_k<<<grid, 256, 0, st>>>(I, J, tmp2, N, W, r);
+    ncc_prod_boxw_launch(I, J, tmp2, N, W, r, st);
     DF_LAUNCH_CHECK();
     box_axis_launch(tmp2, tmp, 5, N, W, H, r, st);
     DF_LAUNCH_CHECK();
@@ -462,7 +550,7 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
   const float wn = (D > 1) ? (float)win * win * win : (float)win * win;
   ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps);
   DF_LAUNCH_CHECK();
-  box_axis_k<<<grid, 256, 0, st>>>(tmp, tmp2, 3, N, 1, W, r);
+  box_axis_launch(tmp, tmp2, 3, N, 1, W, r, st);
   DF_LAUNCH_CHECK();
   box_axis_launch(tmp2, tmp, 3, N, W, H, r, st);
   DF_LAUNCH_CHECK();
