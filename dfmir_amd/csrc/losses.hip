@@ -87,24 +87,36 @@ __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict
 }
 // W % 4 == 0: a thread owns 16-B quads (grid-stride), one float4 load each for the quad, its y + 1 and z + 1 neighbours and
 // one scalar for x + 4: 4 independent loads per 4 elements instead of 12 dependent-ish scalar ones per row walk
-__global__ __launch_bounds__(256) void flow_smooth_fwd_v4_k(const float* __restrict__ f, float* __restrict__ ws,
+// TPR = threads per row (a power of two >= W / 4): (row, quad) come from shifts and the row's (y, z) from 32-bit divisions --
+// the 64-bit `t % Wq`, `row % H`, `row / H % D` of a flat quad index cost more than the loads
+template <int TPR>
+__global__ __launch_bounds__(1024) void flow_smooth_fwd_v4_k(const float* __restrict__ f, float* __restrict__ ws,
                                                             long long planes, int D, int H, int W) {
   __shared__ float sm[17];
   const int Wq = W >> 2;
-  const long long nq = planes * D * H * Wq, HW = (long long)H * W;
+  const unsigned nrow = (unsigned)(planes * D * H);
+  const long long HW = (long long)H * W;
   float sd = 0.f, sh = 0.f, sw = 0.f;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nq; t += (long long)gridDim.x * 256) {
-    const int q = (int)(t % Wq);
-    const long long row = t / Wq;
-    const int y = (int)(row % H), z = (int)((row / H) % D);
-    const float* p = f + row * W + 4 * q;
+  const int q = threadIdx.x & (TPR - 1);
+  // workgroup ids go round-robin over the 8 XCDs (one L2 each): XCD e walks a CONTIGUOUS eighth of the rows, so the y +- 1 /
+  // z +- 1 neighbours of its rows are its own rows (row-interleaved, every row was fetched into three L2s)
+  const unsigned per = (nrow + 7u) / 8u, xbase = (blockIdx.x & 7u) * per;
+  // 1024-thread workgroups, at most 512 of them: every workgroup ends with three atomic adds onto the SAME three floats, and
+  // 2048 x 3 of them serialised in L2 were the whole kernel (102 us whatever the volume)
+  for (unsigned r = ((blockIdx.x >> 3) * 1024u + threadIdx.x) / TPR; r < per && xbase + r < nrow && q < Wq;
+       r += (gridDim.x >> 3) * (1024u / TPR)) {
+    const unsigned row = xbase + r;
+    const unsigned rz = row / (unsigned)H;
+    const int y = (int)(row - rz * (unsigned)H), z = (int)(rz % (unsigned)D);
+    const float* p = f + (long long)row * W + 4 * q;
     const float4 v = *reinterpret_cast<const float4*>(p);
     const bool hy = y + 1 < H, hz = z + 1 < D, hx = q + 1 < Wq;
     float4 vy = v, vz = v;
-    float nx = v.w;
     if (hy) vy = *reinterpret_cast<const float4*>(p + W);
     if (hz) vz = *reinterpret_cast<const float4*>(p + HW);
-    if (hx) nx = p[4];
+    // x + 4 is the next lane's first value (threads of a row are consecutive lanes: TPR <= 64)
+    const float nsh = __shfl_down(v.x, 1, 64);
+    const float nx = hx ? nsh : v.w;
     float d;
     d = v.y - v.x; sw += d * d; d = v.z - v.y; sw += d * d; d = v.w - v.z; sw += d * d; d = nx - v.w; sw += d * d;
     d = vy.x - v.x; sh += d * d; d = vy.y - v.y; sh += d * d; d = vy.z - v.z; sh += d * d; d = vy.w - v.w; sh += d * d;
@@ -119,20 +131,28 @@ __global__ __launch_bounds__(256) void flow_smooth_fwd_v4_k(const float* __restr
     atomicAdd(&ws[2], sw);
   }
 }
+template <int TPR>
 __global__ __launch_bounds__(256) void flow_smooth_bwd_v4_k(const float* __restrict__ f, const float* __restrict__ gout,
                                                             float* __restrict__ df, long long planes, int D, int H,
                                                             int W, float kd, float kh, float kw) {
   const int Wq = W >> 2;
-  const long long nq = planes * D * H * Wq, HW = (long long)H * W;
+  const unsigned nrow = (unsigned)(planes * D * H);
+  const long long HW = (long long)H * W;
   const float g = gout[0];
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nq; t += (long long)gridDim.x * 256) {
-    const int q = (int)(t % Wq);
-    const long long row = t / Wq;
-    const int y = (int)(row % H), z = (int)((row / H) % D);
-    const float* p = f + row * W + 4 * q;
+  const int q = threadIdx.x & (TPR - 1);
+  // workgroup ids go round-robin over the 8 XCDs (one L2 each): XCD e walks a CONTIGUOUS eighth of the rows, so the y +- 1 /
+  // z +- 1 neighbours of its rows are its own rows (row-interleaved, every row was fetched into three L2s)
+  const unsigned per = (nrow + 7u) / 8u, xbase = (blockIdx.x & 7u) * per;
+  for (unsigned r = ((blockIdx.x >> 3) * 256u + threadIdx.x) / TPR; r < per && xbase + r < nrow && q < Wq;
+       r += (gridDim.x >> 3) * (256u / TPR)) {
+    const unsigned row = xbase + r;
+    const unsigned rz = row / (unsigned)H;
+    const int y = (int)(row - rz * (unsigned)H), z = (int)(rz % (unsigned)D);
+    const float* p = f + (long long)row * W + 4 * q;
     const float4 v = *reinterpret_cast<const float4*>(p);
     // a missing neighbour contributes nothing: substitute the centre value (difference 0)
-    const float xl = q > 0 ? p[-1] : v.x, xr = q + 1 < Wq ? p[4] : v.w;
+    const float lsh = __shfl_up(v.w, 1, 64), rsh = __shfl_down(v.x, 1, 64);   // the neighbouring quads are the neighbouring lanes
+    const float xl = q > 0 ? lsh : v.x, xr = q + 1 < Wq ? rsh : v.w;
     const float4 yu = y > 0 ? *reinterpret_cast<const float4*>(p - W) : v;
     const float4 yd = y + 1 < H ? *reinterpret_cast<const float4*>(p + W) : v;
     const float4 zu = z > 0 ? *reinterpret_cast<const float4*>(p - HW) : v;
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(256) void flow_smooth_bwd_v4_k(const float* __restr
     o.y = g * (kw * ((v.y - v.x) - (v.z - v.y)) + kh * ((v.y - yu.y) - (yd.y - v.y)) + kd * ((v.y - zu.y) - (zd.y - v.y)));
     o.z = g * (kw * ((v.z - v.y) - (v.w - v.z)) + kh * ((v.z - yu.z) - (yd.z - v.z)) + kd * ((v.z - zu.z) - (zd.z - v.z)));
     o.w = g * (kw * ((v.w - v.z) - (xr - v.w)) + kh * ((v.w - yu.w) - (yd.w - v.w)) + kd * ((v.w - zu.w) - (zd.w - v.w)));
-    *reinterpret_cast<float4*>(df + row * W + 4 * q) = o;
+    *reinterpret_cast<float4*>(df + (long long)row * W + 4 * q) = o;
   }
 }
 __global__ void flow_smooth_fin_k(const float* ws, float* out, float cd, float ch, float cw, float nd) {
@@ -470,8 +490,12 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   const long long planes = (long long)B * C;
   const long long nrow = planes * D * H;
-  if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(flow) & 15) == 0) {
-    flow_smooth_fwd_v4_k<<<df_grid(nrow * (W >> 2), 256, 2048), 256, 0, st>>>(flow, ws, planes, D, H, W);
+  if ((W & 3) == 0 && W <= 256 && nrow < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(flow) & 15) == 0) {
+    const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);
+    const unsigned grid = 8 * ((df_grid(nrow * tpr, 1024, 512) + 7) / 8);
+    if (tpr == 16) flow_smooth_fwd_v4_k<16><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
+    else if (tpr == 32) flow_smooth_fwd_v4_k<32><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
+    else flow_smooth_fwd_v4_k<64><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
   } else {
     const int rb = (int)((nrow + 2047) / 2048);
     flow_smooth_fwd_k<<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
@@ -493,10 +517,15 @@ extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float
   const double nd = (D > 1) ? 3.0 : 2.0;
   const float kd = cd > 0 ? (float)(2.0 / (cd * nd)) : 0.f, kh = ch > 0 ? (float)(2.0 / (ch * nd)) : 0.f,
               kw = cw > 0 ? (float)(2.0 / (cw * nd)) : 0.f;
-  if ((W & 3) == 0 && ((reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(dflow)) & 15) == 0)
-    flow_smooth_bwd_v4_k<<<df_grid(planes * D * H * (W >> 2), 256, 1 << 15), 256, 0, (hipStream_t)stream>>>(
-        flow, gout, dflow, planes, D, H, W, kd, kh, kw);
-  else if (planes * D * H * W < 0x7FFFFFFFLL)
+  if ((W & 3) == 0 && W <= 256 && planes * D * H < 0x7FFFFFFFLL &&
+      ((reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(dflow)) & 15) == 0) {
+    const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);
+    const unsigned grid = 8 * ((df_grid(planes * D * H * tpr, 256, 1 << 15) + 7) / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (tpr == 16) flow_smooth_bwd_v4_k<16><<<grid, 256, 0, st>>>(flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+    else if (tpr == 32) flow_smooth_bwd_v4_k<32><<<grid, 256, 0, st>>>(flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+    else flow_smooth_bwd_v4_k<64><<<grid, 256, 0, st>>>(flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  } else if (planes * D * H * W < 0x7FFFFFFFLL)
     flow_smooth_bwd_k<unsigned><<<df_grid(planes * D * H * W, 256, 1 << 16), 256, 0, (hipStream_t)stream>>>(
         flow, gout, dflow, planes, D, H, W, kd, kh, kw);
   else
