@@ -95,6 +95,8 @@ def main():
         for k in c:
             if 'conv3d_split_k' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_split_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
+            if 'conv3d_split_m16_k' in k and 'FETCH_SIZE' in c[k]:      # <= 16 output channels: the 16-row MFMA form
+                out["conv3d_split_m16_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
             if 'wgrad_tr' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_wgrad_tr_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
     if not from_prof and os.path.exists(C + "pmc_upconv3d.txt"):
