@@ -18,6 +18,16 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _reap(procs):
+    """A worker that hangs (a collective that never completes) must not outlive its test holding the GPU."""
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -102,10 +112,13 @@ def _run_two_ranks_2d(capture, backend):
     procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     return res
 
 
@@ -192,10 +205,13 @@ def test_registration3d_two_ranks():
     procs = [ctx.Process(target=_worker_3d, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        _reap(procs)
     r0, r1 = res
     assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2]) and np.array_equal(r0[3], r1[3])
     assert not np.array_equal(r0[1], r0[2])                 # the replicas trained
@@ -283,10 +299,13 @@ def test_global_mask_norm_equals_global_batch():
         procs = [ctx.Process(target=_worker_gmn, args=(r, 2, port, q, gmn)) for r in range(2)]
         for p in procs:
             p.start()
-        out = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=120)
-            assert p.exitcode == 0
+        try:
+            out = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=120)
+                assert p.exitcode == 0
+        finally:
+            _reap(procs)
         res[gmn] = out[0]
     # the single-process run on the global batch, from the ranks' (broadcast) weights
     model, opt = _gmn_model(4, "single")
