@@ -23,6 +23,8 @@ P = c_void_p
 _GP = POINTER(DfConvGeom)
 _SIGS = {
     "dfmir_abi_version": [],
+    "dfmir_set_option": [ctypes.c_char_p, ctypes.c_char_p],
+    "dfmir_get_option": [ctypes.c_char_p, ctypes.c_char_p, c_int],
     "dfmir_conv_fwd": [_GP, P, P, P, P, P],
     "dfmir_conv_wgrad": [_GP, P, P, P, P],
     "dfmir_bias_grad": [P, P, c_int, c_int, c_longlong, P],
@@ -169,6 +171,17 @@ def check(rc):
     if rc != 0:
         msg = lib().dfmir_last_error()
         raise DfmirHipError(msg.decode() if msg else "dfmir_hip error %d" % rc)
+
+
+def set_option(name, value=None):
+    """dfmir_set_option: a PROCESS-GLOBAL kernel-selection switch (include/dfmir_hip.h, "Options"); value None = unset."""
+    check(lib().dfmir_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    buf = ctypes.create_string_buffer(256)
+    n = lib().dfmir_get_option(name.encode(), buf, 256)
+    return None if n < 0 else buf.value.decode()
 
 
 def exported_symbols():

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/dfmir_hip.h"
 
 #define DF_LAUNCH_CHECK()                                  \
@@ -15,6 +16,33 @@
   } while (0)
 
 int df_set_error(int code, const char* file, int line);
+
+// Library options (include/dfmir_hip.h, "Options"): PROCESS-GLOBAL A/B switches.  A value set through
+// dfmir_set_option() wins; otherwise the environment variable of the same name is read.  Sites cache the parsed
+// value together with the option generation, which every dfmir_set_option() call bumps.
+const char* df_opt(const char* name);   // current value, nullptr when unset
+int df_opt_gen();
+struct DfOptFlag {                      // "is the option set (to anything)?"
+  const char* name;
+  int gen = -1;
+  bool v = false;
+  bool get() {
+    const int g = df_opt_gen();
+    if (g != gen) { v = df_opt(name) != nullptr; gen = g; }
+    return v;
+  }
+};
+struct DfOptInt {                       // integer value, `def` when unset
+  const char* name;
+  int def;
+  int gen = -1;
+  int v = 0;
+  int get() {
+    const int g = df_opt_gen();
+    if (g != gen) { const char* e = df_opt(name); v = e ? atoi(e) : def; gen = g; }
+    return v;
+  }
+};
 
 static inline unsigned df_grid(long long n, int bs, long long cap = 1LL << 20) {
   long long b = (n + bs - 1) / bs;

@@ -611,12 +611,8 @@ bool df_conv3d_fwd_try(const DfConvGeom* g, const float* x, const float* w_tcc, 
 bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
                          int* rc);
 static bool use_generic_only() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DFMIR_CONV_GENERIC");   // A/B switch: force the generic gather kernels
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
+  static DfOptInt o{"DFMIR_CONV_GENERIC", 0};     // A/B switch (= 1): force the generic gather kernels
+  return o.get() == 1;
 }
 
 static int check_geom(const DfConvGeom* g) {
@@ -695,7 +691,8 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     float* ys = y + (long long)n0 * (out_img / 4);
     long long Ps = (long long)k.g.N * g->Do * g->Ho * g->Wo;
     // dgrad of a stride-2 conv: parity-class enumeration (taps that only meet the inserted zeros are skipped)
-    static const bool dil2_off = getenv("DFMIR_NO_DIL2") != nullptr;
+    static DfOptFlag dil2_o{"DFMIR_NO_DIL2"};
+  const bool dil2_off = dil2_o.get();
     const bool dil2 = g->dil == 2 && g->stride == 1 && g->pad_mode == 0 && g->KD * g->KH * g->KW <= 128 && g->Cout <= 64 && !dil2_off;
     k.ncx = k.ncy = k.ncz = 1;
     k.Dm = g->Do; k.Hm = g->Ho; k.Wm = g->Wo;
@@ -708,7 +705,8 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     }
     // few output voxels (the deep U-Net levels: 8^2 .. 32^2 x 16 images, 10x12x14 voxels): 256-pixel tiles leave most
     // CUs idle while each workgroup walks the whole K loop; 64 x 64 tiles give 4x the workgroups at a quarter of the work
-    static const bool small_off = getenv("DFMIR_NO_SMALL_TILES") != nullptr;
+    static DfOptFlag small_o{"DFMIR_NO_SMALL_TILES"};
+  const bool small_off = small_o.get();
     const bool small_p = !small_off && (Ps + 255) / 256 < 192 && g->Cout > 8;
     if (dil2) {
       if (small_p) {
@@ -724,7 +722,8 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
       conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);
     } else if (g->Cout > 64) {
       const long long big = ((Ps + 127) / 128) * ((g->Cout + 127) / 128);
-      static const int big_min = getenv("DFMIR_GEMM_BIG_MIN") ? atoi(getenv("DFMIR_GEMM_BIG_MIN")) : 256;
+      static DfOptInt big_o{"DFMIR_GEMM_BIG_MIN", 256};
+  const int big_min = big_o.get();
       if (big < big_min) {   // small GEMMs (PatchNCE MLP: 4096 rows x 256): 64x64 tiles fill the 256 CUs
         dim3 grid((unsigned)((Ps + 63) / 64), (unsigned)((g->Cout + 63) / 64));
         conv_mfma_k<2, 2, 1, 1><<<grid, 256, 0, st>>>(xs, w_tcc, bias, ys, k);

@@ -870,19 +870,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
 
 // ------------------------------------------------------------------------------------------------
 static bool split3d_off() {
-  static int v = -1;
-  if (v < 0) v = (getenv("DFMIR_CONV3D_FP32") || getenv("DFMIR_CONV_FP32")) ? 1 : 0;
-  return v == 1;
+  static DfOptFlag a{"DFMIR_CONV3D_FP32"}, b{"DFMIR_CONV_FP32"};
+  return a.get() || b.get();
 }
 static bool pair3d_off() {
-  static int v = -1;
-  if (v < 0) v = getenv("DFMIR_CONV3D_NO_PAIR") ? 1 : 0;
-  return v == 1;
+  static DfOptFlag o{"DFMIR_CONV3D_NO_PAIR"};
+  return o.get();
 }
 static bool m16_off() {       // A/B switch: <= 16 output channels through the plane-pair form instead of the 16-row MFMA form
-  static int v = -1;
-  if (v < 0) v = getenv("DFMIR_CONV3D_NO_M16") ? 1 : 0;
-  return v == 1;
+  static DfOptFlag o{"DFMIR_CONV3D_NO_M16"};
+  return o.get();
 }
 static bool split3d_geom_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
@@ -931,7 +928,8 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   if (w_tcc) {
     // one unit per thread where possible: every workgroup re-reduces max|w| itself (L2-resident), the packing is what
     // parallelises (8 workgroups took 25 us on the 64 -> 64 layers, a latency chain of strided loads)
-    static const int ws_wgs = getenv("DFMIR_WSPLIT_WGS") ? atoi(getenv("DFMIR_WSPLIT_WGS")) : 32;
+    static DfOptInt ws_o{"DFMIR_WSPLIT_WGS", 32};
+  const int ws_wgs = ws_o.get();
     const long long units = (long long)(pair ? 1 : nmt) * nchunk * (pair ? 36 : 28) * 32;
     long long nwg = (units + 1023) / 1024;
     if (nwg > ws_wgs) nwg = ws_wgs;
@@ -942,9 +940,10 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used, 0, act_src, act_slope, act_src ? av_mode : 0};
-  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !getenv("DFMIR_CONV3D_NO_VEC");
+  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !df_opt("DFMIR_CONV3D_NO_VEC");
   // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
-  static const bool multi_off = getenv("DFMIR_CONV3D_NO_MULTI") != nullptr;
+  static DfOptFlag multi_o{"DFMIR_CONV3D_NO_MULTI"};
+  const bool multi_off = multi_o.get();
   // (the 16-row form runs one tile per workgroup: 143 registers = three workgroups per CU beat the shared weight staging
   // of the three-tile form, 32->16: 0.85 -> 0.80 ms, 16->16: 0.55 -> 0.48 ms)
   const int tt = (pair && !m16 && vec && !multi_off && k.ny >= 3) ? 3 : 1;
@@ -955,7 +954,8 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   // current one).  Measured equal within the box-to-box noise on every layer shape (the kernel is bound by the
   // package power, not by the exposed prologue), and the dispatcher balances one-tile workgroups better.
   const unsigned gy = pair ? 1u : (unsigned)((cout_used + 31) / 32);
-  static const int wg_cap = getenv("DFMIR_CONV3D_WGS") ? atoi(getenv("DFMIR_CONV3D_WGS")) : (1 << 30);
+  static DfOptInt wg_o{"DFMIR_CONV3D_WGS", 1 << 30};
+  const int wg_cap = wg_o.get();
   long long nb = 8 * ((k.ntile + 7) / 8);
   const long long cap = 8 * (((long long)wg_cap / gy + 7) / 8);
   if (nb > cap) nb = cap;
@@ -1451,7 +1451,7 @@ extern "C" long long dfmir_conv3d_up_ws_floats(int Ca, int Cout) {
 }
 extern "C" int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W) {
   // D, H, W: the low-resolution volume.  W % 4: 16-B patch loads; sizes: 32-bit buffer offsets on both tensors
-  if (split3d_off() || getenv("DFMIR_CONV3D_NO_UPPHASE")) return 0;
+  if (split3d_off() || df_opt("DFMIR_CONV3D_NO_UPPHASE")) return 0;
   if (N <= 0 || Ca < 8 || (Ca & 7) || Cout < 8 || D < 2 || H < 2 || W < 4 || (W & 3)) return 0;
   if ((long long)Ca * D * H * W * 4 >= 0x7FFFFFFFLL || (long long)Cout * D * H * W * 8 * 4 >= 0x7FFFFFFFLL) return 0;
   return 1;
@@ -2469,7 +2469,7 @@ extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* 
                                               const float* x_amax, int x_amax_n, const float* dy, const float* dy_amax,
                                               int dy_amax_n, float* dw_tcc, float* db, void* stream) {
   DF_ARG_CHECK(g && a && b && Ca > 0 && (Ca & 7) == 0 && Ca < g->Cin && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7));
-  DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !getenv("DFMIR_CONV3D_WGRAD_COPIES") && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
+  DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !df_opt("DFMIR_CONV3D_WGRAD_COPIES") && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
   return conv3d_split_wgrad_impl(g, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream, a, Ca);
 }
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
@@ -2503,7 +2503,8 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
     k.x_n = x_amax_n; k.dy_n = dy_amax_n;
     k.db = db; k.db_from_x = 0;
   }
-  static const bool tr_off = getenv("DFMIR_CONV3D_WGRAD_COPIES") != nullptr;   // A/B: the three-copy kernel
+  static DfOptFlag tr_o{"DFMIR_CONV3D_WGRAD_COPIES"};
+  const bool tr_off = tr_o.get();   // A/B: the three-copy kernel
   k.nz = (g->Di + 1) / 2; k.ny = tr_off ? (g->Hi + 3) / 4 : (g->Hi + 7) / 8; k.nx = (g->Wi + 15) / 16;
   k.npatch = (long long)g->N * k.nz * k.ny * k.nx;
   long long want = 512;
@@ -2512,7 +2513,8 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   // <= 3 chunks of accumulators per workgroup (96 AGPRs + staging registers: two workgroups per CU, so that one
   // converts while the other computes); more input channels = a second workgroup row, which stages dY again
   k.nchunk = (k.Cin + 7) / 8;
-  static const bool pair_off = getenv("DFMIR_CONV3D_WGRAD_NO_PAIR") != nullptr;
+  static DfOptFlag pair_o{"DFMIR_CONV3D_WGRAD_NO_PAIR"};
+  const bool pair_off = pair_o.get();
   const bool pairw = !tr_off && !pair_off && !swapped && k.Cout <= 16;   // (swapped flow head: measured slower, 0.44 vs 0.31 ms)         // (kernel roles) plane-pair columns: 3 accumulators per chunk
   const int per_wg = pairw ? (k.nchunk < 2 ? k.nchunk : 2) : (k.nchunk <= 3 ? k.nchunk : (k.nchunk == 4 ? 2 : 3));
   const unsigned gy = (unsigned)((k.nchunk + per_wg - 1) / per_wg);

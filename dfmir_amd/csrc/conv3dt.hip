@@ -201,9 +201,8 @@ __global__ __launch_bounds__(256) void conv3d_tiny_k(const float* __restrict__ x
 }  // namespace
 
 static bool tiny_off() {
-  static int v = -1;
-  if (v < 0) v = getenv("DFMIR_CONV3D_NO_TINY") ? 1 : 0;
-  return v == 1;
+  static DfOptFlag o{"DFMIR_CONV3D_NO_TINY"};
+  return o.get();
 }
 extern "C" int dfmir_conv3d_tiny_ok(const DfConvGeom* g) {
   if (!g || tiny_off()) return 0;

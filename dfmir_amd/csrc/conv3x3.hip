@@ -551,7 +551,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_small_wgrad_k(const float* __r
 
 bool df_conv3x3_small_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, hipStream_t st,
                                 int* rc) {
-  static const bool off = getenv("DFMIR_NO_SMALL_WGRAD") != nullptr;     // A/B switch
+  static DfOptFlag off_o{"DFMIR_NO_SMALL_WGRAD"};
+  const bool off = off_o.get();     // A/B switch
   if (off) return false;
   if (!(g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 && g->dil == 1))
     return false;

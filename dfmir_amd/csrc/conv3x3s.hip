@@ -196,12 +196,13 @@ __global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ 
 
 // which split form the library runs with (read once): 0 = none (fp32 MFMA), 2 = fp16x2 (default), 3 = bf16x3
 int df_split_mode() {
-  static const int mode = [] {
-    if (getenv("DFMIR_CONV_FP32")) return 0;
-    const char* s = getenv("DFMIR_CONV_SPLIT");
-    if (s && s[0] == 'b') return 3;
-    return 2;
-  }();
+  static int gen = -1, mode = 2;
+  const int g = df_opt_gen();
+  if (g != gen) {
+    const char* s = df_opt("DFMIR_CONV_SPLIT");
+    mode = df_opt("DFMIR_CONV_FP32") ? 0 : ((s && s[0] == 'b') ? 3 : 2);
+    gen = g;
+  }
   return mode;
 }
 
@@ -988,8 +989,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 // res != NULL (y = act(conv + bias) + res): only the shared-tile kernel has that epilogue -- df_conv3x3_split_res_ok(g)
 // tells whether this geometry takes it; otherwise *rc is an error
 static bool cs_plan(const DfConvGeom* g, int* th_out, int* tx_out, int* ty_out) {
-  static const bool use_cs = getenv("DFMIR_CONV_NO_CS") == nullptr;
-  static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
+  static DfOptFlag nocs_o{"DFMIR_CONV_NO_CS"};
+  const bool use_cs = !nocs_o.get();
+  static DfOptFlag plain_o{"DFMIR_CONV_CS_PLAIN"};
+  const bool rr = !plain_o.get();
   if (!(df_split_mode() == 2 && use_cs && (g->Cout > 64 || rr))) return false;
   const int th = g->Cout > 64 ? 8 : 16;
   const int tx = (g->Wo + CS_TW - 1) / CS_TW, ty = (g->Ho + th - 1) / th;
@@ -1026,7 +1029,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
   Conv3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, 0};
   const u32x4* ws = reinterpret_cast<const u32x4*>(split_section(w_packed, g->Cin, g->Cout));
   const SplitScale sc{x_amax, x_n, split_trailer(w_packed, g->Cin, g->Cout, mode)};
-  static const bool rr = getenv("DFMIR_CONV_CS_PLAIN") == nullptr;
+  static DfOptFlag plain_o{"DFMIR_CONV_CS_PLAIN"};
+  const bool rr = !plain_o.get();
   int th = 0, tlx = 0, tly = 0;
   if (mode == 2 && cs_plan(g, &th, &tlx, &tly)) {
     // 8 x 32 tiles (128 couts per workgroup) or 16 x 32 tiles (64 couts).  They fit the forward shapes exactly but
@@ -1041,7 +1045,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
       // fraction 0.432 -> 0.438 (DFMIR_CS_XCD_PAIR=0 restores the 2-D grid; =2: contiguous tile runs per XCD)
       // =2 (default): every XCD walks a contiguous run of tiles (neighbouring tiles share their halo rows in that L2 too):
       // 83.8 -> 82.3 ms, issued 0.432 -> 0.447
-      static const int xcd_pair = getenv("DFMIR_CS_XCD_PAIR") ? atoi(getenv("DFMIR_CS_XCD_PAIR")) : 2;
+      static DfOptInt xcd_o{"DFMIR_CS_XCD_PAIR", 2};
+  const int xcd_pair = xcd_o.get();
       if (xcd_pair && grid.y <= 2 && (nb & 7) == 0) {
         kc.xcd_pair = xcd_pair == 1 ? (grid.y == 2 ? 1 : 0) : (int)grid.y + 1;
         if (kc.xcd_pair) grid = dim3((unsigned)(grid.y * nb), 1u);
@@ -1049,7 +1054,8 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
       if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
       else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
     } else {
-      static const int xcd1 = getenv("DFMIR_CS_XCD_PAIR") ? atoi(getenv("DFMIR_CS_XCD_PAIR")) : 2;
+      static DfOptInt xcd1_o{"DFMIR_CS_XCD_PAIR", 2};
+    const int xcd1 = xcd1_o.get();
       if (xcd1 >= 2 && (nb & 7) == 0) kc.xcd_pair = 2;          // one cout slice: contiguous tile runs per XCD
       conv3x3_split_cs_k<true, 32, 16><<<dim3((unsigned)nb, 1u), 512, 0, st>>>(x, ws, bias, y, kc, sc);
     }
@@ -1733,7 +1739,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 
 // does df_conv3x3_split_wgrad_try run this geometry with swapped roles (and therefore leave db to the caller)?
 bool df_conv3x3_split_wgrad_swaps(const DfConvGeom* g) {
-  static const bool off = getenv("DFMIR_WGRAD_NO_SWAP") != nullptr || getenv("DFMIR_WGRAD_V1") != nullptr;
+  static DfOptFlag ns_o{"DFMIR_WGRAD_NO_SWAP"}, v1_o{"DFMIR_WGRAD_V1"};
+  const bool off = ns_o.get() || v1_o.get();
   return !off && df_split_mode() == 2 && g->KD == 1 && g->KH == 3 && g->KW == 3 && g->Di == 1 && g->Do == 1 && g->stride == 1 &&
          g->dil == 1 && g->ph == 1 && g->pw == 1 && g->pd == 0 && g->Ho == g->Hi && g->Wo == g->Wi && g->pad_mode == 0 &&
          g->Cout == 64 && g->Cin > 64;
@@ -1772,7 +1779,8 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const unsigned nx = (k.runs_total + k.runs_per_block - 1) / k.runs_per_block;
   const dim3 grid(nx, ny, nz);
   if (mode == 2) {
-    static const bool v1 = getenv("DFMIR_WGRAD_V1") != nullptr;      // A/B: the single-buffered kernel
+    static DfOptFlag v1_o{"DFMIR_WGRAD_V1"};
+    const bool v1 = v1_o.get();      // A/B: the single-buffered kernel
     if (swap) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(dy, x, dw_tcc, k);
     else if (wide && !v1) conv3x3_wgrad_split2_k<<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);
     else if (wide) conv3x3_wgrad_split_k<2, 128><<<grid, 512, 0, st>>>(x, dy, dw_tcc, k);

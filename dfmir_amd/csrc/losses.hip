@@ -3,6 +3,11 @@
 // one fp32 atomic per block into a tiny workspace; a 1-thread finaliser forms the scalar on device
 // so the host never synchronises.
 #include "common.h"
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <string.h>
 
 // ---------------------------------------------------------------------------------- masked L1
 __device__ __forceinline__ float l1_mask(const float a, const float b, const unsigned char* mask,
@@ -641,4 +646,44 @@ int df_set_error(int code, const char* file, int line) {
   return code;
 }
 extern "C" const char* dfmir_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// Options: one process-global table (name -> value or "explicitly unset") in front of the environment.
+namespace {
+struct DfOptTable {
+  std::mutex mu;
+  std::map<std::string, std::pair<bool, std::string>> over;    // name -> (is set, value)
+  std::atomic<int> gen{0};
+};
+DfOptTable& df_opt_table() {
+  static DfOptTable* t = new DfOptTable();      // never destroyed: kernels' static caches may outlive exit handlers
+  return *t;
+}
+}  // namespace
+const char* df_opt(const char* name) {
+  DfOptTable& t = df_opt_table();
+  std::lock_guard<std::mutex> lk(t.mu);
+  auto it = t.over.find(name);
+  if (it != t.over.end()) return it->second.first ? it->second.second.c_str() : nullptr;
+  return getenv(name);
+}
+int df_opt_gen() { return df_opt_table().gen.load(std::memory_order_acquire); }
+extern "C" int dfmir_set_option(const char* name, const char* value) {
+  DF_ARG_CHECK(name && strncmp(name, "DFMIR_", 6) == 0);
+  DfOptTable& t = df_opt_table();
+  {
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.over[name] = std::make_pair(value != nullptr, std::string(value ? value : ""));
+  }
+  t.gen.fetch_add(1, std::memory_order_release);
+  return 0;
+}
+extern "C" int dfmir_get_option(const char* name, char* buf, int buf_len) {
+  if (!name) return -1;
+  const char* v = df_opt(name);
+  if (!v) return -1;
+  const int n = (int)strlen(v);
+  if (buf && buf_len > 0) { strncpy(buf, v, (size_t)buf_len - 1); buf[buf_len - 1] = 0; }
+  return n;
+}
 extern "C" int dfmir_abi_version(void) { return DFMIR_ABI_VERSION; }

@@ -998,7 +998,8 @@ extern "C" int dfmir_in_relu_blurdown_fwd(const float* x, float* z, float* mean,
                                           float eps, float* z_amax, void* stream) {
   DF_ARG_CHECK(x && z && mean && rstd && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
   hipStream_t st = (hipStream_t)stream;
-  static const bool banded = getenv("DFMIR_IN_BLUR_BANDED") != nullptr;      // A/B: the LDS-ring form on the 256^2 planes
+  static DfOptFlag banded_o{"DFMIR_IN_BLUR_BANDED"};
+  const bool banded = banded_o.get();      // A/B: the LDS-ring form on the 256^2 planes
   if (!banded) return df_in_relu_blurdown_fwd256_launch(x, z, mean, rstd, planes, eps, z_amax, st, W);
   if (W == 256) in_relu_blurdown_fwd_k<1024, 16><<<planes, 1024, 2 * 16 * 256 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
   else in_relu_blurdown_fwd_k<256, 16><<<planes, 256, 2 * 8 * 128 * 4, st>>>(x, z, mean, rstd, W, eps, z_amax);
@@ -1009,7 +1010,8 @@ extern "C" int dfmir_in_relu_blurdown_bwd(const float* dz, const float* x, const
                                           int planes, int H, int W, float* dx_amax, float* dx_pmax, void* stream) {
   DF_ARG_CHECK(dz && x && mean && rstd && dx && planes > 0 && dfmir_in_relu_blurdown_ok(H, W));
   hipStream_t st = (hipStream_t)stream;
-  static const bool banded = getenv("DFMIR_IN_BLUR_BANDED") != nullptr;
+  static DfOptFlag banded_o{"DFMIR_IN_BLUR_BANDED"};
+  const bool banded = banded_o.get();
   if (!banded) return df_in_relu_blurdown_bwd256_launch(dz, x, mean, rstd, dx, planes, dx_amax, dx_pmax, st, W);
   if (W == 256) in_relu_blurdown_bwd_k<1024, 16><<<planes, 1024, (8 + 1) * 128 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);
   else in_relu_blurdown_bwd_k<256, 16><<<planes, 256, (4 + 1) * 64 * 4, st>>>(dz, x, mean, rstd, dx, W, dx_amax, dx_pmax);

@@ -116,6 +116,25 @@ def end_graph_capture():
     _AMAX_POOL["capturing"] = False
 
 
+def invalidate_after_failed_capture():
+    """A capture that raised has RECORDED launches without running them, while the host-side caches were updated as if
+    they had run: the batched weight re-pack (and the 3-D split workspaces derived from it) is marked current for this
+    weights epoch, and the probe pool handed out during the capture was allocated and zero-filled only by the dead graph.
+    Forget both: the next eager step re-packs every weight, re-splits every 3-D workspace and starts a fresh, really
+    zeroed probe pool."""
+    _AMAX_POOL["buf"] = None
+    _AMAX_POOL["capturing"] = False
+    _PACKS["epoch"] = None
+    _PACKS["key"] = _WS3D["key"] = _JOBS["key"] = None            # job tables uploaded inside the capture never arrived
+    for e in _PACKS["entries"].values():
+        e["epoch"] = None
+    for e in _WS3D["entries"].values():
+        w = e["ref"]()
+        cache = getattr(w, "_df_ws3d", None) if w is not None else None
+        if cache is not None and e["key"] in cache:
+            cache[e["key"]] = (None, cache[e["key"]][1])          # generation None never matches: re-split in place
+
+
 def absmax(t):
     out = amax_slot(t.device)
     check(lib().dfmir_absmax(_p(t), t.numel(), _p(out), _st()))
@@ -1644,9 +1663,6 @@ class PatchGatherFn(Function):
         return dfeat, None, None, None
 
 
-_DISTINCT_CHECKED = {}
-
-
 def mark_distinct(ids):
     """Tag an id tensor as a P-subset per group (what torch.randperm / dfmir_patch_ids_draw yield)."""
     ids._df_distinct = (ids._version, ids.data_ptr())
@@ -1661,16 +1677,17 @@ def ids_distinct(ids, groups=1):
     tag = getattr(ids, "_df_distinct", None)
     if tag is not None and tag == (ids._version, ids.data_ptr()):
         return True
-    key = (ids.data_ptr(), ids._version, tuple(ids.shape), int(groups))
-    hit = _DISTINCT_CHECKED.get(key)
-    if hit is None:
-        if torch.cuda.is_current_stream_capturing():
-            return False                      # no host round trip inside a capture: take the safe (atomic) form
-        srt = torch.sort(ids.reshape(int(groups), -1), dim=1).values
-        hit = bool((srt[:, 1:] != srt[:, :-1]).all()) if srt.shape[1] > 1 else True
-        if len(_DISTINCT_CHECKED) > 256:
-            _DISTINCT_CHECKED.clear()
-        _DISTINCT_CHECKED[key] = hit
+    # the verdict lives ON the tensor object (an address + version key does not identify content: a fresh tensor per
+    # step usually gets the allocator's previous address with version 0)
+    key = (ids._version, ids.data_ptr(), int(groups))
+    seen = getattr(ids, "_df_distinct_checked", None)
+    if seen is not None and seen[0] == key:
+        return seen[1]
+    if torch.cuda.is_current_stream_capturing():
+        return False                          # no host round trip inside a capture: take the safe (atomic) form
+    srt = torch.sort(ids.reshape(int(groups), -1), dim=1).values
+    hit = bool((srt[:, 1:] != srt[:, :-1]).all()) if srt.shape[1] > 1 else True
+    ids._df_distinct_checked = (key, hit)
     return hit
 
 

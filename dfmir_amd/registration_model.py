@@ -256,8 +256,9 @@ class REGISTRATIONModel(BaseModel):
                     self._forward_backward()
             except Exception as exc:                                   # noqa: BLE001 -- keep training, eagerly
                 # nothing of a failed capture has executed: weights, moments and the id counter are where the last
-                # eager step left them; this step and every later one are enqueued eagerly
-                ops.end_graph_capture()
+                # eager step left them -- but the host-side caches believe the recorded re-pack / pool zero-fill ran:
+                # forget them, then this step and every later one are enqueued eagerly
+                ops.invalidate_after_failed_capture()
                 import warnings
                 warnings.warn("capturing the train step failed (%s: %s); the step stays eager" % (type(exc).__name__, exc))
                 st.update(graph=None, force_eager=True, capture_error="%s: %s" % (type(exc).__name__, exc))
@@ -383,6 +384,11 @@ class REGISTRATIONModel(BaseModel):
             all_G_loss = self.loss_R + self.loss_G + self.loss_smooth
         with ops.deferred_weight_grads():
             all_G_loss.backward()
+            if rs is not None:
+                # netR's weight-gradient kernels ran on rs; the flush on exit and optimizer_R.step() run here.  An
+                # explicit join (legal under capture: it becomes the graph's join edge) instead of relying on which
+                # stream autograd bound netR's AccumulateGrad nodes to
+                cur.wait_stream(rs)
 
     def _global_mask_norm(self, *terms):
         """opt.global_mask_norm (build-defined, data-parallel runs only): the reference's DataParallel evaluates

@@ -11,8 +11,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to caller-allocated, contiguous fp32 memory laid out
  *     NCHW / NCDHW exactly like the reference's tensors (2-D tensors are D == 1);
- *   - `stream` is a hipStream_t passed as void*; nothing allocates, nothing synchronises, no
- *     global state except the last-error string -> re-entrant across streams / processes;
+ *   - `stream` is a hipStream_t passed as void*; nothing allocates, nothing synchronises; the only
+ *     state the library keeps is the (thread-local) last-error string and the PROCESS-GLOBAL option
+ *     table below ("Options") -> re-entrant across streams / processes, but two models in one
+ *     process share one set of options;
  *   - return value 0 = launched; >0 = hipError_t; <0 = bad argument.  dfmir_last_error() gives text;
  *   - "accumulates" means the kernel atomically adds into a buffer the caller has zeroed/initialised.
  */
@@ -23,10 +25,31 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 7
+#define DFMIR_ABI_VERSION 8
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Options -- process-global A/B switches of the kernel selection (lab knobs; the defaults are the
+ * product).  dfmir_set_option(name, value) sets `name` (must start with "DFMIR_") to `value`;
+ * value == NULL marks it explicitly UNSET (also hiding an environment variable of that name).
+ * A name never set through this call falls back to the environment variable of the same name.
+ * The change applies to launches issued after the call returns, on every thread (no per-stream or
+ * per-model scope).  Options that change a DATA LAYOUT the caller holds (DFMIR_CONV_SPLIT,
+ * DFMIR_CONV_FP32, DFMIR_CONV3D_FP32: the split sections of packed weights) must be set before the
+ * first dfmir_weight_pack* call, or every packed buffer re-packed after the change.
+ * dfmir_get_option copies the current value into buf (NUL-terminated, truncated to buf_len) and
+ * returns its length, or -1 when the option is unset.
+ *   kernel selection: DFMIR_CONV_FP32, DFMIR_CONV_SPLIT=bf16x3, DFMIR_CONV3D_FP32, DFMIR_CONV_GENERIC=1,
+ *     DFMIR_CONV_NO_CS, DFMIR_CONV_CS_PLAIN, DFMIR_CS_XCD_PAIR=n, DFMIR_WGRAD_V1, DFMIR_WGRAD_NO_SWAP,
+ *     DFMIR_WGRAD_ATOMIC, DFMIR_NO_SMALL_WGRAD, DFMIR_NO_DIL2, DFMIR_NO_SMALL_TILES, DFMIR_GEMM_BIG_MIN=n,
+ *     DFMIR_CONV3D_NO_PAIR, DFMIR_CONV3D_NO_M16, DFMIR_CONV3D_NO_TINY, DFMIR_CONV3D_NO_VEC,
+ *     DFMIR_CONV3D_NO_MULTI, DFMIR_CONV3D_WGS=n, DFMIR_WSPLIT_WGS=n, DFMIR_CONV3D_NO_UPPHASE,
+ *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED.
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_set_option(const char* name, const char* value);
+int dfmir_get_option(const char* name, char* buf, int buf_len);
 
 /* ------------------------------------------------------------------------------------------
  * Convolutions (implicit GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, and -- for the

@@ -30,7 +30,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
     h = dfmir_amd.lib()
-    assert h.dfmir_abi_version() == 7
+    assert h.dfmir_abi_version() == 8
     # a bad-argument call must fail loudly without touching a device
     rc = h.dfmir_scale(None, None, 0, 1.0, None)
     assert rc != 0
@@ -39,3 +39,20 @@ def test_abi_version_and_error_string():
 
 def test_geom_struct_layout():
     assert ctypes.sizeof(_lib.DfConvGeom) == 20 * 4
+
+
+def test_options_table_is_settable_and_falls_back_to_the_environment(monkeypatch):
+    """dfmir_set_option / dfmir_get_option (include/dfmir_hip.h "Options"): the one process-global table in front of
+    the environment that every kernel-selection switch of the library reads."""
+    name = "DFMIR_TEST_ONLY_OPTION"
+    monkeypatch.delenv(name, raising=False)
+    assert _lib.get_option(name) is None
+    monkeypatch.setenv(name, "from-env")
+    assert _lib.get_option(name) == "from-env"            # never set through the API: the environment answers
+    _lib.set_option(name, "41")
+    assert _lib.get_option(name) == "41"
+    _lib.set_option(name, None)                           # explicitly unset hides the environment variable too
+    assert _lib.get_option(name) is None
+    h = dfmir_amd.lib()
+    assert h.dfmir_set_option(b"NOT_OURS", b"1") != 0     # names outside the DFMIR_ namespace are refused
+    assert b"invalid argument" in h.dfmir_last_error()

@@ -410,6 +410,81 @@ def test_graph_captured_step_matches_eager(O):
     assert model._graph['eager_steps'] >= 2
 
 
+def test_failed_capture_falls_back_to_a_correct_eager_step(O):
+    """A capture that raises has recorded the batched weight re-pack and the probe pool's zero fill without running them
+    while the host caches were updated as if they had run (round-3 advisor finding): the eager step that follows must
+    invalidate them.  The third step's capture is made to raise after all of the step has been recorded; that step and
+    the next are compared with the same steps of a forced-eager run from the same state."""
+    import warnings
+    from dfmir_amd import ops
+    from tests.test_oracle_golden import make_step
+    st, size, B = make_step()
+    model, opt = _hip_model_from_oracle(st, size, B, 8)
+    opt.capture_step = True
+    ids_state = ops.seed_patch_ids(777, DEV)
+    A0, B0 = C.image_pair(93, B, size, size)
+    base_forward = model.netF.forward
+    model.netF.forward = lambda feats, num_patches=64, patch_ids=None, bf=base_forward: bf(
+        feats, num_patches, patch_ids if patch_ids is not None else
+        [C.patch_ids(0, i, f.shape[2] * f.shape[3], 256).to(DEV) for i, f in enumerate(feats)])
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    del model.netF.forward
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    batches = []
+    for it in range(4):
+        A_, B_ = C.image_pair(300 + 2 * it, B, size, size)
+        batches.append({"A": A_.to(DEV), "B": B_.to(DEV), "A_paths": [""] * B, "B_paths": [""] * B})
+
+    def run(data):
+        model.set_input(data)
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        return (list(model.get_current_losses().values()), model.fake_B.clone(), model.registered.clone(),
+                [o_.flat_g.clone() for o_ in model.optimizers], [o_.flat_p.clone() for o_ in model.optimizers])
+
+    for it in range(2):
+        run(batches[it])
+    snap = ([(o_.flat_p.clone(), o_.exp_avg.clone(), o_.exp_avg_sq.clone(), o_._steps) for o_ in model.optimizers],
+            ids_state.clone())
+    # reference: steps 3 and 4 enqueued eagerly
+    model._graph_state()['force_eager'] = True
+    ref = [run(batches[2]), run(batches[3])]
+    model._graph_state()['force_eager'] = False
+    for o_, (p_, m_, v_, n_) in zip(model.optimizers, snap[0]):
+        o_.flat_p.copy_(p_); o_.exp_avg.copy_(m_); o_.exp_avg_sq.copy_(v_); o_._steps = n_
+    ids_state.copy_(snap[1])
+    ops.bump_weights_epoch()
+    # now the capture of step 3 records everything and then raises
+    real_fb = model._forward_backward
+
+    def failing_fb():
+        real_fb()
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+    model._forward_backward = failing_fb
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = [run(batches[2])]
+    assert any("capturing the train step failed" in str(x.message) for x in w)
+    assert model._graph['force_eager'] and model._graph['graph'] is None
+    got.append(run(batches[3]))
+    for k, (g_, r_) in enumerate(zip(got, ref)):
+        np.testing.assert_allclose(g_[0], r_[0], rtol=1e-5, atol=1e-9, err_msg="losses, step %d" % (k + 3))
+        close(g_[1], r_[1], rtol=1e-6, what="fake_B step %d" % (k + 3))
+        close(g_[2], r_[2], rtol=1e-6, what="registered step %d" % (k + 3))
+        gscale = max(float(x.norm()) for x in r_[3])
+        for nm, a, b in zip("GRF", g_[3], r_[3]):
+            assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 2e-6 * gscale, (k, nm)
+        if k == 0:
+            # weights after step 3's Adam update: round-off of the weight gradients' float atomics becomes lr-sized
+            # differences on elements whose gradient is at round-off level (0.4 % of the update's norm measured); stale
+            # packed weights or a garbage probe pool would be a different step altogether
+            for nm, a, b in zip("GRF", g_[4], r_[4]):
+                assert float((a - b).norm()) <= 2e-3 * float(b.norm()), (k, nm)
+
+
 def _full_size_oracle(O, B, double=False):
     """256x256, ngf 64 oracle step state with seeded weights, pinned ids, a non-vacuous flow head; optionally fp64."""
     size = 256
