@@ -18,7 +18,9 @@ scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with
                   conv3d_wgrad_tr_k, both scaled fp16x2 on the 16-bit matrix pipe)
   `also_3d_128`   configs[3]: the 3-D step at 128^3 with the plugin's 6-level U-Net features
   `cpu_baseline`  (N = 1) the CPU oracle = a port of the reference's PyTorch-CPU path, timed on the host cores on a
-                  bounded sample: the 2-D step at 256^2 batch 1 and (`also_3d_128`) the 3-D step at 128^3.
+                  bounded sample: the 2-D step at 256^2 batch 1, (`also_3d_128`) the 3-D step at 128^3 and (`also_3d_big`) one
+                  3-D step at 160x192x224.
+  `step_ms`       median / min / max of the K timed steps (HIP events between steps).
 """
 import argparse
 import json
@@ -201,8 +203,28 @@ def cpu_baseline_3d(cores, shape=(128, 128, 128), budget_s=45.0):
                        % ((n, cores) + tuple(shape)))
 
 
+def cpu_baseline_3d_big(cores, shape=(160, 192, 224)):
+    """BASELINE.md section 4's headline 3-D shape on the host cores: ONE bounded train step of the oracle's Registration3DStep
+    at 160x192x224 with the default U-Net features (the 6-level list does not divide this shape), no warm-up
+    step (a step is 15-40 s of CPU work; the first step also pays the allocator's first touches)."""
+    from oracle import dfmir_oracle as O
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    st = O.Registration3DStep(shape, None)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1)
+    A = torch.rand(1, 1, *shape, generator=g) * 2 - 1
+    B = 0.5 * A + 0.5 * (torch.rand(1, 1, *shape, generator=g) * 2 - 1)
+    t0 = time.time()
+    st.step(A, B)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="image-pairs/s", cores=cores, kind="port", cpu_model=cpu_model(),
+                sample="1 train step (no warm-up) of the CPU oracle's Registration3DStep (PyTorch fp32, %d threads) at 3-D "
+                       "%dx%dx%d batch 1, default U-Net features, NCC[9,9,9] + Grad-l2 + Adam" % ((cores,) + tuple(shape)))
+
+
 def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, label="BASELINE configs[4] geometry, one GPU",
-             pmc_key="conv3d_split_k_34_32", steps=5, warmup=3, capture=False, roofline_steps=2):
+             pmc_key="conv3d_split_k_34_32", steps=5, warmup=3, capture=False, roofline_steps=2, rough_steps=0):
     """Auxiliary line: the 3-D step on ONE GPU -- batch 1, VxmDense(int_steps 7, bidir) + NCC[9,9,9] + Grad l2,
     fwd+bwd+Adam: 160x192x224 with the default U-Net features (configs[4]'s per-GPU shard) or
     128^3 with the plugin's 6-level features (configs[3]).  Its roofline: conv3d_split_k (every stride-1 3x3x3 forward /
@@ -247,6 +269,36 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     ops.set_conv_profiler(None)
     losses = m.get_current_losses()
     assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses   # finite
+    rough = None
+    if rough_steps > 0:
+        # The headline step runs on freshly initialised weights, whose flow head N(0, 1e-5) makes the
+        # field ~0: the windowed warp kernels' best case.  Second figure: the same step with the flow head rescaled as in the
+        # parity runs (weight x 1e5, bias N(0, 1)): |phi| of a few voxels through the 7 integration steps and both warps.
+        with torch.no_grad():
+            m.netR.flow.weight.mul_(1e5)
+            m.netR.flow.bias.copy_(torch.randn(m.netR.flow.bias.shape, generator=torch.Generator().manual_seed(8)).to(dev))
+        ops.bump_weights_epoch()
+        m._graph['force_eager'] = True            # (other weights than the captured step's history; timed eagerly)
+        for _ in range(2):
+            m.set_input({"A": A, "B": B})
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        for _ in range(rough_steps):
+            m.set_input({"A": A, "B": B})
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - tr) / rough_steps
+        with torch.no_grad():
+            fl = m.flow.detach() if hasattr(m, "flow") and torch.is_tensor(getattr(m, "flow", None)) else None
+        rl = m.get_current_losses()
+        rough = {"ms_per_step": 1e3 * dtr, "value": 1.0 / dtr, "unit": "image-pairs/s", "steps": rough_steps,
+                 "flow_abs_mean_voxels": float(fl.abs().mean()) if fl is not None else None,
+                 "flow_abs_max_voxels": float(fl.abs().max()) if fl is not None else None,
+                 "losses": {k: round(v, 6) for k, v in rl.items()},
+                 "note": "same step, flow head rescaled (weight x 1e5, bias N(0,1)) so that the deformation is a few voxels; "
+                         "eager submission"}
+        m._graph['force_eager'] = False
     ks = timer.summary()
 
     def agg(kinds):
@@ -304,7 +356,10 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
             "step_submission": "hipGraph replay + eager Adam" if graphed else "eager",
             "conv_tflops": gflop_step / dt / 1e3, "conv_gflop_per_step": gflop_step, "dtype": "f32",
-            "losses": {k: round(v, 6) for k, v in losses.items()}, "roofline": roof}
+            "losses": {k: round(v, 6) for k, v in losses.items()}, "roofline": roof,
+            "field_note": "timed on freshly initialised weights: flow head N(0, 1e-5), i.e. a near-identity field (SURVEY section 8 "
+                          "D2 keeps the headline on init weights); `rough_field` is the same step on a deformation of a few voxels",
+            "rough_field": rough}
 
 
 def bench_warp_hbm(dev, pmc, reps=20):
@@ -430,13 +485,19 @@ def main():
         model._collective_timing = []             # event pairs around every wait for a gradient exchange
     fence()
     timer.enabled = not graphed                   # HIP events cannot be recorded inside a graph replay
+    # one HIP event between consecutive steps (recorded on the step's stream, no host wait): per-step device times for
+    # the median / spread; `value` stays the wall clock of the whole region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         model.set_input(feed(i))
         model.optimize_parameters()
+        marks[i + 1].record()
     host_dt = time.perf_counter() - t0            # host-side enqueue time of the K steps (no device wait inside a step)
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     timer.enabled = False
     coll_pairs = getattr(model, '_collective_timing', None)
     model._collective_timing = None
@@ -458,7 +519,17 @@ def main():
     collective = None
     if distributed:
         exposed = sum(s_.elapsed_time(e_) for s_, e_ in (coll_pairs or [])) / max(args.steps, 1)
-        collective = {"backend": torch.distributed.get_backend(),
+        ones = torch.ones(1, device=dev)
+        if dfdist._staged(ones):                  # gloo over one device (tests): staged through the host
+            h_ = ones.cpu()
+            torch.distributed.all_reduce(h_)
+            ones = h_
+        else:
+            torch.distributed.all_reduce(ones)    # every rank contributes 1 through the data-path backend
+        collective = {"backend": torch.distributed.get_backend(), "rccl_ranks_seen": int(round(float(ones))),
+                      "patch_ids": "one draw shared by all ranks (same generator seed on every rank): the reference draws "
+                                   "one id set per forward and applies it to its whole gathered DataParallel batch "
+                                   "(models/networks.py:577,609-611)",
                       "payload_bytes": 4 * sum(o.flat_g.numel() for o in model.optimizers),
                       "arenas_bytes": [4 * o.flat_g.numel() for o in model.optimizers],
                       "exposed_ms_per_step": dfdist.allreduce_max(exposed, dev),
@@ -506,7 +577,12 @@ def main():
         result = {
             "metric": "train-step image-pairs/sec (fwd+bwd): 2D 256x256 bs=16 and 3D 160^3 bs=1",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "step_ms": {"median": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+                        "min": step_ms[0], "max": step_ms[-1],
+                        "note": "rank 0's device time between HIP events recorded after every step of the timed region (no host "
+                                "wait between steps); ms_per_step / value are the barrier-to-barrier wall clock, max over ranks"},
+            "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
             "step_submission": "hipGraph replay + eager all-reduce/Adam" if graphed else "eager",
             "host_enqueue_note": ("time the host spends inside the submission calls of a step.  With opt.overlap_registration "
                                   "(default) the captured graph has two parallel branches and hipGraphLaunch (ROCm 7.2) returns "
@@ -569,7 +645,7 @@ def main():
             torch.cuda.empty_cache()
             result["roofline_hbm"] = bench_warp_hbm(dev, pmc)
             torch.cuda.empty_cache()
-            result["also_3d"] = bench_3d(dev, pmc)
+            result["also_3d"] = bench_3d(dev, pmc, rough_steps=5)
             torch.cuda.empty_cache()
             # BASELINE configs[3]: 128^3, the plugin's 6-level features (SURVEY section 8 D2 "state which"), one hipGraph
             # replay per step (eager, this size is host-bound: 3.7 ms of enqueue per 5.3 ms step)
@@ -579,6 +655,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(S)
             result["cpu_baseline"]["also_3d_128"] = cpu_baseline_3d(result["cpu_baseline"]["cores"])
+            result["cpu_baseline"]["also_3d_big"] = cpu_baseline_3d_big(result["cpu_baseline"]["cores"])
         print(json.dumps(result))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

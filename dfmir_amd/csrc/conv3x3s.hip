@@ -1487,6 +1487,29 @@ int df_conv3x3_reflect_ring_launch(const DfConvGeom* g, const float* dy, const f
 //   * an operand unit Xc[dx][row] serves both k-steps (row = ks + ty): 12 distinct units per run instead of 18
 //     reads, i.e. 28 ds_read_b128 per 54 MFMAs instead of 40;
 //   * operands are read one unit (3 or 6 MFMAs) ahead; two or three units ahead measured the same.
+#ifdef W2_TRACE
+// trace build (scripts/build_ko.sh conv3x3s W2_TRACE 1): cycle stamps of one workgroup's first 64 runs, per wave:
+// [0] iteration start, [1] after its first phase (group 0: convert + store, group 1: MFMAs), [2] after the second, [3] after the barrier,
+// [4] in the convert phase once the global loads of the run have arrived (an explicit vmcnt(0))
+__device__ unsigned g_w2_trace[8 * 64 * 8];
+extern "C" int dfmir_w2_trace_dump(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w2_trace), sizeof(g_w2_trace));
+}
+#define W2T(slot_) { if (trace_blk && lane == 0 && run - run_beg < 64) g_w2_trace[(wid * 64 + (run - run_beg)) * 8 + (slot_)] = (unsigned)__builtin_readcyclecounter(); }
+#define W2T_VM() { __builtin_amdgcn_s_waitcnt(0x0f70); W2T(4) }
+#else
+#define W2T(slot_)
+#define W2T_VM()
+#endif
+#ifndef W2_PRIO_G0
+#define W2_PRIO_G0 1      // s_setprio of the MFMA phase, wave group 0 (converts first, then computes)
+#endif
+#ifndef W2_PRIO_G1
+// ... wave group 1 (computes first, then converts).  ABOVE group 0's: with equal priorities the arbiter favours the older
+// waves 0-3 whenever both waves of a SIMD have MFMAs ready, group 1 then finishes its MFMAs last and its conversion
+// phase runs with nobody on the matrix pipe (0.440 -> 0.395 ms on 256 -> 256 @64^2, n = 32; profiles/r04_wgrad_prio.txt)
+#define W2_PRIO_G1 2
+#endif
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __restrict__ x,
                                                                  const float* __restrict__ dy,
                                                                  float* __restrict__ dwt, WS3P k) {
@@ -1661,27 +1684,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 
   // two copies of the run loop rather than a branch inside one: each group's loop gets its own register allocation
   // (a branch in the body spilled 270 registers); both execute the same number of barriers
+#ifdef W2_TRACE
+  const bool trace_blk = blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0;
+#endif
   if (wi == 0) {
     for (int run = run_beg; run < run_end; ++run) {
       const int buf = (run - run_beg) & 1;
+      W2T(0)
       W2_PRIO(0);
+      W2T_VM()
       W2_LSTORE(buf ^ 1);
       W2_GLOAD(run + 2);
       __builtin_amdgcn_sched_barrier(0);
-      W2_PRIO(1);
+      W2T(1)
+      W2_PRIO(W2_PRIO_G0);
       W2_MMA_PHASE(buf);
+      W2T(2)
       __syncthreads();
+      W2T(3)
     }
   } else {
     for (int run = run_beg; run < run_end; ++run) {
       const int buf = (run - run_beg) & 1;
-      W2_PRIO(1);
+      W2T(0)
+      W2_PRIO(W2_PRIO_G1);
       W2_MMA_PHASE(buf);
       __builtin_amdgcn_sched_barrier(0);
+      W2T(1)
       W2_PRIO(0);
+      W2T_VM()
       W2_LSTORE(buf ^ 1);
       W2_GLOAD(run + 2);
+      W2T(2)
       __syncthreads();
+      W2T(3)
     }
   }
 #undef W2_GLOAD

@@ -43,7 +43,7 @@ const char* dfmir_last_error(void);
  * returns its length, or -1 when the option is unset.
  *   kernel selection: DFMIR_CONV_FP32, DFMIR_CONV_SPLIT=bf16x3, DFMIR_CONV3D_FP32, DFMIR_CONV_GENERIC=1,
  *     DFMIR_CONV_NO_CS, DFMIR_CONV_CS_PLAIN, DFMIR_CS_XCD_PAIR=n, DFMIR_WGRAD_V1, DFMIR_WGRAD_NO_SWAP,
- *     DFMIR_WGRAD_ATOMIC, DFMIR_NO_SMALL_WGRAD, DFMIR_NO_DIL2, DFMIR_NO_SMALL_TILES, DFMIR_GEMM_BIG_MIN=n,
+ *     DFMIR_NO_SMALL_WGRAD, DFMIR_NO_DIL2, DFMIR_NO_SMALL_TILES, DFMIR_GEMM_BIG_MIN=n,
  *     DFMIR_CONV3D_NO_PAIR, DFMIR_CONV3D_NO_M16, DFMIR_CONV3D_NO_TINY, DFMIR_CONV3D_NO_VEC,
  *     DFMIR_CONV3D_NO_MULTI, DFMIR_CONV3D_WGS=n, DFMIR_WSPLIT_WGS=n, DFMIR_CONV3D_NO_UPPHASE,
  *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED.

@@ -140,3 +140,29 @@ def test_distributed_helpers_single_process():
     assert D.allreduce_arenas([torch.zeros(3)]) == [] and D.allreduce_arenas([torch.zeros(3)], async_op=True) == []
     assert D.allreduce_max(1.5, "cpu") == 1.5
     D.barrier()
+
+
+def test_checkpoint_keys_equal_the_reference_written_files():
+    """Row N2 pinned against the REFERENCE, not the oracle: tests/golden/checkpoint_keys.json lists, for the three .pth
+    files the reference's own save_networks wrote (models/base_model.py:164-180; generated by
+    tests/golden/make_checkpoint_keys.py in the build container), every key in order with shape and dtype.  The HIP-side
+    modules -- which need no device to be constructed -- must produce the same list, so that reference-trained files load
+    with strict=True and files written here load into the reference."""
+    import json
+    import os
+    import torch
+    from dfmir_amd import networks as N
+    from dfmir_amd.voxelmorph import VxmDense
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_keys.json")))
+    sig = lambda net: [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
+    for ngf in (8, 64):
+        want = fx["size64_ngf%d" % ngf]
+        g = N.define_G(1, 1, ngf, 'resnet_9blocks', 'instance', False, 'xavier', 0.02, False, False, [], None)
+        assert sig(g) == want["G"]
+        r = VxmDense((64, 64), [[16, 32, 32, 64, 64, 64], [64, 64, 64, 32, 32, 32, 16]], int_steps=7, bidir=True)
+        assert sig(r) == want["R"]                         # incl. transformer.grid / integrate.transformer.grid buffers
+        import argparse
+        f = N.define_F(1, 'mlp_sample', 'instance', False, 'xavier', 0.02, False, [], argparse.Namespace(netF_nc=256))
+        # the MLPs are created from the five tapped features' channel counts (networks.py:587-595): 1, 2*ngf, 4*ngf x 3
+        f.create_mlp([torch.zeros(1, c, 1, 1) for c in (1, 2 * ngf, 4 * ngf, 4 * ngf, 4 * ngf)])
+        assert sig(f) == want["F"]

@@ -166,6 +166,46 @@ def test_training_driver_two_epochs(tmp_path):
 
 
 @pytest.mark.gpu
+def test_inference_driver_writes_the_reference_outputs(tmp_path):
+    """python -m dfmir_amd.test (reference test.py:14-91): train one epoch on a synthetic folder, then the test driver
+    with isTrain=False loads <epoch>_net_{G,R}.pth, registers every pair and writes deform_trainA/ and deform_label/ in
+    torchvision.utils.save_image's format; the label warp is checked against the oracle's nearest-mode SpatialTransformer
+    on the driver's own flow, the moved image against its own tensor."""
+    from dfmir_amd import test as test_driver
+    from dfmir_amd import train
+    from oracle import dfmir_oracle as O
+    root = os.path.join(str(tmp_path), "data")
+    _make_folders(root, n=3, size=64)
+    os.makedirs(os.path.join(root, "trainA_label"))
+    rng = np.random.RandomState(5)
+    for i in range(3):
+        lab = np.zeros((64, 64), dtype=np.uint8)                                 # the flow's size (test.py:80 hard-codes 256)
+        lab[16:48, 20:52] = 255
+        lab[rng.randint(0, 64, 40), rng.randint(0, 64, 40)] = 128
+        Image.fromarray(lab, mode="L").save(os.path.join(root, "trainA_label", "trainA_%02d.png" % i))
+    ck = os.path.join(str(tmp_path), "ck")
+    train.main(["--dataroot", root, "--name", "t", "--checkpoints_dir", ck, "--batch_size", "1", "--ngf", "8",
+                "--load_size", "64", "--crop_size", "64", "--n_epochs", "1", "--n_epochs_decay", "0",
+                "--print_freq", "2", "--save_epoch_freq", "1", "--num_threads", "0"])
+    assert not os.path.exists(os.path.join(ck, "t", "1_net_D.pth"))
+    recs = test_driver.main(["--dataroot", root, "--name", "t", "--checkpoints_dir", ck, "--ngf", "8", "--load_size", "64",
+                             "--crop_size", "64", "--phase", "train", "--epoch", "1", "--num_test", "2"])
+    assert [r["name"] for r in recs] == ["trainA_00.png", "trainA_01.png"]       # num_test bounds the loop (test.py:46)
+    for r in recs:
+        moved = np.asarray(Image.open(r["moved"]))
+        assert moved.shape == (64, 64, 3) and moved.dtype == np.uint8            # save_image: grey replicated to RGB
+        want = (r["warped_A"][0, 0] / 2 + 0.5).mul(255).add(0.5).clamp(0, 255).to("cpu", torch.uint8).numpy()
+        assert np.array_equal(moved[:, :, 0], want) and np.array_equal(moved[:, :, 1], want)
+        # the label: nearest-mode oracle (SpatialTransformer(mode='nearest'), test.py:80-81) on the driver's own flow
+        lab_in = test_driver.read_label(os.path.join(root, "trainA_label", r["name"]))
+        ref = O.spatial_transform(lab_in, r["flow"].cpu(), mode='nearest')
+        want = ref[0, 0].mul(255).add(0.5).clamp(0, 255).to(torch.uint8).numpy()
+        got = np.asarray(Image.open(r["label"]))
+        assert got.shape == (64, 64, 3)
+        assert float((got[:, :, 0] != want).mean()) < 2e-3                      # (a tie at exactly .5 voxels may round either way)
+
+
+@pytest.mark.gpu
 def test_captured_training_run_stays_finite_and_learns():
     """150 steps of the default step in capture mode (two eager steps, then one hipGraph replay per step) on synthetic
     slices: every loss stays finite, fresh device-drawn patch ids and inputs reach every replay, and the contrastive
