@@ -4,6 +4,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct Conv3P {
   int N, Cin, Cout, Hi, Wi, Ho, Wo, pad, pad_mode, act;

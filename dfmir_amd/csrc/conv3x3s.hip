@@ -745,7 +745,14 @@ extern "C" int dfmir_cs_trace_dump(unsigned* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_trace), sizeof(unsigned) * (8 * 32 * 8 + 8));
 }
 #define TRC(slot_) { if (trace_blk && lane == 0) trc[((grp * 4 + wid) * 32 + (h & 31)) * 8 + (slot_)] = (unsigned)__builtin_readcyclecounter(); }
+// per-workgroup wall-clock stamps of the LAST launch (100 MHz counter): [start, after prologue, end of main loop, end], + HW_ID, XCC_ID
+__device__ unsigned g_cs_wg[2048 * 6];
+extern "C" int dfmir_cs_wg_dump(unsigned* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cs_wg), sizeof(unsigned) * 2048 * 6);
+}
+#define WGT(slot_) { if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0) g_cs_wg[blockIdx.x * 6 + (slot_)] = (unsigned)wall_clock64(); }
 #else
+#define WGT(slot_)
 #define TRC(slot_)
 #endif
 // <RR, CPG, TH>: <*, 64, 8> = 128 output channels per workgroup on an 8 x 32 tile (RR: row-reuse compute phase);
@@ -776,6 +783,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
+  WGT(0)
+#ifdef CS_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0) {
+    g_cs_wg[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg(63492);       // HW_REG_HW_ID
+    g_cs_wg[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg(63508);       // HW_REG_XCC_ID
+  }
+#endif
   int bt = blockIdx.x, bm = blockIdx.y;
   if (k.xcd_pair == 1) { bm = (bt >> 3) & 1; bt = ((bt >> 4) << 3) + (bt & 7); }
   else if (k.xcd_pair >= 2) {   // XCD e = id & 7 walks a contiguous eighth of the tiles; xcd_pair - 1 cout slices of a tile back to back
@@ -883,6 +897,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   if (grp == 0) CS_LSTOREW();
   if (grp == 1) { CS_GLOADW(0); CS_GLOADX(1); }
   __syncthreads();
+  WGT(1)
 
   for (int h = 0; h < 2 * chunks; ++h) {
     const int c = h >> 1;
@@ -926,6 +941,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
     __syncthreads();
     TRC(2)
   }
+  WGT(2)
 #ifdef CS_TRACE
   if (trace_blk) {
     __syncthreads();
@@ -983,6 +999,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       }
     }
   }
+#ifdef CS_TRACE
+  __builtin_amdgcn_s_waitcnt(0x0f70);       // the stores have left the wave
+#endif
+  WGT(3)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1051,6 +1071,10 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
         kc.xcd_pair = xcd_pair == 1 ? (grid.y == 2 ? 1 : 0) : (int)grid.y + 1;
         if (kc.xcd_pair) grid = dim3((unsigned)(grid.y * nb), 1u);
       }
+      // (A persistent form -- one workgroup per CU walking its tiles in one chunk stream, a group's epilogue beside the other
+      // group's compute half-step -- was built and measured in round 4: bit-identical, 16 % SLOWER (0.404 vs 0.348 ms at
+      // n = 32).  The epilogue is a 33 MB burst of stores issued by all 256 CUs in lockstep, i.e. HBM-write-bound wherever
+      // it is placed, and the extra state cost the main loop its registers)
       if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
       else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
     } else {
@@ -1501,6 +1525,9 @@ extern "C" int dfmir_w2_trace_dump(unsigned* out) {
 #define W2T(slot_)
 #define W2T_VM()
 #endif
+#ifndef W2_PRIO_C
+#define W2_PRIO_C 0       // s_setprio of the convert + store phase
+#endif
 #ifndef W2_PRIO_G0
 #define W2_PRIO_G0 1      // s_setprio of the MFMA phase, wave group 0 (converts first, then computes)
 #endif
@@ -1515,7 +1542,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
                                                                  float* __restrict__ dwt, WS3P k) {
   constexpr int NSP = 2, BC = 128, CT = 64;
   using P = Prod<2>;
-  constexpr int XSLAB = 2 * CT;                      // units of one (split, dx, row) slab: [half][ci]
+#ifndef W2_CTPAD
+#define W2_CTPAD 0
+#endif
+  constexpr int CTP = CT + W2_CTPAD;                 // stride of a half inside a slab
+  constexpr int XSLAB = 2 * CTP;                     // units of one (split, dx, row) slab: [half][ci]
   constexpr int XCU = NSP * 3 * 4 * XSLAB, DYU = NSP * 2 * 2 * BC;
   __shared__ __attribute__((aligned(16))) u32x4 Xc[2 * XCU];
   __shared__ __attribute__((aligned(16))) u32x4 Dy[2 * DYU];
@@ -1554,10 +1585,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   }
   __syncthreads();
 
+#ifdef W2_HALF_LANES
+  // Loader roles (round 4): lanes laid out along the ROWS' bytes.  A run's operands are 64-byte row segments (16 pixels of
+  // one channel and row).  X: adjacent lanes take the two 32-byte halves of a segment (xu fastest), so one load
+  // instruction of a wave touches 32 cache lines; dY: four adjacent lanes take the four 16-byte quarters of a segment (16
+  // lines per instruction).  The channel-per-lane form this replaces (W2_CHANNEL_LANES) touched 64 lines per instruction
+  // and 6 instead of 5 loads per thread: ~3 000 tag look-ups of the CU's vector cache per ~3 500-cycle run -- the loads
+  // came back after 3 600 cycles, 1 500 of them exposed per run in wave group 1 (profiles/r04_wgrad_trace.txt).  A form
+  // with X in quarters too needed 24 ds_write_b64 + 8 DPP moves per thread for its three shifted copies and was slower.
+  const int xu = tid & 1, xc = (tid >> 1) & 63, xr = tid >> 7;
+  const int q = tid & 3, dc = tid >> 2;              // dY: quarter q of segment (channel dc, k-step / row j = 0, 1)
+  const bool xin = k.dbx != nullptr && blockIdx.z == 0 && (xr == 1 || xr == 2);     // rows of a run that are not halo
+#else
   // loader roles: X group (patch row xr 0..3, half xu, channel xc 0..63), dY group (k-step dk, half du, channel dc)
   const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
   const int dc = tid & (BC - 1), du = (tid >> 7) & 1, dk = tid >> 8;
   const bool xin = k.dbx != nullptr && blockIdx.z == 0 && (xr == 1 || xr == 2);     // rows of a run that are not halo
+#endif
   const float xscale = pow2f(ex), dscale = pow2f(edc[dc]), oscale = pow2f(-ex), oscale2 = pow2f(-edc[wc * 32 + l31]);
   const unsigned hw4 = (unsigned)HW * 4u;
   constexpr unsigned OOB = 0x80000000u;
@@ -1568,12 +1612,80 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+#ifdef W2_HALF_LANES
+  u32x4 rxa, rxb, rd[2];      // 8 px of X, 4 px of two dY segments
+  unsigned rxo;               // the pixel outside this half's end of the segment (left of half 0, right of half 1)
+  // past the last run of this workgroup the descriptors are empty (loads return zeros, stores are harmless)
+#define W2_GLOAD(run_)                                                                           \
+  {                                                                                              \
+    const bool live_ = (run_) < run_end;                                                         \
+    const int n_ = live_ ? (run_) / k.runs_per_img : 0;                                          \
+    const int q_ = live_ ? (run_) - n_ * k.runs_per_img : 0;                                     \
+    const int yp_ = q_ / k.runs_per_row, xs_ = q_ - yp_ * k.runs_per_row;                        \
+    const int y0_ = 2 * yp_, s0_ = 16 * xs_;                                                     \
+    const __amdgpu_buffer_rsrc_t bx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(x + (long long)n_ * k.Cin * HW), 0, live_ ? (unsigned)(k.Cin * HW) * 4u : 0u, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t bd_ = __builtin_amdgcn_make_buffer_rsrc(                        \
+        const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, live_ ? (unsigned)(k.Cout * HW) * 4u : 0u, 0x00020000); \
+    const bool cok_ = ci0 + xc < k.Cin;                                                          \
+    const unsigned cb_ = (unsigned)(ci0 + xc) * hw4;                                             \
+    int ry_ = y0_ - 1 + xr;                                                                      \
+    bool rok_ = (unsigned)ry_ < (unsigned)k.H;                                                   \
+    if (k.pad_mode == 1) { ry_ = ry_ < 0 ? -ry_ : (ry_ >= k.H ? 2 * (k.H - 1) - ry_ : ry_); rok_ = true; } \
+    const int rb_ = ry_ * k.W;                                                                   \
+    const bool in_ = xu == 0 ? s0_ > 0 : s0_ + 16 < k.W;                                         \
+    const int oc_ = xu == 0 ? (in_ ? s0_ - 1 : 1) : (in_ ? s0_ + 16 : k.W - 2);                  \
+    const unsigned xb_ = (rok_ && cok_) ? cb_ + (unsigned)(rb_ + s0_ + 8 * xu) * 4u : OOB;       \
+    rxa = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_, 0, 0);                                 \
+    rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
+    rxo = __builtin_amdgcn_raw_buffer_load_b32(bx_, (rok_ && cok_ && (in_ || k.pad_mode == 1)) ? cb_ + (unsigned)(rb_ + oc_) * 4u : OOB, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b128(bd_, (co0 + dc >= k.Cout) ? OOB              \
+          : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + j) * k.W + s0_ + 4 * q) * 4u, 0, 0);  \
+  }
+  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour -- the neighbour INSIDE the segment is the other
+  // half's first / last pixel, fetched from the adjacent lane (DPP row shift); pairs (0,1)..(8,9) make the units dx=0
+  // (cols -1..6) and dx=2 (cols 1..8), the odd pairing dx=1 is the even one shifted by a half.
+  // dY: a lane's 4 pixels are 8 bytes (per split) of the unit of half q >> 1.
+#define W2_LSTORE(buf_)                                                                          \
+  {                                                                                              \
+    float r[10];                                                                                 \
+    const unsigned fl_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)rxb[3], 0x111, 0xf, 0xf, true);   /* row_shr:1: lane - 1 */ \
+    const unsigned fr_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)rxa[0], 0x101, 0xf, 0xf, true);   /* row_shl:1: lane + 1 */ \
+    r[0] = __uint_as_float(xu == 0 ? rxo : fl_); r[9] = __uint_as_float(xu == 0 ? fr_ : rxo);    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
+    baccx += xin ? ((r[1] + r[2]) + (r[3] + r[4])) + ((r[5] + r[6]) + (r[7] + r[8])) : 0.f;      \
+    unsigned pa[5][NSP], pb[4][NSP];                                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s) pb[i][s] = __builtin_amdgcn_alignbit(pa[i + 1][s], pa[i][s], 16); \
+    _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
+      u32x4* dst = Xc + (buf_) * XCU + (s * 3 * 4 + xr) * XSLAB + xu * CTP + xc;                 \
+      dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
+      dst[4 * XSLAB] = u32x4{pb[0][s], pb[1][s], pb[2][s], pb[3][s]};                            \
+      dst[8 * XSLAB] = u32x4{pa[1][s], pa[2][s], pa[3][s], pa[4][s]};                            \
+    }                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+      float w[4];                                                                                \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) w[e] = __uint_as_float(rd[j][e]);            \
+      bacc += (w[0] + w[1]) + (w[2] + w[3]);                                                     \
+      unsigned d0[NSP], d1[NSP];                                                                 \
+      split_pair_scaled(w[0], w[1], dscale, d0);                                                 \
+      split_pair_scaled(w[2], w[3], dscale, d1);                                                 \
+      _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                            \
+        reinterpret_cast<u32x2*>(Dy + (buf_) * DYU + ((s * 2 + j) * 2 + (q >> 1)) * BC + dc)[q & 1] = u32x2{d0[s], d1[s]}; \
+    }                                                                                            \
+  }
+#else
   u32x4 rxa, rxb, rda, rdb;   // 8 px of X, 8 px of dY
   unsigned rxl, rxr;          // the pixel left / right of the X group
 
   // past the last run of this workgroup the descriptors are empty (loads return zeros, stores are harmless)
+#ifndef W2_KO
+#define W2_KO 0           // knock-out builds (timing experiments): 1 no global loads, 2 no LDS stores, 4 no conversion, 8 no MFMA phase
+#endif
 #define W2_GLOAD(run_)                                                                           \
-  {                                                                                              \
+  if (!(W2_KO & 1) || k.N < 0) {                                                                 \
     const bool live_ = (run_) < run_end;                                                         \
     const int n_ = live_ ? (run_) / k.runs_per_img : 0;                                          \
     const int q_ = live_ ? (run_) - n_ * k.runs_per_img : 0;                                     \
@@ -1611,11 +1723,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
     baccx += xin ? ((r[1] + r[2]) + (r[3] + r[4])) + ((r[5] + r[6]) + (r[7] + r[8])) : 0.f;      \
     unsigned pa[5][NSP], pb[4][NSP];                                                             \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
+    if (W2_KO & 4) { _Pragma("unroll") for (int i = 0; i < 5; ++i) { pa[i][0] = __float_as_uint(r[2 * i]); pa[i][1] = __float_as_uint(r[2 * i + 1]); } } \
+    else _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
       _Pragma("unroll") for (int s = 0; s < NSP; ++s) pb[i][s] = __builtin_amdgcn_alignbit(pa[i + 1][s], pa[i][s], 16); \
-    _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
-      u32x4* dst = Xc + (buf_) * XCU + ((s * 3 * 4 + xr) * 2 + xu) * CT + xc;                    \
+    if (!(W2_KO & 2) || k.N < 0) _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                 \
+      u32x4* dst = Xc + (buf_) * XCU + (s * 3 * 4 + xr) * XSLAB + xu * CTP + xc;                    \
       dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
       dst[4 * XSLAB] = u32x4{pb[0][s], pb[1][s], pb[2][s], pb[3][s]};                            \
       dst[8 * XSLAB] = u32x4{pa[1][s], pa[2][s], pa[3][s], pa[4][s]};                            \
@@ -1624,12 +1737,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(rda[e]); v[4 + e] = __uint_as_float(rdb[e]); } \
     bacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));                   \
     u32x4 sp[NSP];                                                                               \
+    if (W2_KO & 4) { sp[0] = rda; sp[1] = rdb; } else                                            \
     split8_s<NSP>(v, dscale, sp);                                                                \
-    _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[(buf_) * DYU + ((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
+    if (!(W2_KO & 2) || k.N < 0) _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[(buf_) * DYU + ((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
   }
+#endif
 
   // operand unit indices of this lane: A = Xc[((s*3 + dx)*4 + row)*2 + lhi][ci], B = Dy[(s*2 + ks)*2 + lhi][co]
-  const int abase = lhi * CT + wi * 32 + l31;
+  const int abase = lhi * CTP + wi * 32 + l31;
   const int bbase = lhi * BC + wc * 32 + l31;
   // the 12 operand units of a run in an order that never puts two 3-MFMA units (rows 0, 3) next to each other
   //   unit u -> (dx, row);  MFMAs of a unit: k-steps ks with 0 <= row - ks <= 2, tap = (row - ks)*3 + dx
@@ -1691,14 +1806,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     for (int run = run_beg; run < run_end; ++run) {
       const int buf = (run - run_beg) & 1;
       W2T(0)
-      W2_PRIO(0);
+      W2_PRIO(W2_PRIO_C);
       W2T_VM()
       W2_LSTORE(buf ^ 1);
       W2_GLOAD(run + 2);
       __builtin_amdgcn_sched_barrier(0);
       W2T(1)
       W2_PRIO(W2_PRIO_G0);
-      W2_MMA_PHASE(buf);
+      if (!(W2_KO & 8) || k.N < 0) W2_MMA_PHASE(buf);
       W2T(2)
       __syncthreads();
       W2T(3)
@@ -1708,10 +1823,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
       const int buf = (run - run_beg) & 1;
       W2T(0)
       W2_PRIO(W2_PRIO_G1);
-      W2_MMA_PHASE(buf);
+      if (!(W2_KO & 8) || k.N < 0) W2_MMA_PHASE(buf);
       __builtin_amdgcn_sched_barrier(0);
       W2T(1)
-      W2_PRIO(0);
+      W2_PRIO(W2_PRIO_C);
       W2T_VM()
       W2_LSTORE(buf ^ 1);
       W2_GLOAD(run + 2);

@@ -46,7 +46,7 @@ for n in (32, 48):
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / REPS
-        print("%-5s 256->256 @64^2 n=%d  %7.4f ms  %6.1f TF algorithmic  issued frac %.3f" % (name, n, ms, fl / ms / 1e9, 3 * fl / ms / 1e9 / 2500e3 * 1e3))
+        print("%-13s 256->256 @64^2 n=%d  %7.4f ms  %6.1f TF algorithmic  issued frac %.3f" % (name, n, ms, fl / ms / 1e9, 3 * fl / ms / 1e9 / 2500e3 * 1e3))
 
 h = ctypes.CDLL(dfmir_amd.LIB_PATH)
 if hasattr(h, "dfmir_w2_trace_dump"):
@@ -72,3 +72,51 @@ if hasattr(h, "dfmir_w2_trace_dump"):
     for r in range(8, 12):
         base = int(t[0, r, 0])
         print("  run %d: " % r + "  ".join("w%d %s" % (wv, [int((int(v) - base) & 0xffffffff) if ((int(v) - base) & 0xffffffff) < 1 << 30 else int((int(v) - base) & 0xffffffff) - (1 << 32) for v in t[wv, r]]) for wv in (0, 4)))
+
+if hasattr(h, "dfmir_cs_trace_dump"):
+    import numpy as np
+    buf = np.zeros(8 * 32 * 8 + 8, dtype=np.uint32)
+    h.dfmir_cs_trace_dump(ctypes.c_void_p(buf.ctypes.data))
+    t = buf[:2048].reshape(8, 32, 8).astype(np.int64)          # [group*4 + wave][half-step & 31][slot]
+    d = lambda a, b: (a - b) & 0xffffffff
+    print("forward trace (cycles), one workgroup, half-steps 2..29: [0] start [1] work done [2] after barrier [3] loads arrived (store side) [4] weights stored")
+    for g in range(2):
+        for wv in range(4):
+            w = g * 4 + wv
+            comp = [hh for hh in range(2, 30) if (hh & 1) == g]
+            stor = [hh for hh in range(2, 30) if (hh & 1) != g]
+            c_work = np.mean([d(t[w, hh, 1], t[w, hh, 0]) for hh in comp])
+            c_bar = np.mean([d(t[w, hh, 2], t[w, hh, 1]) for hh in comp])
+            s_wait = np.mean([d(t[w, hh, 3], t[w, hh, 0]) for hh in stor])
+            s_work = np.mean([d(t[w, hh, 1], t[w, hh, 3]) for hh in stor])
+            s_bar = np.mean([d(t[w, hh, 2], t[w, hh, 1]) for hh in stor])
+            print("  group %d wave %d: compute half-step: work %6.0f barrier %5.0f | store half-step: load wait %5.0f convert+store %5.0f barrier %6.0f"
+                  % (g, wv, c_work, c_bar, s_wait, s_work, s_bar))
+    hs = [int(d(t[0, hh + 1, 0], t[0, hh, 0])) for hh in range(0, 31)]
+    print("  half-step lengths (wave 0):", hs)
+    print("  whole kernel of that workgroup: %d cycles, %d wall-clock ticks (100 MHz)" % (int(d(buf[2049], buf[2048])), int(d(buf[2051], buf[2050]))))
+
+if hasattr(h, "dfmir_cs_wg_dump"):
+    import numpy as np
+    nwg = 1536 if which != "fwd32" else 1024                     # the last launch was n = 48: 48 * 16 tiles * 2 cout halves
+    buf = np.zeros(2048 * 6, dtype=np.uint32)
+    h.dfmir_cs_wg_dump(ctypes.c_void_p(buf.ctypes.data))
+    w = buf.reshape(2048, 6)[:nwg].astype(np.int64)
+    t0 = w[:, 0].min()
+    st, pro, lp, en = [(w[:, i] - t0) / 100.0 for i in range(4)]   # microseconds
+    cu = (w[:, 5] & 15) * 65536 + (w[:, 4] & 0xffff00)           # XCC id + (SE, SH, CU) bits of HW_ID (wave / SIMD bits dropped)
+    print("forward kernel, per-workgroup wall clock of the last launch (%d workgroups, %d distinct CUs):" % (nwg, len(set(cu.tolist()))))
+    print("  kernel span %.1f us; workgroup body mean %.1f us (prologue %.1f, main loop %.1f, epilogue %.1f)"
+          % (en.max(), (en - st).mean(), (pro - st).mean(), (lp - pro).mean(), (en - lp).mean()))
+    gaps, per_cu, idle_tail = [], [], []
+    for c in set(cu.tolist()):
+        idx = np.where(cu == c)[0]
+        o = idx[np.argsort(st[idx])]
+        per_cu.append(len(o))
+        for a, b in zip(o[:-1], o[1:]):
+            gaps.append(st[b] - en[a])
+        idle_tail.append(en.max() - en[o[-1]])
+    gaps = np.array(gaps)
+    print("  workgroups per CU: min %d max %d; gap between consecutive workgroups of a CU: mean %.2f us, median %.2f, max %.2f; "
+          "first start spread %.2f us; idle at the end: mean %.1f us max %.1f"
+          % (min(per_cu), max(per_cu), gaps.mean(), np.median(gaps), gaps.max(), st[[np.where(cu == c)[0][np.argmin(st[np.where(cu == c)[0]])] for c in set(cu.tolist())]].max(), np.mean(idle_tail), np.max(idle_tail)))

@@ -589,11 +589,26 @@ def test_full_size_gradients_vs_fp64_oracle(O, capsys):
         print("\n  rel. L2 error vs the fp64 gradient (HIP, fp32 CPU oracle): worst ratios, then worst absolute")
         for e_hip, e_cpu, k in worst:
             print("    %-44s %.2e   %.2e" % (k, e_hip, e_cpu))
-    # measured (MI355X, round 2): HIP 1e-5 .. 2.7e-3 on G / R (the fp32 CPU oracle: 3e-6 .. 2.8e-3, the same layers
-    # at the top: model.1 / 4 / 8 / 12, where the backward is deepest), worst ratio HIP : CPU = 5.0 (model.22);
-    # netF's mlp_0.2.weight 1.1e-2 vs 2.8e-3.  Bounds = measured x 3 in absolute terms, and within 6x of fp32 PyTorch.
+    # What the per-layer ratio measures (round 4, profiles/r04_relu_flips.txt, r04_wgrad_precision.txt, r04_forward_error.txt):
+    # a gradient's distance to fp64 is set by the handful of ReLU decisions behind InstanceNorm that land on the other
+    # side of zero -- 12 of 18.9 M on the HIP path, 8 for fp32 PyTorch, in different layers: ONE flip moves the weight
+    # gradient of the conv in front of it by ~1 / sqrt(2 M) = 7e-4, the size of every entry in this table.  The per-layer
+    # ratio is therefore a lottery with a few tickets per layer (model.19.conv_block.1: 3 flips HIP vs 0 CPU -> 5.7x;
+    # model.14.conv_block.1: 0 vs 3 -> 0.5x), and it does NOT depend on the operand split: DFMIR_CONV_FP32=1 (exact fp32
+    # products) and DFMIR_NO_CH_SCALE give the same table.  What is systematic is a factor ~2 in the forward activations'
+    # distance to fp64 (one fp32 accumulation chain over K = 2304 per output: 5e-7 per conv against mkldnn's blocked
+    # 1.7e-7), hence ~1.5x the flips.  Bounds: the GEOMETRIC MEAN of the ratio over G's layers within 2.5x of fp32
+    # PyTorch (measured 1.8), every single layer within 6x (its lottery) and within 3x of the worst error fp32 PyTorch
+    # itself shows on any layer of the same network (HIP's worst: 2.7e-3, PyTorch's: 2.8e-3).
+    g_rows = [(e_hip, e_cpu) for e_hip, e_cpu, k in rows if k.startswith("G.")]
+    gmean = float(np.exp(np.mean([np.log((eh + 1e-12) / (ec + 1e-12)) for eh, ec in g_rows])))
+    with capsys.disabled():
+        print("    geometric mean of HIP : fp32-CPU over G's layers: %.2f" % gmean)
+    assert gmean <= 2.5, gmean
+    worst_cpu = {t: max(ec for eh, ec, k in rows if k.startswith(t)) for t in ("G.", "R.", "F.")}
     for e_hip, e_cpu, k in rows:
         assert e_hip <= 6.0 * e_cpu + 2e-5, "%s: HIP %.3e vs fp64, fp32 CPU oracle %.3e" % (k, e_hip, e_cpu)
+        assert e_hip <= 3.0 * worst_cpu[k[:2]] + 2e-5, "%s: HIP %.3e vs fp64, worst fp32 CPU layer %.3e" % (k, e_hip, worst_cpu[k[:2]])
         assert e_hip <= (3.5e-2 if k.startswith("F.") else 8e-3), "%s: HIP %.3e vs fp64" % (k, e_hip)
 
 
@@ -664,8 +679,8 @@ def test_batch16_step_vs_oracle(O, capsys):
         print("\n  batch 16: rel. L2 distance of the HIP gradients to the fp32 CPU oracle's, worst 6")
         for e, k in sorted(rows, reverse=True)[:6]:
             print("    %-44s %.2e" % (k, e))
-    for e, k in rows:      # measured (MI355X, round 3): worst 2.8e-4 (G.model.1.weight, the deepest backward)
-        assert e <= 1e-3, "%s: %.3e" % (k, e)
+    for e, k in rows:      # measured (MI355X, rounds 3 / 4): worst 2.8e-4 .. 2.95e-4 (G.model.1.weight, the deepest backward)
+        assert e <= 5e-4, "%s: %.3e" % (k, e)
 
 
 def test_batch16_equals_per_sample_runs(O):
