@@ -1525,6 +1525,9 @@ extern "C" int dfmir_w2_trace_dump(unsigned* out) {
 #define W2T(slot_)
 #define W2T_VM()
 #endif
+#ifndef W2_ALT
+#define W2_ALT 0
+#endif
 #ifndef W2_PRIO_C
 #define W2_PRIO_C 0       // s_setprio of the convert + store phase
 #endif
@@ -1585,23 +1588,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   }
   __syncthreads();
 
-#ifdef W2_HALF_LANES
-  // Loader roles (round 4): lanes laid out along the ROWS' bytes.  A run's operands are 64-byte row segments (16 pixels of
-  // one channel and row).  X: adjacent lanes take the two 32-byte halves of a segment (xu fastest), so one load
-  // instruction of a wave touches 32 cache lines; dY: four adjacent lanes take the four 16-byte quarters of a segment (16
-  // lines per instruction).  The channel-per-lane form this replaces (W2_CHANNEL_LANES) touched 64 lines per instruction
-  // and 6 instead of 5 loads per thread: ~3 000 tag look-ups of the CU's vector cache per ~3 500-cycle run -- the loads
-  // came back after 3 600 cycles, 1 500 of them exposed per run in wave group 1 (profiles/r04_wgrad_trace.txt).  A form
-  // with X in quarters too needed 24 ds_write_b64 + 8 DPP moves per thread for its three shifted copies and was slower.
-  const int xu = tid & 1, xc = (tid >> 1) & 63, xr = tid >> 7;
-  const int q = tid & 3, dc = tid >> 2;              // dY: quarter q of segment (channel dc, k-step / row j = 0, 1)
-  const bool xin = k.dbx != nullptr && blockIdx.z == 0 && (xr == 1 || xr == 2);     // rows of a run that are not halo
-#else
   // loader roles: X group (patch row xr 0..3, half xu, channel xc 0..63), dY group (k-step dk, half du, channel dc)
   const int xc = tid & 63, xu = (tid >> 6) & 1, xr = tid >> 7;
   const int dc = tid & (BC - 1), du = (tid >> 7) & 1, dk = tid >> 8;
   const bool xin = k.dbx != nullptr && blockIdx.z == 0 && (xr == 1 || xr == 2);     // rows of a run that are not halo
-#endif
   const float xscale = pow2f(ex), dscale = pow2f(edc[dc]), oscale = pow2f(-ex), oscale2 = pow2f(-edc[wc * 32 + l31]);
   const unsigned hw4 = (unsigned)HW * 4u;
   constexpr unsigned OOB = 0x80000000u;
@@ -1612,71 +1602,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-#ifdef W2_HALF_LANES
-  u32x4 rxa, rxb, rd[2];      // 8 px of X, 4 px of two dY segments
-  unsigned rxo;               // the pixel outside this half's end of the segment (left of half 0, right of half 1)
-  // past the last run of this workgroup the descriptors are empty (loads return zeros, stores are harmless)
-#define W2_GLOAD(run_)                                                                           \
-  {                                                                                              \
-    const bool live_ = (run_) < run_end;                                                         \
-    const int n_ = live_ ? (run_) / k.runs_per_img : 0;                                          \
-    const int q_ = live_ ? (run_) - n_ * k.runs_per_img : 0;                                     \
-    const int yp_ = q_ / k.runs_per_row, xs_ = q_ - yp_ * k.runs_per_row;                        \
-    const int y0_ = 2 * yp_, s0_ = 16 * xs_;                                                     \
-    const __amdgpu_buffer_rsrc_t bx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
-        const_cast<float*>(x + (long long)n_ * k.Cin * HW), 0, live_ ? (unsigned)(k.Cin * HW) * 4u : 0u, 0x00020000); \
-    const __amdgpu_buffer_rsrc_t bd_ = __builtin_amdgcn_make_buffer_rsrc(                        \
-        const_cast<float*>(dy + (long long)n_ * k.Cout * HW), 0, live_ ? (unsigned)(k.Cout * HW) * 4u : 0u, 0x00020000); \
-    const bool cok_ = ci0 + xc < k.Cin;                                                          \
-    const unsigned cb_ = (unsigned)(ci0 + xc) * hw4;                                             \
-    int ry_ = y0_ - 1 + xr;                                                                      \
-    bool rok_ = (unsigned)ry_ < (unsigned)k.H;                                                   \
-    if (k.pad_mode == 1) { ry_ = ry_ < 0 ? -ry_ : (ry_ >= k.H ? 2 * (k.H - 1) - ry_ : ry_); rok_ = true; } \
-    const int rb_ = ry_ * k.W;                                                                   \
-    const bool in_ = xu == 0 ? s0_ > 0 : s0_ + 16 < k.W;                                         \
-    const int oc_ = xu == 0 ? (in_ ? s0_ - 1 : 1) : (in_ ? s0_ + 16 : k.W - 2);                  \
-    const unsigned xb_ = (rok_ && cok_) ? cb_ + (unsigned)(rb_ + s0_ + 8 * xu) * 4u : OOB;       \
-    rxa = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_, 0, 0);                                 \
-    rxb = __builtin_amdgcn_raw_buffer_load_b128(bx_, xb_ == OOB ? OOB : xb_ + 16u, 0, 0);        \
-    rxo = __builtin_amdgcn_raw_buffer_load_b32(bx_, (rok_ && cok_ && (in_ || k.pad_mode == 1)) ? cb_ + (unsigned)(rb_ + oc_) * 4u : OOB, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
-      rd[j] = __builtin_amdgcn_raw_buffer_load_b128(bd_, (co0 + dc >= k.Cout) ? OOB              \
-          : (unsigned)(co0 + dc) * hw4 + (unsigned)((y0_ + j) * k.W + s0_ + 4 * q) * 4u, 0, 0);  \
-  }
-  // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour -- the neighbour INSIDE the segment is the other
-  // half's first / last pixel, fetched from the adjacent lane (DPP row shift); pairs (0,1)..(8,9) make the units dx=0
-  // (cols -1..6) and dx=2 (cols 1..8), the odd pairing dx=1 is the even one shifted by a half.
-  // dY: a lane's 4 pixels are 8 bytes (per split) of the unit of half q >> 1.
-#define W2_LSTORE(buf_)                                                                          \
-  {                                                                                              \
-    float r[10];                                                                                 \
-    const unsigned fl_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)rxb[3], 0x111, 0xf, 0xf, true);   /* row_shr:1: lane - 1 */ \
-    const unsigned fr_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)rxa[0], 0x101, 0xf, 0xf, true);   /* row_shl:1: lane + 1 */ \
-    r[0] = __uint_as_float(xu == 0 ? rxo : fl_); r[9] = __uint_as_float(xu == 0 ? fr_ : rxo);    \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
-    baccx += xin ? ((r[1] + r[2]) + (r[3] + r[4])) + ((r[5] + r[6]) + (r[7] + r[8])) : 0.f;      \
-    unsigned pa[5][NSP], pb[4][NSP];                                                             \
-    _Pragma("unroll") for (int i = 0; i < 5; ++i) split_pair_scaled(r[2 * i], r[2 * i + 1], xscale, pa[i]); \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
-      _Pragma("unroll") for (int s = 0; s < NSP; ++s) pb[i][s] = __builtin_amdgcn_alignbit(pa[i + 1][s], pa[i][s], 16); \
-    _Pragma("unroll") for (int s = 0; s < NSP; ++s) {                                            \
-      u32x4* dst = Xc + (buf_) * XCU + (s * 3 * 4 + xr) * XSLAB + xu * CTP + xc;                 \
-      dst[0] = u32x4{pa[0][s], pa[1][s], pa[2][s], pa[3][s]};                                    \
-      dst[4 * XSLAB] = u32x4{pb[0][s], pb[1][s], pb[2][s], pb[3][s]};                            \
-      dst[8 * XSLAB] = u32x4{pa[1][s], pa[2][s], pa[3][s], pa[4][s]};                            \
-    }                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
-      float w[4];                                                                                \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) w[e] = __uint_as_float(rd[j][e]);            \
-      bacc += (w[0] + w[1]) + (w[2] + w[3]);                                                     \
-      unsigned d0[NSP], d1[NSP];                                                                 \
-      split_pair_scaled(w[0], w[1], dscale, d0);                                                 \
-      split_pair_scaled(w[2], w[3], dscale, d1);                                                 \
-      _Pragma("unroll") for (int s = 0; s < NSP; ++s)                                            \
-        reinterpret_cast<u32x2*>(Dy + (buf_) * DYU + ((s * 2 + j) * 2 + (q >> 1)) * BC + dc)[q & 1] = u32x2{d0[s], d1[s]}; \
-    }                                                                                            \
-  }
-#else
   u32x4 rxa, rxb, rda, rdb;   // 8 px of X, 8 px of dY
   unsigned rxl, rxr;          // the pixel left / right of the X group
 
@@ -1741,7 +1666,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     split8_s<NSP>(v, dscale, sp);                                                                \
     if (!(W2_KO & 2) || k.N < 0) _Pragma("unroll") for (int s = 0; s < NSP; ++s) Dy[(buf_) * DYU + ((s * 2 + dk) * 2 + du) * BC + dc] = sp[s]; \
   }
-#endif
 
   // operand unit indices of this lane: A = Xc[((s*3 + dx)*4 + row)*2 + lhi][ci], B = Dy[(s*2 + ks)*2 + lhi][co]
   const int abase = lhi * CTP + wi * 32 + l31;
@@ -1774,10 +1698,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     _Pragma("unroll") for (int u = 0; u < 12; ++u) {                                             \
       if (u + W2_LEAD < 12) W2_LOADA((u + W2_LEAD) % (W2_LEAD + 1), u + W2_LEAD)                 \
       const int dx_ = W2_UDX(u), row_ = W2_UROW(u);                                              \
+      /* W2_ALT: the two taps a unit feeds take turns (no two consecutive MFMAs on one accumulator) */ \
+      _Pragma("unroll") for (int qo = 0; qo < (W2_ALT ? P::N : 1); ++qo)                         \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                         \
         const int ty_ = row_ - ks;                                                               \
         if (ty_ >= 0 && ty_ <= 2) {                                                              \
-          _Pragma("unroll") for (int q = 0; q < P::N; ++q)                                       \
+          _Pragma("unroll") for (int q = (W2_ALT ? qo : 0); q < (W2_ALT ? qo + 1 : P::N); ++q)   \
             acc[ty_ * 3 + dx_] = mma16<NSP>(a[u % (W2_LEAD + 1)][P::A[q]], b[ks][P::B[q]], acc[ty_ * 3 + dx_]); \
         }                                                                                        \
       }                                                                                          \
@@ -1888,6 +1814,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
   }
 }
 
+// (Round 4 built and measured two restructurings of this kernel, both bit-compatible and both SLOWER, so neither is kept
+// -- profiles/r04_wgrad_ring_ab.txt, r04_wgrad_trace_ko.txt: (1) a row-ring form: runs walk down a 16-pixel column strip,
+// converted X rows live in a ring of six LDS row slots so that a run stages two new rows instead of four, wave group 0
+// stages X and group 1 stages dY in 64-byte segments (16 instead of 64 cache lines per load instruction): 0.391 ms against
+// 0.379 ms; (2) the same with the conversion cut into slices between the MFMAs of the same wave: 0.413 ms.  The untraced
+// knock-outs say why: with loads, conversion AND LDS stores removed this kernel still takes 0.329 of its 0.386 ms -- the
+// MFMA phases themselves (operand reads one unit ahead, one barrier per 2 x 54 MFMAs, the atomic tail) are what is left.)
 // does df_conv3x3_split_wgrad_try run this geometry with swapped roles (and therefore leave db to the caller)?
 bool df_conv3x3_split_wgrad_swaps(const DfConvGeom* g) {
   static DfOptFlag ns_o{"DFMIR_WGRAD_NO_SWAP"}, v1_o{"DFMIR_WGRAD_V1"};
