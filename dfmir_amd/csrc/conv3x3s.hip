@@ -44,6 +44,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), a in the low half
   const f32x2 v = {a, b};
@@ -630,7 +631,7 @@ __device__ __forceinline__ void cs_mma_chunk(const u32x4* __restrict__ Ab, const
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[2 * i + j] = mma16<2>(a[t & 1][i][P::A[q]], b[t & 1][j][P::B[q]], acc[2 * i + j]);
+          acc[2 * i + j] = mma16<2>(b[t & 1][j][P::B[q]], a[t & 1][i][P::A[q]], acc[2 * i + j]);   // rows = pixels, columns = couts
     const int nds = t < 8 ? 8 : 0, nvm = (3 * t + 3 <= 25) ? 3 : (25 - 3 * t > 0 ? 25 - 3 * t : 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
@@ -713,7 +714,7 @@ __device__ __forceinline__ void cs_mma_chunk_rr(const u32x4* __restrict__ Ab, co
     for (int q = 0; q < P::N; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[j] = mma16<2>(a[st][P::A[q]], xr[kx][ky + j][P::B[q]], acc[j]);
+        acc[j] = mma16<2>(xr[kx][ky + j][P::B[q]], a[st][P::A[q]], acc[j]);   // rows = pixels, columns = couts
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -737,6 +738,10 @@ struct ConvCsP {
   // 1-D grid of 2 x tiles workgroups, the two cout halves of a pixel tile on the SAME XCD, 8 dispatch slots apart:
   // id = 16 g + 8 h + r  ->  tile 8 g + r, half h (workgroup ids go round-robin over the 8 XCDs, one L2 each)
   int xcd_pair;
+  // de-phasing of the CUs: workgroup b < 256 of the first wave of workgroups starts b * dephase / 256 ticks (10 ns) late,
+  // so that the CUs' epilogues (a 33 MB burst of stores when all 256 run in lockstep) spread over the main loops
+  int dephase;
+  int vec4;               // Wo % 4 == 0 and y / res 16-byte aligned: the epilogue moves float4
 };
 
 #ifdef CS_TRACE
@@ -783,6 +788,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
+  if (k.dephase > 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned wait = blockIdx.x * (unsigned)k.dephase >> 8;
+    while ((unsigned)(wall_clock64() - t0) < wait) __builtin_amdgcn_s_sleep(4);
+  }
   WGT(0)
 #ifdef CS_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 2048 && blockIdx.y == 0) {
@@ -938,6 +948,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       }
     }
     TRC(1)
+    // the last half-step is group 1's compute of the last chunk: group 0 has nothing left to stage and goes straight to
+    // its epilogue (its 64 KB of stores leave beside group 1's MFMAs instead of after them: a CU stores at ~12 B/clk)
+#ifndef CS_NO_EARLY_EPI
+    if (h + 1 < 2 * chunks)
+#endif
     __syncthreads();
     TRC(2)
   }
@@ -958,44 +973,81 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 #undef CS_LSTOREW
 #undef CS_LSTOREX
 
+  // Epilogue.  The MFMAs ran with rows = the 32 pixels of a tile row and columns = 32 output channels, so a lane holds
+  // ONE output channel (l31) and, per accumulator quad q, the 4 consecutive pixels 8q + 4 lhi .. + 3 of each of its 4 tile
+  // rows: 16 16-byte stores per lane instead of 64 4-byte ones (the store tail of a workgroup is bound by the number of
+  // store instructions: 8.9 us of an 84-us workgroup with dword stores).  vec4 needs Wo % 4 == 0 and 16-byte aligned bases.
   float* yb = y + (long long)n * k.Cout * HWo;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int i = CPG == 32 ? 0 : (RR ? (wid & 1) : (b >> 1));   // 32-cout block of the group's couts
     const int row = RR ? 4 * rowgrp + b : 2 * wid + (b & 1);
-    const int oy = oy0 + row, ox = ox0 + l31;
-    if (oy >= k.Ho || ox >= k.Wo) continue;
-    const int q = oy * k.Wo + ox;
-    const bool on_ring = k.ring != nullptr && (oy == 1 || oy == k.Ho - 2 || ox == 1 || ox == k.Wo - 2);
-    float rv[16];                                            // residual: all 16 loads in flight before the first use
+    const int oy = oy0 + row;
+    const int cc = CPG * grp + i * 32 + l31, co = m0 + cc;
+#ifdef CS_KO_EPI
+    if (oy >= k.Ho || co >= k.Cout || acc[b][0] != 12345.678f) continue;    // knock-out: no epilogue loads / stores
+#else
+    if (oy >= k.Ho || co >= k.Cout) continue;
+#endif
+    const float bv = bs[cc], osc = oscale * oscale2;
+    const long long rowoff = (long long)co * HWo + (long long)oy * k.Wo;
+    const float* rb = k.res ? k.res + (long long)n * k.Cout * HWo + rowoff : nullptr;
+    const float* rg = k.ring ? k.ring + ((long long)n * 4 * k.Cout + co) * k.ring_rl : nullptr;
+    const long long ss = (long long)k.Cout * k.ring_rl;          // strip stride: top, bottom, left, right
+    const bool row_ring = rg != nullptr && (oy == 1 || oy == k.Ho - 2);
+    float4 rv[4];                                                // residual: all loads in flight before the first use
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-    if (k.res) {
-      const float* rb = k.res + (long long)n * k.Cout * HWo + q;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + CPG * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-        if (co < k.Cout) rv[r] = rb[(long long)co * HWo];
+    for (int q = 0; q < 4; ++q) {
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ox = ox0 + 8 * q + 4 * lhi;
+      if (rb && ox < k.Wo) {
+        if (k.vec4) rv[q] = *reinterpret_cast<const float4*>(rb + ox);
+        else {
+          rv[q].x = rb[ox];
+          if (ox + 1 < k.Wo) rv[q].y = rb[ox + 1];
+          if (ox + 2 < k.Wo) rv[q].z = rb[ox + 2];
+          if (ox + 3 < k.Wo) rv[q].w = rb[ox + 3];
+        }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cc = CPG * grp + i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-      const int co = m0 + cc;
-      if (co < k.Cout) {
-        float v = acc[b][r] * oscale * oscale2 + bs[cc];
-        if (k.act == 1) v = v > 0.f ? v : v * k.slope;
-        else if (k.act == 2) v = tanhf(v);
-        v += rv[r];
-        if (on_ring) {                                       // the reflection folds frame positions onto this pixel
-          const float* rg = k.ring + ((long long)n * 4 * k.Cout + co) * k.ring_rl;
-          const long long ss = (long long)k.Cout * k.ring_rl;      // strip stride: top, bottom, left, right
-          if (oy == 1) v += rg[ox + 1] + (ox == 1 ? rg[0] : 0.f) + (ox == k.Wo - 2 ? rg[k.Wo + 1] : 0.f);
-          if (oy == k.Ho - 2) v += rg[ss + ox + 1] + (ox == 1 ? rg[ss] : 0.f) + (ox == k.Wo - 2 ? rg[ss + k.Wo + 1] : 0.f);
-          if (ox == 1) v += rg[2 * ss + oy + 1];
-          if (ox == k.Wo - 2) v += rg[3 * ss + oy + 1];
+    for (int q = 0; q < 4; ++q) {
+      const int ox = ox0 + 8 * q + 4 * lhi;
+      if (ox >= k.Wo) continue;
+      float v[4];
+      const float r4[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[b][4 * q + e] * osc + bv;
+        if (k.act == 1) t = t > 0.f ? t : t * k.slope;
+        else if (k.act == 2) t = tanhf(t);
+        v[e] = t + r4[e];
+      }
+      if (rg) {                                                  // the reflection folds frame positions onto ring pixels
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int xx = ox + e;
+          if (xx < k.Wo) {
+            if (row_ring) {
+              if (oy == 1) v[e] += rg[xx + 1] + (xx == 1 ? rg[0] : 0.f) + (xx == k.Wo - 2 ? rg[k.Wo + 1] : 0.f);
+              if (oy == k.Ho - 2) v[e] += rg[ss + xx + 1] + (xx == 1 ? rg[ss] : 0.f) + (xx == k.Wo - 2 ? rg[ss + k.Wo + 1] : 0.f);
+            }
+            if (xx == 1) v[e] += rg[2 * ss + oy + 1];
+            if (xx == k.Wo - 2) v[e] += rg[3 * ss + oy + 1];
+          }
         }
-        yb[(long long)co * HWo + q] = v;
+      }
+      float* yp = yb + rowoff + ox;
+#ifdef CS_NT_STORE
+      if (k.vec4) __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(yp));
+#else
+      if (k.vec4) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
+      else {
+        yp[0] = v[0];
+        if (ox + 1 < k.Wo) yp[1] = v[1];
+        if (ox + 2 < k.Wo) yp[2] = v[2];
+        if (ox + 3 < k.Wo) yp[3] = v[3];
       }
     }
   }
@@ -1057,8 +1109,11 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
     // waste 37 % on the 66 x 66 padded frames the dgrad of a reflect-padded conv produces (those go through the
     // zero-padded form + ring kernel instead; what still arrives here unfilled stays on the flat-run kernel below)
     ConvCsP kc{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->Ho, g->Wo, p, g->pad_mode, g->act, g->slope, tlx, tly, res,
-               ring, ring_rl, 0};
+               ring, ring_rl, 0, 0, 0};
+    kc.vec4 = (g->Wo % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0) ? 1 : 0;
+    static DfOptInt dephase_o{"DFMIR_CS_DEPHASE", 0};
     const long long nb = (long long)g->N * tlx * tly;
+    if (nb * ((g->Cout + 127) / 128) >= 512) kc.dephase = dephase_o.get();
     if (g->Cout > 64) {
       dim3 grid((unsigned)nb, (unsigned)((g->Cout + 127) / 128));
       // the two cout halves of a pixel tile on the same XCD (one L2): measured 83.5 -> 83.0 ms per 2-D step, issued

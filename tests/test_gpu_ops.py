@@ -69,6 +69,9 @@ CONV2D = [
     # ragged everything (Cin 20, 40 of 64 couts, last tile row 14 of 16 rows, 60 of 64 columns)
     (48, 64, 3, 1, 1, True, 1, 2, 32, 64),
     (20, 40, 3, 1, 1, False, 0, 1, 30, 60),
+    # width not a multiple of 4: the shared-tile kernel's epilogue leaves its float4 form (scalar stores, ragged last quad)
+    (64, 128, 3, 1, 1, True, 0, 1, 16, 62),
+    (32, 64, 3, 1, 1, False, 1, 2, 31, 61),
     # small-channel wgrad kernel (16x16x4 MFMA, all input channels' patch in LDS): ragged row blocks (34*9 = 306 rows),
     # 2 output channels, 48 input channels with reflect padding, ragged tiles
     (34, 16, 3, 1, 1, False, 0, 2, 64, 96),
