@@ -668,14 +668,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
   C3M_OFFS(0)
 
   // this lane's B positions (plane wid, row j, column l15) and the patch offsets of its taps 4 ks + kg
-  int pbase[NJ], toffs[NKS];
+  // ROW-REUSE k-steps (round 4).  The 27 taps are walked as two sets of four (dz, dx) pairs -- S0 = pairs 0-3, S1 = pairs 4-7,
+  // pair p = (dz = p / 3, dx = p % 3), k group kg <-> pair 4 S + kg -- times the three dy, plus one mixed k-step for pair 8
+  // (dz 2, dx 2: k group kg <-> dy = kg, group 3 = the zero tap 27).  Within a set the B operand of (patch row r) serves
+  // tile row j = r - dy for dy = 0, 1, 2: 10 row reads feed the 24 (row, dy) products of a set instead of 24 reads --
+  // 28 B reads per chunk instead of 56 (the LDS, not the matrix pipe, was what this kernel waited for: 75 % LDS cycles
+  // at 100 % pipe, 39 % pipe busy measured).  Same 7 x 8 x 3 MFMAs per chunk; the order of the taps in the sum changes.
+  const int prow0 = (wid * HY) * HX + l15;                    // patch row r of this wave's plane: prow0 + r * HX
+  int soff[2], tb[2];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) pbase[j] = (wid * HY + j) * HX + l15;
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int t = (4 * ks + kg) < 27 ? 4 * ks + kg : 26;     // tap 27: zero weights, any valid offset
-    toffs[ks] = ((t / 9) * HY + (t / 3) % 3) * HX + t % 3;
+  for (int S = 0; S < 2; ++S) {
+    const int pr = 4 * S + kg;
+    soff[S] = (pr / 3) * HY * HX + pr % 3;
+    tb[S] = (pr / 3) * 9 + pr % 3;                            // tap of (pair, dy) = tb + 3 dy
   }
+  const int moff = 2 * HY * HX + (kg < 3 ? kg : 2) * HX + 2;   // mixed k-step: (dz 2, dy kg, dx 2); group 3 reads any valid unit
+  const int mtap = kg < 3 ? 20 + 3 * kg : 27;
 
   f32x4_3 acc[TT][NJ];
   float rx[NS][8];
@@ -737,19 +745,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
     }                                                                                             \
   }
 #define C3M_LSTORE_W() _Pragma("unroll") for (int j = 0; j < NW; ++j) if (tid + 256 * j < WU) Ws[tid + 256 * j] = rw[j];
-  // operands of a k-step are read at its start (ONE register set: 2 + 16 units; a second set spilled 176 registers in the
-  // three-tile form); the MFMAs start as the reads return in order, the other wave of the SIMD covers the rest
-#define C3M_OPLOAD(ks_)                                                                           \
-  {                                                                                               \
-    const int tap = 4 * (ks_) + kg;                                                               \
-    A0 = Ws[tap * 16 + l15];                                                                      \
-    A1 = Ws[448 + tap * 16 + l15];                                                                \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                              \
-      B0[j] = Xs[pbase[j] + toffs[ks_]];                                                          \
-      B1[j] = Xs[XP + pbase[j] + toffs[ks_]];                                                     \
-    }                                                                                             \
-  }
-  u32x4 A0, A1, B0[NJ], B1[NJ];
+#ifndef C3M_KO
+#define C3M_KO 0          // knock-out builds (timing only): 1 no global X loads, 2 no conversion + LDS stores, 4 no MFMAs, 8 no epilogue stores
+#endif
+#define C3M_PART(p_) { if ((p_) < NPART && (!(C3M_KO & 1) || k.D < 0)) C3M_GLOAD_X(nch, p_); }
+#define C3M_MMA3(acc_, ah_, al_, bh_, bl_)                                                        \
+  { if (!(C3M_KO & 4) || k.D < 0) { acc_ = mma16(bh_, al_, acc_); acc_ = mma16(bl_, ah_, acc_); acc_ = mma16(bh_, ah_, acc_); } }   /* rows = the 16 voxels of a tile row, columns = output channels */
 #pragma unroll
   for (int s = 0; s < NPART; ++s) C3M_GLOAD_X(0, s);
   C3M_GLOAD_W(0);
@@ -778,35 +779,59 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
     }
     if (TT > 1 || tile_end) C3M_OFFS((tt + 1) % TT)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      C3M_OPLOAD(ks);
-      if (ks < NPART) C3M_GLOAD_X(nch, ks);
-      if (NPART > NKS && ks == NKS - 1) {                     // VEC: 8 parts over 7 k-steps
+    for (int S = 0; S < 2; ++S) {
+      u32x4 Ah[3], Al[3], Bh[2], Bl[2];
 #pragma unroll
-        for (int s2 = NKS; s2 < NPART; ++s2) C3M_GLOAD_X(nch, s2);
+      for (int dy = 0; dy < 3; ++dy) {
+        Ah[dy] = Ws[(tb[S] + 3 * dy) * 16 + l15];
+        Al[dy] = Ws[448 + (tb[S] + 3 * dy) * 16 + l15];
       }
-      if (ks == NKS - 1 && tt + 1 == TT) C3M_GLOAD_W(wch);
+      Bh[0] = Xs[prow0 + soff[S]];
+      Bl[0] = Xs[XP + prow0 + soff[S]];
+#pragma unroll
+      for (int r = 0; r < NJ + 2; ++r) {
+        if (r + 1 < NJ + 2) {
+          Bh[(r + 1) & 1] = Xs[prow0 + (r + 1) * HX + soff[S]];
+          Bl[(r + 1) & 1] = Xs[XP + prow0 + (r + 1) * HX + soff[S]];
+        }
+        if ((r & 1) == 0 && r < 8) C3M_PART(4 * S + (r >> 1))
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int j = r - dy;
+          if (j >= 0 && j < NJ) C3M_MMA3(acc[tt][j], Ah[dy], Al[dy], Bh[r & 1], Bl[r & 1])
+        }
+      }
+    }
+    {
+      const u32x4 Ah = Ws[mtap * 16 + l15], Al = Ws[448 + mtap * 16 + l15];
+      u32x4 Bh[2], Bl[2];
+      Bh[0] = Xs[prow0 + moff];
+      Bl[0] = Xs[XP + prow0 + moff];
+      if (tt + 1 == TT) C3M_GLOAD_W(wch);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        acc[tt][j] = mma16(A1, B0[j], acc[tt][j]);
-        acc[tt][j] = mma16(A0, B1[j], acc[tt][j]);
-        acc[tt][j] = mma16(A0, B0[j], acc[tt][j]);
+        if (j + 1 < NJ) {
+          Bh[(j + 1) & 1] = Xs[prow0 + (j + 1) * HX + moff];
+          Bl[(j + 1) & 1] = Xs[XP + prow0 + (j + 1) * HX + moff];
+        }
+        C3M_MMA3(acc[tt][j], Ah, Al, Bh[j & 1], Bl[j & 1])
       }
     }
     if (more) {
       __syncthreads();
-      C3M_LSTORE();
+      if (!(C3M_KO & 2) || k.D < 0) C3M_LSTORE();
       if (tt + 1 == TT) { C3M_LSTORE_W(); }
       __syncthreads();
     }
    }
    const bool tile_done = (ch + 1 == k.nchunk);
    if (!tile_done) { ++ch; continue; }
-   // ---- epilogue: acc[tt][j][i] <-> cout 4 kg + i, voxel (cz0 + wid, yt0 + j, cx0 + l15)
+   // ---- epilogue: the MFMAs ran with rows = voxels, columns = output channels: acc[tt][j][i] <-> cout l15, voxel
+   // (cz0 + wid, yt0 + j, cx0 + 4 kg + i) -- one 16-byte store (and one 16-byte load of the activation source) per tile
+   // row and lane instead of four 4-byte ones (VEC: W % 4 == 0; otherwise element by element)
    __builtin_amdgcn_sched_barrier(0);
-   float bv[4];
-#pragma unroll
-   for (int i = 0; i < 4; ++i) bv[i] = (bias && 4 * kg + i < k.cout_used) ? bias[4 * kg + i] : 0.f;
+   const bool cok = l15 < k.cout_used;
+   const float bv = (bias && cok) ? bias[l15] : 0.f;
    const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
        y + (long long)cn * k.Cout * S, 0, (unsigned)((long long)k.Cout * S * 4), 0x00020000);
    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
@@ -815,34 +840,47 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
 #pragma unroll
    for (int tt = 0; tt < TT; ++tt) {
      const int yt0 = cy0 + tt * TY;
-     const int gz = cz0 + wid, gx = cx0 + l15;
-     float av[2][4];
+     const int gz = cz0 + wid, gx = cx0 + 4 * kg;
+     const unsigned cbyte = (unsigned)l15 * s4;
+     u32x4 av[2];
 #define C3M_AVLOAD(set_, j_)                                                                      \
      if (k.act_src) {                                                                             \
        const int gy_ = yt0 + (j_);                                                                \
-       const bool vok_ = gz < k.D && gy_ < k.H && gx < k.W;                                       \
-       const unsigned vo_ = (unsigned)((gz * k.H + gy_) * k.W + gx) * 4u + (unsigned)(4 * kg) * s4; \
-       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-         av[set_][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                      \
-             a_src, (vok_ && 4 * kg + i < k.cout_used) ? vo_ : OOB, (unsigned)i * s4, 0));        \
+       const bool vok_ = cok && gz < k.D && gy_ < k.H;                                            \
+       const unsigned vo_ = (unsigned)((gz * k.H + gy_) * k.W + gx) * 4u + cbyte;                 \
+       if constexpr (VEC) av[set_] = __builtin_amdgcn_raw_buffer_load_b128(a_src, (vok_ && gx < k.W) ? vo_ : OOB, 0, 0); \
+       else {                                                                                     \
+         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+           av[set_][i] = __builtin_amdgcn_raw_buffer_load_b32(a_src, (vok_ && gx + i < k.W) ? vo_ + 4u * i : OOB, 0, 0); \
+       }                                                                                          \
      }
      C3M_AVLOAD(0, 0)
 #pragma unroll
      for (int j = 0; j < NJ; ++j) {
        if (j + 1 < NJ) C3M_AVLOAD((j + 1) & 1, j + 1)
        const int gy = yt0 + j;
-       const bool vok = gz < k.D && gy < k.H && gx < k.W;
-       const unsigned vo = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u + (unsigned)(4 * kg) * s4;
+       const bool vok = cok && gz < k.D && gy < k.H;
+       const unsigned vo = (unsigned)((gz * k.H + gy) * k.W + gx) * 4u + cbyte;
+       u32x4 out;
 #pragma unroll
        for (int i = 0; i < 4; ++i) {
-         const bool ok = vok && 4 * kg + i < k.cout_used;
-         float v = acc[tt][j][i] * osc + bv[i];
-         if (k.av_mode == 2) v += av[j & 1][i];
+         const bool ok = vok && gx + i < k.W;
+         const float a = __uint_as_float(av[j & 1][i]);
+         float v = acc[tt][j][i] * osc + bv;
+         if (k.av_mode == 2) v += a;
          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
          else if (k.act == 2) v = tanhf(v);
-         if (k.av_mode == 1) v = av[j & 1][i] > 0.f ? v : v * k.act_slope;
-         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_dst, ok ? vo : OOB, (unsigned)i * s4, 0);
+         if (k.av_mode == 1) v = a > 0.f ? v : v * k.act_slope;
+         out[i] = __float_as_uint(v);
          pm = fmaxf(pm, ok ? fabsf(v) : 0.f);
+       }
+       if (!(C3M_KO & 8) || k.D < 0) {
+         if constexpr (VEC) __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (vok && gx < k.W) ? vo : OOB, 0, 0);
+         else {
+#pragma unroll
+           for (int i = 0; i < 4; ++i)
+             __builtin_amdgcn_raw_buffer_store_b32(out[i], y_dst, (vok && gx + i < k.W) ? vo + 4u * i : OOB, 0, 0);
+         }
        }
      }
 #undef C3M_AVLOAD
@@ -861,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_m16_k(const float* __rest
 #undef C3M_SPLIT8
 #undef C3M_LSTORE
 #undef C3M_LSTORE_W
-#undef C3M_OPLOAD
+#undef C3M_PART
+#undef C3M_MMA3
   if (y_amax) {
     __syncthreads();
     publish_block_absmax_acc(pm, &smax, y_amax);
@@ -940,7 +979,9 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   }
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used, 0, act_src, act_slope, act_src ? av_mode : 0};
-  const bool vec = (g->Wi % 4) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !df_opt("DFMIR_CONV3D_NO_VEC");
+  // vec: 16-byte loads of the patch rows and (16-row form) 16-byte stores of the result / loads of the activation source
+  const bool vec = (g->Wi % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                         reinterpret_cast<uintptr_t>(act_src)) & 15) == 0 && !df_opt("DFMIR_CONV3D_NO_VEC");
   // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
   static DfOptFlag multi_o{"DFMIR_CONV3D_NO_MULTI"};
   const bool multi_off = multi_o.get();
