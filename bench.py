@@ -523,6 +523,21 @@ def main():
             model.optimize_parameters()
         torch.cuda.synchronize()
         timer.enabled = False
+        # ... and once more with netR on the SAME stream (opt.overlap_registration off): the launch durations without
+        # the share of the CUs the second stream takes -> roofline.single_stream
+        ks_overlapped = timer.summary()
+        timer.records = {}
+        prev_ov = getattr(opt, 'overlap_registration', True)
+        opt.overlap_registration = False
+        timer.enabled = True
+        for i in range(args.roofline_steps):
+            model.set_input(feed(args.steps + args.roofline_steps + i))
+            model.optimize_parameters()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        ks_single = timer.summary()
+        timer.records = {}
+        opt.overlap_registration = prev_ov
         model._graph['force_eager'] = False
 
     dt = dfdist.allreduce_max(dt, dev)            # the slowest rank's clock
@@ -561,7 +576,8 @@ def main():
         torch.cuda.synchronize()
         host_rate = B * world * args.host_input_steps / (time.perf_counter() - th)
 
-    ks = timer.summary()
+    ks = ks_overlapped if graphed else timer.summary()
+    ks1 = ks_single if graphed else {}
     result = None
     if rank == 0:
         pairs = B * world * args.steps
@@ -629,6 +645,11 @@ def main():
                                           "(opt.overlap_registration): a launch's duration includes the share of the CUs they take -- "
                                           "with DFMIR_NO_OVERLAP_R=1 the same kernel measures ~371 TF / issued 0.445 "
                                           "(profiles/README.md) and the step is 1.3 ms longer"),
+                         "single_stream": ({k2: (ks1[k1]["flops"] / (ks1[k1]["ms"] * 1e-3) / 1e12 * npm / peak) if k1 in ks1 and ks1[k1]["ms"] > 0 else None
+                                            for k1, k2 in (("conv3x3_L", "issued_frac"), ("wgrad3x3_L", "wgrad_issued_frac"))}
+                                           if ks1 else None),
+                         "single_stream_note": "the same launches over as many eager steps with opt.overlap_registration off (netR on "
+                                               "the generator's stream): the kernels' own rate, without the CUs the second stream takes",
                          "launches_timed": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
                          "timed_over": ("%d eager steps right after the timed region (which replays one hipGraph per step; "
                                         "events cannot be recorded inside a replay); the rocprofv3 kernel trace of the "

@@ -19,7 +19,7 @@ python scripts/bench_in_blurdown.py > $O/bench_in_blurdown.txt 2>&1
 DFMIR_IN_BLUR_BANDED=1 python scripts/bench_in_blurdown.py >> $O/bench_in_blurdown.txt 2>&1
 python scripts/conv2d_layer_census.py > $O/conv2d_layer_census.txt 2>&1
 python scripts/conv3d_step_census.py > $O/conv3d_step_census.txt 2>&1
-for sw in DFMIR_NO_OVERLAP_R DFMIR_NO_NCE_FUSED DFMIR_WGRAD_NO_SWAP DFMIR_IN_BLUR_BANDED NONE; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_round3_switches.txt 2>&1
+for sw in DFMIR_NO_OVERLAP_R DFMIR_NO_NCE_FUSED DFMIR_WGRAD_NO_SWAP DFMIR_CONV_CS_PLAIN NONE; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_switches.txt 2>&1
 for u in mfma_peak lds_unaligned valu_under_mfma; do   # built from source on the box (binaries are not tracked)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u scripts/ubench/$u.hip && /tmp/$u > $O/ubench_$u.txt 2>&1
 done
@@ -44,4 +44,4 @@ bash scripts/prof_step.sh scripts/bench_3d_128.py 3d128 50 > $O/step_trace_3d_12
 bash scripts/prof_upconv3d.sh > $O/pmc_upconv3d.txt 2>&1
 for v in 0 2; do DFMIR_CS_XCD_PAIR=$v python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('DFMIR_CS_XCD_PAIR=$v', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step issued_frac', round(r['roofline']['issued_frac'],4))"; done > $O/ab_xcd_order.txt 2>&1
 rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d $R/gpurun_out/upconv_prof
-python scripts/pmc_json.py r03 > $O/pmc_json.log 2>&1; cp profiles/r03_pmc.json $O/
+TAG=${TAG:-r04}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json

@@ -1,8 +1,8 @@
 """Copy gpurun_out/collect/* (scripts/collect_profiles.sh on a GPU box) into profiles/<TAG>_* and regenerate the
 PMC summaries (<TAG>_conv3x3s_pmc.md, <TAG>_conv3d_pmc.md, <TAG>_conv3dup_pmc.md) from the raw counter output.
-usage: python scripts/publish_profiles.py [r03]"""
+usage: python scripts/publish_profiles.py [r04]"""
 import ast, os, re, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C, P = R + '/gpurun_out/collect/', R + '/profiles/'
 cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b16_eager.json', 'bench_kernel_stats.csv': TAG + '_bench_b16_kernel_stats.csv',
@@ -13,7 +13,7 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'step_trace_3d.txt': TAG + '_step_trace_3d.txt', 'sustain3d.txt': TAG + '_power_clock_3d.txt', 'pmc_warp.txt': TAG + '_warp_pmc_raw.txt',
       'step_trace_3d_128.txt': TAG + '_step_trace_3d_128.txt', 'bench_upconv3d.txt': TAG + '_bench_upconv3d.txt',
       'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'overlap_trace.txt': TAG + '_overlap_trace.txt', 'bench_in_blurdown.txt': TAG + '_bench_in_blurdown.txt',
-      'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'r03_pmc.json': TAG + '_pmc.json'}
+      'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json'}
 def clean(txt):
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
 for a, b in cp.items():
@@ -45,13 +45,13 @@ def row(name, dur, c, gflop, note=""):
 hdr = "| kernel | duration → algorithmic rate | clock (GRBM_GUI_ACTIVE/8 ÷ t) | matrix pipe busy: SQ_VALU_MFMA_BUSY_CYCLES ÷ (1024 SIMD × cycles) | LDS active | HBM side | note |\n|---|---|---|---|---|---|---|\n"
 d, c = parse(raw2d)
 k1 = [k for k in c if 'split_cs_k' in k][0]; k2 = [k for k in c if 'wgrad_split2' in k][0]
-md = ("# PMC counters of the split 3×3 kernels on the round-3 binary (`csrc/conv3x3s.hip`), re-taken with the final profile run\n\n"
+md = ("# PMC counters of the split 3×3 kernels on this round's binary (`csrc/conv3x3s.hip`), re-taken with the final profile run\n\n"
       "Command: `scripts/prof_conv.sh {fwd|wgrad} 256 256 64 32` — one counter group per pass, `--kernel-trace` only (MI355X_MICROARCH.md): 256→256 3×3 reflect @64², n = 32, **154.6 GFLOP** algorithmic per launch.  Raw: `{TAG}_conv3x3s_pmc_raw.txt`.  Counters summed over the 8 XCDs; FETCH/WRITE_SIZE in KiB.\n\n" + hdr)
 md += row(k1, d[k1], c[k1], 154.6, "non-MFMA VALU per wave and 16-channel chunk: %.0f" % ((c[k1]['SQ_INSTS_VALU'] - c[k1]['SQ_VALU_MFMA_BUSY_CYCLES'] / 32) / (8192 * 16))) + "\n"
 md += row(k2, d[k2], c[k2], 154.6, "non-MFMA VALU per wave and run: %.0f; FETCH of its 16-B/lane streams under-counts by 2 (guide's correction)" % ((c[k2]['SQ_INSTS_VALU'] - c[k2]['SQ_VALU_MFMA_BUSY_CYCLES'] / 32) / (2048 * 128))) + "\n"
-md += "\nBoth kernels sit on the 1 400 W package cap (`r01_power_clock.md`); the busy fraction moves with the clock the box sustains (round 1: 68.0 % / 56.8 % at 1.72 / 1.84 GHz).  `bench.py` prices the same kernels over the step's shape mix: `roofline.frac` 0.40–0.43 (forward / dgrad), `wgrad_frac` 0.41–0.46.\n"
+md += "\nBoth kernels sit on the 1 400 W package cap (`r01_power_clock.md`); the busy fraction moves with the clock the box sustains (round 1: 68.0 % / 56.8 % at 1.72 / 1.84 GHz).  `bench.py` prices the same kernels over the step's shape mix as `roofline.issued_frac` / `wgrad_issued_frac` (3 products per MAC over the 2.5 PFLOP/s dense fp16 peak; `frac` is the algorithmic third of it) -- see the committed `{TAG}_bench_b16.json`.\n"
 open(P + TAG + '_conv3x3s_pmc.md', 'w').write(md.replace('{TAG}', TAG))
-md3 = ("# PMC counters of the 3-D split kernels (`csrc/conv3ds.hip`), final round-3 binary\n\n"
+md3 = ("# PMC counters of the 3-D split kernels (`csrc/conv3ds.hip`), this round's final binary\n\n"
        "Command: `scripts/prof_conv3d.sh 34-32` and `… 32-16` (`scripts/bench_conv3d.py` under `rocprofv3 --kernel-trace --pmc <group>`, one group per pass): 160×192×224, 404.3 GFLOP (34→32) / 190.3 GFLOP (32→16) per launch.  Raw: `{TAG}_conv3d_pmc_raw.txt`.  The clock column is what the counters give for the profiler's serialised single launches between other work; the sustained figures are below.\n\n" + hdr)
 for sec, gf in ((s1, 404.29), (s2, 190.25)):
     d, c = parse(sec)
