@@ -146,6 +146,10 @@ def lib():
     """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm first: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so).  Loaded AFTER this
+        # library (which names /opt/rocm's) the process would hold two runtimes and the kernels here would be launched
+        # on one that has enumerated no device ("no ROCm-capable device is detected" at the first launch).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise DfmirHipError(
                 "libdfmir_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "

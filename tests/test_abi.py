@@ -56,3 +56,15 @@ def test_options_table_is_settable_and_falls_back_to_the_environment(monkeypatch
     h = dfmir_amd.lib()
     assert h.dfmir_set_option(b"NOT_OURS", b"1") != 0     # names outside the DFMIR_ namespace are refused
     assert b"invalid argument" in h.dfmir_last_error()
+
+
+def test_library_is_loaded_after_pytorch_rocm():
+    """dfmir_amd.lib() imports torch before it dlopens libdfmir_hip.so: PyTorch-ROCm carries its own HIP runtime, and a
+    process that loaded this library first ended up with two runtimes -- the kernels here were then launched on one that had
+    enumerated no device (found with `python __graft_entry__.py --smoke`, which builds and smokes in ONE process)."""
+    import subprocess, sys, os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import dfmir_amd; assert 'torch' not in sys.modules; "
+            "dfmir_amd.lib(); assert 'torch' in sys.modules; print('ok')" % repo)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -711,11 +711,12 @@ def test_shared_tap_sparse_gradient(ops):
               what="fork_tap grad main=%s rows=%s" % (use_main, use_rows))
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (1, 72, 12, 40), (1, 40, 8, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 32), (1, 72, 12, 40), (1, 40, 8, 16), (1, 64, 16, 62), (2, 128, 64, 64)])
 def test_reflect_conv_skip_gradient(ops, shape):
     """conv(reflection_pad(x)) whose input also leaves through the skip output (ResnetBlock): dx = dgrad + d skip.
     64 / 72 channels take the zero-padded dgrad with the residual in its epilogue + the ring kernel; 40 x (8 x 16) the
-    ring with a separate add (tiles under-filled); all against torch."""
+    ring with a separate add (tiles under-filled); 16 x 62: a width that is not a multiple of 4 (the shared-tile kernel's epilogue
+    leaves its float4 form: element loads of the residual, element stores); 128 x 64 x 64: the step's own geometry; all against torch."""
     N, Cch, H, W = shape
     x = C.randn(91, *shape)
     w = C.randn(92, Cch, Cch, 3, 3) * 0.05
