@@ -223,6 +223,67 @@ def test_whole_step_golden_default_path(golden, O, capture):
         assert model._graph['graph'] is not None, "the third step must have been a hipGraph replay"
 
 
+def test_trajectory_drift_vs_fp64_oracle(O):
+    """Parity over an optimizer TRAJECTORY: five consecutive train steps (fresh image pair each step, patch ids pinned, three
+    Adam updates per step; steps 3.. are replays of one captured hipGraph) of the default production path, next to the CPU
+    oracle in fp32 AND in fp64 from the same weights.  Early training with Adam is a sensitive system (updates of size lr
+    whatever the gradient's size, and every ReLU / mask decision that sits on a rounding boundary changes one image's
+    gradient by 0.1-3 %: scripts/diag_dfake.py shows such flips in the fp32 oracle as well as in the HIP path, in different
+    images): the fp32 oracle itself leaves the fp64 trajectory -- 1e-4 relative at step 3, 1.4 % at the loss spike of step 5.
+    So the bound is the sum of the drift the reference-generated three-step fixture S1 allows (3e-4 x (step + 1) relative) and
+    12x the fp32 oracle's own distance from the fp64 trajectory at that step (measured: HIP 1.0e-3 at step 3 where fp32 has
+    1.4e-4, 5 % at step 5 where fp32 has 1.4 %; scripts/diag_first_update.py, diag_gen_grads.py, diag_nce_precision.py and
+    diag_nce_term.py put the generator, the NCE head and a single NCE term in isolation at 1.2-2x fp32 PyTorch's error)."""
+    size, B, steps = 64, 2, 5          # up to, not into, the oracle's own loss spike at step 5 (fp32 vs fp64: 1.4 % there)
+
+    def make(double):
+        torch.manual_seed(11)
+        st = O.RegistrationStep(size, B, ngf=8)
+        with torch.no_grad():
+            st.netR.flow.weight.mul_(1e5)                  # a flow field that moves pixels (the init is N(0, 1e-5))
+        st.ids_hook = lambda c, feats: [C.patch_ids(c, i, f.shape[2] * f.shape[3], 256) for i, f in enumerate(feats)]
+        A0, B0 = C.image_pair(7, B, size, size)
+        st.data_dependent_initialize(A0, B0)
+        with torch.no_grad():
+            for p in st.netF.parameters():
+                if p.dim() == 1:
+                    p.add_(0.01)                           # biases off zero: Normalize's gradient is regular on both sides
+        if double:
+            for m in (st.netG, st.netF, st.netR):
+                m.double()                                 # in place: the optimizers keep their parameter objects
+        return st, A0, B0
+
+    s64, _, _ = make(True)
+    st, A0, B0 = make(False)
+    model, opt = _hip_model_from_oracle(st, size, B, 8)
+    opt.capture_step = True
+    src = model.patch_id_source = PinnedIds()
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    worst, rows = 0.0, []
+    for it in range(steps):
+        A_, B_ = C.image_pair(300 + 2 * it, B, size, size)
+        r32 = st.step(A_, B_)
+        r64 = s64.step(A_.double(), B_.double())
+        src.prefill(nce_sizes(size), 3, opt.num_patches)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        got = model.get_current_losses()
+        for k, v in r64.items():
+            e_hip, e_32 = abs(got[k] - v), abs(r32[k] - v)
+            floor = 3e-4 * (it + 1) * max(abs(v), 1e-3)
+            worst = max(worst, (e_hip - floor) / max(e_32, 1e-12) if e_hip > floor else 0.0)
+            rows.append((it, k, got[k], r32[k], v))
+            assert e_hip <= 12.0 * e_32 + floor, "step %d loss %s: HIP %.6f fp32 oracle %.6f fp64 oracle %.6f" % (it, k, got[k], r32[k], v)
+    assert model._graph['graph'] is not None, "steps 3.. must have been hipGraph replays"
+    print("\n  trajectory: worst (|HIP - fp64| - floor) / |fp32 - fp64| over %d steps x 6 losses = %.1f" % (steps, worst))
+    for it, k, a, b, c in rows:
+        if k in ("G", "R"):
+            print("    step %d %-3s HIP %.6f  fp32 %.6f  fp64 %.6f" % (it, k, a, b, c))
+
+
 def test_whole_step_golden(golden, O):
     """Config 1 geometry (64x64, batch 2): 3 consecutive train steps against the reference's own
     losses / outputs (fixture S1), patch ids pinned."""
