@@ -243,23 +243,32 @@ __global__ __launch_bounds__(256, 2) void conv7x7_c1_fwd_k(const float* __restri
     const int off = (t / S7_K) * S7_PW + (t % S7_K) + l31;
 #pragma unroll
     for (int j = 0; j < S7_RW; ++j)
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], patch[(rg * S7_RW + j) * S7_PW + off], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(patch[(rg * S7_RW + j) * S7_PW + off], a[s2], acc[j], 0, 0, 0);   // rows = pixels, columns = couts
   }
+  // rows = the 32 pixels of a tile row, columns = output channels: a lane ends with ONE channel (co) and 4 consecutive pixels
+  // per accumulator quad -- 16 16-byte stores per lane instead of 64 4-byte ones (W % 4 == 0; otherwise element by element)
   float* yn = y + (long long)n * Cout * H * W;
-  float bz[16];                                            // this lane's 16 output channels' biases
+  const float bz = (bias && co < Cout) ? bias[co] : 0.f;
+  const bool vec = (W & 3) == 0 && ((reinterpret_cast<unsigned long long>(y) & 15) == 0);
+  if (co < Cout) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-    bz[r] = (bias && c < Cout) ? bias[c] : 0.f;
-  }
+    for (int j = 0; j < S7_RW; ++j) {
+      const int oy = ty0 + rg * S7_RW + j;
+      if (oy >= H) continue;
+      float* row = yn + ((long long)co * H + oy) * W;
 #pragma unroll
-  for (int j = 0; j < S7_RW; ++j) {
-    const int oy = ty0 + rg * S7_RW + j, ox = tx0 + l31;
-    if (oy >= H || ox >= W) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-      if (c < Cout) yn[((long long)c * H + oy) * W + ox] = acc[j][r] + bz[r];
+      for (int q = 0; q < 4; ++q) {
+        const int ox = tx0 + 8 * q + 4 * lhi;
+        if (ox >= W) continue;
+        const float v0 = acc[j][4 * q] + bz, v1 = acc[j][4 * q + 1] + bz, v2 = acc[j][4 * q + 2] + bz, v3 = acc[j][4 * q + 3] + bz;
+        if (vec) *reinterpret_cast<float4*>(row + ox) = make_float4(v0, v1, v2, v3);
+        else {
+          row[ox] = v0;
+          if (ox + 1 < W) row[ox + 1] = v1;
+          if (ox + 2 < W) row[ox + 2] = v2;
+          if (ox + 3 < W) row[ox + 3] = v3;
+        }
+      }
     }
   }
 }
