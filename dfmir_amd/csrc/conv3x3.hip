@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);   // rows = pixels, columns = couts
       }
     }
     if (more) {
@@ -175,24 +175,37 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ 
 #undef C3_GLOAD
 #undef C3_LSTORE
 
-  // ---- epilogue
+  // ---- epilogue: rows = 32 consecutive (flat) pixels of the run, columns = output channels: a lane ends with one channel
+  // and 4 consecutive pixels per accumulator quad -> 16-byte stores (H*W % 4 == 0 and an aligned base; else per element)
   float* yb = y + (long long)n * k.Cout * HWo;
+  const bool vec = (HWo & 3) == 0 && (p0 & 3) == 0 && (reinterpret_cast<unsigned long long>(y) & 15) == 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int q = p0 + (wn * TN + j) * 32 + l31;
-    if (q >= pend) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int cl = (wm * TM + i) * 32 + 4 * lhi;
+      const int c = (wm * TM + i) * 32 + l31;
+      const int co = m0 + c;
+      if (co >= k.Cout) continue;
+      const float bv = bs[c];
+      float* row = yb + (long long)co * HWo;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = cl + (r & 3) + 8 * (r >> 2);
-        const int co = m0 + c;
-        if (co < k.Cout) {
-          float v = acc[i][j][r] + bs[c];
-          if (k.act == 1) v = v > 0.f ? v : v * k.slope;
-          else if (k.act == 2) v = tanhf(v);
-          yb[(long long)co * HWo + q] = v;
+      for (int qd = 0; qd < 4; ++qd) {
+        const int q = p0 + (wn * TN + j) * 32 + 8 * qd + 4 * lhi;
+        if (q >= pend) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][4 * qd + e] + bv;
+          if (k.act == 1) t = t > 0.f ? t : t * k.slope;
+          else if (k.act == 2) t = tanhf(t);
+          v[e] = t;
+        }
+        if (vec && q + 3 < pend) *reinterpret_cast<float4*>(row + q) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+          row[q] = v[0];
+          if (q + 1 < pend) row[q + 1] = v[1];
+          if (q + 2 < pend) row[q + 2] = v[2];
+          if (q + 3 < pend) row[q + 3] = v[3];
         }
       }
     }
