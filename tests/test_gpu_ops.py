@@ -212,6 +212,10 @@ CONV3D = [
     # channel groups (Cin > 32), the 34-channel concat layer and its dgrad (Cout' = 34 -> 3 row tiles)
     (34, 32, 3, 1, 1, 1, 6, 16, 32),
     (32, 16, 3, 1, 1, 1, 5, 10, 20),
+    # widths that are a multiple of 32: the 16-row kernel's 32-voxel-wide tile (ragged in z and y, two tiles along x,
+    # 12 of 16 output channels, batch 2)
+    (32, 16, 3, 1, 1, 1, 5, 10, 32),
+    (16, 12, 3, 1, 1, 2, 6, 9, 64),
     (16, 16, 3, 1, 1, 2, 4, 8, 16),
     (48, 32, 3, 1, 1, 1, 4, 12, 24),
     (64, 32, 3, 1, 1, 1, 3, 8, 16),
