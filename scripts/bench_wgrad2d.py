@@ -120,3 +120,18 @@ if hasattr(h, "dfmir_cs_wg_dump"):
     print("  workgroups per CU: min %d max %d; gap between consecutive workgroups of a CU: mean %.2f us, median %.2f, max %.2f; "
           "first start spread %.2f us; idle at the end: mean %.1f us max %.1f"
           % (min(per_cu), max(per_cu), gaps.mean(), np.median(gaps), gaps.max(), st[[np.where(cu == c)[0][np.argmin(st[np.where(cu == c)[0]])] for c in set(cu.tolist())]].max(), np.mean(idle_tail), np.max(idle_tail)))
+
+if hasattr(h, "dfmir_w1_trace_dump"):
+    import numpy as np
+    buf = np.zeros(4 * 64 * 4, dtype=np.uint32)
+    h.dfmir_w1_trace_dump(ctypes.c_void_p(buf.ctypes.data))
+    t = buf.reshape(4, 64, 4).astype(np.int64)
+    print("w1 trace (cycles), stages 3..44: [first half, vmcnt wait, barrier wait, second half + copy] | stage")
+    for wv in range(4):
+        a = t[wv, 3:45]
+        nxt = t[wv, 4:46, 0]
+        d = [((a[:, 1] - a[:, 0]) & 0xffffffff).mean(), ((a[:, 2] - a[:, 1]) & 0xffffffff).mean(), ((a[:, 3] - a[:, 2]) & 0xffffffff).mean(), ((nxt - a[:, 3]) & 0xffffffff).mean(), ((nxt - a[:, 0]) & 0xffffffff).mean()]
+        print("  wave %d: %7.0f %7.0f %7.0f %7.0f | %7.0f" % ((wv,) + tuple(d)))
+    for kx in range(3):
+        a = t[0, 3 + kx:45:3]; nxt = t[0, 4 + kx:46:3, 0]
+        print("  wave 0, kx %d: first half %.0f  vmcnt %.0f  barrier %.0f  second half %.0f" % (kx, ((a[:, 1] - a[:, 0]) & 0xffffffff).mean(), ((a[:, 2] - a[:, 1]) & 0xffffffff).mean(), ((a[:, 3] - a[:, 2]) & 0xffffffff).mean(), ((nxt[:len(a)] - a[:len(nxt), 3]) & 0xffffffff).mean()))
