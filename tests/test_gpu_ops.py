@@ -114,6 +114,37 @@ def test_conv2d(ops, cfg):
     close(bg.grad, br.grad, rtol=3e-4, what="db")
 
 
+@pytest.mark.parametrize("cfg", [(256, 256, True, 2, 64, 64), (64, 128, False, 2, 32, 32), (128, 256, True, 1, 16, 64)])
+def test_conv3x3_one_wave_per_simd_form(ops, cfg):
+    """DFMIR_CONV_W1=1: conv3x3_split_w1_k (one wave per SIMD, 16 x 32 x 128 tiles, weights by buffer_load...lds; an experiment
+    kept behind the switch) computes what the shared-tile kernel computes -- forward and input gradient (the zero-padded dgrad
+    with the skip gradient and the reflect ring in its epilogue) against torch, and against the default path to round-off."""
+    from dfmir_amd import _lib
+    Cin, Cout, reflect, N, H, W = cfg
+    x = C.randn(201, N, Cin, H, W)
+    w = C.randn(202, Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    b = C.randn(203, Cout) * 0.1
+    c1 = C.randn(204, N, Cout, H, W)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = torch_conv(xr, wr, b, 1, 1, reflect, 0, 2)
+    (yr * c1).sum().backward()
+
+    def run():
+        xg, wg = x.clone().to(DEV).requires_grad_(), w.clone().to(DEV).requires_grad_()
+        yg = ops.conv(xg, wg, b.to(DEV), None, 1, 1, 1 if reflect else 0, 0, 0.0)
+        (yg * c1.to(DEV)).sum().backward()
+        return yg.detach(), xg.grad.detach()
+
+    y0, dx0 = run()
+    _lib.set_option("DFMIR_CONV_W1", "1")
+    try:
+        y1, dx1 = run()
+    finally:
+        _lib.set_option("DFMIR_CONV_W1", None)
+    close(y1, yr, what="y (w1)"); close(dx1, xr.grad, rtol=2e-4, what="dx (w1)")
+    close(y1, y0, rtol=2e-6, what="w1 vs default y"); close(dx1, dx0, rtol=2e-6, what="w1 vs default dx")
+
+
 @pytest.mark.parametrize("xs,ws,gs", [(1e-12, 1.0, 1e-14), (3e9, 1e-6, 7e5), (1.0, 40.0, 1e-30), (0.0, 1.0, 1.0)],
                          ids=["tiny", "huge", "denormal_grads", "zero_input"])
 def test_conv3x3_split_dynamic_range(ops, xs, ws, gs):
