@@ -52,6 +52,8 @@ _SIGS = {
     "dfmir_conv3d_up_ok": [c_int] * 6,
     "dfmir_conv3d_wsplit_batch": [P, c_int, P],
     "dfmir_conv3d_split_is_pair": [c_int],
+    "dfmir_conv3d_march_ok": [_GP],
+    "dfmir_conv3d_march_fwd": [_GP, P, P, c_int, P, P, P, P, P, c_float, P],
     "dfmir_conv3d_tiny_ok": [_GP],
     "dfmir_conv3d_tiny_fwd": [_GP, P, P, P, P, P, P, c_float, P],
     "dfmir_conv3d_s2c2_ok": [_GP],

@@ -1,0 +1,460 @@
+// 3-D 3x3x3 stride-1 "same" convolution (forward and dgrad) of the FULL-RESOLUTION VoxelMorph layers -- 32 -> 16, 16 -> 16
+// and the input gradients 16 <- 16, 32 <- 16 (torchvoxelmorph/networks.py:73-86,1506-1521: the `extras` chain behind the
+// decoder) -- as a z-MARCHING kernel: the scaled fp16x2 split form of conv3ds.hip (a = (a0 + a1) / s, a b ~= a0b0 + a0b1 +
+// a1b0, fp32 accumulate on the 16-bit matrix pipe), re-tiled for layers whose Cin x Cout <= 512.
+//
+// These layers are as much an HBM problem as a matrix problem (32 -> 16 at 160 x 192 x 224: 1.3 GB moved for 190 GFLOP), and
+// the 4 x 8 x 16 tiles of conv3d_split_k / conv3d_split_m16_k stage a 6 x 10 x 18 halo patch (2.1 x the tile) per 8-channel
+// chunk together with a fresh copy of that chunk's weights, behind two barriers.  Here instead:
+//   * a workgroup (512 threads, one per CU) owns a 16 x 32 COLUMN of the volume and marches along z over a segment of
+//     planes.  Every input plane (18 x 34 positions x ALL input channels, split into fp16 pairs as it is written to LDS) is
+//     staged ONCE and contributes to the three output planes z - 1, z, z + 1 through the nine taps of dz = 2, 1, 0: the
+//     halo is in-plane only (1.2 x) -- 43 % less staging work (global loads, conversions, LDS stores) per output voxel;
+//   * the accumulators of the three open output planes ROLL through the registers (the plane loop is unrolled by three so
+//     that the rotation is a renaming); when input plane P has been consumed output plane P - 1 is complete and leaves
+//     through the epilogue (bias, LeakyReLU or the LeakyReLU derivative of a dgrad, range probe) -- 16-byte stores that are
+//     spread evenly over the kernel's lifetime instead of a burst at the end of every tile;
+//   * ALL weights of the layer (<= 61 KB as fp16 pairs) are split by the workgroup itself in its prologue and stay in
+//     LDS: no weight staging in the loop, no separate weight-split launch, no workspace;
+//   * Cin = 16: two plane slots, plane P + 1 is converted and stored while plane P is consumed (one barrier per plane);
+//     Cin = 32: one slot (84 KB) -- the next plane waits in registers and is written between two barriers (~8 % of a plane
+//     step: a step is 648 MFMAs per SIMD).
+// MFMA forms.  Cout = 16: v_mfma_f32_16x16x32_f16, rows = 16 voxels of a tile row, columns = the output channels,
+// K = 32 = one tap x 32 channels (Cin = 32) or two taps x 16 channels (Cin = 16: the nine taps of a dz are walked as
+// (dy, dx 0 | dx 1) x 3, (dy 0 | dy 1, dx 2), (dy 2, dx 2 | zero) -- 10 / 9 of the useful products).  Cout = 32 (Cin = 16):
+// v_mfma_f32_32x32x16_f16, rows = the 32 voxels of a tile row, K = 16 = one tap.  A wave owns two tile rows x three
+// planes; the voxel operands of a tap column are read once per patch row and serve the (dy, dz) products that use them
+// (0.26-0.48 LDS operand reads per MFMA).  MFMA rows = voxels, so a lane ends with 4 consecutive voxels of one channel.
+#include "conv3x3_common.h"
+#include <type_traits>
+
+typedef _Float16 f16x8_m __attribute__((ext_vector_type(8)));
+typedef float f32x4_m __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int scale_exp_m(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  int e = (amax > 0.f) ? 14 - be : 0;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return e;
+}
+__device__ __forceinline__ float pow2f_m(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+// (x0, x1) * s -> leading fp16 pair h and residual pair r
+__device__ __forceinline__ void split_pair_m(float x0, float x1, float s, unsigned& h, unsigned& r) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ void split8_m(const float (&v)[8], float s, u32x4& h, u32x4& r) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned hh, rr;
+    split_pair_m(v[2 * q], v[2 * q + 1], s, hh, rr);
+    h[q] = hh; r[q] = rr;
+  }
+}
+__device__ __forceinline__ f32x4_m mma16m(u32x4 a, u32x4 b, f32x4_m c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_m, a), __builtin_bit_cast(f16x8_m, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma32m(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_m, a), __builtin_bit_cast(f16x8_m, b), c, 0, 0, 0);
+}
+
+struct MarchP {
+  int N, D, H, W;
+  int nty, ntx, nseg, zlen;      // 16 x 32 columns per plane, z segments of zlen planes
+  int x_n;                       // floats of the input range probe
+  int act;                       // 0 none, 1 LeakyReLU(slope)
+  float slope;
+  const float* act_src;          // dgrad into the output of a LeakyReLU: multiply by its derivative (conv3ds.hip, av_mode 1)
+  float act_slope;
+  long long nwork;               // N * nseg * nty * ntx
+};
+
+template <int CIN, int COUT>
+struct MarchCfg {
+  static_assert((CIN == 32 && COUT == 16) || (CIN == 16 && (COUT == 16 || COUT == 32)), "layer shapes of the march kernel");
+  static constexpr bool B32 = COUT == 32;                       // 32x32x16 MFMAs (one tap per k-step)
+  static constexpr int NO = CIN / 8;                            // channel octets
+  static constexpr int NSTEP = (CIN == 32 || B32) ? 9 : 5;      // k-steps per dz
+  static constexpr int NH = B32 ? 1 : 2;                        // voxel operands per tile row (32 / 16 voxels each)
+  static constexpr int WU = NSTEP * 3 * 2 * 64;                 // weight units: (step, dz, split, lane)
+  static constexpr int SLOTS = CIN == 32 ? 1 : 2;
+  static constexpr int SR = 19, RS = 34;                        // slot rows (18 + one finite pad row), row stride in units
+  static constexpr int OP = ((SR * RS + 15) / 16) * 16;         // octet plane stride: = 0 mod 16 -> conflict-free b128 reads
+  static constexpr int SU = 2 * NO * OP;                        // units of a slot: [split][octet][row][col]
+  static constexpr int NQ = NO * 18 * 8, NSG = NO * 18 * 2;     // staging jobs: 16-byte quads, halo columns
+  static constexpr int NJ = NQ + NSG, NR = (NJ + 511) / 512;    // rounds of jobs per thread
+};
+
+// (kind, first patch row) of k-step j: the voxel operands of a kind are read once per patch row q = 0..3 of the wave's two
+// tile rows and serve every k-step of that kind
+template <int CIN, int COUT> __device__ constexpr int step_kind(int j) { return MarchCfg<CIN, COUT>::NSTEP == 9 ? j / 3 : (j < 3 ? 0 : 1); }
+template <int CIN, int COUT> __device__ constexpr int step_qoff(int j) { return MarchCfg<CIN, COUT>::NSTEP == 9 ? j % 3 : (j < 3 ? j : (j == 3 ? 0 : 2)); }
+// operand rows (kind * 4 + q, bit mask) whose reads are issued at the head of step j: each row's registers are re-used by
+// the next kind as soon as the last k-step that needs the old contents has been issued
+template <int CIN, int COUT> __device__ constexpr unsigned step_loads(int j) {
+  if (MarchCfg<CIN, COUT>::NSTEP == 9) {
+    const int k = j / 3, d = j % 3;
+    unsigned m = 0;
+    if (d == 0) m |= 1u << (k * 4 + 2);
+    if (d == 1) { m |= 1u << (k * 4 + 3); if (k < 2) m |= 1u << ((k + 1) * 4 + 0); }
+    if (d == 2 && k < 2) m |= 1u << ((k + 1) * 4 + 1);
+    return m;
+  }
+  return j == 0 ? (1u << 2) : j == 1 ? ((1u << 3) | (1u << 4)) : j == 2 ? (1u << 5) : j == 3 ? ((1u << 6) | (1u << 7)) : 0u;
+}
+
+template <int CIN, int COUT, bool ACTG>
+__global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                         const float* __restrict__ w_tcc, const float* __restrict__ bias,
+                                                         float* __restrict__ y, float* __restrict__ y_amax, MarchP k) {
+  using C = MarchCfg<CIN, COUT>;
+  constexpr bool B32 = C::B32;
+  constexpr int NO = C::NO, NSTEP = C::NSTEP, NH = C::NH, WU = C::WU, SLOTS = C::SLOTS, RS = C::RS, OP = C::OP, SU = C::SU;
+  constexpr int NQ = C::NQ, NJ = C::NJ, NR = C::NR;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) u32x4 Xs[SLOTS * SU];
+  __shared__ __attribute__((aligned(16))) u32x4 Ws[WU];
+  __shared__ float red[17];
+  __shared__ unsigned smax;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4, l31 = lane & 31, lhi = lane >> 5;
+
+  // workgroup -> (image, z segment, column): the dispatcher deals consecutive ids round-robin to the 8 XCDs (one L2
+  // each); ids with the same residue walk one contiguous eighth of the work list (x fastest, then y, then segment), so
+  // the columns that share halo rows / columns march through the same L2 side by side
+  const long long per_xcd = (k.nwork + 7) / 8;
+  const long long lin = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((long long)(blockIdx.x >> 3) >= per_xcd || lin >= k.nwork) return;
+  long long t_ = lin;
+  const int tx = (int)(t_ % k.ntx); t_ /= k.ntx;
+  const int ty = (int)(t_ % k.nty); t_ /= k.nty;
+  const int seg = (int)(t_ % k.nseg);
+  const int n = (int)(t_ / k.nseg);
+  const int y0 = ty * 16, x0 = tx * 32;
+  const int zs = seg * k.zlen, ze = (zs + k.zlen < k.D) ? zs + k.zlen : k.D;
+  const int nst = ze - zs + 2;                               // input planes zs - 1 .. ze
+  const int HW = k.H * k.W;
+  const long long S = (long long)k.D * HW;
+  const unsigned s4 = (unsigned)S * 4u, hw4 = (unsigned)HW * 4u;
+
+  // ---- prologue: zero the plane slots (pad row / pad units must be finite: they meet zero weights), scales, weights
+  for (int u = tid; u < SLOTS * SU; u += 512) Xs[u] = u32x4{0u, 0u, 0u, 0u};
+  const float amax = reduce_absmax(x_amax, k.x_n, red);
+  const int ex = scale_exp_m(amax);
+  float wm = 0.f;
+  for (int i = tid; i < 27 * CIN * COUT / 4; i += 512) {
+    const float4 v = reinterpret_cast<const float4*>(w_tcc)[i];
+    wm = fmaxf(wm, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  wm = block_max(wm, red);
+  if (!(wm == wm)) wm = __uint_as_float(0x7f800000u);
+  const int ew = scale_exp_m(wm);
+  const float xscale = pow2f_m(ex), wscale = pow2f_m(ew), osc = pow2f_m(-ex) * pow2f_m(-ew);
+  if (tid == 0) smax = 0u;
+  // weight units [(step j, dz)][split][lane]: the lane's 8 reduction values of its k group, for its output channel
+  for (int u = tid; u < NSTEP * 3 * 64; u += 512) {
+    const int ln = u & 63, jd = u >> 6, j = jd / 3, dz = jd % 3;
+    int co, tap, c0;                                         // tap < 0: zero unit
+    if constexpr (B32) {
+      co = ln & 31; c0 = 8 * (ln >> 5);
+      tap = dz * 9 + (j % 3) * 3 + j / 3;
+    } else if constexpr (CIN == 32) {
+      co = ln & 15; c0 = 8 * (ln >> 4);
+      tap = dz * 9 + (j % 3) * 3 + j / 3;
+    } else {
+      co = ln & 15;
+      const int g = ln >> 4, t2 = g >> 1;
+      c0 = 8 * (g & 1);
+      int dy, dx;
+      if (j < 3) { dy = j; dx = t2; }
+      else if (j == 3) { dy = t2; dx = 2; }
+      else { dy = 2; dx = 2; }
+      tap = (j == 4 && t2 == 1) ? -1 : dz * 9 + dy * 3 + dx;
+    }
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = tap >= 0 ? w_tcc[((long long)tap * CIN + c0 + c) * COUT + co] : 0.f;
+    u32x4 h, r;
+    split8_m(v, wscale, h, r);
+    Ws[(jd * 2 + 0) * 64 + ln] = h;
+    Ws[(jd * 2 + 1) * 64 + ln] = r;
+  }
+
+  // ---- staging jobs of this thread (the same for every plane): job < NQ = the 16-byte quad xq of patch row q, octet o
+  // (8 buffer_load_dwordx4, one per channel -> 4 positions x 2 split units), else one halo column position (8 dword loads)
+  unsigned jvo[NR];            // byte offset of (channel 8 o, plane 0, row, column) or OOB
+  int jpos[NR];                // LDS unit of the (first) position within a split section; < 0: no job
+  bool jquad[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int job = tid + 512 * r;
+    jvo[r] = OOB; jpos[r] = -1; jquad[r] = job < NQ;
+    if (job < NJ) {
+      int o, q, col, gx;
+      if (job < NQ) { const int xq = job & 7; q = (job >> 3) % 18; o = (job >> 3) / 18; col = 1 + 4 * xq; gx = x0 + 4 * xq; }
+      else { const int s_ = job - NQ, side = s_ & 1; q = (s_ >> 1) % 18; o = (s_ >> 1) / 18; col = side ? 33 : 0; gx = side ? x0 + 32 : x0 - 1; }
+      const int gy = y0 - 1 + q;
+      jpos[r] = o * OP + q * RS + col;
+      if ((unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
+        jvo[r] = (unsigned)(gy * k.W + gx) * 4u + (unsigned)(8 * o) * s4;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (long long)n * CIN * S), 0, (unsigned)((long long)CIN * S * 4), 0x00020000);
+  u32x4 rq[NR][8];
+#define M3_GLOAD(z_)                                                                              \
+  {                                                                                               \
+    const int zz_ = (z_);                                                                         \
+    const bool zok_ = (unsigned)zz_ < (unsigned)k.D;                                              \
+    const unsigned zb_ = zok_ ? (unsigned)zz_ * hw4 : 0u;                                         \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                              \
+      const unsigned vo_ = zok_ ? jvo[r] : OOB;                                                   \
+      if (jquad[r]) {                                                                             \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                             \
+          rq[r][c] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
+      } else if (jpos[r] >= 0) {                                                                  \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                             \
+          rq[r][c][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
+      }                                                                                           \
+    }                                                                                             \
+  }
+#define M3_LSTORE(sl_)                                                                            \
+  {                                                                                               \
+    u32x4* Xd_ = Xs + (sl_) * SU;                                                                 \
+    _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                              \
+      if (jquad[r]) {                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+          float v_[8];                                                                            \
+          _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r][c][e]);     \
+          u32x4 h_, r_;                                                                           \
+          split8_m(v_, xscale, h_, r_);                                                           \
+          Xd_[jpos[r] + e] = h_;                                                                  \
+          Xd_[NO * OP + jpos[r] + e] = r_;                                                        \
+        }                                                                                         \
+      } else if (jpos[r] >= 0) {                                                                  \
+        float v_[8];                                                                              \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r][c][0]);       \
+        u32x4 h_, r_;                                                                             \
+        split8_m(v_, xscale, h_, r_);                                                             \
+        Xd_[jpos[r]] = h_;                                                                        \
+        Xd_[NO * OP + jpos[r]] = r_;                                                              \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  // ---- MFMA operand addresses.  Voxel operand of (kind, patch row q, half h, split s):
+  //   Xs[slot][s * NO * OP + vb[kind] + q * RS + 16 h]
+  int vb[3];
+  if constexpr (B32) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) vb[d] = lhi * OP + (2 * wid) * RS + l31 + d;
+  } else if constexpr (CIN == 32) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) vb[d] = kg * OP + (2 * wid) * RS + l15 + d;
+  } else {
+    vb[0] = (kg & 1) * OP + (2 * wid) * RS + l15 + (kg >> 1);            // (dy, dx 0 | dx 1)
+    vb[1] = (kg & 1) * OP + (2 * wid + (kg >> 1)) * RS + l15 + 2;        // (dy | dy + 1, dx 2)
+    vb[2] = 0;
+  }
+
+  // accumulators of the three open output planes: [plane slot][tile row][half]
+  using acc_t = typename std::conditional<B32, f32x16, f32x4_m>::type;
+  acc_t acc[3][2][NH];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < (B32 ? 16 : 4); ++i) acc[a][r][h][i] = 0.f;
+
+  // epilogue constants: lane = one output channel, 4 consecutive voxels per accumulator quad
+  const int co = B32 ? l31 : l15;
+  const float bv = bias ? bias[co] : 0.f;
+  const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
+      y + (long long)n * COUT * S, 0, (unsigned)((long long)COUT * S * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((k.act_src ? k.act_src : y) + (long long)n * COUT * S), 0, (unsigned)((long long)COUT * S * 4), 0x00020000);
+  constexpr int NE = B32 ? 8 : 4;                            // 16-byte stores per lane and plane: [row][half or quad]
+  unsigned evo[NE];                                          // byte offset at plane 0 (or OOB)
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int r = B32 ? (e >> 2) : (e >> 1);
+    const int gy = y0 + 2 * wid + r;
+    const int gx = B32 ? (x0 + 8 * (e & 3) + 4 * lhi) : (x0 + 16 * (e & 1) + 4 * kg);
+    evo[e] = (gy < k.H && gx < k.W) ? (unsigned)(gy * k.W + gx) * 4u + (unsigned)co * s4 : OOB;
+  }
+  float pm = 0.f;
+
+  // ---- one plane step: consume input plane P (slot sl_) with roles rotated by PH = (P - (zs - 1)) % 3, then finish
+  // output plane P - 1
+#define M3_BREAD(kind_, q_)                                                                       \
+  {                                                                                               \
+    _Pragma("unroll") for (int h = 0; h < NH; ++h)                                                \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+        Bu[q_][h][s] = Xc[s * NO * OP + vb[kind_] + (q_) * RS + 16 * h];                          \
+  }
+#define M3_AREAD(buf_, jd_)                                                                       \
+  { Aw[buf_][0] = Ws[((jd_) * 2 + 0) * 64 + lane]; Aw[buf_][1] = Ws[((jd_) * 2 + 1) * 64 + lane]; }
+#define M3_STEP(PH_, sl_, P_)                                                                     \
+  {                                                                                               \
+    const u32x4* Xc = Xs + (sl_) * SU;                                                            \
+    u32x4 Bu[4][NH][2], Aw[2][2], av[ACTG ? NE : 1];                                              \
+    M3_BREAD(0, 0) M3_BREAD(0, 1)                                                                 \
+    M3_AREAD(0, 0)                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NSTEP; ++j) {                                           \
+      const unsigned lmask = step_loads<CIN, COUT>(j);                                            \
+      _Pragma("unroll") for (int b = 0; b < 12; ++b)                                              \
+        if (lmask & (1u << b)) M3_BREAD(b >> 2, b & 3)                                            \
+      if (ACTG && j == (NSTEP > 5 ? NSTEP - 3 : NSTEP - 2)) {                                     \
+        const int p_ = (P_) - 1;                                                                  \
+        const bool pok_ = p_ >= zs && p_ < ze;                                                    \
+        _Pragma("unroll") for (int e = 0; e < NE; ++e)                                            \
+          av[e] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e] : OOB, (unsigned)p_ * hw4, 0); \
+      }                                                                                           \
+      const int qo = step_qoff<CIN, COUT>(j);                                                     \
+      _Pragma("unroll") for (int dz = 0; dz < 3; ++dz) {                                          \
+        const int jd = j * 3 + dz, cur = jd & 1;                                                  \
+        if (jd + 1 < NSTEP * 3) M3_AREAD(cur ^ 1, jd + 1)                                         \
+        const int a = ((PH_) + 4 - dz) % 3;                                                       \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                           \
+          const int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
+          _Pragma("unroll") for (int r = 0; r < 2; ++r)                                           \
+            _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                      \
+              if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
+              else acc[a][r][h] = mma16m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]);          \
+            }                                                                                     \
+        }                                                                                         \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
+    /* output plane P - 1 is complete */                                                          \
+    {                                                                                             \
+      const int p_ = (P_) - 1, a = ((PH_) + 2) % 3;                                               \
+      const bool pok_ = p_ >= zs && p_ < ze;                                                      \
+      const unsigned pb_ = (unsigned)p_ * hw4;                                                    \
+      _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                            \
+        const int r = B32 ? (e >> 2) : (e >> 1), h = B32 ? 0 : (e & 1), q4 = B32 ? 4 * (e & 3) : 0; \
+        const bool ok = pok_ && evo[e] != OOB;                                                    \
+        u32x4 out;                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+          float v = acc[a][r][h][q4 + i] * osc + bv;                                              \
+          if (k.act == 1) v = v > 0.f ? v : v * k.slope;                                          \
+          if (ACTG) v = __uint_as_float(av[ACTG ? e : 0][i]) > 0.f ? v : v * k.act_slope;          \
+          out[i] = __float_as_uint(v);                                                            \
+          pm = fmaxf(pm, ok ? fabsf(v) : 0.f);                                                    \
+          acc[a][r][h][q4 + i] = 0.f;                                                             \
+        }                                                                                         \
+        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, ok ? evo[e] : OOB, pb_, 0);            \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  const int P0 = zs - 1;
+  M3_GLOAD(P0)
+  __syncthreads();                                           // slots zeroed, weights in place
+  M3_LSTORE(0)
+  if (nst > 1) M3_GLOAD(P0 + 1)
+  __syncthreads();
+
+  // one step of the march with its staging protocol; i = index of the input plane within the segment
+#define M3_ITER(PH_, i_)                                                                          \
+  {                                                                                               \
+    const int ii = (i_);                                                                          \
+    if constexpr (SLOTS == 2) {                                                                   \
+      if (ii + 1 < nst) M3_LSTORE((ii + 1) & 1)                                                   \
+      if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                     \
+      M3_STEP(PH_, ii & 1, P0 + ii)                                                               \
+      __syncthreads();                                                                            \
+    } else {                                                                                      \
+      M3_STEP(PH_, 0, P0 + ii)                                                                    \
+      if (ii + 1 < nst) {                                                                         \
+        __syncthreads();                                                                          \
+        M3_LSTORE(0)                                                                              \
+        __syncthreads();                                                                          \
+        if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                   \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  for (int i = 0; i < nst; i += 3) {
+    M3_ITER(0, i)
+    if (i + 1 < nst) M3_ITER(1, i + 1)
+    if (i + 2 < nst) M3_ITER(2, i + 2)
+  }
+#undef M3_ITER
+#undef M3_STEP
+#undef M3_AREAD
+#undef M3_BREAD
+#undef M3_LSTORE
+#undef M3_GLOAD
+  if (y_amax) {
+    __syncthreads();
+    publish_block_absmax_acc(pm, &smax, y_amax);
+  }
+}
+
+bool march_off() {
+  static DfOptFlag a{"DFMIR_CONV3D_NO_MARCH"}, b{"DFMIR_CONV3D_FP32"}, c{"DFMIR_CONV_FP32"};
+  return a.get() || b.get() || c.get();
+}
+bool march_geom_ok(const DfConvGeom* g) {
+  const bool shape = (g->Cin == 32 && g->Cout == 16) || (g->Cin == 16 && (g->Cout == 16 || g->Cout == 32));
+  return shape && g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
+         g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && (g->act == 0 || g->act == 1) &&
+         g->Di >= 4 && g->Hi >= 8 && g->Wi >= 16 && (g->Wi % 4) == 0 &&
+         (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;
+}
+
+}  // namespace
+
+extern "C" int dfmir_conv3d_march_ok(const DfConvGeom* g) { return (g && !march_off() && march_geom_ok(g)) ? 1 : 0; }
+
+extern "C" int dfmir_conv3d_march_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
+                                      const float* w_tcc, const float* bias, float* y, float* y_amax,
+                                      const float* act_src, float act_slope, void* stream) {
+  DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && w_tcc && y);
+  DF_ARG_CHECK(!march_off() && march_geom_ok(g) && (act_src == nullptr || g->act == 0));
+  DF_ARG_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(act_src) |
+                 reinterpret_cast<uintptr_t>(w_tcc)) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  MarchP k{};
+  k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
+  k.nty = (g->Hi + 15) / 16; k.ntx = (g->Wi + 31) / 32;
+  k.x_n = x_amax_n; k.act = g->act; k.slope = g->slope; k.act_src = act_src; k.act_slope = act_slope;
+  // z segments: every workgroup pays two halo planes; pick the count that minimises (rounds of 256 CUs) x (planes per
+  // workgroup).  DFMIR_MARCH_NSEG=<n> forces it.
+  static DfOptInt nseg_o{"DFMIR_MARCH_NSEG", 0};
+  const long long cols = (long long)g->N * k.nty * k.ntx;
+  int best = 1;
+  long long best_cost = -1;
+  for (int ns = 1; ns <= g->Di / 2 && ns <= 128; ++ns) {
+    const int zl = (g->Di + ns - 1) / ns;
+    if ((long long)(ns - 1) * zl >= g->Di) continue;         // an empty last segment
+    const long long rounds = (cols * ns + 255) / 256;
+    const long long cost = rounds * (zl + 2);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  if (nseg_o.get() > 0 && nseg_o.get() <= g->Di) best = nseg_o.get();
+  k.nseg = best;
+  k.zlen = (g->Di + best - 1) / best;
+  k.nseg = (g->Di + k.zlen - 1) / k.zlen;
+  k.nwork = cols * k.nseg;
+  const unsigned grid = (unsigned)(8 * ((k.nwork + 7) / 8));
+#define M3_LAUNCH(CI_, CO_)                                                                       \
+  {                                                                                               \
+    if (act_src) conv3d_march_k<CI_, CO_, true><<<grid, 512, 0, st>>>(x, x_amax, w_tcc, bias, y, y_amax, k);  \
+    else conv3d_march_k<CI_, CO_, false><<<grid, 512, 0, st>>>(x, x_amax, w_tcc, bias, y, y_amax, k);         \
+  }
+  if (g->Cin == 32) M3_LAUNCH(32, 16)
+  else if (g->Cout == 16) M3_LAUNCH(16, 16)
+  else M3_LAUNCH(16, 32)
+#undef M3_LAUNCH
+  DF_LAUNCH_CHECK();
+  return 0;
+}

@@ -215,6 +215,9 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
     if cout_used is not None and not split3d:
         cout_used = None                                     # only the split 3-D kernel computes a channel subset
+    # the full-resolution layers with Cin x Cout <= 512: the z-marching kernel (csrc/conv3dm.hip)
+    march3d = (split3d and (cout_used is None or cout_used == Cout) and Wi % 4 == 0
+               and bool(lib().dfmir_conv3d_march_ok(ctypes.byref(g))))
     if act_src is not None and not ((split3d or tiny3d) and act == 0 and tuple(act_src.shape) == tuple(y.shape)
                                     and act_src.is_contiguous()):
         act_src = None                                       # ... and only these epilogues apply an activation derivative
@@ -232,6 +235,12 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         elif s2c2:
             slot = amax_slot(x5.device, PROBE_SLOTS)
             check(lib().dfmir_conv3d_s2c2_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _st()))
+            tag_amax(y, slot)
+            _LAST_CONV_AMAX[0] = slot
+        elif march3d:
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_march_fwd(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(bias),
+                                               _p(y), _p(slot), _p(act_src), float(act_slope), _st()))
             tag_amax(y, slot)
             _LAST_CONV_AMAX[0] = slot
         elif split3d:
@@ -288,6 +297,8 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
             form_ = lib().dfmir_conv3d_split_is_pair(cu)      # 0: 32 rows, 1: plane pairs (36 taps'), 2: 16 rows
             pad_k = (36.0 if form_ == 1 else 28.0) / 27.0 * (8.0 * ((Cin + 7) // 8)) / Cin
             pad_m = (16.0 / cu) if form_ else (32.0 * ((cu + 31) // 32)) / cu
+            if march3d:                                       # no padded rows; 16 -> 16 walks 10 tap slots per 9 taps
+                pad_k, pad_m = ((10.0 / 9.0) if (Cin == 16 and Cout == 16) else 1.0), 1.0
             if getattr(prof, "accepts_issued", False):
                 prof(kind, flops * cu / Cout, launch, 3.0 * pad_k * pad_m * flops * cu / Cout)
             else:

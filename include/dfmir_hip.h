@@ -46,7 +46,8 @@ const char* dfmir_last_error(void);
  *     DFMIR_NO_SMALL_WGRAD, DFMIR_NO_DIL2, DFMIR_NO_SMALL_TILES, DFMIR_GEMM_BIG_MIN=n,
  *     DFMIR_CONV3D_NO_PAIR, DFMIR_CONV3D_NO_M16, DFMIR_CONV3D_NO_TINY, DFMIR_CONV3D_NO_VEC,
  *     DFMIR_CONV3D_NO_MULTI, DFMIR_CONV3D_WGS=n, DFMIR_WSPLIT_WGS=n, DFMIR_CONV3D_NO_UPPHASE,
- *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED.
+ *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED, DFMIR_CONV3D_NO_MARCH,
+ *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (experimental one-wave kernel).
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);
@@ -141,6 +142,20 @@ int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W);
  * _up_skip2_fwd's (K = Ca, Cb = skip channels or 0), 2 = dfmir_conv3d_up_dgrad's.  The entry points then take w_tcc = NULL. */
 int dfmir_conv3d_wsplit_batch(const void* jobs_dev, int njobs, void* stream);
 int dfmir_conv3d_split_is_pair(int cout_used);
+/* The full-resolution 3x3x3 stride-1 layers with Cin x Cout <= 512 -- 32 -> 16, 16 -> 16 and the input gradients 16 <- 16,
+ * 32 <- 16 of the `extras` chain (models/voxelmorph/torchvoxelmorph/networks.py:73-86,1506-1521) -- as a z-MARCHING kernel
+ * (csrc/conv3dm.hip): a workgroup owns a 16 x 32 column of the volume and walks a segment of planes; every input plane is
+ * staged once (in-plane halo only), the accumulators of the three open output planes roll through the registers, the
+ * layer's weights are split by the workgroup itself and stay in LDS (no workspace, no weight-split launch).  Same
+ * arithmetic as dfmir_conv3d_split_fwd (scaled fp16x2 products, fp32 accumulation); x_amax as there; y_amax
+ * (DFMIR_PROBE_SLOTS floats, zeroed by the caller, or NULL) receives the range probe of y.  act_src != NULL (g->act == 0):
+ * the result is multiplied by the LeakyReLU derivative act_src > 0 ? 1 : act_slope, as dfmir_conv3d_split_fwd_actgrad.
+ * Needs W % 4 == 0 and 16-byte aligned x, y, act_src, w_tcc; dfmir_conv3d_march_ok says whether the geometry is taken
+ * (0 under DFMIR_CONV3D_NO_MARCH / DFMIR_CONV3D_FP32 / DFMIR_CONV_FP32). */
+int dfmir_conv3d_march_ok(const DfConvGeom* g);
+int dfmir_conv3d_march_fwd(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* w_tcc,
+                           const float* bias, float* y, float* y_amax, const float* act_src, float act_slope,
+                           void* stream);
 /* The flow head (models/voxelmorph/torchvoxelmorph/networks.py:1076-1080: Conv3d(16, 3, 3, padding=1)) and its data
  * gradient (3 -> 16) as plain fp32 FMAs -- neither side fills a matrix-core tile (3 of 16 rows / 3 of 8 K channels).
  * w_tcc: the fp32 tap-major packing [27][Cin][Cout] of dfmir_weight_pack (mode 0 forward, mode 1 data gradient);

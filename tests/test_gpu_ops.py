@@ -267,6 +267,11 @@ CONV3D = [
     (2, 16, 3, 2, 1, 1, 12, 10, 16),
     (2, 16, 3, 2, 1, 2, 9, 17, 72),
     (2, 16, 3, 2, 1, 1, 7, 33, 136),
+    # the z-marching kernel of the full-resolution layers (conv3dm.hip: 32 -> 16, 16 -> 16, and 16 -> 32 as their input
+    # gradients and as a forward): several 16 x 32 columns in x and y with ragged last ones, batch 2, odd depths
+    (32, 16, 3, 1, 1, 2, 9, 37, 72),
+    (16, 16, 3, 1, 1, 1, 13, 20, 40),
+    (16, 32, 3, 1, 1, 1, 6, 18, 36),
 ]
 
 
@@ -289,6 +294,59 @@ def test_conv3d(ops, cfg):
     close(xg.grad, xr.grad, what="dx")
     close(wg.grad, wr.grad, rtol=3e-4, what="dw")
     close(bg.grad, br.grad, rtol=3e-4, what="db")
+
+
+@pytest.mark.parametrize("cfg", [(32, 16, 1, 11, 24, 64), (16, 16, 2, 7, 16, 32), (16, 32, 1, 10, 33, 48)],
+                         ids=["32to16", "16to16-batch2", "16to32"])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_conv3d_march_kernel(ops, cfg, nseg):
+    """conv3d_march_k (csrc/conv3dm.hip): forward with LeakyReLU and the input gradient with the LeakyReLU derivative of
+    the producing block in its epilogue, against torch fp64 and against the tiled kernels (DFMIR_CONV3D_NO_MARCH=1) -- with
+    one z segment per column and with three (every segment re-stages one halo plane at each end; the open accumulators of
+    a segment's first and last planes are discarded)."""
+    from dfmir_amd import _lib
+    Cin, Cout, N, D, H, W = cfg
+    x = C.randn(301, N, Cin, D, H, W)
+    w = C.randn(302, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5
+    b = C.randn(303, Cout) * 0.1
+    cot = C.randn(304, N, Cout, D, H, W)
+    src = C.randn(305, N, Cin, D, H, W)                      # the activation source of the folded LeakyReLU backward
+    xr, wr = x.double().requires_grad_(), w.double()
+    yr = F.leaky_relu(F.conv3d(xr, wr, b.double(), padding=1), 0.2)
+    (yr * cot.double()).sum().backward()
+    dxr = xr.grad * torch.where(src.double() > 0, 1.0, 0.2)
+
+    def run():
+        g = ops.DfConvGeom
+        xg, wg, bg = x.to(DEV), w.to(DEV), b.to(DEV)
+        wt = ops.weight_pack(wg, 0)
+        y = ops.conv_raw(xg.contiguous(), wt, bg, Cout, (3, 3, 3), 1, (1, 1, 1), 1, 0, 1, 0.2, (D, H, W), x_amax=ops.absmax(xg))
+        dy = (cot.to(DEV) * torch.where(y > 0, 1.0, 0.2)).contiguous()
+        wtd = ops.weight_pack(wg, 1)                          # dgrad packing: taps flipped, channel roles swapped
+        dx = ops.conv_raw(dy, wtd, None, Cin, (3, 3, 3), 1, (1, 1, 1), 1, 0, 0, 0.0, (D, H, W), x_amax=ops.absmax(dy),
+                          act_src=src.to(DEV).contiguous(), act_slope=0.2)
+        assert ops._LAST_ACTGRAD[0]
+        probe = float(ops.amax_of(dx).max())
+        torch.cuda.synchronize()
+        return y, dx, probe
+
+    _lib.set_option("DFMIR_MARCH_NSEG", str(nseg))
+    try:
+        assert ops.lib().dfmir_conv3d_march_ok is not None
+        y1, dx1, probe = run()
+    finally:
+        _lib.set_option("DFMIR_MARCH_NSEG", None)
+    _lib.set_option("DFMIR_CONV3D_NO_MARCH", "1")
+    try:
+        y0, dx0, _ = run()
+    finally:
+        _lib.set_option("DFMIR_CONV3D_NO_MARCH", None)
+    close(y1, yr.detach().float(), rtol=2e-5, what="y vs fp64")
+    close(dx1, dxr.float(), rtol=2e-5, what="dx vs fp64")
+    close(y1, y0, rtol=2e-6, what="march vs tiled y")
+    close(dx1, dx0, rtol=2e-6, what="march vs tiled dx")
+    true = float(dx1.abs().max())
+    assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)     # the epilogue's range probe of its output
 
 
 @pytest.mark.parametrize("cfg", [(16, 2, 32, 1, 6, 10, 12, 1), (32, 16, 32, 1, 5, 9, 20, 1), (8, 3, 16, 2, 4, 8, 8, 0),
