@@ -351,7 +351,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
           pm = fmaxf(pm, ok ? fabsf(v) : 0.f);                                                    \
           acc[a][r][h][q4 + i] = 0.f;                                                             \
         }                                                                                         \
-        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, ok ? evo[e] : OOB, pb_, 0);            \
+        /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
+        /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
+        /* the last lanes of every 16 was lost once in ~10^4 launches)                                              */ \
+        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, ok ? evo[e] + pb_ : OOB, 0, 0);        \
       }                                                                                           \
     }                                                                                             \
   }

@@ -30,7 +30,10 @@ __device__ __forceinline__ float2 irb_ld2(__amdgpu_buffer_rsrc_t r, unsigned vof
 __device__ __forceinline__ void irb_st4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   irb_u32x4 t;
   t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+  // the offset goes through the VGPR and soffset stays a literal 0: behind a 16-byte store with an SGPR soffset hipcc issues
+  // a VALU write of the data registers without a wait state, and gfx950 then stores the NEW dword 0 for some lanes
+  // (found with csrc/conv3dm.hip, same instruction form)
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff + soff, 0, 0);
 }
 __device__ __forceinline__ void irb_st2(float2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   irb_u32x2 t;
