@@ -30,6 +30,22 @@
 
 typedef _Float16 f16x8_m __attribute__((ext_vector_type(8)));
 typedef float f32x4_m __attribute__((ext_vector_type(4)));
+#ifndef M3_KO
+#define M3_KO 0      // knock-out builds (timing only, scripts/build_ko_march.sh): 1 no MFMAs, 2 no staging loads, 4 no conversion +
+#endif               // LDS stores, 8 no epilogue stores, 16 no epilogue at all, 32 no operand reads after the first plane
+#define M3_SINK(v_) asm volatile("" ::"v"(v_))
+#ifdef M3_TRACE      // timing build: per-wave cycle sums of the phases of one workgroup's plane steps -> dfmir_m3_trace()
+__device__ unsigned long long m3_trace[8 * 8];
+#define M3_T0() unsigned long long tlast = __builtin_readcyclecounter(); const bool trace_blk = blockIdx.x == 77;
+#define M3_T(i_) { if (trace_blk && lane == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); m3_trace[wid * 8 + (i_)] += t_ - tlast; tlast = t_; __builtin_amdgcn_sched_barrier(0); } }
+extern "C" void dfmir_m3_trace(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(m3_trace), sizeof(m3_trace));
+  if (reset) { unsigned long long z[64] = {}; hipMemcpyToSymbol(HIP_SYMBOL(m3_trace), z, sizeof(z)); }
+}
+#else
+#define M3_T0()
+#define M3_T(i_)
+#endif
 
 namespace {
 
@@ -207,13 +223,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (long long)n * CIN * S), 0, (unsigned)((long long)CIN * S * 4), 0x00020000);
   u32x4 rq[NR][8];
+  bool ko_st = true;                                         // (knock-out builds switch the staging stores off after the prologue)
 #define M3_GLOAD(z_)                                                                              \
   {                                                                                               \
     const int zz_ = (z_);                                                                         \
     const bool zok_ = (unsigned)zz_ < (unsigned)k.D;                                              \
     const unsigned zb_ = zok_ ? (unsigned)zz_ * hw4 : 0u;                                         \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                              \
-      const unsigned vo_ = zok_ ? jvo[r] : OOB;                                                   \
+      const unsigned vo_ = (zok_ && !((M3_KO & 2) && k.D > 0)) ? jvo[r] : OOB;                    \
       if (jquad[r]) {                                                                             \
         _Pragma("unroll") for (int c = 0; c < 8; ++c)                                             \
           rq[r][c] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     }                                                                                             \
   }
 #define M3_LSTORE(sl_)                                                                            \
-  {                                                                                               \
+  if (ko_st) {                                                                                    \
     u32x4* Xd_ = Xs + (sl_) * SU;                                                                 \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                              \
       if (jquad[r]) {                                                                             \
@@ -295,17 +312,27 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   // ---- one plane step: consume input plane P (slot sl_) with roles rotated by PH = (P - (zs - 1)) % 3, then finish
   // output plane P - 1
 #define M3_BREAD(kind_, q_)                                                                       \
-  {                                                                                               \
+  if (M3_KO_RD) {                                                                                 \
     _Pragma("unroll") for (int h = 0; h < NH; ++h)                                                \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
         Bu[q_][h][s] = Xc[s * NO * OP + vb[kind_] + (q_) * RS + 16 * h];                          \
   }
 #define M3_AREAD(buf_, jd_)                                                                       \
-  { Aw[buf_][0] = Ws[((jd_) * 2 + 0) * 64 + lane]; Aw[buf_][1] = Ws[((jd_) * 2 + 1) * 64 + lane]; }
+  if (M3_KO_RD) { Aw[buf_][0] = Ws[((jd_) * 2 + 0) * 64 + lane]; Aw[buf_][1] = Ws[((jd_) * 2 + 1) * 64 + lane]; }
+#if M3_KO & 32
+  u32x4 Bu[4][NH][2], Aw[2][2];
+  bool ko_rd = true;
+#define M3_KO_DECL
+#define M3_KO_RD ko_rd
+#else
+#define M3_KO_DECL u32x4 Bu[4][NH][2], Aw[2][2];
+#define M3_KO_RD true
+#endif
 #define M3_STEP(PH_, sl_, P_)                                                                     \
   {                                                                                               \
     const u32x4* Xc = Xs + (sl_) * SU;                                                            \
-    u32x4 Bu[4][NH][2], Aw[2][2], av[ACTG ? NE : 1];                                              \
+    M3_KO_DECL                                                                                    \
+    u32x4 av[ACTG ? NE : 1];                                                                      \
     M3_BREAD(0, 0) M3_BREAD(0, 1)                                                                 \
     M3_AREAD(0, 0)                                                                                \
     _Pragma("unroll") for (int j = 0; j < NSTEP; ++j) {                                           \
@@ -327,15 +354,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
           const int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
           _Pragma("unroll") for (int r = 0; r < 2; ++r)                                           \
             _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                      \
-              if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
+              if ((M3_KO & 1) && k.D > 0) { M3_SINK(Bu[r + qo][h][sb]); M3_SINK(Aw[cur][sa]); }  \
+              else if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
               else acc[a][r][h] = mma16m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]);          \
             }                                                                                     \
         }                                                                                         \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
+    M3_T(2)                                                                                       \
     /* output plane P - 1 is complete */                                                          \
-    {                                                                                             \
+    if (!((M3_KO & 16) && k.D > 0)) {                                                             \
       const int p_ = (P_) - 1, a = ((PH_) + 2) % 3;                                               \
       const bool pok_ = p_ >= zs && p_ < ze;                                                      \
       const unsigned pb_ = (unsigned)p_ * hw4;                                                    \
@@ -354,17 +383,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
         /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
         /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
         /* the last lanes of every 16 was lost once in ~10^4 launches)                                              */ \
-        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, ok ? evo[e] + pb_ : OOB, 0, 0);        \
+        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[e] + pb_ : OOB, 0, 0); \
       }                                                                                           \
     }                                                                                             \
+    M3_T(3)                                                                                       \
   }
 
   const int P0 = zs - 1;
+  M3_T0()
   M3_GLOAD(P0)
   __syncthreads();                                           // slots zeroed, weights in place
   M3_LSTORE(0)
   if (nst > 1) M3_GLOAD(P0 + 1)
   __syncthreads();
+  ko_st = !((M3_KO & 4) && k.D > 0);
+  M3_T(6)
+#if M3_KO & 32
+  { const u32x4* Xc = Xs; M3_BREAD(0, 0) M3_BREAD(0, 1) M3_BREAD(0, 2) M3_BREAD(0, 3) M3_AREAD(0, 0) M3_AREAD(1, 1) }
+  ko_rd = k.D < 0;
+#endif
 
   // one step of the march with its staging protocol; i = index of the input plane within the segment
 #define M3_ITER(PH_, i_)                                                                          \
@@ -372,16 +409,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     const int ii = (i_);                                                                          \
     if constexpr (SLOTS == 2) {                                                                   \
       if (ii + 1 < nst) M3_LSTORE((ii + 1) & 1)                                                   \
+      M3_T(0)                                                                                     \
       if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                     \
+      M3_T(1)                                                                                     \
       M3_STEP(PH_, ii & 1, P0 + ii)                                                               \
       __syncthreads();                                                                            \
+      M3_T(4)                                                                                     \
     } else {                                                                                      \
       M3_STEP(PH_, 0, P0 + ii)                                                                    \
       if (ii + 1 < nst) {                                                                         \
         __syncthreads();                                                                          \
+        M3_T(4)                                                                                   \
         M3_LSTORE(0)                                                                              \
+        M3_T(0)                                                                                   \
         __syncthreads();                                                                          \
+        M3_T(5)                                                                                   \
         if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                   \
+        M3_T(1)                                                                                   \
       }                                                                                           \
     }                                                                                             \
   }
@@ -392,6 +436,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   }
 #undef M3_ITER
 #undef M3_STEP
+#undef M3_KO_DECL
+#undef M3_KO_RD
 #undef M3_AREAD
 #undef M3_BREAD
 #undef M3_LSTORE
