@@ -34,6 +34,12 @@ typedef float f32x4_m __attribute__((ext_vector_type(4)));
 #define M3_KO 0      // knock-out builds (timing only, scripts/build_ko_march.sh): 1 no MFMAs, 2 no staging loads, 4 no conversion +
 #endif               // LDS stores, 8 no epilogue stores, 16 no epilogue at all, 32 no operand reads after the first plane
 #define M3_SINK(v_) asm volatile("" ::"v"(v_))
+#ifndef M3_ADEPTH
+#define M3_ADEPTH 1  // weight operands are read this many (k-step, dz) blocks ahead of their MFMAs
+#endif
+#ifndef M3_PRIO
+#define M3_PRIO 0    // 1: the two waves of a SIMD (w, w + 4) alternate s_setprio 1 / 0 block by block; 2: waves 4-7 at 1
+#endif
 #ifdef M3_TRACE      // timing build: per-wave cycle sums of the phases of one workgroup's plane steps -> dfmir_m3_trace()
 __device__ unsigned long long m3_trace[8 * 8];
 #define M3_T0() unsigned long long tlast = __builtin_readcyclecounter(); const bool trace_blk = blockIdx.x == 77;
@@ -76,6 +82,16 @@ __device__ __forceinline__ f32x4_m mma16m(u32x4 a, u32x4 b, f32x4_m c) {
 }
 __device__ __forceinline__ f32x16 mma32m(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_m, a), __builtin_bit_cast(f16x8_m, b), c, 0, 0, 0);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1 (the plane step's schedule is a table over its
+// MFMA groups; `#pragma unroll` left some of these loops peeled instead of unrolled and the register arrays in scratch)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_m(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_m<B + 1, E>(f);
+  }
 }
 
 struct MarchP {
@@ -212,7 +228,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     jvo[r] = OOB; jpos[r] = -1; jquad[r] = job < NQ;
     if (job < NJ) {
       int o, q, col, gx;
-      if (job < NQ) { const int xq = job & 7; q = (job >> 3) % 18; o = (job >> 3) / 18; col = 1 + 4 * xq; gx = x0 + 4 * xq; }
+      if (job < NQ) {
+        // 8 consecutive lanes (one service group of ds_write_b128) = four quads of TWO consecutive rows: their units sit
+        // at 4 xq + 34 (q & 1) + e -> 8 distinct 16-byte bank groups (quads 0..7 of one row: 2-way conflicts)
+        const int xq = (job & 3) | (((job >> 3) & 1) << 2), q2 = (job >> 4) % 9;
+        q = 2 * q2 + ((job >> 2) & 1); o = (job >> 4) / 9; col = 1 + 4 * xq; gx = x0 + 4 * xq;
+      }
       else { const int s_ = job - NQ, side = s_ & 1; q = (s_ >> 1) % 18; o = (s_ >> 1) / 18; col = side ? 33 : 0; gx = side ? x0 + 32 : x0 - 1; }
       const int gy = y0 - 1 + q;
       jpos[r] = o * OP + q * RS + col;
@@ -320,48 +341,101 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
 #define M3_AREAD(buf_, jd_)                                                                       \
   if (M3_KO_RD) { Aw[buf_][0] = Ws[((jd_) * 2 + 0) * 64 + lane]; Aw[buf_][1] = Ws[((jd_) * 2 + 1) * 64 + lane]; }
 #if M3_KO & 32
-  u32x4 Bu[4][NH][2], Aw[2][2];
+  u32x4 Bu[4][NH][2], Aw[M3_ADEPTH + 1][2];
   bool ko_rd = true;
 #define M3_KO_DECL
 #define M3_KO_RD ko_rd
 #else
-#define M3_KO_DECL u32x4 Bu[4][NH][2], Aw[2][2];
+#define M3_KO_DECL u32x4 Bu[4][NH][2], Aw[M3_ADEPTH + 1][2];
 #define M3_KO_RD true
 #endif
-#define M3_STEP(PH_, sl_, P_)                                                                     \
+  // Staging work of a plane step is cut into ATOMS that ride between the MFMA groups of the step (group t = 3 x block + product
+  // term; a block = the 12 / 6 MFMAs of one (k-step, dz)), so that neither the vector-memory queue (a burst of 16 x 1 KB loads
+  // per wave blocked the ISSUE of everything behind it for 17-19 % of a step) nor the conversion sits in front of the MFMAs:
+  //   two slots:  t = 0..7    convert + store plane P + 1 (quad position e = t / 2; half of the channel pairs per atom)
+  //               t = 9, 11, .. 23   the 8 channel loads of plane P + 2;   t = 10, 12, ..   the activation-source quads
+  //   one slot:   t = 0, 2, .. 30   the 16 channel loads of plane P + 1 (two job rounds), converted and stored between the
+  //               two barriers (converting in place during the MFMA phase costs a second register set: a position's unit
+  //               needs one component of eight 4-register load results);   t = 45, 47, ..   the activation-source quads
+  u32x4 cvh, cvr;                                                   // two slots: the unit being converted
+#define M3_CONV_HALF(r_, e_, half_, H_, R_)     /* (every lane converts: no predicate, no merge with old register contents) */ \
+  {                                                                                               \
+    _Pragma("unroll") for (int q = 2 * (half_); q < 2 * (half_) + 2; ++q) {                       \
+      unsigned hh_, rr_;                                                                          \
+      split_pair_m(__uint_as_float(rq[r_][2 * q][e_]), __uint_as_float(rq[r_][2 * q + 1][e_]), xscale, hh_, rr_); \
+      H_[q] = hh_; R_[q] = rr_;                                                                   \
+    }                                                                                             \
+  }
+#define M3_LOAD1(r_, c_, z_)                                                                      \
+  {                                                                                               \
+    const int zz_ = (z_);                                                                         \
+    const bool zok_ = (unsigned)zz_ < (unsigned)k.D && !((M3_KO & 2) && k.D > 0);                 \
+    const unsigned zb_ = zok_ ? (unsigned)zz_ * hw4 : 0u;                                         \
+    const unsigned vo_ = zok_ ? jvo[r_] : OOB;                                                    \
+    if (jquad[r_]) rq[r_][c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
+    else if (jpos[r_] >= 0) rq[r_][c_][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
+  }
+#define M3_AVLOAD(e_, P_)                                                                         \
+  {                                                                                               \
+    const int p_ = (P_) - 1;                                                                      \
+    const bool pok_ = p_ >= zs && p_ < ze;                                                        \
+    av[e_] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e_] + (unsigned)p_ * hw4 : OOB, 0, 0); \
+  }
+#define M3_ATOMS(t, P_, sl_, st_, ld_)                                                            \
+  {                                                                                               \
+    if constexpr (SLOTS == 2) {                                                                   \
+      if constexpr (t < 8) {                                                                      \
+        if ((st_) && ko_st) {                                                                     \
+          constexpr int e = t >> 1;                                                               \
+          M3_CONV_HALF(0, e, t & 1, cvh, cvr)                                                     \
+          if constexpr ((t & 1) == 1) {                                                           \
+            if (jpos[0] >= 0 && (jquad[0] || e == 0)) {                                           \
+              u32x4* Xd_ = Xs + ((sl_) ^ 1) * SU;                                                 \
+              Xd_[jpos[0] + e] = cvh;                                                             \
+              Xd_[NO * OP + jpos[0] + e] = cvr;                                                   \
+            }                                                                                     \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      if constexpr (t >= 9 && t <= 23 && (t & 1) == 1) { if (ld_) M3_LOAD1(0, (t - 9) >> 1, (P_) + 2) } \
+      if constexpr (ACTG && t >= 10 && t < 10 + 2 * NE && (t & 1) == 0) M3_AVLOAD((t - 10) >> 1, P_) \
+    } else {                                                                                      \
+      if constexpr (t <= 30 && (t & 1) == 0) { if (st_) M3_LOAD1((t >> 1) >> 3, (t >> 1) & 7, (P_) + 1) } \
+      if constexpr (ACTG && t >= 45 && t < 45 + 2 * NE && (t & 1) == 1) M3_AVLOAD((t - 45) >> 1, P_) \
+    }                                                                                             \
+  }
+#define M3_STEP(PH_, sl_, P_, st_, ld_)                                                           \
   {                                                                                               \
     const u32x4* Xc = Xs + (sl_) * SU;                                                            \
     M3_KO_DECL                                                                                    \
     u32x4 av[ACTG ? NE : 1];                                                                      \
     M3_BREAD(0, 0) M3_BREAD(0, 1)                                                                 \
-    M3_AREAD(0, 0)                                                                                \
-    _Pragma("unroll") for (int j = 0; j < NSTEP; ++j) {                                           \
-      const unsigned lmask = step_loads<CIN, COUT>(j);                                            \
-      _Pragma("unroll") for (int b = 0; b < 12; ++b)                                              \
-        if (lmask & (1u << b)) M3_BREAD(b >> 2, b & 3)                                            \
-      if (ACTG && j == (NSTEP > 5 ? NSTEP - 3 : NSTEP - 2)) {                                     \
-        const int p_ = (P_) - 1;                                                                  \
-        const bool pok_ = p_ >= zs && p_ < ze;                                                    \
-        _Pragma("unroll") for (int e = 0; e < NE; ++e)                                            \
-          av[e] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e] : OOB, (unsigned)p_ * hw4, 0); \
-      }                                                                                           \
-      const int qo = step_qoff<CIN, COUT>(j);                                                     \
-      _Pragma("unroll") for (int dz = 0; dz < 3; ++dz) {                                          \
-        const int jd = j * 3 + dz, cur = jd & 1;                                                  \
-        if (jd + 1 < NSTEP * 3) M3_AREAD(cur ^ 1, jd + 1)                                         \
-        const int a = ((PH_) + 4 - dz) % 3;                                                       \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                           \
-          const int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
-          _Pragma("unroll") for (int r = 0; r < 2; ++r)                                           \
-            _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                      \
-              if ((M3_KO & 1) && k.D > 0) { M3_SINK(Bu[r + qo][h][sb]); M3_SINK(Aw[cur][sa]); }  \
-              else if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
-              else acc[a][r][h] = mma16m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]);          \
-            }                                                                                     \
+    static_for_m<0, M3_ADEPTH>([&](auto dc_) __attribute__((always_inline)) { M3_AREAD(decltype(dc_)::value, decltype(dc_)::value) }); \
+    static_for_m<0, NSTEP * 9>([&](auto tc_) __attribute__((always_inline)) {                     \
+      constexpr int t = decltype(tc_)::value, jd = t / 3, p = t % 3, j = jd / 3, dz = jd % 3, cur = jd % (M3_ADEPTH + 1); \
+      constexpr unsigned lmask = step_loads<CIN, COUT>(j);                                        \
+      constexpr int qo = step_qoff<CIN, COUT>(j);                                                 \
+      constexpr int a = ((PH_) + 4 - dz) % 3;                                                     \
+      if constexpr (p == 0) {                                                                     \
+        if constexpr (M3_PRIO == 1) { if (wid >= 4) __builtin_amdgcn_s_setprio((jd + 1) & 1); else __builtin_amdgcn_s_setprio(jd & 1); } \
+        if constexpr (jd + M3_ADEPTH < NSTEP * 3) M3_AREAD((jd + M3_ADEPTH) % (M3_ADEPTH + 1), jd + M3_ADEPTH) \
+        if constexpr (dz == 0) {                                                                  \
+          static_for_m<0, 12>([&](auto bc_) __attribute__((always_inline)) {                      \
+            constexpr int b = decltype(bc_)::value;                                               \
+            if constexpr ((lmask >> b) & 1u) M3_BREAD(b >> 2, b & 3)                              \
+          });                                                                                     \
         }                                                                                         \
       }                                                                                           \
+      M3_ATOMS(t, P_, sl_, st_, ld_)                                                              \
+      constexpr int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
+      _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                          \
+          if ((M3_KO & 1) && k.D > 0) { M3_SINK(Bu[r + qo][h][sb]); M3_SINK(Aw[cur][sa]); }      \
+          else if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
+          else acc[a][r][h] = mma16m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]);              \
+        }                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-    }                                                                                             \
+    });                                                                                           \
     M3_T(2)                                                                                       \
     /* output plane P - 1 is complete */                                                          \
     if (!((M3_KO & 16) && k.D > 0)) {                                                             \
@@ -388,13 +462,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     }                                                                                             \
     M3_T(3)                                                                                       \
   }
-
+  // one slot: the converted units of the next plane go to the slot between the two barriers
+  if (M3_PRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);
   const int P0 = zs - 1;
   M3_T0()
   M3_GLOAD(P0)
   __syncthreads();                                           // slots zeroed, weights in place
   M3_LSTORE(0)
-  if (nst > 1) M3_GLOAD(P0 + 1)
+  if (SLOTS == 2 && nst > 1) M3_GLOAD(P0 + 1)
   __syncthreads();
   ko_st = !((M3_KO & 4) && k.D > 0);
   M3_T(6)
@@ -408,15 +483,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   {                                                                                               \
     const int ii = (i_);                                                                          \
     if constexpr (SLOTS == 2) {                                                                   \
-      if (ii + 1 < nst) M3_LSTORE((ii + 1) & 1)                                                   \
-      M3_T(0)                                                                                     \
-      if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                     \
-      M3_T(1)                                                                                     \
-      M3_STEP(PH_, ii & 1, P0 + ii)                                                               \
+      M3_STEP(PH_, ii & 1, P0 + ii, ii + 1 < nst, ii + 2 < nst)                                   \
       __syncthreads();                                                                            \
       M3_T(4)                                                                                     \
     } else {                                                                                      \
-      M3_STEP(PH_, 0, P0 + ii)                                                                    \
+      M3_STEP(PH_, 0, P0 + ii, ii + 1 < nst, false)                                               \
       if (ii + 1 < nst) {                                                                         \
         __syncthreads();                                                                          \
         M3_T(4)                                                                                   \
@@ -424,8 +495,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
         M3_T(0)                                                                                   \
         __syncthreads();                                                                          \
         M3_T(5)                                                                                   \
-        if (ii + 2 < nst) M3_GLOAD(P0 + ii + 2)                                                   \
-        M3_T(1)                                                                                   \
       }                                                                                           \
     }                                                                                             \
   }
@@ -436,6 +505,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   }
 #undef M3_ITER
 #undef M3_STEP
+#undef M3_ATOMS
+#undef M3_AVLOAD
+#undef M3_LOAD1
+#undef M3_CONV_HALF
 #undef M3_KO_DECL
 #undef M3_KO_RD
 #undef M3_AREAD

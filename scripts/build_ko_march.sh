@@ -11,7 +11,12 @@ for ko in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ko/libdfmir_hip_m3trace.so $OBJS /tmp/conv3dm_trace.o
     echo built m3trace; continue
   fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DM3_KO=$ko -c conv3dm.hip -o /tmp/conv3dm_ko$ko.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ko/libdfmir_hip_m3ko$ko.so $OBJS /tmp/conv3dm_ko$ko.o
-  echo built m3ko$ko
+  case "$ko" in
+    [0-9]*) defs="-DM3_KO=$ko";;
+    *) defs=$(echo "$ko" | sed 's/^/-D/; s/,/ -D/g');;          # e.g. M3_PRIO=1,M3_ADEPTH=2
+  esac
+  tag=$(echo "$ko" | tr -d 'M3_=' | tr ',' '_')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $defs -c conv3dm.hip -o /tmp/conv3dm_ko$tag.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ko/libdfmir_hip_m3ko$tag.so $OBJS /tmp/conv3dm_ko$tag.o
+  echo built m3ko$tag
 done
