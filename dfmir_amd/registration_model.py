@@ -172,8 +172,8 @@ class REGISTRATIONModel(BaseModel):
 
     # -- registration_model.py:138-171
     def optimize_parameters(self):
-        if getattr(self.opt, 'capture_step', False) and self.isTrain:
-            return self._optimize_parameters_graphed()
+        if getattr(self.opt, 'capture_step', False) and self.isTrain and not self.opt.flip_equivariance:
+            return self._optimize_parameters_graphed()     # (FastCUT draws its flip on the host, step by step)
         self._forward_backward()
         self._apply_updates()
 
@@ -311,6 +311,7 @@ class REGISTRATIONModel(BaseModel):
             self.forward()
             y_output = self.netR(self.real_A, self.real_B)
         self.regA = y_output[0]
+        self.pos_flow = y_output[2]                        # the deformation field (registration_model.py:144 keeps it in a local)
 
         def registration_losses():
             # registration_model.py:147-166: the warp of the translated image, the checkerboard visual, the two masked-L1
@@ -346,18 +347,23 @@ class REGISTRATIONModel(BaseModel):
             self.optimizer_F.zero_grad()
 
         self._nce_terms = None
+        idt = bool(self.opt.nce_idt)
         if (getattr(self.opt, 'batch_query_passes', True) and not os.environ.get('DFMIR_NO_STACKED_Q')
-                and self.opt.lambda_NCE > 0.0 and self.opt.nce_idt
-                and self.opt.lambda_GAN <= 0.0):
+                and self.opt.lambda_NCE > 0.0 and self.opt.lambda_GAN <= 0.0):
             # The three NCE terms each run G's encoder on their own query batch (fake_B, idt_B, regA) with the same
             # weights: one pass over the three stacked along the batch instead (per-sample kernels; same random
-            # draws in the same order -- only the key side draws).  Terms in the reference's order.
+            # draws in the same order -- only the key side draws).  Terms in the reference's order; without nce_idt
+            # (FastCUT) the identity term is not computed: two terms, queries cat(fake_B, regA).
             self._nce_terms = self.calculate_NCE_losses_stacked(
-                ((self.real_A, None), (self.real_B, None), (self.real_B, y_output[0])))
+                ((self.real_A, None), (self.real_B, None), (self.real_B, y_output[0])) if idt
+                else ((self.real_A, self.fake_B), (self.real_B, y_output[0])))
         stacked = self._nce_terms is not None
         if stacked:
             self.loss_G_GAN = 0.0
-            self.loss_NCE, self.loss_NCE_Y, nce_local = self._nce_terms
+            if idt:
+                self.loss_NCE, self.loss_NCE_Y, nce_local = self._nce_terms
+            else:
+                (self.loss_NCE, nce_local), self.loss_NCE_Y = self._nce_terms, 0.0
             self._nce_terms = None
         else:
             self.loss_G = self.compute_G_loss()
@@ -372,10 +378,16 @@ class REGISTRATIONModel(BaseModel):
             # registration_model.py:163-166,230-234 as ONE launch (and one for its gradient):
             #   loss_G = (NCE + NCE_Y) * 0.5;  loss_local = nce_local * 0.25;  loss_R = l1_reg + l1_idt + loss_local
             #   loss_smooth = smooth * 0.20;   total = loss_R + loss_G + loss_smooth
-            out = ops.scalar_combine(
-                [[0.5, 0.5, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.0, 0.25, 0.0, 0.0, 0.0],
-                 [0.0, 0.0, 0.0, 0.0, 0.0, 0.20], [0.5, 0.5, 0.25, 1.0, 1.0, 0.20]],
-                [self.loss_NCE, self.loss_NCE_Y, nce_local, l1_reg, l1_idt, smooth])
+            if idt:
+                out = ops.scalar_combine(
+                    [[0.5, 0.5, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.0, 0.25, 0.0, 0.0, 0.0],
+                     [0.0, 0.0, 0.0, 0.0, 0.0, 0.20], [0.5, 0.5, 0.25, 1.0, 1.0, 0.20]],
+                    [self.loss_NCE, self.loss_NCE_Y, nce_local, l1_reg, l1_idt, smooth])
+            else:                                          # loss_G = NCE (registration_model.py:228-232)
+                out = ops.scalar_combine(
+                    [[1.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.25, 0.0, 0.0, 0.0],
+                     [0.0, 0.0, 0.0, 0.0, 0.20], [1.0, 0.25, 1.0, 1.0, 0.20]],
+                    [self.loss_NCE, nce_local, l1_reg, l1_idt, smooth])
             self.loss_G, self.loss_R, self.loss_local, self.loss_smooth, all_G_loss = out.unbind(0)
         else:
             self.loss_local = nce_local * 0.25
@@ -420,11 +432,19 @@ class REGISTRATIONModel(BaseModel):
     # -- registration_model.py:185-196
     def forward(self):
         self.real = ops.cat_batch(self.real_A, self.real_B)
+        self.flipped_for_equivariance = False
         if self.opt.flip_equivariance:
-            raise NotImplementedError("flip_equivariance (FastCUT) is not on the registration path")
+            # FastCUT (registration_model.py:188-191): with probability 1/2 the generator sees the batch mirrored along W;
+            # calculate_NCE_loss mirrors the query features back.  `flip_draw` (build-defined hook, default the reference's
+            # `np.random.random() < 0.5`) lets tests force the branch.  A host-side draw per step: such a step is not captured.
+            draw = getattr(self, 'flip_draw', None)
+            self.flipped_for_equivariance = self.isTrain and bool(draw() if draw is not None else np.random.random() < 0.5)
+            if self.flipped_for_equivariance:
+                self.real = torch.flip(self.real, [3])
         nb = self.real_A.size(0)
         self._key_feats = None
-        if self.isTrain and self.opt.lambda_NCE > 0.0 and getattr(self.opt, 'reuse_key_features', True):
+        if (self.isTrain and self.opt.lambda_NCE > 0.0 and getattr(self.opt, 'reuse_key_features', True)
+                and not self.flipped_for_equivariance):    # (the tapped features would be those of the MIRRORED inputs)
             # The reference re-runs G's encoder on real_A / real_B for the (detached) key side of every
             # NCE term (registration_model.py:244) with the weights this very pass used.  Every
             # kernel on the path is per-sample and batch-size independent, so those activations are
@@ -465,6 +485,8 @@ class REGISTRATIONModel(BaseModel):
     def calculate_NCE_loss(self, src, tgt):
         n_layers = len(self.nce_layers)
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
+        if self.opt.flip_equivariance and self.flipped_for_equivariance:     # registration_model.py:241-242
+            feat_q = [torch.flip(fq, [3]) for fq in feat_q]
         with torch.no_grad():  # feat_k is detached inside PatchNCELoss (patchnce.py:17): forward only
             feat_k = self._encode_keys(src)
             pinned = None
@@ -492,8 +514,10 @@ class REGISTRATIONModel(BaseModel):
         reference's order, as before."""
         T = len(terms)
         n_layers = len(self.nce_layers)
-        tgt = ops.cat_batch(self.fake, terms[2][1])
+        tgt = ops.cat_batch(self.fake, terms[2][1]) if T == 3 else ops.cat_batch(terms[0][1], terms[1][1])
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
+        if self.opt.flip_equivariance and self.flipped_for_equivariance:     # registration_model.py:241-242, every term
+            feat_q = [torch.flip(fq, [3]) for fq in feat_q]
         sizes = [f.shape[2] * f.shape[3] for f in feat_q]
         P = self.opt.num_patches
         per_term_groups = 1 if self.opt.nce_includes_all_negatives_from_minibatch else self.opt.batch_size

@@ -335,8 +335,13 @@ class RegistrationStep(object):
     pin the patch ids; otherwise torch.randperm is drawn like the reference."""
 
     def __init__(self, size, batch_size, ngf=64, n_blocks=9, lr=2e-4, betas=(0.5, 0.999), num_patches=256,
-                 nce_T=0.07, lambda_NCE=0.25, nce_layers=(0, 4, 8, 12, 16), netF_nc=256):
+                 nce_T=0.07, lambda_NCE=0.25, nce_layers=(0, 4, 8, 12, 16), netF_nc=256, nce_idt=True,
+                 flip_equivariance=False):
         self.bs, self.size = batch_size, size
+        # FastCUT (registration_model.py:63-67): nce_idt False, lambda_NCE 10, flip_equivariance True.  `flip_draw()` ->
+        # bool stands in for `np.random.random() < 0.5` (registration_model.py:189) so that tests can force the flip.
+        self.nce_idt, self.flip_equivariance, self.flipped = nce_idt, flip_equivariance, False
+        self.flip_draw = lambda: bool(__import__("numpy").random.random() < 0.5)
         self.netG = Generator(1, 1, ngf, n_blocks)
         init_weights_xavier(self.netG)
         self.netF = PatchSampler(netF_nc, True)
@@ -353,12 +358,19 @@ class RegistrationStep(object):
 
     def forward(self, A, B):
         self.real_A, self.real_B = A, B
-        fake = self.netG(torch.cat((A, B), dim=0))
+        real = torch.cat((A, B), dim=0)
+        if self.flip_equivariance:                         # registration_model.py:188-191
+            self.flipped = self.flip_draw()
+            if self.flipped:
+                real = torch.flip(real, [3])
+        fake = self.netG(real)
         self.fake_B, self.idt_B = fake[:A.shape[0]], fake[A.shape[0]:]
 
     def nce(self, src, tgt):
         """registration_model.py:237-253."""
         fq = self.netG(tgt, self.nce_layers, encode_only=True)
+        if self.flip_equivariance and self.flipped:        # registration_model.py:241-242
+            fq = [torch.flip(f, [3]) for f in fq]
         fk = self.netG(src, self.nce_layers, encode_only=True)
         ids = self.ids_hook(self._nce_calls, fk) if self.ids_hook is not None else None
         self._nce_calls += 1
@@ -373,6 +385,9 @@ class RegistrationStep(object):
     def g_loss(self):
         """registration_model.py:213-235 with nce_idt."""
         self.loss_NCE = self.nce(self.real_A, self.fake_B)
+        if not self.nce_idt:                               # registration_model.py:228-232
+            self.loss_NCE_Y = 0.0
+            return self.loss_NCE
         self.loss_NCE_Y = self.nce(self.real_B, self.idt_B)
         return (self.loss_NCE + self.loss_NCE_Y) * 0.5
 

@@ -371,6 +371,10 @@ def main():
     model.data_dependent_initialize(data)
     model.netF.load_state_dict(ostep.netF.state_dict())
     out = dict(wsum=np.array(C.multi_state_checksum((ostep.netG, ostep.netF, ostep.netR))))
+    # the deformation field: optimize_parameters keeps netR's output in a local (registration_model.py:143-147), so it
+    # is taken from the module's own forward through a hook -- y_output[2] of the step's one netR call
+    flows = []
+    hook = model.netR.register_forward_hook(lambda mod, inp, outp: flows.append(outp[2].detach().clone()))
     for it in range(3):
         A_, B_ = C.image_pair(100 + 2 * it, B, size, size)
         model.set_input({"A": A_, "B": B_, "A_paths": ["a"] * B, "B_paths": ["b"] * B})
@@ -379,12 +383,14 @@ def main():
         out["losses_%d" % it] = np.array([ls[k] for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y")], dtype=np.float64)
         if it == 0:
             out.update(fake_B=npy(model.fake_B), registered=npy(model.registered), regA=npy(model.regA),
-                       idt_B=npy(model.idt_B),
+                       idt_B=npy(model.idt_B), pos_flow=npy(flows[0]),
                        # row A12: the decoded test pattern the reference warped (input) and the visual it produced
                        dvf_image=npy(RM.open_image_to_torch("./deform256.jpg", 256)[:1]), dvf=npy(model.dvf))
             for nm, net in (("G", model.netG), ("F", model.netF), ("R", model.netR)):
                 g2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters() if p.grad is not None)
                 out["gradnorm_" + nm] = np.array(g2 ** 0.5)
+    hook.remove()
+    assert len(flows) == 3, len(flows)
     save("step.npz", **out)
     RM.open_image_to_torch = orig_open
 

@@ -15,7 +15,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def close(got, ref, rtol=1e-4, atol=1e-6, what=""):
+ELEMENTWISE = []      # (what, norm-wise rel, element-wise max / 99.9 % / median rel) of every close(..., elem_rtol=...) call
+
+
+def close(got, ref, rtol=1e-4, atol=1e-6, what="", elem_rtol=None, elem_floor=1e-6):
+    """Norm-wise bound: max |got - ref| <= atol + rtol * max |ref|.  elem_rtol (the outputs north_star names: translated
+    image, deformation field, warped image) adds the ELEMENT-wise one, |got_i - ref_i| <= elem_rtol * max(|ref_i|,
+    elem_floor * max |ref|) for every element, and records the measured element-wise figures in ELEMENTWISE."""
     got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
     ref = ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
     assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
@@ -23,6 +29,11 @@ def close(got, ref, rtol=1e-4, atol=1e-6, what=""):
     scale = max(float(np.abs(ref).max()), 1e-30)
     err = float(np.abs(got - ref).max())
     assert err <= atol + rtol * scale, "%s: max abs err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+    if elem_rtol is not None:
+        rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), elem_floor * scale)
+        ELEMENTWISE.append((what, err / scale, float(rel.max()), float(np.quantile(rel, 0.999)), float(np.median(rel))))
+        assert float(rel.max()) <= elem_rtol, "%s: element-wise rel err %.3e (floor %.0e of the max) > %.1e" % (
+            what, float(rel.max()), elem_floor, elem_rtol)
 
 
 @pytest.fixture(scope="module")

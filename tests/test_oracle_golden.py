@@ -226,6 +226,7 @@ def test_whole_step(golden):
         np.testing.assert_allclose(got, g["losses_%d" % it], rtol=2e-4 * (it + 1), atol=1e-6)
         if it == 0:
             close(st.fake_B, g["fake_B"]); close(st.registered, g["registered"]); close(st.regA, g["regA"])
+            close(st.flow, g["pos_flow"])                     # the deformation field of the reference's own netR call
             close(st.idt_B, g["idt_B"])
             for nm, net in (("G", st.netG), ("F", st.netF), ("R", st.netR)):
                 n2 = sum(float((p.grad.double() ** 2).sum()) for p in net.parameters() if p.grad is not None) ** 0.5
