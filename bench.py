@@ -573,6 +573,10 @@ def main():
                       "payload_bytes": 4 * sum(o.flat_g.numel() for o in model.optimizers),
                       "arenas_bytes": [4 * o.flat_g.numel() for o in model.optimizers],
                       "exposed_ms_per_step": dfdist.allreduce_max(exposed, dev),
+                      # per-rank median step time (HIP events on each rank's stream), rank order: the spread says whether one
+                      # GPU of the node holds the others back (value is computed from the slowest rank's wall clock)
+                      "step_ms_by_rank": dfdist.allgather_float(
+                          step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]), dev),
                       "note": "one all-reduce per network arena (G, R, F) issued back to back after the graph replay; "
                               "exposed = the compute stream's wait for each arena (HIP event pairs), max over ranks; R's and "
                               "F's exchange ride under G's Adam launch"}

@@ -88,6 +88,17 @@ def allreduce_max(value, device):
     return float(t.item())
 
 
+def allgather_float(value, device):
+    """every rank's python float, in rank order (bench: per-rank step times)."""
+    if not is_distributed():
+        return [float(value)]
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def barrier():
     if is_distributed():
         dist.barrier()

@@ -51,9 +51,10 @@ agg = collections.OrderedDict()
 for kind, fl, s, e in recs:
     if not os.environ.get("ALL") and " 256->256 k1x3x3" in kind:
         continue
-    c = agg.setdefault(kind, [0, 0.0, fl]); c[0] += 1; c[1] += s.elapsed_time(e)
+    c = agg.setdefault(kind, [0, 0.0, fl, []]); c[0] += 1; c[1] += s.elapsed_time(e); c[3].append(s.elapsed_time(e))
 tot = 0
-for kind, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+for kind, (n, ms, fl, each) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tot += ms
-    print("%-74s %7.2f GF x%3d %7.3f ms  %6.1f TF" % (kind, fl / 1e9, n, ms, fl * n / ms / 1e9 if ms else 0))
+    print("%-74s %7.2f GF x%3d %7.3f ms  %6.1f TF" % (kind, fl / 1e9, n, ms, fl * n / ms / 1e9 if ms else 0)
+          + ("   each: " + " ".join("%.3f" % t for t in each) if 1 < n <= 4 else ""))
 print("total (listed)", round(tot, 2), "ms")

@@ -36,7 +36,7 @@ def _free_port():
     return p
 
 
-def _worker_2d(rank, world, port, q, capture, backend="gloo"):
+def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, REPO)
@@ -47,8 +47,9 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo"):
     from tests.golden import common as C
     D.init_from_env()
     try:
-        size, B = 64, 2
-        opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=8, gpu_ids=[torch.cuda.current_device()],
+        size, B, ngf = cfg
+        big = size * size * B * ngf > 64 * 64 * 2 * 8           # full geometry: arenas travel back as digests
+        opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=ngf, gpu_ids=[torch.cuda.current_device()],
                               checkpoints_dir="/tmp/dfmir_ddp", name="r%d" % rank, capture_step=capture)
         torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights
         model = REGISTRATIONModel(opt)
@@ -83,8 +84,15 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo"):
         losses = model.get_current_losses()
         w_end = [o.flat_p.cpu() for o in model.optimizers]
         graphed = bool(getattr(model, '_graph', {}).get('graph') is not None)
-        q.put((rank, [w.numpy() for w in w_after_bcast], [s.numpy() for s in summed], [g.numpy() for g in gathered],
-               [w.numpy() for w in w_end], dict(losses), graphed))
+        if big:
+            import hashlib
+            dig = lambda ts: [hashlib.sha1(t.numpy().tobytes()).hexdigest() for t in ts]
+            sum_ok = [bool(np.allclose(s_.numpy(), g_.numpy(), rtol=1e-6, atol=1e-12)) and float(s_.abs().sum()) > 0
+                      for s_, g_ in zip(summed, gathered)]
+            q.put((rank, dig(w_after_bcast), dig(summed), sum_ok, dig(w_end), dict(losses), graphed))
+        else:
+            q.put((rank, [w.numpy() for w in w_after_bcast], [s.numpy() for s in summed], [g.numpy() for g in gathered],
+                   [w.numpy() for w in w_end], dict(losses), graphed))
     finally:
         dist.destroy_process_group()
 
@@ -105,11 +113,25 @@ def test_registration_model_two_ranks(capture):
     assert r0[6] == r1[6] == capture
 
 
-def _run_two_ranks_2d(capture, backend):
+def test_registration_model_two_ranks_full_geometry():
+    """BASELINE configs[2]'s per-GPU shard as quoted -- batch 16 per rank, 256 x 256, ngf 64, the step captured into a
+    hipGraph -- on two ranks (sharing the one GPU over gloo): identical weights after the broadcast, flat_g after the
+    exchange = the sum of the ranks' local gradients, both ranks hold the same reduced arenas, replicas bit-identical
+    after the eager steps and the graph replays (arenas compared by SHA-1: 45 MB each)."""
+    r0, r1 = _run_two_ranks_2d(True, "gloo", cfg=(256, 16, 64))
+    assert r0[1] == r1[1], "weights must be identical after the rank-0 broadcast in parallelize()"
+    assert r0[2] == r1[2], "both ranks hold the same reduced arena"
+    assert all(r0[3]) and all(r1[3]), "flat_g after sync_gradients = sum of the ranks' local gradients"
+    assert r0[4] == r1[4], "replicas stay bit-identical through the optimizer steps"
+    assert all(np.isfinite(v) for v in r0[5].values()) and r0[5] != r1[5]
+    assert r0[6] and r1[6], "the later steps must have been hipGraph replays"
+
+
+def _run_two_ranks_2d(capture, backend, cfg=(64, 2, 8)):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend, cfg)) for r in range(2)]
     for p in procs:
         p.start()
     try:
