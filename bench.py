@@ -456,6 +456,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-3d", action="store_true", help="skip the auxiliary 3-D (config 5 geometry) measurement")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--bucket-allreduce", action="store_true",
+                    help="N > 1: G's late layers (45 %% of its arena) start their all-reduce inside backward (opt.bucket_allreduce; "
+                         "inside a captured step only with DFMIR_BUCKET_IN_GRAPH=1)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="eager steps after the timed region that time the dominant kernels")
     ap.add_argument("--host-input-steps", type=int, default=5,
                     help="extra steps fed from pinned HOST memory (PCIe-inclusive rate, reported beside the headline)")
@@ -471,7 +474,8 @@ def main():
 
     B, S = args.batch, args.size
     opt = default_options(batch_size=B, crop_size=S, load_size=S, ngf=args.ngf, gpu_ids=[dev.index],
-                          checkpoints_dir="/tmp/dfmir_bench", name="bench", capture_step=not args.no_graph)
+                          checkpoints_dir="/tmp/dfmir_bench", name="bench", capture_step=not args.no_graph,
+                          bucket_allreduce=args.bucket_allreduce)
     torch.manual_seed(0)                      # same weights on every rank (also broadcast in parallelize())
     model = REGISTRATIONModel(opt)
     timer = KernelTimer(["conv3x3_L", "wgrad3x3_L"])
@@ -577,6 +581,10 @@ def main():
                       # GPU of the node holds the others back (value is computed from the slowest rank's wall clock)
                       "step_ms_by_rank": dfdist.allgather_float(
                           step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]), dev),
+                      "early_bucket": (None if getattr(model, '_bucket', None) is None else
+                                       {"arena": "G", "bytes": 4 * (model.optimizer_G.flat_g.numel() - model._bucket['off']),
+                                        "fired_steps": model._bucket['fired'],
+                                        "what": "modules %d.. of G all-reduced from inside backward" % model._bucket['idx']}),
                       "note": "one all-reduce per network arena (G, R, F) issued back to back after the graph replay; "
                               "exposed = the compute stream's wait for each arena (HIP event pairs), max over ranks; R's and "
                               "F's exchange ride under G's Adam launch"}

@@ -25,6 +25,17 @@ from . import distributed as dfdist
 from . import networks
 
 
+class _JoinedWork(object):
+    """wait() for the two halves of one arena's exchange."""
+
+    def __init__(self, *works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class BaseModel(object):
     def __init__(self, opt):
         self.opt = opt
@@ -88,13 +99,32 @@ class BaseModel(object):
             o.grad_scale = 1.0 / dfdist.world_size()      # the average is folded into the Adam kernel
         from . import ops
         ops.bump_weights_epoch()                          # packed-weight caches: rank 0's weights now
+        self._setup_gradient_buckets()
+
+    def _setup_gradient_buckets(self):
+        """Subclasses may split an arena into depth buckets whose exchange starts inside backward."""
+        self._early = {}
 
     def sync_gradients(self, async_op=False):
         """All-reduce every network's flat gradient arena (in self.optimizers order).  async_op=True returns one
-        work handle (or None: already complete) per arena."""
+        work handle (or None: already complete) per arena.  An arena whose LATE part [off, n) already left from inside
+        backward (self._early[id(optimizer)] = (off, work)) exchanges only its remaining head [0, off) here; the handle
+        returned for it waits for both."""
         if not self._ddp:
             return []
-        return dfdist.allreduce_arenas([o.flat_g for o in self._arena_optimizers()], async_op=async_op)
+        early = getattr(self, '_early', {})
+        flats, joins = [], []
+        for o in self._arena_optimizers():
+            e = early.pop(id(o), None)
+            flats.append(o.flat_g if e is None else o.flat_g[:e[0]])
+            joins.append(None if e is None else e[1])
+        works = dfdist.allreduce_arenas(flats, async_op=async_op)
+        if not async_op:
+            for j in joins:
+                if j is not None:
+                    j.wait()
+            return []
+        return [w if j is None else _JoinedWork(w, j) for w, j in zip(works, joins)]
 
     # ---- inference -----------------------------------------------------------------------------------
     def eval(self):

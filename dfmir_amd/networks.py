@@ -316,6 +316,11 @@ class ResnetGenerator(nn.Module):
 
         while i < n:
             m = mods[i]
+            gb = getattr(self, 'grad_boundary', None)
+            if gb is not None and i == gb[0] and feat.requires_grad and torch.is_grad_enabled():
+                # build-defined hook (data-parallel gradient buckets): fires when backward has produced the gradient of
+                # module i's INPUT, i.e. when every weight gradient of modules i.. has been enqueued
+                feat.register_hook(lambda g_, cb=gb[1]: (cb(), None)[1])
             if isinstance(m, ReflectionPad2d) and i + 1 < n and isinstance(mods[i + 1], Conv2d):
                 if i in want:
                     if emit(i, m(feat), shared=False):

@@ -125,7 +125,9 @@ def invalidate_after_failed_capture():
     _AMAX_POOL["buf"] = None
     _AMAX_POOL["capturing"] = False
     _PACKS["epoch"] = None
-    _PACKS["key"] = _WS3D["key"] = _JOBS["key"] = None            # job tables uploaded inside the capture never arrived
+    _PACKS["key"] = _WS3D["key"] = None                           # job tables uploaded inside the capture never arrived
+    for j_ in _JOBS_BY_GROUP.values():
+        j_["key"] = None
     for e in _PACKS["entries"].values():
         e["epoch"] = None
     for e in _WS3D["entries"].values():
@@ -519,12 +521,25 @@ class deferred_weight_grads:
 
 
 _JOBS = {"key": None, "dev": None, "max": 0}
+_JOBS_BY_GROUP = {"all": _JOBS}
 
 
-def _flush_deferred(items):
+def flush_deferred_subset(owner_ids, group):
+    """Flush NOW the deferred accumulators of the modules in `owner_ids` (ids) whose weight gradients are final -- a
+    gradient bucket that leaves for its all-reduce before backward has finished (registration_model._bucket_ready).
+    `group` names the job table (one device table per group: a captured step holds it by address)."""
+    pend = _DEFER["pending"]
+    items = [pend.pop(i) for i in list(pend.keys()) if i in owner_ids]
+    if items:
+        _flush_deferred(items, group)
+    return len(items)
+
+
+def _flush_deferred(items, group="all"):
     """grad += unpack(accumulator); accumulator = 0 for every deferred conv, one launch (the job table is uploaded
     once and reused while the same buffers come back, i.e. every step after the first)."""
     import numpy as np
+    _JOBS = _JOBS_BY_GROUP.setdefault(group, {"key": None, "dev": None, "max": 0})
     key = tuple((buf.data_ptr(), owner.weight.grad.data_ptr(), tuple(shape)) for owner, buf, shape in items)
     if _JOBS["key"] != key:
         tab = np.zeros((len(items), 4), dtype=np.int64)            # struct DfUnpackJob = 2 pointers + 4 ints

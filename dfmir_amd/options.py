@@ -21,6 +21,7 @@ def default_options(**overrides):
         dvf_image='synthetic',     # build-defined: None = ./deform256.jpg as in the reference (raises when absent)
         reuse_key_features=True,   # build-defined: tap NCE key features in forward() (exact, see registration_model.forward)
         batch_query_passes=True,   # build-defined: one encoder pass for the three NCE terms' query batches
+        bucket_allreduce=False,    # build-defined (data-parallel): G's late layers start their all-reduce inside backward
         nce_sequential_keys=False,  # build-defined: key side of the NCE terms one netF call per term (reference order, host ids)
         skip_unused_target=True,   # build-defined: do not compute VxmDense's discarded warp(target, -flow) output
         global_mask_norm=False,    # build-defined, DDP: masked-L1 normalised by the GLOBAL batch's mask sums (DataParallel semantics)

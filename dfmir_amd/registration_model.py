@@ -283,6 +283,48 @@ class REGISTRATIONModel(BaseModel):
         return (self.isTrain and self.device.type == 'cuda' and getattr(self.opt, 'overlap_registration', True)
                 and not os.environ.get('DFMIR_NO_OVERLAP_R'))
 
+    # -- data-parallel gradient buckets (build-defined; replaces nothing in the reference, whose DataParallel reduces on
+    # device 0, base_model.py:103-107).  opt.bucket_allreduce: G's arena leaves in two depth buckets.  The query pass of the
+    # NCE terms stops at module max(nce_layers) = 16, so modules 17.. (4 ResNet blocks, the decoder, the head: 45 % of G's
+    # parameters) receive their only weight gradients in the first part of the main pass's backward; when the gradient of
+    # module 17's input exists they are final: their deferred accumulators are flushed and the arena's tail starts its
+    # all-reduce while backward goes on through the other 16 modules (and netR's stream).  The head [0, off) and the
+    # other arenas follow after backward as before.
+    def _setup_gradient_buckets(self):
+        self._early = {}
+        self._bucket = None
+        self.netG.grad_boundary = None
+        if not (self._ddp and getattr(self.opt, 'bucket_allreduce', False) and self.isTrain):
+            return
+        mods = list(self.netG.model)
+        idx = max(self.nce_layers) + 1
+        if not (0 < idx < len(mods)):
+            return
+        late = [p for m in mods[idx:] for p in m.parameters()]
+        if not late:
+            return
+        off = 0
+        for p in self.optimizer_G.param_groups[0]['params']:
+            if p is late[0]:
+                break
+            off += p.numel()
+        assert off + sum(p.numel() for p in late) == self.optimizer_G.flat_g.numel(), "arena order = module order"
+        owners = set(id(sub) for m in mods[idx:] for sub in m.modules() if getattr(sub, 'weight', None) is not None)
+        self._bucket = dict(idx=idx, off=off, owners=owners, fired=0)
+        self.netG.grad_boundary = (idx, self._bucket_ready)
+
+    def _bucket_ready(self):
+        b = self._bucket
+        if b is None or id(self.optimizer_G) in self._early:
+            return
+        if torch.cuda.is_current_stream_capturing() and not os.environ.get('DFMIR_BUCKET_IN_GRAPH'):
+            return                                         # a captured step keeps its exchange behind the replay
+        from . import distributed as dfdist
+        ops.flush_deferred_subset(b['owners'], 'late')
+        works = dfdist.allreduce_arenas([self.optimizer_G.flat_g[b['off']:]], async_op=True)
+        self._early[id(self.optimizer_G)] = (b['off'], works[0] if works else None)
+        b['fired'] += 1
+
     def _graph_state(self):
         return self.__dict__.setdefault('_graph', {'eager_steps': 0, 'graph': None, 'shape': None, 'force_eager': False,
                                                    'stream': torch.cuda.Stream(device=self.device)})

@@ -36,7 +36,7 @@ def _free_port():
     return p
 
 
-def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8)):
+def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bucket=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DFMIR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, REPO)
@@ -50,7 +50,8 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8)):
         size, B, ngf = cfg
         big = size * size * B * ngf > 64 * 64 * 2 * 8           # full geometry: arenas travel back as digests
         opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=ngf, gpu_ids=[torch.cuda.current_device()],
-                              checkpoints_dir="/tmp/dfmir_ddp", name="r%d" % rank, capture_step=capture)
+                              checkpoints_dir="/tmp/dfmir_ddp", name="r%d" % rank, capture_step=capture,
+                              bucket_allreduce=bucket)
         torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights
         model = REGISTRATIONModel(opt)
         with torch.no_grad():
@@ -63,6 +64,14 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8)):
         model.parallelize()
         assert model._ddp and all(o.grad_scale == 0.5 for o in model.optimizers)
         w_after_bcast = [o.flat_p.cpu() for o in model.optimizers]
+        if bucket:                                           # the arena's tail leaves INSIDE backward: whole steps only
+            for it in range(5):
+                model.set_input(data)
+                model.optimize_parameters()
+            assert model._bucket is not None and model._bucket['fired'] == 5 and not model._early
+            q.put((rank, [w.numpy() for w in w_after_bcast], None, model._bucket['off'],
+                   [o.flat_p.cpu().numpy() for o in model.optimizers], dict(model.get_current_losses()), False))
+            return
         # one step by hand: local gradients, then the exchange
         model.set_input(data)
         model._forward_backward()
@@ -113,6 +122,21 @@ def test_registration_model_two_ranks(capture):
     assert r0[6] == r1[6] == capture
 
 
+def test_gradient_buckets_change_nothing():
+    """opt.bucket_allreduce: G's late layers (modules 17.., final when the main pass's backward has reached module 16)
+    are flushed and all-reduced from INSIDE backward, the rest of the arena after it.  Five steps on two ranks end with
+    bit-identical replicas, and with exactly the weights of the one-exchange-per-arena protocol (a sum of two ranks'
+    values is the same number whichever slice of the arena carries it)."""
+    b0, b1 = _run_two_ranks_2d(False, "gloo", bucket=True)
+    p0, p1 = _run_two_ranks_2d(False, "gloo")
+    assert 0 < b0[3] == b1[3]                                # the bucket boundary inside G's arena
+    for a, b in zip(b0[4], b1[4]):
+        assert np.array_equal(a, b), "replicas stay bit-identical with the early bucket"
+    for a, b in zip(b0[4], p0[4]):
+        assert np.array_equal(a, b), "same weights as with one exchange per arena after backward"
+    assert b0[5] == p0[5] and b1[5] == p1[5]
+
+
 def test_registration_model_two_ranks_full_geometry():
     """BASELINE configs[2]'s per-GPU shard as quoted -- batch 16 per rank, 256 x 256, ngf 64, the step captured into a
     hipGraph -- on two ranks (sharing the one GPU over gloo): identical weights after the broadcast, flat_g after the
@@ -127,11 +151,11 @@ def test_registration_model_two_ranks_full_geometry():
     assert r0[6] and r1[6], "the later steps must have been hipGraph replays"
 
 
-def _run_two_ranks_2d(capture, backend, cfg=(64, 2, 8)):
+def _run_two_ranks_2d(capture, backend, cfg=(64, 2, 8), bucket=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend, cfg)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend, cfg, bucket)) for r in range(2)]
     for p in procs:
         p.start()
     try:
