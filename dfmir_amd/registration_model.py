@@ -182,6 +182,9 @@ class REGISTRATIONModel(BaseModel):
         arena all-reduces are issued back to back (G 45.5 MB first, then R, F) and each network's Adam launch waits
         only for its own: R's and F's exchange overlaps G's optimizer pass instead of following it."""
         opts = [self.optimizer_G, self.optimizer_R] + ([self.optimizer_F] if self.opt.netF == 'mlp_sample' else [])
+        b = getattr(self, '_bucket', None)
+        if b is not None and b.get('in_graph') and id(self.optimizer_G) not in self._early:
+            self._early[id(self.optimizer_G)] = (b['off'], None)   # the replayed graph has already exchanged the tail
         works = self.sync_gradients(async_op=True)
         timing = getattr(self, '_collective_timing', None) if works else None     # bench.py: exposed collective time
         for i, o in enumerate(opts):
@@ -324,6 +327,7 @@ class REGISTRATIONModel(BaseModel):
         works = dfdist.allreduce_arenas([self.optimizer_G.flat_g[b['off']:]], async_op=True)
         self._early[id(self.optimizer_G)] = (b['off'], works[0] if works else None)
         b['fired'] += 1
+        b['in_graph'] = bool(torch.cuda.is_current_stream_capturing())   # experimental: every replay then repeats it
 
     def _graph_state(self):
         return self.__dict__.setdefault('_graph', {'eager_steps': 0, 'graph': None, 'shape': None, 'force_eager': False,

@@ -64,12 +64,19 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
         model.parallelize()
         assert model._ddp and all(o.grad_scale == 0.5 for o in model.optimizers)
         w_after_bcast = [o.flat_p.cpu() for o in model.optimizers]
-        if bucket:                                           # the arena's tail leaves INSIDE backward: whole steps only
-            for it in range(5):
+        if bucket:                                           # the arena's tail leaves INSIDE backward
+            model.set_input(data)
+            model._forward_backward()
+            assert model._bucket['fired'] == 1 and len(model._early) == 1
+            model.sync_gradients()                             # the arena's head and the other arenas
+            summed = [o.flat_g.cpu().numpy() for o in model.optimizers]
+            for o in model.optimizers:
+                o.step()
+            for it in range(4):
                 model.set_input(data)
                 model.optimize_parameters()
-            assert model._bucket is not None and model._bucket['fired'] == 5 and not model._early
-            q.put((rank, [w.numpy() for w in w_after_bcast], None, model._bucket['off'],
+            assert model._bucket['fired'] == 5 and not model._early
+            q.put((rank, [w.numpy() for w in w_after_bcast], summed, model._bucket['off'],
                    [o.flat_p.cpu().numpy() for o in model.optimizers], dict(model.get_current_losses()), False))
             return
         # one step by hand: local gradients, then the exchange
@@ -125,16 +132,26 @@ def test_registration_model_two_ranks(capture):
 def test_gradient_buckets_change_nothing():
     """opt.bucket_allreduce: G's late layers (modules 17.., final when the main pass's backward has reached module 16)
     are flushed and all-reduced from INSIDE backward, the rest of the arena after it.  Five steps on two ranks end with
-    bit-identical replicas, and with exactly the weights of the one-exchange-per-arena protocol (a sum of two ranks'
-    values is the same number whichever slice of the arena carries it)."""
+    bit-identical replicas, and with the weights of the one-exchange-per-arena protocol."""
     b0, b1 = _run_two_ranks_2d(False, "gloo", bucket=True)
     p0, p1 = _run_two_ranks_2d(False, "gloo")
     assert 0 < b0[3] == b1[3]                                # the bucket boundary inside G's arena
     for a, b in zip(b0[4], b1[4]):
         assert np.array_equal(a, b), "replicas stay bit-identical with the early bucket"
+    # against a separate run of the one-exchange protocol: the reduced gradient arenas of the first step agree to the
+    # run-to-run noise of the split-K weight-gradient atomics (head AND tail of G's arena), the weights after five Adam
+    # steps within the movement that noise can cause (an entry with a near-zero gradient moves by +-lr per step)
+    for a, b0_, b1_ in zip(p0[2], b0[2], b1[2]):
+        assert np.array_equal(b0_, b1_), "both ranks hold the same reduced arena"
+        assert float(np.linalg.norm(a - b0_)) <= 1e-4 * float(np.linalg.norm(a)), float(np.linalg.norm(a - b0_) / np.linalg.norm(a))
+    off = b0[3]
+    g_plain, g_bucket = p0[2][0], b0[2][0]
+    for sl in (slice(0, off), slice(off, None)):
+        assert float(np.linalg.norm(g_plain[sl] - g_bucket[sl])) <= 1e-4 * float(np.linalg.norm(g_plain[sl]))
     for a, b in zip(b0[4], p0[4]):
-        assert np.array_equal(a, b), "same weights as with one exchange per arena after backward"
-    assert b0[5] == p0[5] and b1[5] == p1[5]
+        assert float(np.abs(a - b).max()) <= 2 * 5 * 2e-4 and float(np.linalg.norm(a - b)) <= 5e-3 * float(np.linalg.norm(b))
+    for k in b0[5]:
+        assert abs(b0[5][k] - p0[5][k]) <= 2e-2 * max(abs(p0[5][k]), 1e-6), (k, b0[5][k], p0[5][k])
 
 
 def test_registration_model_two_ranks_full_geometry():
