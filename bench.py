@@ -28,6 +28,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -456,6 +458,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-3d", action="store_true", help="skip the auxiliary 3-D (config 5 geometry) measurement")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--pil-workers", type=int, default=4, help="DataLoader worker processes of the value_pil_loader measurement (0 = skip)")
     ap.add_argument("--bucket-allreduce", action="store_true",
                     help="N > 1: G's late layers (45 %% of its arena) start their all-reduce inside backward (opt.bucket_allreduce; "
                          "inside a captured step only with DFMIR_BUCKET_IN_GRAPH=1)")
@@ -603,6 +606,42 @@ def main():
         torch.cuda.synchronize()
         host_rate = B * world * args.host_input_steps / (time.perf_counter() - th)
 
+    # ... and the same step fed by the plugin's own data pipeline (row N3): PNG slices on disk -> PIL decode -> grayscale ->
+    # bicubic resize 286 -> random crop 256 -> flip -> [-1, 1] -> pinned batch, in DataLoader worker processes beside the
+    # training process (dfmir_amd/data.py = data/unaligned_dataset.py + base_dataset.py:82-145) -> `value_pil_loader`
+    pil_rate = None
+    if args.host_input_steps > 0 and args.pil_workers > 0:
+        import copy
+        import tempfile
+        from PIL import Image
+        from dfmir_amd.data import create_dataset
+        root = tempfile.mkdtemp(prefix="dfmir_bench_data_")
+        rs = np.random.RandomState(11 + rank)
+        n_img = B * (args.host_input_steps + 3)
+        for sub in ("trainA", "trainB"):
+            os.makedirs(os.path.join(root, sub))
+            for i in range(n_img):
+                base = rs.randint(0, 256, size=(9, 9)).astype(np.uint8)
+                Image.fromarray(base).resize((300, 300), Image.BICUBIC).save(os.path.join(root, sub, "%04d.png" % i))
+        lo = copy.copy(opt)
+        lo.dataroot, lo.phase, lo.num_threads, lo.serial_batches = root, "train", args.pil_workers, False
+        lo.load_size, lo.crop_size, lo.preprocess, lo.no_flip, lo.max_dataset_size = 286, args.size, "resize_and_crop", False, float("inf")
+        it = iter(create_dataset(lo))
+        first = next(it)                                        # workers started, first batches in flight
+        model.set_input(first); model.optimize_parameters()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        n_done = 0
+        for data in it:
+            model.set_input(data)
+            model.optimize_parameters()
+            n_done += 1
+            if n_done >= args.host_input_steps:
+                break
+        torch.cuda.synchronize()
+        pil_rate = B * world * n_done / (time.perf_counter() - th) if n_done else None
+        del it
+
     ks = ks_overlapped if graphed else timer.summary()
     ks1 = ks_single if graphed else {}
     result = None
@@ -641,7 +680,9 @@ def main():
                                   "(default) the captured graph has two parallel branches and hipGraphLaunch (ROCm 7.2) returns "
                                   "only when the second branch has been handed to the GPU, ~60 % into the step; "
                                   "DFMIR_NO_OVERLAP_R=1: one chain, 0.5 ms of host time and a 1.3 ms longer step"),
-            "value_host_inputs": host_rate, "higher_is_better": True,
+            "value_host_inputs": host_rate,
+            "value_pil_loader": pil_rate,       # fed by dfmir_amd.data's DataLoader (PNG decode + transforms in worker processes)
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "2-D %dx%d T1<->T2-shaped synthetic slice pairs, batch %d per GPU, ngf %d: "
                                    "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
