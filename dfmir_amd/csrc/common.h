@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "../../include/dfmir_hip.h"
 
 #define DF_LAUNCH_CHECK()                                  \
@@ -20,26 +21,38 @@ int df_set_error(int code, const char* file, int line);
 // Library options (include/dfmir_hip.h, "Options"): PROCESS-GLOBAL A/B switches.  A value set through
 // dfmir_set_option() wins; otherwise the environment variable of the same name is read.  Sites cache the parsed
 // value together with the option generation, which every dfmir_set_option() call bumps.
-const char* df_opt(const char* name);   // current value, nullptr when unset
+// df_opt_get copies the current value out UNDER the table's lock (a concurrent dfmir_set_option on the same name cannot
+// free it under the reader); the cached flags keep (generation, value) in ONE atomic word, so launching threads may
+// race on them freely.
+bool df_opt_get(const char* name, char* buf, int buf_len);   // false when unset; value truncated to buf_len - 1
 int df_opt_gen();
-struct DfOptFlag {                      // "is the option set (to anything)?"
+static inline bool df_opt_on(const char* name) {             // set to anything but "" / "0"
+  char b[8];
+  return df_opt_get(name, b, sizeof(b)) && b[0] != 0 && !(b[0] == '0' && b[1] == 0);
+}
+struct DfOptFlag {                      // "is the option ON?"  (unset, "" and "0" are off)
   const char* name;
-  int gen = -1;
-  bool v = false;
+  std::atomic<long long> st{-1};        // (generation << 1) | value
   bool get() {
     const int g = df_opt_gen();
-    if (g != gen) { v = df_opt(name) != nullptr; gen = g; }
+    const long long s = st.load(std::memory_order_relaxed);
+    if (s >= 0 && (int)(s >> 1) == g) return (s & 1) != 0;
+    const bool v = df_opt_on(name);
+    st.store(((long long)g << 1) | (v ? 1 : 0), std::memory_order_relaxed);
     return v;
   }
 };
 struct DfOptInt {                       // integer value, `def` when unset
   const char* name;
   int def;
-  int gen = -1;
-  int v = 0;
+  std::atomic<long long> st{-1};        // (generation << 32) | (unsigned) value
   int get() {
     const int g = df_opt_gen();
-    if (g != gen) { const char* e = df_opt(name); v = e ? atoi(e) : def; gen = g; }
+    const long long s = st.load(std::memory_order_relaxed);
+    if (s >= 0 && (int)(s >> 32) == g) return (int)(unsigned)(s & 0xffffffffLL);
+    char b[32];
+    const int v = df_opt_get(name, b, sizeof(b)) ? atoi(b) : def;
+    st.store(((long long)g << 32) | (unsigned)v, std::memory_order_relaxed);
     return v;
   }
 };

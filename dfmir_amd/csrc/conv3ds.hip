@@ -968,7 +968,7 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
     // one unit per thread where possible: every workgroup re-reduces max|w| itself (L2-resident), the packing is what
     // parallelises (8 workgroups took 25 us on the 64 -> 64 layers, a latency chain of strided loads)
     static DfOptInt ws_o{"DFMIR_WSPLIT_WGS", 32};
-  const int ws_wgs = ws_o.get();
+    const int ws_wgs = ws_o.get();
     const long long units = (long long)(pair ? 1 : nmt) * nchunk * (pair ? 36 : 28) * 32;
     long long nwg = (units + 1023) / 1024;
     if (nwg > ws_wgs) nwg = ws_wgs;
@@ -980,8 +980,9 @@ static int conv3d_split_fwd_impl(const DfConvGeom* g, const float* x, const floa
   C3sP k{g->N, g->Cin, g->Cout, g->Di, g->Hi, g->Wi, g->act, g->slope, (g->Di + 3) / 4, (g->Hi + 7) / 8, (g->Wi + 15) / 16,
          nchunk, x_amax_n, cout_used, 0, act_src, act_slope, act_src ? av_mode : 0};
   // vec: 16-byte loads of the patch rows and (16-row form) 16-byte stores of the result / loads of the activation source
+  static DfOptFlag novec_o{"DFMIR_CONV3D_NO_VEC"};
   const bool vec = (g->Wi % 4) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
-                                         reinterpret_cast<uintptr_t>(act_src)) & 15) == 0 && !df_opt("DFMIR_CONV3D_NO_VEC");
+                                         reinterpret_cast<uintptr_t>(act_src)) & 15) == 0 && !novec_o.get();
   // plane-pair form: three y-stacked tiles per workgroup share one staging of each chunk's weights
   static DfOptFlag multi_o{"DFMIR_CONV3D_NO_MULTI"};
   const bool multi_off = multi_o.get();
@@ -1492,7 +1493,8 @@ extern "C" long long dfmir_conv3d_up_ws_floats(int Ca, int Cout) {
 }
 extern "C" int dfmir_conv3d_up_ok(int N, int Ca, int Cout, int D, int H, int W) {
   // D, H, W: the low-resolution volume.  W % 4: 16-B patch loads; sizes: 32-bit buffer offsets on both tensors
-  if (split3d_off() || df_opt("DFMIR_CONV3D_NO_UPPHASE")) return 0;
+  static DfOptFlag noup_o{"DFMIR_CONV3D_NO_UPPHASE"};
+  if (split3d_off() || noup_o.get()) return 0;
   if (N <= 0 || Ca < 8 || (Ca & 7) || Cout < 8 || D < 2 || H < 2 || W < 4 || (W & 3)) return 0;
   if ((long long)Ca * D * H * W * 4 >= 0x7FFFFFFFLL || (long long)Cout * D * H * W * 8 * 4 >= 0x7FFFFFFFLL) return 0;
   return 1;
@@ -2510,7 +2512,8 @@ extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* 
                                               const float* x_amax, int x_amax_n, const float* dy, const float* dy_amax,
                                               int dy_amax_n, float* dw_tcc, float* db, void* stream) {
   DF_ARG_CHECK(g && a && b && Ca > 0 && (Ca & 7) == 0 && Ca < g->Cin && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7));
-  DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !df_opt("DFMIR_CONV3D_WGRAD_COPIES") && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
+  static DfOptFlag copies_o{"DFMIR_CONV3D_WGRAD_COPIES"};
+  DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !copies_o.get() && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
   return conv3d_split_wgrad_impl(g, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream, a, Ca);
 }
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,

@@ -197,13 +197,14 @@ __global__ __launch_bounds__(256) void weight_split_k(const float* __restrict__ 
 
 // which split form the library runs with (read once): 0 = none (fp32 MFMA), 2 = fp16x2 (default), 3 = bf16x3
 int df_split_mode() {
-  static int gen = -1, mode = 2;
+  static std::atomic<long long> st{-1};                   // (generation << 8) | mode
   const int g = df_opt_gen();
-  if (g != gen) {
-    const char* s = df_opt("DFMIR_CONV_SPLIT");
-    mode = df_opt("DFMIR_CONV_FP32") ? 0 : ((s && s[0] == 'b') ? 3 : 2);
-    gen = g;
-  }
+  const long long cur = st.load(std::memory_order_relaxed);
+  if (cur >= 0 && (int)(cur >> 8) == g) return (int)(cur & 0xff);
+  char s[16];
+  const bool has = df_opt_get("DFMIR_CONV_SPLIT", s, sizeof(s));
+  const int mode = df_opt_on("DFMIR_CONV_FP32") ? 0 : ((has && s[0] == 'b') ? 3 : 2);
+  st.store(((long long)g << 8) | mode, std::memory_order_relaxed);
   return mode;
 }
 

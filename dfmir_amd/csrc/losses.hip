@@ -660,12 +660,16 @@ DfOptTable& df_opt_table() {
   return *t;
 }
 }  // namespace
-const char* df_opt(const char* name) {
+bool df_opt_get(const char* name, char* buf, int buf_len) {
   DfOptTable& t = df_opt_table();
-  std::lock_guard<std::mutex> lk(t.mu);
+  std::lock_guard<std::mutex> lk(t.mu);        // the copy happens under the lock: no pointer into the table escapes
+  const char* v = nullptr;
   auto it = t.over.find(name);
-  if (it != t.over.end()) return it->second.first ? it->second.second.c_str() : nullptr;
-  return getenv(name);
+  if (it != t.over.end()) v = it->second.first ? it->second.second.c_str() : nullptr;
+  else v = getenv(name);
+  if (!v) return false;
+  if (buf && buf_len > 0) { strncpy(buf, v, (size_t)buf_len - 1); buf[buf_len - 1] = 0; }
+  return true;
 }
 int df_opt_gen() { return df_opt_table().gen.load(std::memory_order_acquire); }
 extern "C" int dfmir_set_option(const char* name, const char* value) {
@@ -680,10 +684,10 @@ extern "C" int dfmir_set_option(const char* name, const char* value) {
 }
 extern "C" int dfmir_get_option(const char* name, char* buf, int buf_len) {
   if (!name) return -1;
-  const char* v = df_opt(name);
-  if (!v) return -1;
-  const int n = (int)strlen(v);
-  if (buf && buf_len > 0) { strncpy(buf, v, (size_t)buf_len - 1); buf[buf_len - 1] = 0; }
+  char tmp[512];
+  if (!df_opt_get(name, tmp, sizeof(tmp))) return -1;
+  const int n = (int)strlen(tmp);
+  if (buf && buf_len > 0) { strncpy(buf, tmp, (size_t)buf_len - 1); buf[buf_len - 1] = 0; }
   return n;
 }
 extern "C" int dfmir_abi_version(void) { return DFMIR_ABI_VERSION; }

@@ -58,6 +58,14 @@ def zeros_like(t):
     return zero_(torch.empty_like(t, memory_format=torch.contiguous_format))
 
 
+def _env_on(name):
+    """A/B switch from the environment, read at import: on unless unset, "" or "0" (the semantics of the library's own
+    DfOptFlag, include/dfmir_hip.h "Options").  These Python-side switches select host-side call paths and are
+    ENVIRONMENT-ONLY: dfmir_set_option() after import changes the C side alone."""
+    v = os.environ.get(name)
+    return v is not None and v not in ("", "0")
+
+
 # ------------------------------------------------------------------------------------------------
 # raw launches
 # ------------------------------------------------------------------------------------------------
@@ -74,7 +82,7 @@ def set_conv_profiler(fn):
 # a pool (one fill per 4096 probes).  A producer that computes the maximum as a by-product (InstanceNorm
 # forward / backward) tags its output tensor with it; `amax_of` reuses the tag while the tensor is unmodified.
 PROBE_SLOTS = 64          # DFMIR_PROBE_SLOTS: floats of an InstanceNorm by-product probe
-_AMAX_POOL = {"buf": None, "next": 0}
+_AMAX_POOL = {"buf": None, "next": 0, "gen": 0}
 
 
 def amax_slot(device, n=1):
@@ -124,6 +132,7 @@ def invalidate_after_failed_capture():
     zeroed probe pool."""
     _AMAX_POOL["buf"] = None
     _AMAX_POOL["capturing"] = False
+    _AMAX_POOL["gen"] += 1                                         # tags that point into the dead capture's pool expire
     _PACKS["epoch"] = None
     _PACKS["key"] = _WS3D["key"] = None                           # job tables uploaded inside the capture never arrived
     for j_ in _JOBS_BY_GROUP.values():
@@ -144,25 +153,32 @@ def absmax(t):
 
 
 def tag_amax(t, slot):
-    t._df_amax = (slot, t._version, t.data_ptr())
+    t._df_amax = (slot, t._version, t.data_ptr(), _AMAX_POOL["gen"])
     return t
+
+
+def _amax_ok(t, tag):
+    """The tag still describes t (same version, same storage) AND its slot comes from a probe pool that really ran: a
+    capture that failed hands out slots of a graph-private pool that no launch ever filled (invalidate_after_failed_capture
+    bumps the pool generation)."""
+    return tag[1] == t._version and tag[2] == t.data_ptr() and tag[3] == _AMAX_POOL["gen"]
 
 
 def amax_of(t):
     tag = getattr(t, "_df_amax", None)
-    if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr():
+    if tag is not None and _amax_ok(t, tag):
         return tag[0]
     return absmax(t)
 
 
-_NO_SPLIT3D = bool(os.environ.get("DFMIR_CONV3D_FP32") or os.environ.get("DFMIR_CONV_FP32"))
+_NO_SPLIT3D = _env_on("DFMIR_CONV3D_FP32") or _env_on("DFMIR_CONV_FP32")
 
 # Probe audit (DFMIR_PROBE_AUDIT=1 or set_probe_audit(True); debugging / test mode, one device sync per conv launch).
 # The fp16x2 split scales a tensor by its range PROBE, and probes are inherited (blur outputs, nearest_up2 + cat,
 # sampled-feature scatters, dgrad epilogues); a probe below the true maximum would overflow fp16 silently.  In audit
 # mode every split launch first measures the true max |t| of each operand with dfmir_absmax and raises if the probe
 # it was handed is smaller (per-plane dY maxima of the weight gradient included).
-_PROBE_AUDIT = {"on": bool(os.environ.get("DFMIR_PROBE_AUDIT")), "log": []}
+_PROBE_AUDIT = {"on": _env_on("DFMIR_PROBE_AUDIT"), "log": []}
 
 
 def set_probe_audit(on):
@@ -311,8 +327,8 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
 
 _LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
-_NO_TINY3D = bool(os.environ.get("DFMIR_CONV3D_NO_TINY"))  # A/B switch: the flow head on the split kernels
-_NO_ACTGRAD = bool(os.environ.get("DFMIR_NO_ACTGRAD"))     # A/B switch: LeakyReLU backward always as its own pass
+_NO_TINY3D = _env_on("DFMIR_CONV3D_NO_TINY")  # A/B switch: the flow head on the split kernels
+_NO_ACTGRAD = _env_on("DFMIR_NO_ACTGRAD")     # A/B switch: LeakyReLU backward always as its own pass
 
 
 def _tag_ok(t, tag):
@@ -495,10 +511,10 @@ def bump_weights_epoch():
 # wgrad kernels of all those passes accumulate into ONE persistent tap-major buffer per module and the
 # bias gradients straight into `bias.grad`; the buffers are unpacked into `weight.grad` once, on exit.
 # Without it every pass pays a zero-fill, an unpack and an autograd `add` per parameter (~900 tiny launches).
-_NO_RES = bool(os.environ.get("DFMIR_NO_RES"))       # A/B switch: residual added by a separate kernel
-_NO_DEAD_TAIL = bool(os.environ.get("DFMIR_NO_DEAD_TAIL"))   # A/B switch: dgrad also for skip channels that need none
-_NO_CH_SCALE = bool(os.environ.get("DFMIR_NO_CH_SCALE"))   # A/B switch: one dY scale per tensor in the split wgrad
-_NO_RING = bool(os.environ.get("DFMIR_NO_RING"))     # A/B switch: reflect dgrad as padded-frame conv + fold
+_NO_RES = _env_on("DFMIR_NO_RES")       # A/B switch: residual added by a separate kernel
+_NO_DEAD_TAIL = _env_on("DFMIR_NO_DEAD_TAIL")   # A/B switch: dgrad also for skip channels that need none
+_NO_CH_SCALE = _env_on("DFMIR_NO_CH_SCALE")   # A/B switch: one dY scale per tensor in the split wgrad
+_NO_RING = _env_on("DFMIR_NO_RING")     # A/B switch: reflect dgrad as padded-frame conv + fold
 _DEFER = {"on": False, "pending": {}}
 
 
@@ -849,7 +865,7 @@ class Stem7Fn(Function):
         return dx, dw, db, None
 
 
-_NO_STEM7 = bool(os.environ.get("DFMIR_NO_STEM7"))    # A/B switch: the stem through tap stack + 1x1 GEMM
+_NO_STEM7 = _env_on("DFMIR_NO_STEM7")    # A/B switch: the stem through tap stack + 1x1 GEMM
 
 
 def conv_taps(x, weight, bias, pad, pad_mode, act=0, slope=0.0):
@@ -931,7 +947,7 @@ def instance_norm(x, res=None, relu=False, eps=1e-5):
     return tag_amax(y, _LAST_AMAX[0])
 
 
-_NO_IN_BLUR = bool(os.environ.get("DFMIR_NO_IN_BLUR"))     # A/B switch: InstanceNorm+ReLU and Downsample as two passes
+_NO_IN_BLUR = _env_on("DFMIR_NO_IN_BLUR")     # A/B switch: InstanceNorm+ReLU and Downsample as two passes
 
 
 class InstNormReluBlurDownFn(Function):
@@ -1020,7 +1036,7 @@ def _bound_from(y, x):
     """y is a convex combination of x's values (the [1,2,1] blurs: non-negative taps summing to 1 per output), so
     max|x| bounds max|y|: x's range probe serves y's split conversion (no standalone absmax launch)."""
     tag = getattr(x, "_df_amax", None)
-    if tag is not None and tag[1] == x._version and tag[2] == x.data_ptr():
+    if tag is not None and _amax_ok(x, tag):
         tag_amax(y, tag[0])
     return y
 
@@ -1071,7 +1087,7 @@ class UpCatFn(Function):
 
 def _valid_amax(t):
     tag = getattr(t, "_df_amax", None)
-    if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() and tag[0].numel() == PROBE_SLOTS:
+    if tag is not None and _amax_ok(t, tag) and tag[0].numel() == PROBE_SLOTS:
         return tag[0]
     return None
 
@@ -1103,17 +1119,17 @@ def upcat(a, b):
     return y
 
 
-_NO_UPWGRAD = bool(os.environ.get("DFMIR_CONV3D_NO_UPWGRAD"))     # A/B switch: weight gradient from the materialised cat
-_NO_UPDGRAD = bool(os.environ.get("DFMIR_CONV3D_NO_UPDGRAD"))     # A/B switch: d(a) through the full-resolution dgrad + pool
-_NO_UPSKIP2 = bool(os.environ.get("DFMIR_CONV3D_NO_UPSKIP2"))     # A/B switch: <= 2 skip channels as a second launch
-_NO_UPPHASE = bool(os.environ.get("DFMIR_CONV3D_NO_UPPHASE"))     # A/B switch: materialise nearest_up2 + cat, one conv
+_NO_UPWGRAD = _env_on("DFMIR_CONV3D_NO_UPWGRAD")     # A/B switch: weight gradient from the materialised cat
+_NO_UPDGRAD = _env_on("DFMIR_CONV3D_NO_UPDGRAD")     # A/B switch: d(a) through the full-resolution dgrad + pool
+_NO_UPSKIP2 = _env_on("DFMIR_CONV3D_NO_UPSKIP2")     # A/B switch: <= 2 skip channels as a second launch
+_NO_UPPHASE = _env_on("DFMIR_CONV3D_NO_UPPHASE")     # A/B switch: materialise nearest_up2 + cat, one conv
 
 
 # Registry of the split-weight workspaces of persistent packed buffers: after the batched re-pack of an optimizer step
 # (_repack_all) every registered split is re-made by ONE launch (dfmir_conv3d_wsplit_batch) instead of one launch per
 # layer and mode at its first use.
 _WS3D = {"entries": {}, "key": None, "dev": None}
-_NO_WS_BATCH = bool(os.environ.get("DFMIR_NO_WSPLIT_BATCH"))
+_NO_WS_BATCH = _env_on("DFMIR_NO_WSPLIT_BATCH")
 
 
 def _ws3d_register(w_tcc, key, ws, job):
@@ -1456,7 +1472,7 @@ def _warp_bwd(dout, src, flow, dsrc, dflow, add_identity, into_src):
                                      add_identity, into_src, _st()))
 
 
-_WARP_ATOMIC = bool(os.environ.get("DFMIR_WARP_ATOMIC"))     # A/B switch: d(src) through global atomics
+_WARP_ATOMIC = _env_on("DFMIR_WARP_ATOMIC")     # A/B switch: d(src) through global atomics
 
 
 def _warp_bwd_dsrc(dout, src, flow, dflow, add_identity, into_src):
@@ -1534,7 +1550,7 @@ def vecint_step(v):
     return VecIntStepFn.apply(v)
 
 
-_RESIZE_ONEPASS = bool(os.environ.get("DFMIR_RESIZE_ONEPASS"))     # A/B switch: the one-pass gather adjoint
+_RESIZE_ONEPASS = _env_on("DFMIR_RESIZE_ONEPASS")     # A/B switch: the one-pass gather adjoint
 
 
 class ResizeFn(Function):
@@ -1601,7 +1617,7 @@ class TapForkFn(Function):
             elif not g.is_contiguous():
                 g = g.contiguous()
             atag = getattr(g, "_df_amax", None)
-            if atag is not None and not (atag[1] == g._version and atag[2] == g.data_ptr()):
+            if atag is not None and not _amax_ok(g, atag):
                 atag = None
             ptag = getattr(g, "_df_pmax", None)
             if ptag is not None and not (ptag[1] == g._version and ptag[2] == g.data_ptr()):
@@ -1645,7 +1661,7 @@ def fork_tap(feat):
     main, tap = TapForkFn.apply(feat, stash)
     tap._df_tap_stash = stash
     tag = getattr(feat, "_df_amax", None)
-    if tag is not None and tag[1] == feat._version and tag[2] == feat.data_ptr():
+    if tag is not None and _amax_ok(feat, tag):
         tag_amax(main, tag[0])
         tag_amax(tap, tag[0])
     return main, tap
@@ -1931,7 +1947,7 @@ def patch_gather_multi(srcs, ids):
     return out
 
 
-_NO_NCE_FUSED = bool(os.environ.get("DFMIR_NO_NCE_FUSED"))     # A/B switch: gather, two 1x1 convs and l2norm as 4 launches
+_NO_NCE_FUSED = _env_on("DFMIR_NO_NCE_FUSED")     # A/B switch: gather, two 1x1 convs and l2norm as 4 launches
 
 
 def nce_head_ok(C, nc, use_mlp):

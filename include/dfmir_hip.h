@@ -40,7 +40,9 @@ const char* dfmir_last_error(void);
  * DFMIR_CONV_FP32, DFMIR_CONV3D_FP32: the split sections of packed weights) must be set before the
  * first dfmir_weight_pack* call, or every packed buffer re-packed after the change.
  * dfmir_get_option copies the current value into buf (NUL-terminated, truncated to buf_len) and
- * returns its length, or -1 when the option is unset.
+ * returns its length, or -1 when the option is unset.  Flag options (everything below without "=n") are ON when set to
+ * anything but "" or "0" -- set_option(name, "0") switches a flag off like set_option(name, NULL) does.  Reads are
+ * thread-safe: values are copied out under the table's lock, the per-site caches are single atomic words.
  *   kernel selection: DFMIR_CONV_FP32, DFMIR_CONV_SPLIT=bf16x3, DFMIR_CONV3D_FP32, DFMIR_CONV_GENERIC=1,
  *     DFMIR_CONV_NO_CS, DFMIR_CONV_CS_PLAIN, DFMIR_CS_XCD_PAIR=n, DFMIR_WGRAD_V1, DFMIR_WGRAD_NO_SWAP,
  *     DFMIR_NO_SMALL_WGRAD, DFMIR_NO_DIL2, DFMIR_NO_SMALL_TILES, DFMIR_GEMM_BIG_MIN=n,

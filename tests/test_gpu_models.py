@@ -646,6 +646,39 @@ def _full_size_hip(st, size, B, A0, B0, default_path=False):
     return model
 
 
+def test_config0_geometry_at_full_width(O):
+    """BASELINE configs[0] -- 64 x 64 pairs, batch 2 -- at the generator's real width (ngf 64: 16 x 16 maps with 256
+    channels through the flat-run `pp` kernel, the NCE head on 4 x 4 ... 64 x 64 feature maps with P = 256 of S = 256
+    positions at the deepest layers), one whole step against the oracle."""
+    size, B, ngf = 64, 2, 64
+    torch.manual_seed(13)
+    st = O.RegistrationStep(size, B, ngf=ngf)
+    with torch.no_grad():
+        st.netR.flow.weight.mul_(1e5)
+    st.ids_hook = lambda c, feats: [C.patch_ids(c, i, f.shape[2] * f.shape[3], 256) for i, f in enumerate(feats)]
+    A0, B0 = C.image_pair(15, B, size, size)
+    st.data_dependent_initialize(A0, B0)
+    with torch.no_grad():
+        for p in st.netF.parameters():
+            if p.dim() == 1:
+                p.add_(0.01)
+    model, opt = _hip_model_from_oracle(st, size, B, ngf)
+    model.patch_id_source = PinnedIds()
+    model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    A_, B_ = C.image_pair(17, B, size, size)
+    ref = st.step(A_, B_)
+    model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+    model.optimize_parameters()
+    ls = model.get_current_losses()
+    close(model.fake_B, st.fake_B, what="fake_B"); close(model.regA, st.regA, what="regA")
+    close(model.registered, st.registered, what="registered"); close(model.pos_flow, st.flow, what="pos_flow")
+    for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
+        assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
+
+
 @pytest.mark.parametrize("default_path", [False, True], ids=["per-term-keys", "default-batched-head"])
 def test_full_size_step_vs_oracle(O, default_path, capsys):
     """256x256, ngf=64 (BASELINE configs[1] geometry) at batch 2: one step of the HIP path against the oracle on
