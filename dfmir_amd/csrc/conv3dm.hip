@@ -302,9 +302,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
 
   // accumulators of the three open output planes: [plane slot][tile row][half]
   using acc_t = typename std::conditional<B32, f32x16, f32x4_m>::type;
-  acc_t acc[3][2][NH];
+  // NSETS = 4 (16 -> 16): the finished plane keeps its set for one more step, during which its epilogue rides between
+  // the MFMA groups like the staging atoms (10-13 % of a step was an epilogue with nothing on the matrix pipe); the
+  // 32-column form has no registers for a fourth set (96 + 32) and finishes its plane at the end of the step
+  constexpr int NSETS = (B32 || CIN == 32) ? 3 : 4;      // (32 input channels: two job rounds of staging registers)
+  acc_t acc[NSETS][2][NH];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < NSETS; ++a)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -375,13 +379,35 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     if (jquad[r_]) rq[r_][c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
     else if (jpos[r_] >= 0) rq[r_][c_][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
   }
-#define M3_AVLOAD(e_, P_)                                                                         \
+#define M3_AVLOAD(e_, P_)                  /* activation source of the plane whose epilogue comes next */ \
   {                                                                                               \
-    const int p_ = (P_) - 1;                                                                      \
+    const int p_ = (P_) - (NSETS == 4 ? 2 : 1);                                                   \
     const bool pok_ = p_ >= zs && p_ < ze;                                                        \
     av[e_] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e_] + (unsigned)p_ * hw4 : OOB, 0, 0); \
   }
-#define M3_ATOMS(t, P_, sl_, st_, ld_)                                                            \
+  // store e of the finished plane p_ (accumulator set a_): bias, LeakyReLU or the folded LeakyReLU derivative, range probe;
+  // the set leaves zeroed
+#define M3_EPI_ONE(a_, e_, p_)                                                                    \
+  {                                                                                               \
+    constexpr int ea_ = (a_), ee_ = (e_);                                                         \
+    constexpr int r = B32 ? (ee_ >> 2) : (ee_ >> 1), h = B32 ? 0 : (ee_ & 1), q4 = B32 ? 4 * (ee_ & 3) : 0; \
+    const int pp_ = (p_);                                                                         \
+    const bool ok = pp_ >= zs && pp_ < ze && evo[ee_] != OOB;                                     \
+    u32x4 out;                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      float v = acc[ea_][r][h][q4 + i] * osc + bv;                                                \
+      if (k.act == 1) v = v > 0.f ? v : v * k.slope;                                              \
+      if (ACTG) v = __uint_as_float(av[ACTG ? ee_ : 0][i]) > 0.f ? v : v * k.act_slope;            \
+      out[i] = __float_as_uint(v);                                                                \
+      pm = fmaxf(pm, ok ? fabsf(v) : 0.f);                                                        \
+      acc[ea_][r][h][q4 + i] = 0.f;                                                               \
+    }                                                                                             \
+    /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
+    /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
+    /* the last lanes of every 16 was lost once in ~10^4 launches)                                              */ \
+    __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[ee_] + (unsigned)pp_ * hw4 : OOB, 0, 0); \
+  }
+#define M3_ATOMS(t, PH_, P_, sl_, st_, ld_)                                                            \
   {                                                                                               \
     if constexpr (SLOTS == 2) {                                                                   \
       if constexpr (t < 8) {                                                                      \
@@ -399,9 +425,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       }                                                                                           \
       if constexpr (t >= 9 && t <= 23 && (t & 1) == 1) { if (ld_) M3_LOAD1(0, (t - 9) >> 1, (P_) + 2) } \
       if constexpr (ACTG && t >= 10 && t < 10 + 2 * NE && (t & 1) == 0) M3_AVLOAD((t - 10) >> 1, P_) \
+      if constexpr (NSETS == 4 && t >= 30 && t < 30 + 3 * NE && (t - 30) % 3 == 0) M3_EPI_ONE(((PH_) + 2) % 4, (t - 30) / 3, (P_) - 2) \
     } else {                                                                                      \
       if constexpr (t <= 30 && (t & 1) == 0) { if (st_) M3_LOAD1((t >> 1) >> 3, (t >> 1) & 7, (P_) + 1) } \
-      if constexpr (ACTG && t >= 45 && t < 45 + 2 * NE && (t & 1) == 1) M3_AVLOAD((t - 45) >> 1, P_) \
+      if constexpr (ACTG && t >= 1 && t < 1 + 2 * NE && (t & 1) == 1) M3_AVLOAD((t - 1) >> 1, P_) \
+      if constexpr (NSETS == 4 && t >= 33 && t < 33 + 2 * NE && (t & 1) == 1) M3_EPI_ONE(((PH_) + 2) % 4, (t - 33) >> 1, (P_) - 2) \
     }                                                                                             \
   }
 #define M3_STEP(PH_, sl_, P_, st_, ld_)                                                           \
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       constexpr int t = decltype(tc_)::value, jd = t / 3, p = t % 3, j = jd / 3, dz = jd % 3, cur = jd % (M3_ADEPTH + 1); \
       constexpr unsigned lmask = step_loads<CIN, COUT>(j);                                        \
       constexpr int qo = step_qoff<CIN, COUT>(j);                                                 \
-      constexpr int a = ((PH_) + 4 - dz) % 3;                                                     \
+      constexpr int a = ((PH_) + 1 - dz + NSETS) % NSETS;                                         \
       if constexpr (p == 0) {                                                                     \
         if constexpr (M3_PRIO == 1) { if (wid >= 4) __builtin_amdgcn_s_setprio((jd + 1) & 1); else __builtin_amdgcn_s_setprio(jd & 1); } \
         if constexpr (jd + M3_ADEPTH < NSTEP * 3) M3_AREAD((jd + M3_ADEPTH) % (M3_ADEPTH + 1), jd + M3_ADEPTH) \
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
           });                                                                                     \
         }                                                                                         \
       }                                                                                           \
-      M3_ATOMS(t, P_, sl_, st_, ld_)                                                              \
+      M3_ATOMS(t, PH_, P_, sl_, st_, ld_)                                                         \
       constexpr int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
       _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
         _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                          \
@@ -437,27 +465,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       __builtin_amdgcn_sched_barrier(0);                                                          \
     });                                                                                           \
     M3_T(2)                                                                                       \
-    /* output plane P - 1 is complete */                                                          \
-    if (!((M3_KO & 16) && k.D > 0)) {                                                             \
-      const int p_ = (P_) - 1, a = ((PH_) + 2) % 3;                                               \
-      const bool pok_ = p_ >= zs && p_ < ze;                                                      \
-      const unsigned pb_ = (unsigned)p_ * hw4;                                                    \
-      _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                            \
-        const int r = B32 ? (e >> 2) : (e >> 1), h = B32 ? 0 : (e & 1), q4 = B32 ? 4 * (e & 3) : 0; \
-        const bool ok = pok_ && evo[e] != OOB;                                                    \
-        u32x4 out;                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-          float v = acc[a][r][h][q4 + i] * osc + bv;                                              \
-          if (k.act == 1) v = v > 0.f ? v : v * k.slope;                                          \
-          if (ACTG) v = __uint_as_float(av[ACTG ? e : 0][i]) > 0.f ? v : v * k.act_slope;          \
-          out[i] = __float_as_uint(v);                                                            \
-          pm = fmaxf(pm, ok ? fabsf(v) : 0.f);                                                    \
-          acc[a][r][h][q4 + i] = 0.f;                                                             \
-        }                                                                                         \
-        /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
-        /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
-        /* the last lanes of every 16 was lost once in ~10^4 launches)                                              */ \
-        __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[e] + pb_ : OOB, 0, 0); \
+    /* output plane P - 1 is complete; NSETS == 3: its epilogue now, else inside the next step */  \
+    if constexpr (NSETS == 3) {                                                                   \
+      if (!((M3_KO & 16) && k.D > 0)) {                                                           \
+        static_for_m<0, NE>([&](auto ec_) __attribute__((always_inline)) { M3_EPI_ONE(((PH_) + 2) % 3, decltype(ec_)::value, (P_) - 1) }); \
       }                                                                                           \
     }                                                                                             \
     M3_T(3)                                                                                       \
@@ -498,14 +509,40 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       }                                                                                           \
     }                                                                                             \
   }
-  for (int i = 0; i < nst; i += 3) {
-    M3_ITER(0, i)
-    if (i + 1 < nst) M3_ITER(1, i + 1)
-    if (i + 2 < nst) M3_ITER(2, i + 2)
+  if constexpr (NSETS == 3) {
+    for (int i = 0; i < nst; i += 3) {
+      M3_ITER(0, i)
+      if (i + 1 < nst) M3_ITER(1, i + 1)
+      if (i + 2 < nst) M3_ITER(2, i + 2)
+    }
+  } else {
+    for (int i = 0; i < nst; i += 4) {
+      M3_ITER(0, i)
+      if (i + 1 < nst) M3_ITER(1, i + 1)
+      if (i + 2 < nst) M3_ITER(2, i + 2)
+      if (i + 3 < nst) M3_ITER(3, i + 3)
+    }
+    // the last finished plane (input plane P0 + nst - 1 closed output plane ze - 1) still holds its set
+    if (!((M3_KO & 16) && k.D > 0)) {
+      u32x4 av[ACTG ? NE : 1];
+      const int pl = P0 + nst - 2;
+      if constexpr (ACTG) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+          av[e] = __builtin_amdgcn_raw_buffer_load_b128(a_src, (pl >= zs && pl < ze && evo[e] != OOB) ? evo[e] + (unsigned)pl * hw4 : OOB, 0, 0);
+      }
+      switch ((nst + 2) & 3) {                               // set of plane index (nst - 2) relative to P0: (nst - 2 + 4) % 4
+        case 0: static_for_m<0, NE>([&](auto ec_) __attribute__((always_inline)) { M3_EPI_ONE(0, decltype(ec_)::value, pl) }); break;
+        case 1: static_for_m<0, NE>([&](auto ec_) __attribute__((always_inline)) { M3_EPI_ONE(1, decltype(ec_)::value, pl) }); break;
+        case 2: static_for_m<0, NE>([&](auto ec_) __attribute__((always_inline)) { M3_EPI_ONE(2, decltype(ec_)::value, pl) }); break;
+        default: static_for_m<0, NE>([&](auto ec_) __attribute__((always_inline)) { M3_EPI_ONE(NSETS == 4 ? 3 : 0, decltype(ec_)::value, pl) }); break;
+      }
+    }
   }
 #undef M3_ITER
 #undef M3_STEP
 #undef M3_ATOMS
+#undef M3_EPI_ONE
 #undef M3_AVLOAD
 #undef M3_LOAD1
 #undef M3_CONV_HALF
