@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 8
+#define DFMIR_ABI_VERSION 9
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);

@@ -19,7 +19,7 @@ python scripts/bench_in_blurdown.py > $O/bench_in_blurdown.txt 2>&1
 DFMIR_IN_BLUR_BANDED=1 python scripts/bench_in_blurdown.py >> $O/bench_in_blurdown.txt 2>&1
 python scripts/conv2d_layer_census.py > $O/conv2d_layer_census.txt 2>&1
 python scripts/conv3d_step_census.py > $O/conv3d_step_census.txt 2>&1
-for sw in DFMIR_NO_OVERLAP_R DFMIR_NO_NCE_FUSED DFMIR_WGRAD_NO_SWAP DFMIR_CONV_CS_PLAIN NONE; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_switches.txt 2>&1
+for sw in DFMIR_NO_OVERLAP_R DFMIR_CONV_CS_PLAIN NONE; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_switches.txt 2>&1
 for u in mfma_peak lds_unaligned valu_under_mfma; do   # built from source on the box (binaries are not tracked)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$u scripts/ubench/$u.hip && /tmp/$u > $O/ubench_$u.txt 2>&1
 done
@@ -39,9 +39,14 @@ bash scripts/prof_conv.sh wgrad 256 256 64 32 > $O/pmc_conv_wgrad.txt 2>&1
 CELL=32 AMP=1.0 bash scripts/prof_warp.sh > $O/pmc_warp.txt 2>&1
 bash scripts/prof_conv3d.sh 34-32 > $O/pmc_conv3d_34_32.txt 2>&1
 bash scripts/prof_conv3d.sh 32-16 > $O/pmc_conv3d_32_16.txt 2>&1
+bash scripts/prof_conv3d.sh 16-16,16-32 > $O/pmc_conv3d_march.txt 2>&1
+python scripts/bench_march.py > $O/bench_march.txt 2>&1
+if [ -f build/ko/libdfmir_hip_m3trace.so ]; then DFMIR_HIP_LIB=$PWD/build/ko/libdfmir_hip_m3trace.so python scripts/march_trace.py 2>&1 | grep -v amdgpu.ids > $O/march_trace.txt; fi
+DFMIR_CONV3D_NO_MARCH=1 TAG=tiled python scripts/bench_march.py >> $O/bench_march.txt 2>&1
 bash scripts/prof_3d_step.sh 60 > $O/step_trace_3d.txt 2>&1
 bash scripts/prof_step.sh scripts/bench_3d_128.py 3d128 50 > $O/step_trace_3d_128.txt 2>&1
 bash scripts/prof_upconv3d.sh > $O/pmc_upconv3d.txt 2>&1
+for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_CONV3D_NO_MARCH=1; else unset DFMIR_CONV3D_NO_MARCH; fi; echo "DFMIR_CONV3D_NO_MARCH=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-72; done > $O/ab_march_3d.txt 2>&1; unset DFMIR_CONV3D_NO_MARCH
 for v in 0 2; do DFMIR_CS_XCD_PAIR=$v python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('DFMIR_CS_XCD_PAIR=$v', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step issued_frac', round(r['roofline']['issued_frac'],4))"; done > $O/ab_xcd_order.txt 2>&1
 rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d $R/gpurun_out/upconv_prof
-TAG=${TAG:-r04}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json
+TAG=${TAG:-r05}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json

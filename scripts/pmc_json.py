@@ -20,7 +20,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def parse(txt):
     dur, ctr = {}, {}
-    for l in txt.splitlines():
+    for l in txt.replace("(anonymous namespace)::", "").splitlines():
         m = re.match(r'^(void )?([A-Za-z0-9_]+(?:<[^>]*>)?)\(.*? (\d+) ([\d.]+)$', l)
         if m:
             dur.setdefault(m.group(2), float(m.group(4)))
@@ -50,7 +50,7 @@ def entry(name, dur, c, alg_bytes, shape):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     from_prof = "--from-profiles" in sys.argv
     P = R + "/profiles/"
     C = R + "/gpurun_out/collect/"
@@ -99,6 +99,16 @@ def main():
                 out["conv3d_split_m16_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
             if 'wgrad_tr' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_wgrad_tr_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
+            if 'conv3d_march_k' in k and 'FETCH_SIZE' in c[k]:          # the z-marching kernel (csrc/conv3dm.hip)
+                out["conv3d_march_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
+    if not from_prof and os.path.exists(C + "pmc_conv3d_march.txt"):
+        d, c = parse(open(C + "pmc_conv3d_march.txt").read())
+        for k in c:
+            m_ = re.match(r'conv3d_march_k<(\d+), (\d+)', k)
+            if m_ and 'FETCH_SIZE' in c[k]:
+                cin, cout = int(m_.group(1)), int(m_.group(2))
+                out["conv3d_march_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], 4.0 * nv * (cin + cout) + 27 * cin * cout * 4,
+                                                                  "%d->%d 3x3x3 @160x192x224" % (cin, cout))
     if not from_prof and os.path.exists(C + "pmc_upconv3d.txt"):
         d, c = parse(open(C + "pmc_upconv3d.txt").read())
         lo = 80 * 96 * 112
