@@ -13,9 +13,13 @@ scaling; configs[2] is the same thing at N = 8).  One JSON line on rank 0 with
                   `issued_frac` (= 3 x frac, what the matrix pipe executes) beside it; `traffic` = HBM-side bytes per
                   launch from the committed PMC passes (profiles/rNN_pmc.json)
   `roofline_hbm`  the trilinear warp (grid_sample) forward / backward at 160x192x224, algorithmic bytes / HIP-event time
-                  against 8 TB/s, measured in the same process, on a smooth and on a rough field
-  `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (conv3d_split_k forward / dgrad and
-                  conv3d_wgrad_tr_k, both scaled fp16x2 on the 16-bit matrix pipe)
+                  against 8 TB/s, measured in the same process, on a smooth and on a rough field -- COLD (four rotating
+                  buffer sets: > 256 MiB between two uses of a buffer) with the cache-warm figure beside it as `warm`
+  `also_3d`       the 3-D step of configs[4] geometry on one GPU with its own roofline (the tiled conv3d_split_k /
+                  conv3d_split_m16_k and the z-marching conv3d_march_k forward / dgrad kernels, conv3d_wgrad_tr_k, all scaled
+                  fp16x2 on the 16-bit matrix pipe)
+  `value_host_inputs`, `value_pil_loader`  the same step fed from pinned host tensors / from the plugin's own PNG -> PIL ->
+                  transforms DataLoader (worker processes): PCIe- and pipeline-inclusive rates, never the headline
   `also_3d_128`   configs[3]: the 3-D step at 128^3 with the plugin's 6-level U-Net features
   `cpu_baseline`  (N = 1) the CPU oracle = a port of the reference's PyTorch-CPU path, timed on the host cores on a
                   bounded sample: the 2-D step at 256^2 batch 1, (`also_3d_128`) the 3-D step at 128^3 and (`also_3d_big`) one
@@ -338,8 +342,10 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
                                  "issued_* count every product the matrix pipe executes",
                 "issued_tflops": sp_issued, "issued_frac": sp_issued / FP16_MFMA_PEAK_TFLOPS, "products_per_mac": 3.0,
                 "frac_of_fp32_mfma_peak": sp_tf / FP32_MFMA_PEAK_TFLOPS,
-                "kernel": "conv3d_split_k (v_mfma_f32_32x32x16_f16, 4x8x16-voxel x 32-cout tiles, LDS halo patch split into "
-                          "fp16 pairs per 8-channel chunk): forward + dgrad of every stride-1 3x3x3 conv",
+                "kernel": "conv3d_split_k / conv3d_split_m16_k (4x8x16-voxel tiles, LDS halo patch split into fp16 pairs per "
+                          "8-channel chunk) and, for the full-resolution layers with Cin x Cout <= 512, conv3d_march_k (16x32 "
+                          "columns marched along z, weights resident in LDS): forward + dgrad of every stride-1 3x3x3 conv",
+                "march_traffic": {k_: pmc_traffic(pmc, k_) for k_ in ("conv3d_march_k_32_16", "conv3d_march_k_16_16", "conv3d_march_k_16_32")},
                 "launches_timed": sp_n, "avg_launch_ms": sp_ms / max(sp_n, 1), "timed_over": timed_over}
     else:
         roof = {"bound": "mfma", "achieved": fw_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
