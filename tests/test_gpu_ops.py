@@ -366,6 +366,37 @@ def test_conv3d_march_kernel(ops, cfg, nseg):
     assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)     # the epilogue's range probe of its output
 
 
+@pytest.mark.parametrize("cfg", [(32, 16), (16, 16), (16, 32)], ids=["32to16", "16to16", "16to32"])
+def test_conv3d_march_writes_every_voxel_and_is_reproducible(ops, cfg):
+    """150 launches of conv3d_march_k into NaN-filled outputs (batch 2, 20 x 80 x 96: 30 columns, three z segments, with and
+    without the folded LeakyReLU derivative): every voxel written, every launch bit-identical to the first.  This loop is
+    what exposed the gfx950 store hazard (a 16-byte buffer store with an SGPR soffset followed directly by a VALU write of
+    its data registers: DESIGN section 4, hardware fact 7) -- one wrong dword in ~10^4 launches."""
+    import ctypes
+    from dfmir_amd.ops import DfConvGeom, _p, _st, check, lib
+    Cin, Cout = cfg
+    N, D, H, W = 2, 20, 80, 96
+    x = C.randn(311, N, Cin, D, H, W).to(DEV)
+    w = (C.randn(312, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5).to(DEV)
+    src = C.randn(313, N, Cout, D, H, W).to(DEV)
+    wt = ops.weight_pack(w, 0)
+    xa = ops.absmax(x)
+    g = DfConvGeom(N, Cin, Cout, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 0, 0, 0.0)
+    assert lib().dfmir_conv3d_march_ok(ctypes.byref(g))
+    for actg in (False, True):
+        ref = None
+        for rep in range(75):
+            y = torch.full((N, Cout, D, H, W), float("nan"), device=DEV)
+            slot = ops.amax_slot(x.device, ops.PROBE_SLOTS)
+            check(lib().dfmir_conv3d_march_fwd(ctypes.byref(g), _p(x), _p(xa), 1, _p(wt), None, _p(y), _p(slot),
+                                               _p(src) if actg else None, 0.2, _st()))
+            if ref is None:
+                ref = y
+                assert not bool(torch.isnan(y).any()), "unwritten output voxels"
+                continue
+            assert torch.equal(y, ref), "launch %d differs from the first (actg=%s)" % (rep, actg)
+
+
 @pytest.mark.parametrize("cfg", [(16, 2, 32, 1, 6, 10, 12, 1), (32, 16, 32, 1, 5, 9, 20, 1), (8, 3, 16, 2, 4, 8, 8, 0),
                                  (64, 64, 64, 1, 3, 5, 8, 1), (32, 2, 32, 1, 9, 17, 36, 1)],
                          ids=["16+2->32", "32+16->32", "8+3->16-pair-batch2", "64+64->64", "32+2->32-ragged"])
