@@ -1313,6 +1313,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
 #ifndef C3U_SKIP_PREFETCH
 #define C3U_SKIP_PREFETCH 0   // 1: the skip patch's loads ride in the last chunk's k-steps -- measured SLOWER (0.74 -> 0.82 ms:
 #endif                        //    22 registers spill although the staging registers are shared); 0: loaded after that chunk
+#ifndef C3U_KO
+#define C3U_KO 0     // knock-out builds (timing only): 1 no epilogue stores, 2 no skip-channel phase, 4 no conversion + LDS stores, 8 no MFMAs
+#endif
 #ifndef C3U_SB
 #define C3U_SB 1     // 1: operands of a k-step are read at its start (single register set: no scratch spills; the other
 #endif               //    wave of the SIMD covers the LDS latency); 0: one step ahead (31 spilled registers)
@@ -1339,6 +1342,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
       if (!C3U_SB && tp + 1 < 8) C3U_OPLOAD(cur ^ 1, tp + 1);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+        if ((C3U_KO & 8) && k.D > 0) { acc[tp >> 2][j][0] += __uint_as_float(A1[cur][0] ^ B0[cur][j][1] ^ A0[cur][2] ^ B1[cur][j][3]); continue; }
         acc[tp >> 2][j] = mma3(A1[cur], B0[cur][j], acc[tp >> 2][j]);
         acc[tp >> 2][j] = mma3(A0[cur], B1[cur][j], acc[tp >> 2][j]);
         acc[tp >> 2][j] = mma3(A0[cur], B0[cur][j], acc[tp >> 2][j]);
@@ -1352,7 +1356,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
     }
     if (more) {
       __syncthreads();
-      C3U_LSTORE();
+      if (!((C3U_KO & 4) && k.D > 0)) C3U_LSTORE();
       __syncthreads();
     }
   }
@@ -1365,7 +1369,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
 #undef C3U_OPLOAD
 
   float osc_f = osc;
-  if constexpr (SKIP2) {
+  if (SKIP2 && !((C3U_KO & 2) && k.D > 0)) {
     // ---- the skip channels: accumulators to the skip products' scale, stage the patch + weights, 2 x 5 k-steps
     __syncthreads();                                       // every wave is done with Xs / Ws
     const float bmax = reduce_absmax(k.b_amax, k.b_n, red);
@@ -1478,7 +1482,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
       u32x2_ v2;
       v2[0] = __float_as_uint(v0);
       v2[1] = __float_as_uint(v1);
-      __builtin_amdgcn_raw_buffer_store_b64(v2, y_dst, ok ? vo : OOB, (unsigned)cou * sf4, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(v2, y_dst, (ok && !((C3U_KO & 1) && k.D > 0)) ? vo : OOB, (unsigned)cou * sf4, 0);
     }
   }
   if (SKIP2 && k.y_amax) {
