@@ -37,6 +37,9 @@ typedef float f32x4_m __attribute__((ext_vector_type(4)));
 #ifndef M3_ADEPTH
 #define M3_ADEPTH 1  // weight operands are read this many (k-step, dz) blocks ahead of their MFMAs
 #endif
+#ifndef M3_B32_RC
+#define M3_B32_RC 1  // 32-column form: MFMA rows = output channels, columns = the 32 voxels of a tile row -> 4-byte epilogue
+#endif               // accesses, each a full 128-byte row segment of one channel (0: rows = voxels, 16-byte pieces of 32 channels)
 #ifndef M3_PRIO
 #define M3_PRIO 0    // 1: the two waves of a SIMD (w, w + 4) alternate s_setprio 1 / 0 block by block; 2: waves 4-7 at 1
 #endif
@@ -152,9 +155,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   __shared__ __attribute__((aligned(16))) u32x4 Ws[WU];
   __shared__ float red[17];
   __shared__ unsigned smax;
+  __shared__ float sbias[32];
+  constexpr bool RC = B32 && (M3_B32_RC != 0);             // rows = output channels (see M3_B32_RC)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4, l31 = lane & 31, lhi = lane >> 5;
+  if (tid < 32) sbias[tid] = (bias && tid < COUT) ? bias[tid] : 0.f;
 
   // workgroup -> (image, z segment, column): the dispatcher deals consecutive ids round-robin to the 8 XCDs (one L2
   // each); ids with the same residue walk one contiguous eighth of the work list (x fastest, then y, then segment), so
@@ -329,8 +335,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   for (int e = 0; e < NE; ++e) {
     const int r = B32 ? (e >> 2) : (e >> 1);
     const int gy = y0 + 2 * wid + r;
-    const int gx = B32 ? (x0 + 8 * (e & 3) + 4 * lhi) : (x0 + 16 * (e & 1) + 4 * kg);
-    evo[e] = (gy < k.H && gx < k.W) ? (unsigned)(gy * k.W + gx) * 4u + (unsigned)co * s4 : OOB;
+    const int gx = RC ? (x0 + l31) : (B32 ? (x0 + 8 * (e & 3) + 4 * lhi) : (x0 + 16 * (e & 1) + 4 * kg));
+    // RC: element i of group e = (row, q) is channel 8 q + 4 lhi + i at voxel x0 + l31 (channel step in the soffset)
+    evo[e] = (gy < k.H && gx < k.W) ? (unsigned)(gy * k.W + gx) * 4u + (unsigned)(RC ? 8 * (e & 3) + 4 * lhi : co) * s4 : OOB;
   }
   float pm = 0.f;
 
@@ -383,7 +390,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   {                                                                                               \
     const int p_ = (P_) - (NSETS == 4 ? 2 : 1);                                                   \
     const bool pok_ = p_ >= zs && p_ < ze;                                                        \
-    av[e_] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e_] + (unsigned)p_ * hw4 : OOB, 0, 0); \
+    if constexpr (RC) {                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+        av[e_][i] = __builtin_amdgcn_raw_buffer_load_b32(a_src, pok_ ? evo[e_] + (unsigned)p_ * hw4 : OOB, (unsigned)i * s4, 0); \
+    } else {                                                                                      \
+      av[e_] = __builtin_amdgcn_raw_buffer_load_b128(a_src, pok_ ? evo[e_] + (unsigned)p_ * hw4 : OOB, 0, 0); \
+    }                                                                                             \
   }
   // store e of the finished plane p_ (accumulator set a_): bias, LeakyReLU or the folded LeakyReLU derivative, range probe;
   // the set leaves zeroed
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     const bool ok = pp_ >= zs && pp_ < ze && evo[ee_] != OOB;                                     \
     u32x4 out;                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-      float v = acc[ea_][r][h][q4 + i] * osc + bv;                                                \
+      float v = acc[ea_][r][h][q4 + i] * osc + (RC ? sbias[(8 * (ee_ & 3) + 4 * lhi + i) & 31] : bv);  \
       if (k.act == 1) v = v > 0.f ? v : v * k.slope;                                              \
       if (ACTG) v = __uint_as_float(av[ACTG ? ee_ : 0][i]) > 0.f ? v : v * k.act_slope;            \
       out[i] = __float_as_uint(v);                                                                \
@@ -405,7 +417,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
     /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
     /* the last lanes of every 16 was lost once in ~10^4 launches)                                              */ \
-    __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[ee_] + (unsigned)pp_ * hw4 : OOB, 0, 0); \
+    if constexpr (RC) {                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+        __builtin_amdgcn_raw_buffer_store_b32(out[i], y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[ee_] + (unsigned)pp_ * hw4 : OOB, (unsigned)i * s4, 0); \
+    } else {                                                                                      \
+      __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[ee_] + (unsigned)pp_ * hw4 : OOB, 0, 0); \
+    }                                                                                             \
   }
 #define M3_ATOMS(t, PH_, P_, sl_, st_, ld_)                                                            \
   {                                                                                               \
@@ -459,6 +476,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
         _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                          \
           if ((M3_KO & 1) && k.D > 0) { M3_SINK(Bu[r + qo][h][sb]); M3_SINK(Aw[cur][sa]); }      \
+          else if constexpr (RC) acc[a][r][h] = mma32m(Aw[cur][sa], Bu[r + qo][h][sb], acc[a][r][h]); \
           else if constexpr (B32) acc[a][r][h] = mma32m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]); \
           else acc[a][r][h] = mma16m(Bu[r + qo][h][sb], Aw[cur][sa], acc[a][r][h]);              \
         }                                                                                         \
