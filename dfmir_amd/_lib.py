@@ -68,6 +68,9 @@ _SIGS = {
     "dfmir_conv3d_split_wgrad_ok": [_GP],
     "dfmir_conv3d_split_wgrad": [_GP, P, P, c_int, P, P, c_int, P, P],
     "dfmir_conv3d_split_wgrad_upcat": [_GP, P, P, c_int, P, c_int, P, P, c_int, P, P, P],
+    "dfmir_conv3d_upwgrad_ok": [_GP, c_int],
+    "dfmir_conv3d_upwgrad_ws_floats": [],
+    "dfmir_conv3d_upwgrad": [_GP, P, P, c_int, P, c_int, P, P, c_int, P, P, P, P],
     "dfmir_conv3d_split_wgrad_db": [_GP, P, P, c_int, P, P, c_int, P, P, P],
     "dfmir_probe_merge": [P, P, P, P],
     "dfmir_act_bwd_amax": [P, P, P, c_longlong, c_int, c_float, P, P],
@@ -165,6 +168,7 @@ def lib():
         h.dfmir_conv3d_split_ws_floats.restype = c_longlong
         h.dfmir_conv3d_up_ws_floats.restype = c_longlong
         h.dfmir_conv3d_up_dgrad_ws_floats.restype = c_longlong
+        h.dfmir_conv3d_upwgrad_ws_floats.restype = c_longlong
         h.dfmir_warp_bwd_own_ws_floats.restype = c_longlong
         h.dfmir_resize_bwd_ws_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []

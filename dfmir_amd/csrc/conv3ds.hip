@@ -2508,7 +2508,7 @@ extern "C" int dfmir_conv3d_split_wgrad_ok(const DfConvGeom* g) {
 }
 static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                    const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
-                                   void* stream, const float* xa = nullptr, int Ca = 0);
+                                   void* stream, const float* xa = nullptr, int Ca = 0, long long s_tap_full = 0);
 // The weight gradient of conv3x3x3 over X = cat(nearest_up2(a), b) without building X: a [N, Ca, D/2, H/2, W/2] is read
 // at (z >> 1, y >> 1, x >> 1) while the operand patch is staged.  g: the full layer (Cin = Ca + Cb); Ca % 8 == 0; even
 // D, H, W; x_amax: a range probe valid for both parts.
@@ -2519,6 +2519,34 @@ extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* 
   static DfOptFlag copies_o{"DFMIR_CONV3D_WGRAD_COPIES"};
   DF_ARG_CHECK(split3d_wgrad_geom_ok(g) && !copies_o.get() && (reinterpret_cast<uintptr_t>(a) & 7) == 0);
   return conv3d_split_wgrad_impl(g, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, stream, a, Ca);
+}
+// The same gradient with the up-sampled channels in PARITY CLASSES (conv3duw.hip: 8 / 27 of their products, one pass over
+// dY at 1.0 x) and the skip channels b on the direct kernel, which also carries the bias gradient.  Ca == 32 (every
+// decoder level of the VoxelMorph U-Net), Cout a multiple of 8 up to 32.  ws: dfmir_conv3d_upwgrad_ws_floats() floats,
+// private to the stream while the call is in flight.
+int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* dy, const float* dy_amax, int dy_n,
+                             float* dwt, long long s_tap, float* ws, int N, int Dl, int Hl, int Wl, int Cout,
+                             hipStream_t st);
+static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
+  static DfOptFlag off_o{"DFMIR_CONV3D_NO_UPWGRAD"};
+  return !off_o.get() && !split3d_off() && split3d_wgrad_common_ok(g) && Ca == 32 && g->Cin > Ca && g->Cin - Ca <= 128 &&
+         g->Cout >= 8 && g->Cout <= 32 && (g->Cout & 7) == 0 && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7);
+}
+extern "C" int dfmir_conv3d_upwgrad_ok(const DfConvGeom* g, int Ca) { return (g && upwgrad_geom_ok(g, Ca)) ? 1 : 0; }
+extern "C" long long dfmir_conv3d_upwgrad_ws_floats(void) { return 64LL * 1024; }
+extern "C" int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax,
+                                    int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
+                                    float* db, float* ws, void* stream) {
+  DF_ARG_CHECK(g && a && b && ws && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
+  DF_ARG_CHECK(upwgrad_geom_ok(g, Ca) && (reinterpret_cast<uintptr_t>(a) & 15) == 0);
+  const long long s_tap = (long long)g->Cin * g->Cout;
+  const int rc = df_conv3d_upwgrad_launch(a, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, s_tap, ws, g->N, g->Di / 2,
+                                          g->Hi / 2, g->Wi / 2, g->Cout, (hipStream_t)stream);
+  if (rc) return rc;
+  DfConvGeom gb = *g;
+  gb.Cin = g->Cin - Ca;
+  return conv3d_split_wgrad_impl(&gb, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc + (long long)Ca * g->Cout, db,
+                                 stream, nullptr, 0, s_tap);
 }
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                         const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
@@ -2532,11 +2560,14 @@ extern "C" int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, 
 }
 static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
                                    const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db,
-                                   void* stream, const float* xa, int Ca) {
+                                   void* stream, const float* xa, int Ca, long long s_tap_full) {
   DF_ARG_CHECK(g && x && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
-  DF_ARG_CHECK(!split3d_off() && (split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
+  // s_tap_full: the rows of a wider gradient [27][Ctot][Cout] (dw_tcc points at this operand's first row): the skip
+  // channels of dfmir_conv3d_upwgrad, any Cin >= 1 (a partial 8-channel chunk reads zeros beyond Cin)
+  const bool rows = s_tap_full > 0 && split3d_wgrad_common_ok(g) && g->Cin >= 1 && g->Cin <= 128 && g->Cout >= 8 && g->Cout <= 32;
+  DF_ARG_CHECK(!split3d_off() && (rows || split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
   hipStream_t st = (hipStream_t)stream;
-  const bool swapped = !split3d_wgrad_geom_ok(g);
+  const bool swapped = !rows && !split3d_wgrad_geom_ok(g);
   W3sP k{};
   k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
   k.xa = xa; k.Ca = xa ? Ca : 0;
@@ -2547,7 +2578,7 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
     k.db = db; k.db_from_x = 1;
   } else {
     k.Cin = g->Cin; k.Cout = g->Cout;
-    k.s_tap = (long long)g->Cin * g->Cout; k.s_row = g->Cout; k.s_col = 1; k.flip = 0;
+    k.s_tap = rows ? s_tap_full : (long long)g->Cin * g->Cout; k.s_row = g->Cout; k.s_col = 1; k.flip = 0;
     k.x_n = x_amax_n; k.dy_n = dy_amax_n;
     k.db = db; k.db_from_x = 0;
   }

@@ -1,0 +1,395 @@
+// Weight gradient of the decoder ConvBlocks that consume cat(nearest_up2(a), b) (torchvoxelmorph/networks.py:64,97-100,
+// 1506-1521: nn.Upsample(scale 2, nearest) + torch.cat + Conv3d(3, padding 1)) -- the share of the UP-SAMPLED channels, in
+// PARITY CLASSES.  The forward kernel (conv3d_up_phase_k, conv3ds.hip) already uses that a 3x3x3 tap of output voxel
+// 2V + p over nearest_up2(a) reads a[V + floor((p + d - 1) / 2)]: per axis and parity p the three taps fall on TWO
+// low-resolution voxels (p = 0: V - 1 for d = 0, V for d = 1, 2;  p = 1: V for d = 0, 1, V + 1 for d = 2).  The adjoint of
+// that statement for the weights:
+//     G[p][i] = sum_V  a[V + (p - 1 + i)]  (x)  dY[2V + p]           p, i in {0, 1}^3   (64 matrices of Ca x Cout)
+//     dW[d]   = sum of the 8 G[p][i] with d in D(p, i) per axis,      D(0,0) = {0}, D(0,1) = {1, 2}, D(1,0) = {0, 1}, D(1,1) = {2}
+// -- 64 products per LOW-resolution voxel instead of 27 per full-resolution one: 8 / 27 of the multiplications of the
+// direct form (conv3d_wgrad_tr_k<., ., UPCAT>, which multiplies every duplicated value again), the same sums in another
+// order.  Zero padding carries over (a[-1] = a[D/2] = 0 are exactly the padded voxels of the up-sampled tensor).
+//
+// Kernel.  G does not depend on the position, so a workgroup keeps ALL of it in registers for its whole life: 512
+// threads = 8 waves = (py, px) x (iz), a wave holds the 2 (pz) x 4 (iy, ix) tiles of 32 x 32 (128 accumulator registers)
+// and the workgroup marches along z over 4 x 16 low-resolution columns: every plane of `a` (6 x 18 positions x 32
+// channels, ring of three) and every plane of dY (8 x 32 voxels x 32 channels, de-interleaved into its four (py, px)
+// sub-lattices as it is written to LDS, two buffers) is staged ONCE, as scaled fp16 pairs (a = (a0 + a1) / s, products
+// a0 b0 + a0 b1 + a1 b0 on v_mfma_f32_32x32x16_f16, fp32 accumulate: conv3ds.hip).  K = 16 low-resolution voxels of an
+// x-row; both operands are K-major reads of channel-minor images through ds_read_b64_tr_b16 (conv3d_wgrad_tr_k has the
+// lane algebra); an `a` row serves the two dY rows it meets (iy = 0 / 1): 56 operand reads per 48 MFMAs.  One barrier per
+// half-step (one dY plane = 48 MFMAs per wave); the next plane's global loads are spread over the MFMA groups.
+// A workgroup walks several (column, z-segment) items and ends with ONE set of atomics into the 64-tile workspace; a small
+// second kernel folds the workspace into the tap-major gradient.  The skip channels b (2 at the top level) keep the
+// direct kernel (conv3ds.hip::dfmir_conv3d_upwgrad).
+#include "conv3x3_common.h"
+#include <type_traits>
+
+typedef _Float16 f16x8_u __attribute__((ext_vector_type(8)));
+typedef short s16x4_u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_u* lds_tr_ptr_u;
+#ifndef UW_LDPOS
+#define UW_LDPOS 0   // staging loads of a half-step: 0 one per MFMA group 1..8, 1 all before the first group, 2 two per group 0..3
+#endif
+#ifndef UW_KO
+#define UW_KO 0      // knock-out builds (timing only): 1 no MFMAs, 2 no staging loads, 4 no conversion + LDS stores, 8 no operand reads,
+                     // 16 no epilogue atomics (one store per lane instead)
+#endif
+
+namespace {
+
+__device__ __forceinline__ int scale_exp_u(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  int e = (amax > 0.f) ? 14 - be : 0;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return e;
+}
+__device__ __forceinline__ float pow2f_u(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+// (x0, x1) * s -> leading fp16 pair h and residual pair r
+__device__ __forceinline__ void split_pair_u(float x0, float x1, float s, unsigned& h, unsigned& r) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ f32x16 mma_u(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_u, a), __builtin_bit_cast(f16x8_u, b), c, 0, 0, 0);
+}
+// 16 lanes x 8 bytes: lane 4 j + q supplies the address of (voxel j, channel quad q); lane 4 q + c receives the c-th
+// channel of quad q at voxels j = 0..3 (scripts/ubench/tr_read_probe.hip)
+__device__ __forceinline__ uint2 tr_read_u(unsigned byte_addr) {
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_u)(uintptr_t)byte_addr));
+}
+__device__ __forceinline__ u32x4 tr_pair_u(unsigned a0, unsigned a1) {
+  const uint2 u0 = tr_read_u(a0), u1 = tr_read_u(a1);
+  return u32x4{u0.x, u0.y, u1.x, u1.y};
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_u(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_u<B + 1, E>(f);
+  }
+}
+
+struct UwP {
+  int N, Dl, Hl, Wl, Cout;       // a: [N, 32, Dl, Hl, Wl];  dY: [N, Cout, 2 Dl, 2 Hl, 2 Wl]
+  int a_n, dy_n;                 // floats of the two range probes
+  int ncy, ncx, nseg, zlen;      // 4 x 16 columns per low-resolution plane, z segments of zlen planes
+  int nitems;                    // N * nseg * ncy * ncx
+};
+
+constexpr unsigned UW_ASPLIT = 108u * 64u;          // one split of an `a` plane slot: 6 x 18 positions x 32 channels x fp16
+constexpr unsigned UW_ASLOT = 2u * UW_ASPLIT;
+constexpr unsigned UW_YOFF = 3u * UW_ASLOT;         // 41 472
+constexpr unsigned UW_YSPLIT = 16384u;              // 4 classes x 64 voxels x 64 B
+constexpr unsigned UW_YBUF = 2u * UW_YSPLIT;
+constexpr unsigned UW_LDS = UW_YOFF + 2u * UW_YBUF; // 107 008 bytes
+
+__global__ __launch_bounds__(512, 1) void conv3d_upwgrad_k(const float* __restrict__ a, const float* __restrict__ a_amax,
+                                                           const float* __restrict__ dy, const float* __restrict__ dy_amax,
+                                                           float* __restrict__ gws, UwP k) {
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[UW_LDS];
+  __shared__ float red[17];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int px = wid & 1, py = (wid >> 1) & 1, szi = wid >> 2;
+
+  const int ea = scale_exp_u(reduce_absmax(a_amax, k.a_n, red));
+  __syncthreads();
+  const int ed = scale_exp_u(reduce_absmax(dy_amax, k.dy_n, red));
+  const float ascale = pow2f_u(ea), dscale = pow2f_u(ed), osc_a = pow2f_u(-ea), osc_d = pow2f_u(-ed);
+
+  const int D = 2 * k.Dl, H = 2 * k.Hl, W = 2 * k.Wl;
+  (void)D;
+  const unsigned HW = (unsigned)(H * W), HWl = (unsigned)(k.Hl * k.Wl);
+  const unsigned S4 = HW * (unsigned)D * 4u, Sl4 = HWl * (unsigned)k.Dl * 4u;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][s][r] = 0.f;
+
+  // ---- operand addresses (bytes in LDS).  Source role of this lane in its 16-lane group: voxel sj, channel quad cq.
+  const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const int sj = (lane & 15) >> 2, cq = 4 * ((lane >> 4) & 1) + (lane & 3);
+  unsigned bl[2], al[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int vx = 8 * hi + 4 * i + sj;
+    bl[i] = lbase + UW_YOFF + (unsigned)((py * 2 + px) * 4096 + (vx * 4 + ((cq >> 1) ^ ((vx >> 2) & 3))) * 16 + (cq & 1) * 8);
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix) {
+      const int hx = vx + px + ix;
+      al[i][ix] = lbase + (unsigned)(py * 1152 + (hx * 4 + ((cq >> 1) ^ ((hx >> 2) & 3))) * 16 + (cq & 1) * 8);
+    }
+  }
+
+  // ---- staging roles (every thread has both).  dY: thread = (channel group cg of 4, row r of 8, x pair xp of 16) of the
+  // plane's 8 x 32 voxels: eight 8-byte loads; element e of the pair belongs to class px = e at Vx = xp, the row to
+  // py = r & 1 at Vy = r >> 1.  a: thread mod 432 = (channel group, halo position of 6 x 18): eight 4-byte loads (threads
+  // 432 .. 511 repeat the first 80 jobs: same data to the same address, no branch in the MFMA stream).
+  const int yxp = tid & 15, yr = (tid >> 4) & 7, ycg = tid >> 7;
+  const int aj = tid < 432 ? tid : tid - 432, acg = aj / 108, apos = aj - 108 * acg, ahy = apos / 18, ahx = apos - 18 * ahy;
+  // store addresses (bytes): dY element e: + e * 4096 (+ buffer);  a: + slot
+  const unsigned yst0 = lbase + UW_YOFF + (unsigned)((yr & 1) * 8192 + (yr >> 1) * 1024 + yxp * 64 + ((ycg ^ ((yxp >> 2) & 3)) << 4));
+  const unsigned ast0 = lbase + (unsigned)(apos * 64 + ((acg ^ ((ahx >> 2) & 3)) << 4));
+
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  u32x2v rq0[8], rq1[8];                                    // dY planes in flight: even / odd half-steps
+  unsigned ra[8];                                           // the `a` plane in flight
+  unsigned ybase = OOB, abase = OOB;                        // element offsets of this thread's jobs inside a plane
+  __amdgpu_buffer_rsrc_t ysrc, asrc;
+  int z0 = 0, z1 = 0;
+
+#define UW_YLOAD(rq_, c_, off_)                                                                   \
+  if (!(UW_KO & 2)) rq_[c_] = __builtin_amdgcn_raw_buffer_load_b64(ysrc, (off_) == OOB ? OOB : (off_) + (unsigned)(ycg * 8 + (c_)) * S4, 0, 0);
+#define UW_ALOAD(ra_, c_, off_)                                                                   \
+  if (!(UW_KO & 2)) ra_[c_] = __builtin_amdgcn_raw_buffer_load_b32(asrc, (off_) == OOB ? OOB : (off_) + (unsigned)(acg * 8 + (c_)) * Sl4, 0, 0);
+  // convert 8 channels (expression v_(c)) and write the two 16-byte units at addr_ and addr_ + lo_
+#define UW_LDS_ST(addr_, v_) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(addr_) = (v_);
+#define UW_CONV_ST(V_, scale_, addr_, lo_)                                                        \
+  if (!(UW_KO & 4)) {                                                                             \
+    u32x4 h_, r_;                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                            \
+      unsigned hh_, rr_;                                                                          \
+      split_pair_u(__uint_as_float(V_(2 * q_)), __uint_as_float(V_(2 * q_ + 1)), scale_, hh_, rr_); \
+      h_[q_] = hh_; r_[q_] = rr_;                                                                 \
+    }                                                                                             \
+    UW_LDS_ST(addr_, h_) UW_LDS_ST((addr_) + (lo_), r_)                                           \
+  }
+#define UW_V_RQ0_E0(c_) rq0[c_][0]
+#define UW_V_RQ0_E1(c_) rq0[c_][1]
+#define UW_V_RQ1_E0(c_) rq1[c_][0]
+#define UW_V_RQ1_E1(c_) rq1[c_][1]
+#define UW_V_RA(c_) ra[c_]
+  // global offsets (bytes) of this thread's jobs in plane P_ of dY (full resolution) / a (low resolution)
+#define UW_YOFFS(P_, ok_) ((ybase != OOB && (ok_)) ? (ybase + (unsigned)(P_) * HW) * 4u : OOB)
+#define UW_AOFFS(P_, ok_) ((abase != OOB && (ok_)) ? (abase + (unsigned)(P_) * HWl) * 4u : OOB)
+
+  // One half-step h = (z, PZ_): dY plane 2 z + PZ_ (buffer PZ_) against the `a` planes z + PZ_ - 1 + iz (sa_: this wave's
+  // slot).  Meanwhile: the loads of dY plane h + 2 go out (register set PZ_), the set that holds plane h + 1 is
+  // converted into buffer PZ_ ^ 1; `a` plane z + 2 is loaded during PZ_ = 0 and converted into slot sn_ during PZ_ = 1 --
+  // every load has more than a half-step to arrive and the memory pipe always has one plane in flight.
+#define UW_HALF(PZ_, sa_, sn_, yoff_, aoff_)                                                      \
+  {                                                                                               \
+    const unsigned ab_ = (sa_);                                                                   \
+    const unsigned bb0_ = bl[0] + (PZ_) * UW_YBUF, bb1_ = bl[1] + (PZ_) * UW_YBUF;                \
+    const unsigned yst_ = yst0 + ((PZ_) ^ 1) * UW_YBUF;                                           \
+    u32x4 B0[2], B1[2], A0, A1;                                                                   \
+    static_for_u<0, 10>([&](auto jc_) __attribute__((always_inline)) {                            \
+      constexpr int j_ = decltype(jc_)::value, R_ = j_ >> 1, ix_ = j_ & 1;                        \
+      if constexpr (ix_ == 0 && R_ < 4) {                                                         \
+        if (!(UW_KO & 8) || R_ == 0) {                                                            \
+          B0[R_ & 1] = tr_pair_u(bb0_ + R_ * 1024, bb1_ + R_ * 1024);                             \
+          B1[R_ & 1] = tr_pair_u(bb0_ + R_ * 1024 + UW_YSPLIT, bb1_ + R_ * 1024 + UW_YSPLIT);     \
+        }                                                                                         \
+      }                                                                                           \
+      if (!(UW_KO & 8) || j_ == 0) {                                                              \
+        A0 = tr_pair_u(al[0][ix_] + ab_ + R_ * 1152, al[1][ix_] + ab_ + R_ * 1152);               \
+        A1 = tr_pair_u(al[0][ix_] + ab_ + R_ * 1152 + UW_ASPLIT, al[1][ix_] + ab_ + R_ * 1152 + UW_ASPLIT); \
+      }                                                                                           \
+      if constexpr (j_ < 4) {                                                                     \
+        if constexpr ((PZ_) == 0) { UW_YLOAD(rq0, 2 * j_, yoff_) UW_YLOAD(rq0, 2 * j_ + 1, yoff_) } \
+        else { UW_YLOAD(rq1, 2 * j_, yoff_) UW_YLOAD(rq1, 2 * j_ + 1, yoff_) }                    \
+      }                                                                                           \
+      if constexpr ((PZ_) == 0 && (j_ == 4 || j_ == 5)) {                                         \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) { UW_ALOAD(ra, 4 * (j_ - 4) + c_, aoff_) } \
+      }                                                                                           \
+      if constexpr (j_ == 6) {                                                                    \
+        if constexpr ((PZ_) == 0) { UW_CONV_ST(UW_V_RQ1_E0, dscale, yst_, UW_YSPLIT) }            \
+        else { UW_CONV_ST(UW_V_RQ0_E0, dscale, yst_, UW_YSPLIT) }                                 \
+      }                                                                                           \
+      if constexpr (j_ == 7) {                                                                    \
+        if constexpr ((PZ_) == 0) { UW_CONV_ST(UW_V_RQ1_E1, dscale, yst_ + 4096u, UW_YSPLIT) }    \
+        else { UW_CONV_ST(UW_V_RQ0_E1, dscale, yst_ + 4096u, UW_YSPLIT) }                         \
+      }                                                                                           \
+      if constexpr ((PZ_) == 1 && j_ == 8) { UW_CONV_ST(UW_V_RA, ascale, ast0 + (sn_), UW_ASPLIT) } \
+      if (!(UW_KO & 1)) {                                                                         \
+        if constexpr (R_ < 4) {       /* iy = 0: dY row R */                                      \
+          acc[PZ_][ix_] = mma_u(A1, B0[R_ & 1], acc[PZ_][ix_]);                                   \
+          acc[PZ_][ix_] = mma_u(A0, B1[R_ & 1], acc[PZ_][ix_]);                                   \
+          acc[PZ_][ix_] = mma_u(A0, B0[R_ & 1], acc[PZ_][ix_]);                                   \
+        }                                                                                         \
+        if constexpr (R_ >= 1) {      /* iy = 1: dY row R - 1 */                                  \
+          acc[PZ_][2 + ix_] = mma_u(A1, B0[(R_ - 1) & 1], acc[PZ_][2 + ix_]);                     \
+          acc[PZ_][2 + ix_] = mma_u(A0, B1[(R_ - 1) & 1], acc[PZ_][2 + ix_]);                     \
+          acc[PZ_][2 + ix_] = mma_u(A0, B0[(R_ - 1) & 1], acc[PZ_][2 + ix_]);                     \
+        }                                                                                         \
+      } else {                                                                                    \
+        acc[PZ_][ix_][0] += __uint_as_float(A0[0] ^ A1[1] ^ B0[R_ & 1][2] ^ B1[R_ & 1][3]);       \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);   /* the compiler otherwise sinks the loads to the conversion behind the last MFMA */ \
+    });                                                                                           \
+  }
+
+  for (int item = blockIdx.x; item < k.nitems; item += gridDim.x) {
+    // ---- item = (n, segment, column): segment-major so that the workgroups of one wave of items share planes in L2
+    int q = item;
+    const int cx = q % k.ncx; q /= k.ncx;
+    const int cy = q % k.ncy; q /= k.ncy;
+    const int seg = q % k.nseg;
+    const int n = q / k.nseg;
+    z0 = seg * k.zlen;
+    z1 = z0 + k.zlen < k.Dl ? z0 + k.zlen : k.Dl;
+    const int y0 = cy * 4, x0 = cx * 16;
+    ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (long long)n * k.Cout * (S4 >> 2)), 0,
+                                             (unsigned)k.Cout * S4, 0x00020000);
+    asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a + (long long)n * 32 * (Sl4 >> 2)), 0, 32u * Sl4, 0x00020000);
+    {
+      const int gy = 2 * y0 + yr, gx = 2 * x0 + 2 * yxp;
+      ybase = (gy < H && gx < W) ? (unsigned)(gy * W + gx) : OOB;
+      const int ay = y0 - 1 + ahy, ax = x0 - 1 + ahx;
+      abase = ((unsigned)ay < (unsigned)k.Hl && (unsigned)ax < (unsigned)k.Wl) ? (unsigned)(ay * k.Wl + ax) : OOB;
+    }
+    // ---- prologue: a planes z0 - 1, z0, z0 + 1 into slots 0, 1, 2; dY plane 2 z0 into buffer 0; plane 2 z0 + 1 stays in
+    // flight in set 1 (converted during the first half-step)
+    unsigned so0 = 0, so1 = UW_ASLOT, so2 = 2 * UW_ASLOT;
+    {
+      unsigned pa[3][8];
+      const unsigned y0off = UW_YOFFS(2 * z0, true), y1off = UW_YOFFS(2 * z0 + 1, true);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { UW_YLOAD(rq0, c, y0off) }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned ao = UW_AOFFS(z0 - 1 + p, z0 - 1 + p >= 0 && z0 - 1 + p < k.Dl);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { UW_ALOAD(pa[p], c, ao) }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { UW_YLOAD(rq1, c, y1off) }
+      UW_CONV_ST(UW_V_RQ0_E0, dscale, yst0, UW_YSPLIT)
+      UW_CONV_ST(UW_V_RQ0_E1, dscale, yst0 + 4096u, UW_YSPLIT)
+#define UW_V_PA0(c_) pa[0][c_]
+#define UW_V_PA1(c_) pa[1][c_]
+#define UW_V_PA2(c_) pa[2][c_]
+      UW_CONV_ST(UW_V_PA0, ascale, ast0 + so0, UW_ASPLIT)
+      UW_CONV_ST(UW_V_PA1, ascale, ast0 + so1, UW_ASPLIT)
+      UW_CONV_ST(UW_V_PA2, ascale, ast0 + so2, UW_ASPLIT)
+#undef UW_V_PA0
+#undef UW_V_PA1
+#undef UW_V_PA2
+    }
+    __syncthreads();
+
+    for (int z = z0; z < z1; ++z) {
+      {   // pz = 0: a planes z - 1 (iz = 0), z (iz = 1)
+        const unsigned yoff = UW_YOFFS(2 * z + 2, z + 1 < z1), aoff = UW_AOFFS(z + 2, z + 2 < k.Dl);
+        UW_HALF(0, szi ? so1 : so0, 0u, yoff, aoff)
+        __syncthreads();
+      }
+      {   // pz = 1: a planes z (iz = 0), z + 1 (iz = 1); plane z + 2 replaces plane z - 1
+        const unsigned yoff = UW_YOFFS(2 * z + 3, z + 1 < z1);
+        UW_HALF(1, szi ? so2 : so1, so0, yoff, OOB)
+        __syncthreads();
+      }
+      const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
+    }
+  }
+#undef UW_YLOAD
+#undef UW_ALOAD
+#undef UW_LDS_ST
+#undef UW_CONV_ST
+#undef UW_YOFFS
+#undef UW_AOFFS
+#undef UW_HALF
+
+  // ---- epilogue: acc[pz][iy * 2 + ix][r] <-> row ci = (r >> 2) * 8 + hi * 4 + (r & 3), column co = l31 of tile
+  // (pz, py, px, iz, iy, ix)
+  if (l31 < k.Cout && !(UW_KO & 16)) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int tile = ((((p * 2 + py) * 2 + px) * 2 + szi) * 2 + (s >> 1)) * 2 + (s & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (r >> 2) * 8 + hi * 4 + (r & 3);
+          atomicAdd(&gws[tile * 1024 + ci * 32 + l31], acc[p][s][r] * osc_a * osc_d);
+        }
+      }
+  }
+  if (UW_KO & 16) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[p][s][r];
+    gws[tid] = t * osc_a * osc_d;
+  }
+}
+
+// dW[tap][ci][co] += the 8 tiles of the workspace that contain tap = (dz, dy, dx): per axis d = 0: (p, i) = (0,0), (1,0);
+// d = 1: (0,1), (1,0);  d = 2: (0,1), (1,1)
+__global__ __launch_bounds__(256) void conv3d_upwgrad_fold_k(const float* __restrict__ gws, float* __restrict__ dwt, int Cout,
+                                                              long long s_tap, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int co = idx % Cout, ci = (idx / Cout) & 31, tap = idx / (Cout * 32);
+  const int d[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+  int pi[3][2];                                             // the two (p * 2 + i) codes of each axis
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    pi[ax][0] = d[ax] == 0 ? 0 : 1;                         // (0,0) | (0,1)
+    pi[ax][1] = d[ax] == 2 ? 3 : 2;                         // (1,1) | (1,0)
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int cz = pi[0][m >> 2], cy = pi[1][(m >> 1) & 1], cx = pi[2][m & 1];
+    const int tile = (((((cz >> 1) * 2 + (cy >> 1)) * 2 + (cx >> 1)) * 2 + (cz & 1)) * 2 + (cy & 1)) * 2 + (cx & 1);
+    s += gws[tile * 1024 + ci * 32 + co];
+  }
+  dwt[tap * s_tap + (long long)ci * Cout + co] += s;
+}
+
+}  // namespace
+
+// Host side of the up-sampled share (conv3ds.hip::dfmir_conv3d_upwgrad calls this, then the direct kernel for b).
+// dwt: tap-major gradient [27][Ctot][Cout] (s_tap = Ctot * Cout), rows 0 .. 31 are written; ws: 64 * 1024 floats.
+int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* dy, const float* dy_amax, int dy_n,
+                             float* dwt, long long s_tap, float* ws, int N, int Dl, int Hl, int Wl, int Cout,
+                             hipStream_t st) {
+  UwP k{};
+  k.N = N; k.Dl = Dl; k.Hl = Hl; k.Wl = Wl; k.Cout = Cout;
+  k.a_n = a_n; k.dy_n = dy_n;
+  k.ncy = (Hl + 3) / 4; k.ncx = (Wl + 15) / 16;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    else ncu = 256;
+  }
+  // z segments: a workgroup (one per CU) walks ceil(items / CUs) items of zlen planes, each with a prologue worth ~2 planes
+  const long long cols = (long long)N * k.ncy * k.ncx;
+  static DfOptInt nseg_o{"DFMIR_UPWGRAD_NSEG", 0};
+  int best = 1;
+  long long best_cost = -1;
+  for (int s = 1; s <= Dl && s <= 64; ++s) {
+    const int zl = (Dl + s - 1) / s;
+    const int ns = (Dl + zl - 1) / zl;
+    const long long rounds = (cols * ns + ncu - 1) / ncu;
+    const long long cost = rounds * (zl + 2);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  const long long forced = nseg_o.get();
+  if (forced > 0 && forced <= Dl) best = (int)forced;
+  k.zlen = (Dl + best - 1) / best;
+  k.nseg = (Dl + k.zlen - 1) / k.zlen;
+  k.nitems = (int)(cols * k.nseg);
+  const unsigned grid = (unsigned)(k.nitems < ncu ? k.nitems : ncu);
+  if (hipMemsetAsync(ws, 0, 64 * 1024 * sizeof(float), st) != hipSuccess) return 2;
+  conv3d_upwgrad_k<<<grid, 512, 0, st>>>(a, a_amax, dy, dy_amax, ws, k);
+  const int total = 27 * 32 * Cout;
+  conv3d_upwgrad_fold_k<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, dwt, Cout, s_tap, total);
+  DF_LAUNCH_CHECK();
+  return 0;
+}

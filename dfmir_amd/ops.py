@@ -335,6 +335,21 @@ def _tag_ok(t, tag):
     return tag is not None and tag[-2] == t._version and tag[-1] == t.data_ptr()
 
 
+_UPWGRAD_MIN_VOX = int(os.environ.get("DFMIR_UPWGRAD_MIN_VOX", "400000"))   # low-resolution voxels per image: below, the
+# direct kernel over both parts is faster (profiles/r05_bench_upwgrad.txt: the skip share is 16-32 channels there)
+_UPWGRAD_WS = {}
+
+
+def _upwgrad_ws(device):
+    """64 accumulator tiles of dfmir_conv3d_upwgrad: one buffer per (device, stream) -- the call zeroes it, fills it and
+    folds it on the caller's stream, so launches of one stream may share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _UPWGRAD_WS.get(key)
+    if ws is None:
+        ws = _UPWGRAD_WS[key] = torch.zeros(int(lib().dfmir_conv3d_upwgrad_ws_floats()), device=device)
+    return ws
+
+
 def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None,
                    parts=None):
     """dW in the tap-major packing; `out` (same packing) is accumulated into when given.  parts = (a, b): the operand is
@@ -363,6 +378,9 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             pm_ = dy_pmax if (dy_pmax is not None and dy_pmax.numel() == N * Cout and not split3d) else None
             _audit_probe(dy5, dy_amax, "wgrad dY %s" % (tuple(dy5.shape),), plane_max=pm_)
 
+    # the up-sampled channels in parity classes (csrc/conv3duw.hip) where the volume fills the chip
+    upw = (parts is not None and parts[0].numel() // parts[0].shape[1] >= _UPWGRAD_MIN_VOX
+           and bool(lib().dfmir_conv3d_upwgrad_ok(ctypes.byref(g), parts[0].shape[1])))
     s2c2 = (parts is None and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and not _NO_TINY3D
             and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
 
@@ -373,6 +391,11 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             check(lib().dfmir_conv3d_s2c2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
             return
         if parts is not None:
+            if upw:
+                check(lib().dfmir_conv3d_upwgrad(ctypes.byref(g), _p(parts[0]), _p(parts[1]), parts[0].shape[1],
+                                                 _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax), dy_amax.numel(),
+                                                 _p(dw), _p(db), _p(_upwgrad_ws(dy5.device)), _st()))
+                return
             check(lib().dfmir_conv3d_split_wgrad_upcat(ctypes.byref(g), _p(parts[0]), _p(parts[1]), parts[0].shape[1],
                                                        _p(x_amax), x_amax.numel(), _p(dy5), _p(dy_amax), dy_amax.numel(),
                                                        _p(dw), _p(db), _st()))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 9
+#define DFMIR_ABI_VERSION 10
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -206,6 +206,17 @@ int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x
 int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax,
                                    int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                    float* db, void* stream);
+/* The same gradient, the up-sampled channels in PARITY CLASSES (csrc/conv3duw.hip): a 3x3x3 tap of output voxel 2V + p over
+ * nearest_up2(a) reads a[V + floor((p + d - 1) / 2)], so G[p][i] = sum_V a[V + p - 1 + i] (x) dy[2V + p] (64 matrices per
+ * layer, K = the LOW-resolution voxels) holds the whole gradient: 8 / 27 of the direct form's products and one pass over dy
+ * with no halo.  The skip channels b run on the direct kernel (which also sums db).  Ca == 32, Cout % 8 == 0, Cout <= 32,
+ * D, H even, W % 8 == 0; ws = dfmir_conv3d_upwgrad_ws_floats() floats, owned by the call until the stream has passed it.
+ * A/B switch: DFMIR_CONV3D_NO_UPWGRAD=1 (dfmir_conv3d_upwgrad_ok then answers 0); DFMIR_UPWGRAD_NSEG forces the z split. */
+int dfmir_conv3d_upwgrad_ok(const DfConvGeom* g, int Ca);
+long long dfmir_conv3d_upwgrad_ws_floats(void);
+int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax, int x_amax_n,
+                         const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db, float* ws,
+                         void* stream);
 /* The same, also accumulating the bias gradient db[Cout] += sum dy from the units it stages anyway (db may be NULL).
  * Layers with fewer than 8 output channels (the 16 -> 3 flow conv, networks.py:1077) are taken with the operand roles
  * swapped: rows = (tap, co) from shifted dy, columns = ci. */

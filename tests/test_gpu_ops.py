@@ -398,8 +398,10 @@ def test_conv3d_march_writes_every_voxel_and_is_reproducible(ops, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(16, 2, 32, 1, 6, 10, 12, 1), (32, 16, 32, 1, 5, 9, 20, 1), (8, 3, 16, 2, 4, 8, 8, 0),
-                                 (64, 64, 64, 1, 3, 5, 8, 1), (32, 2, 32, 1, 9, 17, 36, 1)],
-                         ids=["16+2->32", "32+16->32", "8+3->16-pair-batch2", "64+64->64", "32+2->32-ragged"])
+                                 (64, 64, 64, 1, 3, 5, 8, 1), (32, 2, 32, 1, 9, 17, 36, 1), (32, 32, 16, 2, 4, 6, 20, 0),
+                                 (32, 8, 24, 1, 7, 5, 12, 1)],
+                         ids=["16+2->32", "32+16->32", "8+3->16-pair-batch2", "64+64->64", "32+2->32-ragged",
+                              "32+32->16-batch2", "32+8->24"])
 def test_upcat_conv3d_parity_class_form(ops, cfg):
     """ConvBlock over cat([nearest_up2(a), b], 1) (torchvoxelmorph/networks.py:64,97-100,1506-1521) in the form that
     never builds the concatenation -- up-sampled channels as eight 8-tap parity-class convolutions of `a` with summed
