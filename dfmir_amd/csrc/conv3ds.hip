@@ -2524,25 +2524,29 @@ extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* 
 // dY at 1.0 x) and the skip channels b on the direct kernel, which also carries the bias gradient.  Ca == 32 (every
 // decoder level of the VoxelMorph U-Net), Cout a multiple of 8 up to 32.  ws: dfmir_conv3d_upwgrad_ws_floats() floats,
 // private to the stream while the call is in flight.
-int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* dy, const float* dy_amax, int dy_n,
-                             float* dwt, long long s_tap, float* ws, int N, int Dl, int Hl, int Wl, int Cout,
-                             hipStream_t st);
+int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* b, const float* dy, const float* dy_amax,
+                             int dy_n, float* dwt, long long s_tap, float* db, float* ws, int N, int Dl, int Hl, int Wl,
+                             int Cout, hipStream_t st);
 static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
   static DfOptFlag off_o{"DFMIR_CONV3D_NO_UPWGRAD"};
   return !off_o.get() && !split3d_off() && split3d_wgrad_common_ok(g) && Ca == 32 && g->Cin > Ca && g->Cin - Ca <= 128 &&
          g->Cout >= 8 && g->Cout <= 32 && (g->Cout & 7) == 0 && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7);
 }
 extern "C" int dfmir_conv3d_upwgrad_ok(const DfConvGeom* g, int Ca) { return (g && upwgrad_geom_ok(g, Ca)) ? 1 : 0; }
-extern "C" long long dfmir_conv3d_upwgrad_ws_floats(void) { return 64LL * 1024; }
+extern "C" long long dfmir_conv3d_upwgrad_ws_floats(void) { return 72LL * 1024; }
 extern "C" int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax,
                                     int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                     float* db, float* ws, void* stream) {
   DF_ARG_CHECK(g && a && b && ws && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
   DF_ARG_CHECK(upwgrad_geom_ok(g, Ca) && (reinterpret_cast<uintptr_t>(a) & 15) == 0);
   const long long s_tap = (long long)g->Cin * g->Cout;
-  const int rc = df_conv3d_upwgrad_launch(a, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, s_tap, ws, g->N, g->Di / 2,
-                                          g->Hi / 2, g->Wi / 2, g->Cout, (hipStream_t)stream);
-  if (rc) return rc;
+  // two skip channels (the network's input images at the top level): fused into the same launch, with the bias gradient
+  static DfOptFlag nofuse_o{"DFMIR_UPWGRAD_NO_FUSEB"};
+  const bool fuse = g->Cin - Ca == 2 && !nofuse_o.get();
+  const int rc = df_conv3d_upwgrad_launch(a, x_amax, x_amax_n, fuse ? b : nullptr, dy, dy_amax, dy_amax_n, dw_tcc, s_tap,
+                                          fuse ? db : nullptr, ws, g->N, g->Di / 2, g->Hi / 2, g->Wi / 2, g->Cout,
+                                          (hipStream_t)stream);
+  if (rc || fuse) return rc;
   DfConvGeom gb = *g;
   gb.Cin = g->Cin - Ca;
   return conv3d_split_wgrad_impl(&gb, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc + (long long)Ca * g->Cout, db,

@@ -33,7 +33,7 @@ typedef __attribute__((address_space(3))) s16x4_u* lds_tr_ptr_u;
 #endif
 #ifndef UW_KO
 #define UW_KO 0      // knock-out builds (timing only): 1 no MFMAs, 2 no staging loads, 4 no conversion + LDS stores, 8 no operand reads,
-                     // 16 no epilogue atomics (one store per lane instead)
+                     // 16 no epilogue atomics (one store per lane instead), 32 dY loads from a cache-resident 4 KB (4-wave kernel)
 #endif
 
 namespace {
@@ -54,6 +54,13 @@ __device__ __forceinline__ void split_pair_u(float x0, float x1, float s, unsign
 }
 __device__ __forceinline__ f32x16 mma_u(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_u, a), __builtin_bit_cast(f16x8_u, b), c, 0, 0, 0);
+}
+// the same with the accumulator in VGPRs.  The 16 `a` tiles of conv3d_upwgrad4_k fill the 256 AGPRs; the compiler only
+// emits the AGPR form of an MFMA and would swap whole tiles between the two files around every b product (152 v_accvgpr
+// moves per half-step).  Hazards the compiler cannot see behind the asm: the tile is only ever read by the next product of
+// its own chain (same vDst as SrcC: back-to-back issue is legal) until the epilogue, which waits first.
+__device__ __forceinline__ void mma_v(u32x4 a, u32x4 b, f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 // 16 lanes x 8 bytes: lane 4 j + q supplies the address of (voxel j, channel quad q); lane 4 q + c receives the c-th
 // channel of quad q at voxels j = 0..3 (scripts/ubench/tr_read_probe.hip)
@@ -327,6 +334,422 @@ __global__ __launch_bounds__(512, 1) void conv3d_upwgrad_k(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product with ONE wave per SIMD and the two skip channels of the top level FUSED.  256 threads = 4 waves =
+// the (py, px) classes, 512 registers per lane: a wave holds its class's 2 (pz) x 2 (iz) x 4 (iy, ix) tiles (256
+// accumulator registers) and, FUSEB, two more tiles for the direct weight gradient of b: rows = (tap, cb) -- the dY operand
+// is already in registers, so the skip channels cost 6 MFMAs per 24 and no second pass over dY (the direct kernel spent 0.40
+// ms of its 1.43 on them).  b [N, 2, D, H, W] is staged as (channel 0, channel 1) fp16 pairs, 4 bytes per voxel, one
+// full-resolution plane (10 x 34 positions) per half-step in a ring of four, TWICE: x-major (X image) and y-major (Y image).
+// An 8-byte transposing read then yields 4 operand rows = 2 neighbouring voxels x 2 channels; with the class's parity the
+// neighbours along x are taps (px, px + 1) and the remaining x tap dxs = 2 - 2 px is taken as the y pair (py, py + 1) from
+// the Y image plus a single (dys = 2 - 2 py) whose partner rows are discarded: 15 quads = 60 rows of 64 for the 54
+// (tap, channel) rows, every read 8-byte aligned (the K index V moves the full-resolution position by two voxels, so the
+// parity of an address is a property of the class).  conv3d_upwgrad_foldb_k knows the row tables.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned UW_BIMG = 1360u;                 // one image of a b plane: 10 x 34 positions x (2 channels x fp16)
+constexpr unsigned UW_BSPLIT = 2u * UW_BIMG;        // [X image][Y image]
+constexpr unsigned UW_BSLOT = 2u * UW_BSPLIT;       // [leading][residual]
+constexpr unsigned UW_BOFF = UW_LDS;                // behind the a ring and the dY buffers
+constexpr unsigned UW_LDS4 = UW_BOFF + 4u * UW_BSLOT;   // 128 768 bytes
+
+template <bool FUSEB>
+__global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restrict__ a, const float* __restrict__ a_amax,
+                                                            const float* __restrict__ b, const float* __restrict__ dy,
+                                                            const float* __restrict__ dy_amax, float* __restrict__ gws, UwP k) {
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FUSEB ? UW_LDS4 + UW_BSPLIT + 16 : UW_LDS];
+  __shared__ float red[17];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int px = wid & 1, py = wid >> 1;
+
+  const int ea = scale_exp_u(reduce_absmax(a_amax, k.a_n, red));
+  __syncthreads();
+  const int ed = scale_exp_u(reduce_absmax(dy_amax, k.dy_n, red));
+  const float ascale = pow2f_u(ea), dscale = pow2f_u(ed), osc_a = pow2f_u(-ea), osc_d = pow2f_u(-ed);
+
+  const int D = 2 * k.Dl, H = 2 * k.Hl, W = 2 * k.Wl;
+  const unsigned HW = (unsigned)(H * W), HWl = (unsigned)(k.Hl * k.Wl);
+  const unsigned S4 = HW * (unsigned)D * 4u, Sl4 = HWl * (unsigned)k.Dl * 4u;
+
+  f32x16 acc[2][2][4], accb[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[p][z][s][r] = 0.f;
+    accb[0][r] = 0.f; accb[1][r] = 0.f;
+  }
+
+  // ---- operand addresses (bytes in LDS): conv3d_upwgrad_k
+  const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const int sj = (lane & 15) >> 2, cq = 4 * ((lane >> 4) & 1) + (lane & 3);
+  unsigned bl[2], al[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int vx = 8 * hi + 4 * i + sj;
+    bl[i] = lbase + UW_YOFF + (unsigned)((py * 2 + px) * 4096 + (vx * 4 + ((cq >> 1) ^ ((vx >> 2) & 3))) * 16 + (cq & 1) * 8);
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix) {
+      const int hx = vx + px + ix;
+      al[i][ix] = lbase + (unsigned)(py * 1152 + (hx * 4 + ((cq >> 1) ^ ((hx >> 2) & 3))) * 16 + (cq & 1) * 8);
+    }
+  }
+  // b operand: tile T = rows 32 T .., this lane supplies quad Q = 8 T + 4 (lane group) + (lane & 3) at voxel sj
+  unsigned qb[2][2], qstep[2];
+  int qdz[2];
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const int Q = 8 * T + 4 * ((lane >> 4) & 1) + (lane & 3);   // quad 15: the constant (1, 0, 0, 0) -> row 28 of tile 1 = sum of dY
+    const int dxs = 2 - 2 * px, dys = 2 - 2 * py;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int vx = 8 * hi + 4 * i + sj;
+      int o;
+      if (Q < 9) o = ((py + Q % 3) * 34 + 2 * vx + 2 * px) * 4;                               // x pair (px, px + 1) of (dz, dy)
+      else if (Q < 12) o = (int)UW_BIMG + ((2 * vx + px + dxs) * 10 + 2 * py) * 4;           // y pair (py, py + 1) at dx = dxs
+      else if (Q < 15) o = ((py + dys) * 34 + 2 * vx + (px ? 0 : 2)) * 4;                    // single (dys, dxs)
+      else o = (int)(UW_LDS4 - UW_BOFF);
+      qb[T][i] = lbase + UW_BOFF + (unsigned)o;
+    }
+    qstep[T] = Q == 15 ? 0u : ((Q >= 9 && Q < 12) ? 8u : 272u);   // K-block Vy -> Vy + 1: two full-resolution rows
+    qdz[T] = Q < 9 ? Q / 3 : (Q < 12 ? Q - 9 : (Q < 15 ? Q - 12 : 3));
+  }
+  if (FUSEB && tid < 4) {                                   // the ones quad (leading image) and its zero residual
+    *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(lbase + UW_LDS4 + (unsigned)(tid & 1) * 4u + (unsigned)(tid >> 1) * UW_BSPLIT) =
+        tid == 0 ? 0x3c00u : 0u;
+  }
+
+  // ---- staging roles.  dY: thread = (channel group = wave, row r of 8, aligned quad q of 8): eight 16-byte loads;
+  // element e of the quad belongs to class px = e & 1 at Vx = 2 q + (e >> 1), the row to py = r & 1 at Vy = r >> 1.
+  // a: 432 jobs (channel group, halo position of 6 x 18), eight 4-byte loads each: jobs tid and tid + 256 (threads 176 ..
+  // 255 repeat jobs 0 .. 79: same data to the same address).  b: positions tid and tid + 256 of the plane's 10 x 34.
+  const int yq = tid & 7, yr = (tid >> 3) & 7, ycg = wid;
+  const int ja1 = tid < 176 ? tid + 256 : tid - 176;
+  const int acg0 = tid / 108, apos0 = tid - 108 * acg0, acg1 = ja1 / 108, apos1 = ja1 - 108 * acg1;
+  const int ahy0 = apos0 / 18, ahx0 = apos0 - 18 * ahy0, ahy1 = apos1 / 18, ahx1 = apos1 - 18 * ahy1;
+  const unsigned yst0 = lbase + UW_YOFF + (unsigned)((yr & 1) * 8192 + (yr >> 1) * 1024 + yq * 128 + ((ycg ^ ((yq >> 1) & 3)) << 4));
+  const unsigned ast0 = lbase + (unsigned)(apos0 * 64 + ((acg0 ^ ((ahx0 >> 2) & 3)) << 4));
+  const unsigned ast1 = lbase + (unsigned)(apos1 * 64 + ((acg1 ^ ((ahx1 >> 2) & 3)) << 4));
+  const int bp1 = tid + 256;
+  const int br0 = tid / 34, bc0 = tid - 34 * br0, br1 = bp1 / 34, bc1 = bp1 - 34 * br1;
+  const unsigned bst0 = lbase + UW_BOFF + (unsigned)((br0 * 34 + bc0) * 4), bsy0 = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc0 * 10 + br0) * 4);
+  const unsigned bst1 = lbase + UW_BOFF + (unsigned)((br1 * 34 + bc1) * 4), bsy1 = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc1 * 10 + br1) * 4);
+
+  u32x4 rq[8];                                              // the dY plane in flight
+  unsigned ra0[8], ra1[8];                                  // the `a` plane in flight
+  unsigned rb[4];
+
+  unsigned ybase = OOB, abase0 = OOB, abase1 = OOB, bbase0 = OOB, bbase1 = OOB;   // element offsets of this thread's jobs inside a plane
+  __amdgpu_buffer_rsrc_t ysrc, asrc, bsrc;
+  int z0 = 0, z1 = 0;
+
+#define UW_YLOAD(c_, off_)                                                                        \
+  if (!(UW_KO & 2)) rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, (off_) == OOB ? OOB : ((UW_KO & 32) ? (unsigned)(tid * 16) : (off_)) + (unsigned)(ycg * 8 + (c_)) * S4, 0, 0);
+#define UW_ALOAD(c_, off0_, off1_)                                                                \
+  if (!(UW_KO & 2)) {                                                                             \
+    ra0[c_] = __builtin_amdgcn_raw_buffer_load_b32(asrc, (off0_) == OOB ? OOB : (off0_) + (unsigned)(acg0 * 8 + (c_)) * Sl4, 0, 0); \
+    ra1[c_] = __builtin_amdgcn_raw_buffer_load_b32(asrc, (off1_) == OOB ? OOB : (off1_) + (unsigned)(acg1 * 8 + (c_)) * Sl4, 0, 0); \
+  }
+#define UW_BLOAD(off0_, off1_)                                                                    \
+  if (FUSEB && !(UW_KO & 2)) {                                                                    \
+    rb[0] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off0_), 0, 0);                            \
+    rb[1] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off0_) == OOB ? OOB : (off0_) + S4, 0, 0); \
+    rb[2] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off1_), 0, 0);                            \
+    rb[3] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off1_) == OOB ? OOB : (off1_) + S4, 0, 0); \
+  }
+#define UW_LDS_ST(addr_, v_) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(addr_) = (v_);
+#define UW_LDS_ST4(addr_, v_) *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(addr_) = (v_);
+  // convert 8 channels (V_(c)) and write the two 16-byte units
+#define UW_CONV_ST(V_, scale_, addr_, lo_)                                                        \
+  if (!(UW_KO & 4)) {                                                                             \
+    u32x4 h_, r_;                                                                                 \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                            \
+      unsigned hh_, rr_;                                                                          \
+      split_pair_u(__uint_as_float(V_(2 * q_)), __uint_as_float(V_(2 * q_ + 1)), scale_, hh_, rr_); \
+      h_[q_] = hh_; r_[q_] = rr_;                                                                 \
+    }                                                                                             \
+    UW_LDS_ST(addr_, h_) UW_LDS_ST((addr_) + (lo_), r_)                                           \
+  }
+#define UW_V_E0(c_) rq[c_][0]
+#define UW_V_E1(c_) rq[c_][1]
+#define UW_V_E2(c_) rq[c_][2]
+#define UW_V_E3(c_) rq[c_][3]
+#define UW_V_A0(c_) ra0[c_]
+#define UW_V_A1(c_) ra1[c_]
+#define UW_YADDR(e_, buf_) (yst0 + (unsigned)(buf_) * UW_YBUF + (unsigned)(((e_) & 1) * 4096 + ((e_) >> 1) * 64))
+#define UW_YCONV(e_, buf_)                                                                        \
+  {                                                                                               \
+    if constexpr ((e_) == 0) { UW_CONV_ST(UW_V_E0, dscale, UW_YADDR(0, buf_), UW_YSPLIT) }        \
+    else if constexpr ((e_) == 1) { UW_CONV_ST(UW_V_E1, dscale, UW_YADDR(1, buf_), UW_YSPLIT) }   \
+    else if constexpr ((e_) == 2) { UW_CONV_ST(UW_V_E2, dscale, UW_YADDR(2, buf_), UW_YSPLIT) }   \
+    else { UW_CONV_ST(UW_V_E3, dscale, UW_YADDR(3, buf_), UW_YSPLIT) }                            \
+  }
+#define UW_ACONV(j_, slot_)                                                                       \
+  {                                                                                               \
+    if constexpr ((j_) == 0) { UW_CONV_ST(UW_V_A0, ascale, ast0 + (slot_), UW_ASPLIT) }           \
+    else { UW_CONV_ST(UW_V_A1, ascale, ast1 + (slot_), UW_ASPLIT) }                               \
+  }
+#define UW_BCONV(slot_)                                                                           \
+  if (FUSEB && !(UW_KO & 4)) {                                                                    \
+    unsigned h0_, r0_, h1_, r1_;                                                                  \
+    split_pair_u(__uint_as_float(rb[0]), __uint_as_float(rb[1]), ascale, h0_, r0_);               \
+    split_pair_u(__uint_as_float(rb[2]), __uint_as_float(rb[3]), ascale, h1_, r1_);               \
+    UW_LDS_ST4(bst0 + (slot_), h0_) UW_LDS_ST4(bsy0 + (slot_), h0_)                               \
+    UW_LDS_ST4(bst0 + (slot_) + UW_BSPLIT, r0_) UW_LDS_ST4(bsy0 + (slot_) + UW_BSPLIT, r0_)       \
+    if (tid < 84) {                                                                               \
+      UW_LDS_ST4(bst1 + (slot_), h1_) UW_LDS_ST4(bsy1 + (slot_), h1_)                             \
+      UW_LDS_ST4(bst1 + (slot_) + UW_BSPLIT, r1_) UW_LDS_ST4(bsy1 + (slot_) + UW_BSPLIT, r1_)     \
+    }                                                                                             \
+  }
+#define UW_YOFFS(P_, ok_) ((ybase != OOB && (ok_)) ? (ybase + (unsigned)(P_) * HW) * 4u : OOB)
+#define UW_AOFFS(ab_, P_, ok_) (((ab_) != OOB && (ok_)) ? ((ab_) + (unsigned)(P_) * HWl) * 4u : OOB)
+#define UW_BOFFS(bb_, P_, ok_) (((bb_) != OOB && (ok_)) ? ((bb_) + (unsigned)(P_) * HW) * 4u : OOB)
+
+  // One half-step h = (z, PZ_), dY plane P = 2 z + PZ_ (buffer PZ_): 24 groups -- per `a` row R = 0..4 the dY operand
+  // of K-block R with the b tiles, then (ix, iz) x the products with rows R (iy = 0) and R - 1 (iy = 1).  Loads and
+  // conversions ride in fixed groups: dY plane P + 1 (loaded during the previous half-step) is converted into buffer
+  // PZ_ ^ 1 in groups 0-3 and the loads of plane P + 2 follow at once (groups 4-11); `a` plane z + 2 is loaded in groups
+  // 12-19 of PZ_ = 0 and converted in groups 12-13 of PZ_ = 1; b plane P + 2: loads in group 0, conversion in group 23
+  // (into the ring's free slot).
+#define UW4_HALF(PZ_, sa0_, sa1_, sn_, yoff_, aoff0_, aoff1_, boff0_, boff1_, sbf_)               \
+  {                                                                                               \
+    const unsigned bb0_ = bl[0] + (PZ_) * UW_YBUF, bb1_ = bl[1] + (PZ_) * UW_YBUF;                \
+    u32x4 B0[2], B1[2], A0[2], A1[2];                                                             \
+    /* operands of group g (see below) into A buffer g & 1: issued one group ahead of their MFMAs */ \
+    auto rd_ = [&](auto gc2_) __attribute__((always_inline)) {                                    \
+      constexpr int g2_ = decltype(gc2_)::value, R2_ = g2_ < 20 ? g2_ / 5 : 4, k2_ = g2_ < 20 ? g2_ % 5 : g2_ - 19; \
+      if constexpr (g2_ < 24) {                                                                   \
+        if constexpr (k2_ == 0) {                                                                 \
+          B0[R2_ & 1] = tr_pair_u(bb0_ + R2_ * 1024, bb1_ + R2_ * 1024);                          \
+          B1[R2_ & 1] = tr_pair_u(bb0_ + R2_ * 1024 + UW_YSPLIT, bb1_ + R2_ * 1024 + UW_YSPLIT);  \
+        } else {                                                                                  \
+          constexpr int ix2_ = (k2_ - 1) >> 1, iz2_ = (k2_ - 1) & 1;                              \
+          const unsigned ab_ = iz2_ ? (sa1_) : (sa0_);                                            \
+          A0[g2_ & 1] = tr_pair_u(al[0][ix2_] + ab_ + R2_ * 1152, al[1][ix2_] + ab_ + R2_ * 1152); \
+          A1[g2_ & 1] = tr_pair_u(al[0][ix2_] + ab_ + R2_ * 1152 + UW_ASPLIT, al[1][ix2_] + ab_ + R2_ * 1152 + UW_ASPLIT); \
+        }                                                                                         \
+      }                                                                                           \
+    };                                                                                            \
+    rd_(std::integral_constant<int, 0>{});                                                        \
+    static_for_u<0, 24>([&](auto gc_) __attribute__((always_inline)) {                            \
+      constexpr int g_ = decltype(gc_)::value, R_ = g_ < 20 ? g_ / 5 : 4, kk_ = g_ < 20 ? g_ % 5 : g_ - 19; \
+      constexpr int ix_ = kk_ ? (kk_ - 1) >> 1 : 0, iz_ = kk_ ? (kk_ - 1) & 1 : 0;                \
+      constexpr bool nextb_ = g_ + 1 < 20 && (g_ + 1) % 5 == 0;   /* the next group opens a row: its dY operand replaces */ \
+      if constexpr (!nextb_) {                                    /* one that this group's iy = 1 products still read    */ \
+        if (!(UW_KO & 8) || g_ == 0) rd_(std::integral_constant<int, g_ + 1>{});                  \
+      }                                                                                           \
+      if constexpr (g_ < 4) { UW_YCONV(g_, (PZ_) ^ 1) }                                           \
+      if constexpr (g_ >= 4 && g_ < 12) { UW_YLOAD(g_ - 4, yoff_) }                               \
+      if constexpr ((PZ_) == 0 && g_ >= 12 && g_ < 20) { UW_ALOAD(g_ - 12, aoff0_, aoff1_) }      \
+      if constexpr ((PZ_) == 1 && (g_ == 12 || g_ == 13)) { UW_ACONV(g_ - 12, sn_) }              \
+      if constexpr (g_ == 0) { UW_BLOAD(boff0_, boff1_) }                                         \
+      if constexpr (g_ == 23) { UW_BCONV(sbf_) }                                                  \
+      if (!(UW_KO & 1)) {                                                                         \
+        if constexpr (kk_ == 0) {                                                                 \
+          if constexpr (FUSEB) {      /* b tiles: their operands are read here (the A buffer of this group is free) */ \
+            _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_) {                                    \
+              const unsigned so_ = qdz[T_] == 0 ? sb0 : (qdz[T_] == 1 ? sb1 : (qdz[T_] == 2 ? sb2 : 0u)); \
+              const unsigned q0_ = qb[T_][0] + so_ + R_ * qstep[T_], q1_ = qb[T_][1] + so_ + R_ * qstep[T_]; \
+              A0[g_ & 1] = tr_pair_u(q0_, q1_);                                                   \
+              A1[g_ & 1] = tr_pair_u(q0_ + UW_BSPLIT, q1_ + UW_BSPLIT);                           \
+              mma_v(A1[g_ & 1], B0[R_ & 1], accb[T_]);                                            \
+              mma_v(A0[g_ & 1], B1[R_ & 1], accb[T_]);                                            \
+              mma_v(A0[g_ & 1], B0[R_ & 1], accb[T_]);                                            \
+            }                                                                                     \
+          }                                                                                       \
+        } else {                                                                                  \
+          if constexpr (R_ < 4) {       /* iy = 0: dY row R */                                    \
+            acc[PZ_][iz_][ix_] = mma_u(A1[g_ & 1], B0[R_ & 1], acc[PZ_][iz_][ix_]);               \
+            acc[PZ_][iz_][ix_] = mma_u(A0[g_ & 1], B1[R_ & 1], acc[PZ_][iz_][ix_]);               \
+            acc[PZ_][iz_][ix_] = mma_u(A0[g_ & 1], B0[R_ & 1], acc[PZ_][iz_][ix_]);               \
+          }                                                                                       \
+          if constexpr (R_ >= 1) {      /* iy = 1: dY row R - 1 */                                \
+            acc[PZ_][iz_][2 + ix_] = mma_u(A1[g_ & 1], B0[(R_ - 1) & 1], acc[PZ_][iz_][2 + ix_]); \
+            acc[PZ_][iz_][2 + ix_] = mma_u(A0[g_ & 1], B1[(R_ - 1) & 1], acc[PZ_][iz_][2 + ix_]); \
+            acc[PZ_][iz_][2 + ix_] = mma_u(A0[g_ & 1], B0[(R_ - 1) & 1], acc[PZ_][iz_][2 + ix_]); \
+          }                                                                                       \
+        }                                                                                         \
+      } else if constexpr (kk_ != 0) {                                                            \
+        acc[PZ_][iz_][ix_][0] += __uint_as_float(A0[g_ & 1][0] ^ A1[g_ & 1][1] ^ B0[R_ & 1][2] ^ B1[R_ & 1][3]); \
+      }                                                                                           \
+      if constexpr (nextb_) {                                                                     \
+        if (!(UW_KO & 8)) rd_(std::integral_constant<int, g_ + 1>{});                             \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    });                                                                                           \
+  }
+
+  for (int item = blockIdx.x; item < k.nitems; item += gridDim.x) {
+    int q = item;
+    const int cx = q % k.ncx; q /= k.ncx;
+    const int cy = q % k.ncy; q /= k.ncy;
+    const int seg = q % k.nseg;
+    const int n = q / k.nseg;
+    z0 = seg * k.zlen;
+    z1 = z0 + k.zlen < k.Dl ? z0 + k.zlen : k.Dl;
+    const int y0 = cy * 4, x0 = cx * 16;
+    ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (long long)n * k.Cout * (S4 >> 2)), 0,
+                                             (unsigned)k.Cout * S4, 0x00020000);
+    asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a + (long long)n * 32 * (Sl4 >> 2)), 0, 32u * Sl4, 0x00020000);
+    if (FUSEB) bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b + (long long)n * 2 * (S4 >> 2)), 0, 2u * S4, 0x00020000);
+    {
+      const int gy = 2 * y0 + yr, gx = 2 * x0 + 4 * yq;
+      ybase = (gy < H && gx < W) ? (unsigned)(gy * W + gx) : OOB;
+      const int ay0 = y0 - 1 + ahy0, ax0 = x0 - 1 + ahx0, ay1 = y0 - 1 + ahy1, ax1 = x0 - 1 + ahx1;
+      abase0 = ((unsigned)ay0 < (unsigned)k.Hl && (unsigned)ax0 < (unsigned)k.Wl) ? (unsigned)(ay0 * k.Wl + ax0) : OOB;
+      abase1 = ((unsigned)ay1 < (unsigned)k.Hl && (unsigned)ax1 < (unsigned)k.Wl) ? (unsigned)(ay1 * k.Wl + ax1) : OOB;
+      const int by0 = 2 * y0 - 1 + br0, bx0 = 2 * x0 - 1 + bc0, by1 = 2 * y0 - 1 + br1, bx1 = 2 * x0 - 1 + bc1;
+      bbase0 = ((unsigned)by0 < (unsigned)H && (unsigned)bx0 < (unsigned)W) ? (unsigned)(by0 * W + bx0) : OOB;
+      bbase1 = (tid < 84 && (unsigned)by1 < (unsigned)H && (unsigned)bx1 < (unsigned)W) ? (unsigned)(by1 * W + bx1) : OOB;
+    }
+    // ---- prologue: a planes z0 - 1, z0, z0 + 1 into slots 0, 1, 2; b planes 2 z0 - 1, 2 z0, 2 z0 + 1 into slots 0, 1, 2;
+    // dY plane 2 z0 into buffer 0; plane 2 z0 + 1 stays in flight (converted at the head of the first half-step)
+    unsigned so0 = 0, so1 = UW_ASLOT, so2 = 2 * UW_ASLOT;
+    unsigned sb0 = 0, sb1 = UW_BSLOT, sb2 = 2 * UW_BSLOT, sb3 = 3 * UW_BSLOT;
+    {
+      const unsigned y0off = UW_YOFFS(2 * z0, true), y1off = UW_YOFFS(2 * z0 + 1, true);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { UW_YLOAD(c, y0off) }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int P = z0 - 1 + p;
+        const bool ok = P >= 0 && P < k.Dl;
+        const unsigned a0 = UW_AOFFS(abase0, P, ok), a1 = UW_AOFFS(abase1, P, ok);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { UW_ALOAD(c, a0, a1) }
+        UW_ACONV(0, (unsigned)p * UW_ASLOT) UW_ACONV(1, (unsigned)p * UW_ASLOT)
+      }
+      if constexpr (FUSEB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const int P = 2 * z0 - 1 + p;
+          UW_BLOAD(UW_BOFFS(bbase0, P, P >= 0), UW_BOFFS(bbase1, P, P >= 0))
+          UW_BCONV((unsigned)p * UW_BSLOT)
+        }
+      }
+      UW_YCONV(0, 0) UW_YCONV(1, 0) UW_YCONV(2, 0) UW_YCONV(3, 0)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { UW_YLOAD(c, y1off) }
+    }
+    __syncthreads();
+
+    for (int z = z0; z < z1; ++z) {
+      {   // pz = 0: P = 2 z; a planes z - 1 (iz = 0), z (iz = 1); b planes P - 1, P, P + 1 in sb0..2, P + 2 -> sb3
+        const unsigned yoff = UW_YOFFS(2 * z + 2, z + 1 < z1);
+        const unsigned ao0 = UW_AOFFS(abase0, z + 2, z + 2 < k.Dl), ao1 = UW_AOFFS(abase1, z + 2, z + 2 < k.Dl);
+        const unsigned bo0 = UW_BOFFS(bbase0, 2 * z + 2, 2 * z + 2 < D), bo1 = UW_BOFFS(bbase1, 2 * z + 2, 2 * z + 2 < D);
+        UW4_HALF(0, so0, so1, 0u, yoff, ao0, ao1, bo0, bo1, sb3)
+        __syncthreads();
+        const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
+      }
+      {   // pz = 1: P = 2 z + 1; a planes z (iz = 0), z + 1 (iz = 1); plane z + 2 replaces plane z - 1
+        const unsigned yoff = UW_YOFFS(2 * z + 3, z + 1 < z1);
+        const unsigned bo0 = UW_BOFFS(bbase0, 2 * z + 3, 2 * z + 3 < D), bo1 = UW_BOFFS(bbase1, 2 * z + 3, 2 * z + 3 < D);
+        UW4_HALF(1, so1, so2, so0, yoff, OOB, OOB, bo0, bo1, sb3)
+        __syncthreads();
+        const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
+      }
+      const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
+    }
+  }
+#undef UW_YLOAD
+#undef UW_ALOAD
+#undef UW_V_E0
+#undef UW_V_E1
+#undef UW_V_E2
+#undef UW_V_E3
+#undef UW_V_A0
+#undef UW_V_A1
+#undef UW_YADDR
+#undef UW_BLOAD
+#undef UW_LDS_ST
+#undef UW_LDS_ST4
+#undef UW_CONV_ST
+#undef UW_YCONV
+#undef UW_ACONV
+#undef UW_BCONV
+#undef UW_YOFFS
+#undef UW_AOFFS
+#undef UW_BOFFS
+#undef UW4_HALF
+
+  // ---- epilogue: acc[pz][iz][iy * 2 + ix][r] <-> row ci = (r >> 2) * 8 + hi * 4 + (r & 3), column co = l31 of tile
+  // (pz, py, px, iz, iy, ix); the b tiles follow the 64: (class, T) with row = (r >> 2) * 8 + hi * 4 + (r & 3) of tile T
+  if constexpr (FUSEB) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last b product's result (mma_v)
+  if (l31 < k.Cout && !(UW_KO & 16)) {
+    const float sc = osc_a * osc_d;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int tile = ((((p * 2 + py) * 2 + px) * 2 + iz) * 2 + (s >> 1)) * 2 + (s & 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = (r >> 2) * 8 + hi * 4 + (r & 3);
+            atomicAdd(&gws[tile * 1024 + ci * 32 + l31], acc[p][iz][s][r] * sc);
+          }
+        }
+    if constexpr (FUSEB) {
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r >> 2) * 8 + hi * 4 + (r & 3);          // row 28 of tile 1: sum of dY (ones operand, unscaled)
+          atomicAdd(&gws[(64 + (py * 2 + px) * 2 + T) * 1024 + row * 32 + l31], accb[T][r] * ((T == 1 && row == 28) ? osc_d : sc));
+        }
+    }
+  }
+  if (UW_KO & 16) {
+    float t = accb[0][0] + accb[1][0];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[p][iz][s][r];
+    gws[tid] = t * osc_a * osc_d;
+  }
+}
+
+// dWb[tap][cb][co] += the rows of the 8 b tiles (class (py, px), T) that hold (tap, cb): see conv3d_upwgrad4_k
+__global__ __launch_bounds__(256) void conv3d_upwgrad_foldb_k(const float* __restrict__ gws, float* __restrict__ dwt, int Cout,
+                                                               long long s_tap, int total, float* __restrict__ db) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total + Cout) return;
+  if (idx >= total) {                                       // bias gradient: row 28 of the classes' second tiles
+    const int co = idx - total;
+    float s = 0.f;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) s += gws[(64 + cls * 2 + 1) * 1024 + 28 * 32 + co];
+    if (db) db[co] += s;
+    return;
+  }
+  const int co = idx % Cout, cb = (idx / Cout) & 1, tap = idx / (Cout * 2);
+  const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
+  float s = 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    int Q, pos;
+    if (dx == px || dx == px + 1) { Q = dz * 3 + dyy; pos = (dx - px) * 2 + cb; }
+    else if (dyy == py || dyy == py + 1) { Q = 9 + dz; pos = (dyy - py) * 2 + cb; }
+    else { Q = 12 + dz; pos = (px ? 2 : 0) + cb; }
+    s += gws[(64 + cls * 2 + (Q >> 3)) * 1024 + ((Q & 7) * 4 + pos) * 32 + co];
+  }
+  dwt[tap * s_tap + (long long)cb * Cout + co] += s;
+}
+
 // dW[tap][ci][co] += the 8 tiles of the workspace that contain tap = (dz, dy, dx): per axis d = 0: (p, i) = (0,0), (1,0);
 // d = 1: (0,1), (1,0);  d = 2: (0,1), (1,1)
 __global__ __launch_bounds__(256) void conv3d_upwgrad_fold_k(const float* __restrict__ gws, float* __restrict__ dwt, int Cout,
@@ -353,11 +776,12 @@ __global__ __launch_bounds__(256) void conv3d_upwgrad_fold_k(const float* __rest
 
 }  // namespace
 
-// Host side of the up-sampled share (conv3ds.hip::dfmir_conv3d_upwgrad calls this, then the direct kernel for b).
-// dwt: tap-major gradient [27][Ctot][Cout] (s_tap = Ctot * Cout), rows 0 .. 31 are written; ws: 64 * 1024 floats.
-int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* dy, const float* dy_amax, int dy_n,
-                             float* dwt, long long s_tap, float* ws, int N, int Dl, int Hl, int Wl, int Cout,
-                             hipStream_t st) {
+// Host side.  b != NULL (two skip channels): everything in one launch, rows 0 .. 33 of the tap-major gradient
+// [27][Ctot][Cout] (s_tap = Ctot * Cout) and db; b == NULL: rows 0 .. 31 (conv3ds.hip::dfmir_conv3d_upwgrad runs the
+// direct kernel on the skip channels).  ws: 72 * 1024 floats.
+int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* b, const float* dy, const float* dy_amax,
+                             int dy_n, float* dwt, long long s_tap, float* db, float* ws, int N, int Dl, int Hl, int Wl,
+                             int Cout, hipStream_t st) {
   UwP k{};
   k.N = N; k.Dl = Dl; k.Hl = Hl; k.Wl = Wl; k.Cout = Cout;
   k.a_n = a_n; k.dy_n = dy_n;
@@ -386,10 +810,14 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
   k.nseg = (Dl + k.zlen - 1) / k.zlen;
   k.nitems = (int)(cols * k.nseg);
   const unsigned grid = (unsigned)(k.nitems < ncu ? k.nitems : ncu);
-  if (hipMemsetAsync(ws, 0, 64 * 1024 * sizeof(float), st) != hipSuccess) return 2;
-  conv3d_upwgrad_k<<<grid, 512, 0, st>>>(a, a_amax, dy, dy_amax, ws, k);
+  if (hipMemsetAsync(ws, 0, 72 * 1024 * sizeof(float), st) != hipSuccess) return 2;
+  static DfOptFlag v1_o{"DFMIR_UPWGRAD_8WAVE"};             // A/B: the two-waves-per-SIMD form of the up-sampled share
+  if (b) conv3d_upwgrad4_k<true><<<grid, 256, 0, st>>>(a, a_amax, b, dy, dy_amax, ws, k);
+  else if (v1_o.get()) conv3d_upwgrad_k<<<grid, 512, 0, st>>>(a, a_amax, dy, dy_amax, ws, k);
+  else conv3d_upwgrad4_k<false><<<grid, 256, 0, st>>>(a, a_amax, nullptr, dy, dy_amax, ws, k);
   const int total = 27 * 32 * Cout;
   conv3d_upwgrad_fold_k<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, dwt, Cout, s_tap, total);
+  if (b) conv3d_upwgrad_foldb_k<<<(unsigned)((27 * 2 * Cout + Cout + 255) / 256), 256, 0, st>>>(ws, dwt + 32LL * Cout, Cout, s_tap, 27 * 2 * Cout, db);
   DF_LAUNCH_CHECK();
   return 0;
 }

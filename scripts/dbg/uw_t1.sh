@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "upcat_conv3d_parity" 2>&1 | tail -5
-timeout 500 bash scripts/gpu_upwgrad_ko.sh - 2 14 15 2>&1 | grep -v amdgpu.ids
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "upwgrad or upcat_conv3d_parity" 2>&1 | tail -4
+for i in 1 2; do LEVELS=1 timeout 200 python scripts/bench_upwgrad.py 2>&1 | tail -1; done

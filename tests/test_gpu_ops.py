@@ -443,6 +443,55 @@ def test_upcat_conv3d_parity_class_form(ops, cfg):
     close(yg, y2, rtol=2e-5, what="y vs materialised")
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 1, 9, 17, 36), (2, 32, 2, 5, 6, 16), (2, 16, 1, 13, 8, 20), (2, 24, 1, 4, 9, 12),
+                                 (16, 32, 1, 6, 10, 20), (8, 16, 2, 4, 5, 16)],
+                         ids=["+2->32-ragged", "+2->32-batch2", "+2->16-z-segments", "+2->24", "+16->32", "+8->16-batch2"])
+@pytest.mark.parametrize("form", ["4wave", "8wave"])
+def test_upwgrad_parity_class_kernel(ops, cfg, form, monkeypatch):
+    """dfmir_conv3d_upwgrad (csrc/conv3duw.hip): the weight gradient of Conv3d(3, padding 1) over cat([nearest_up2(a), b], 1)
+    (torchvoxelmorph/networks.py:64,97-100) with the 32 up-sampled channels in parity classes -- 64 products per
+    LOW-resolution voxel -- against torch fp64 on the materialised tensor: dW and db.  Two skip channels ride in the same
+    launch (rows = (tap, channel) from the x-/y-paired images of b, the bias gradient as the ones row); more skip channels
+    go through the direct kernel.  Shapes with ragged columns (H/2 % 4, W/2 % 16 != 0), several z segments, a batch, fewer
+    than 32 output channels; `8wave` = the two-waves-per-SIMD form of the up-sampled share (DFMIR_UPWGRAD_8WAVE)."""
+    import ctypes
+    from dfmir_amd._lib import set_option
+    from dfmir_amd.ops import DfConvGeom, lib
+    Cb, Cout, N, D, H, W = cfg
+    if form == "8wave" and Cb == 2:
+        pytest.skip("two skip channels are always fused into the one-wave-per-SIMD kernel")
+    monkeypatch.setattr(ops, "_UPWGRAD_MIN_VOX", 0)
+    a = C.randn(211, N, 32, D, H, W)
+    b = C.randn(212, N, Cb, 2 * D, 2 * H, 2 * W)
+    dy = C.randn(213, N, Cout, 2 * D, 2 * H, 2 * W) * 1e-3
+    xr = torch.cat([F.interpolate(a.double(), scale_factor=2, mode="nearest"), b.double()], 1)
+    wr = torch.zeros(Cout, 32 + Cb, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xr, wr, None, padding=1).backward(dy.double())
+    ref = wr.grad.permute(2, 3, 4, 1, 0).reshape(27, 32 + Cb, Cout)          # tap-major packing [27][Cin][Cout]
+    ag, bg, dyg = a.to(DEV), b.to(DEV), dy.to(DEV)
+    xa = ops.absmax(torch.cat([ag.flatten(), bg.flatten()])).clone()
+    da = ops.absmax(dyg).clone()
+    g = DfConvGeom(N, 32 + Cb, Cout, 2 * D, 2 * H, 2 * W, 2 * D, 2 * H, 2 * W, 3, 3, 3, 1, 1, 1, 1, 1, 0, 0, 0.0)
+    assert lib().dfmir_conv3d_upwgrad_ok(ctypes.byref(g), 32)
+    set_option("DFMIR_UPWGRAD_8WAVE", "1" if form == "8wave" else None)
+    try:
+        for nseg in (None, 3):                                            # the launcher's choice, then forced z segments
+            set_option("DFMIR_UPWGRAD_NSEG", nseg)
+            db = torch.zeros(Cout, device=DEV)
+            dw = ops.conv_wgrad_raw(None, dyg, (3, 3, 3), 1, (1, 1, 1), 0, x_amax=xa, dy_amax=da, db=db, parts=(ag, bg))
+            close(dw, ref, rtol=1e-4, atol=0, what="dW nseg=%s" % nseg)
+            close(dw[:, :32], ref[:, :32], rtol=1e-4, atol=0, what="dW up-sampled rows nseg=%s" % nseg)
+            close(dw[:, 32:], ref[:, 32:], rtol=1e-4, atol=0, what="dW skip rows nseg=%s" % nseg)
+            close(db, dy.double().sum((0, 2, 3, 4)), rtol=1e-4, atol=0, what="db nseg=%s" % nseg)
+            dw2 = ops.conv_wgrad_raw(None, dyg, (3, 3, 3), 1, (1, 1, 1), 0, out=dw.clone(), x_amax=xa, dy_amax=da, db=db,
+                                     parts=(ag, bg))                     # accumulates into `out` and `db`
+            close(dw2, 2 * ref, rtol=1e-4, atol=0, what="dW accumulated")
+            close(db, 2 * dy.double().sum((0, 2, 3, 4)), rtol=1e-4, atol=0, what="db accumulated")
+    finally:
+        set_option("DFMIR_UPWGRAD_8WAVE", None)
+        set_option("DFMIR_UPWGRAD_NSEG", None)
+
+
 def test_conv3d_chain_folds_leaky_relu_backward(ops):
     """A chain of LeakyReLU ConvBlocks whose outputs feed only the next conv (conv(sole=True)): the consumer's dgrad
     epilogue applies the activation's derivative (dfmir_conv3d_split_fwd_actgrad), so no act_bwd pass runs between
