@@ -428,41 +428,40 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 
   // ---- staging roles.  dY: thread = (channel group = wave, row r of 8, aligned quad q of 8): eight 16-byte loads;
   // element e of the quad belongs to class px = e & 1 at Vx = 2 q + (e >> 1), the row to py = r & 1 at Vy = r >> 1.
-  // a: 432 jobs (channel group, halo position of 6 x 18), eight 4-byte loads each: jobs tid and tid + 256 (threads 176 ..
-  // 255 repeat jobs 0 .. 79: same data to the same address).  b: positions tid and tid + 256 of the plane's 10 x 34.
-  const int yq = tid & 7, yr = (tid >> 3) & 7, ycg = wid;
-  const int ja1 = tid < 176 ? tid + 256 : tid - 176;
-  const int acg0 = tid / 108, apos0 = tid - 108 * acg0, acg1 = ja1 / 108, apos1 = ja1 - 108 * acg1;
-  const int ahy0 = apos0 / 18, ahx0 = apos0 - 18 * ahy0, ahy1 = apos1 / 18, ahx1 = apos1 - 18 * ahy1;
-  const unsigned yst0 = lbase + UW_YOFF + (unsigned)((yr & 1) * 8192 + (yr >> 1) * 1024 + yq * 128 + ((ycg ^ ((yq >> 1) & 3)) << 4));
-  const unsigned ast0 = lbase + (unsigned)(apos0 * 64 + ((acg0 ^ ((ahx0 >> 2) & 3)) << 4));
-  const unsigned ast1 = lbase + (unsigned)(apos1 * 64 + ((acg1 ^ ((ahx1 >> 2) & 3)) << 4));
-  const int bp1 = tid + 256;
-  const int br0 = tid / 34, bc0 = tid - 34 * br0, br1 = bp1 / 34, bc1 = bp1 - 34 * br1;
-  const unsigned bst0 = lbase + UW_BOFF + (unsigned)((br0 * 34 + bc0) * 4), bsy0 = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc0 * 10 + br0) * 4);
-  const unsigned bst1 = lbase + UW_BOFF + (unsigned)((br1 * 34 + bc1) * 4), bsy1 = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc1 * 10 + br1) * 4);
+  // a: 240 jobs (channel group, halo row of 6, position pair of 10: x0 - 2 + 2 p ..), eight 8-byte loads each; threads
+  // 240 .. 255 repeat jobs 0 .. 15 (same data to the same address).  b: 180 jobs (row of 10, position pair of 18: 2 x0 - 2
+  // + 2 p ..) x both channels; threads 180 .. 255 repeat jobs 0 .. 75.  Pair elements outside the patch are not stored.
+  const int yq = tid & 7, yr = (tid >> 3) & 7;
+  const int ja = tid < 240 ? tid : tid - 240, acg = ja / 60, arr = ja - 60 * acg, ahy = arr / 10, apr = arr - 10 * ahy;
+  const int jb = tid < 180 ? tid : tid - 180, brw = jb / 18, bpr = jb - 18 * brw;
+  const unsigned yst0 = lbase + UW_YOFF + (unsigned)((yr & 1) * 8192 + (yr >> 1) * 1024 + yq * 128 + ((wid ^ ((yq >> 1) & 3)) << 4));
+  unsigned ast[2], bst[2], bsy[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int hx = 2 * apr - 1 + e, bc = 2 * bpr - 1 + e;
+    ast[e] = (hx >= 0 && hx <= 17) ? lbase + (unsigned)((ahy * 18 + hx) * 64 + ((acg ^ ((hx >> 2) & 3)) << 4)) : OOB;
+    bst[e] = (bc >= 0 && bc <= 33) ? lbase + UW_BOFF + (unsigned)((brw * 34 + bc) * 4) : OOB;
+    bsy[e] = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc * 10 + brw) * 4);
+  }
 
+  typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
   u32x4 rq[8];                                              // the dY plane in flight
-  unsigned ra0[8], ra1[8];                                  // the `a` plane in flight
-  unsigned rb[4];
+  u32x2w ra[8];                                             // the `a` plane in flight
+  u32x2w rb[2];
 
-  unsigned ybase = OOB, abase0 = OOB, abase1 = OOB, bbase0 = OOB, bbase1 = OOB;   // element offsets of this thread's jobs inside a plane
+  unsigned ybase = OOB, abase = OOB, bbase = OOB;           // byte offsets of this thread's jobs inside plane 0 (a: + its channel group)
   __amdgpu_buffer_rsrc_t ysrc, asrc, bsrc;
   int z0 = 0, z1 = 0;
 
+  // the channel stride rides in the scalar offset (no address arithmetic per load; an out-of-range voffset stays so)
 #define UW_YLOAD(c_, off_)                                                                        \
-  if (!(UW_KO & 2)) rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, (off_) == OOB ? OOB : ((UW_KO & 32) ? (unsigned)(tid * 16) : (off_)) + (unsigned)(ycg * 8 + (c_)) * S4, 0, 0);
-#define UW_ALOAD(c_, off0_, off1_)                                                                \
-  if (!(UW_KO & 2)) {                                                                             \
-    ra0[c_] = __builtin_amdgcn_raw_buffer_load_b32(asrc, (off0_) == OOB ? OOB : (off0_) + (unsigned)(acg0 * 8 + (c_)) * Sl4, 0, 0); \
-    ra1[c_] = __builtin_amdgcn_raw_buffer_load_b32(asrc, (off1_) == OOB ? OOB : (off1_) + (unsigned)(acg1 * 8 + (c_)) * Sl4, 0, 0); \
-  }
-#define UW_BLOAD(off0_, off1_)                                                                    \
+  if (!(UW_KO & 2)) rq[c_] = __builtin_amdgcn_raw_buffer_load_b128(ysrc, (UW_KO & 32) ? (unsigned)(tid * 16) : (off_), (unsigned)(wid * 8 + (c_)) * S4, 0);
+#define UW_ALOAD(c_, off_)                                                                        \
+  if (!(UW_KO & 2)) ra[c_] = __builtin_amdgcn_raw_buffer_load_b64(asrc, (off_), (unsigned)(c_) * Sl4, 0);
+#define UW_BLOAD(off_)                                                                            \
   if (FUSEB && !(UW_KO & 2)) {                                                                    \
-    rb[0] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off0_), 0, 0);                            \
-    rb[1] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off0_) == OOB ? OOB : (off0_) + S4, 0, 0); \
-    rb[2] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off1_), 0, 0);                            \
-    rb[3] = __builtin_amdgcn_raw_buffer_load_b32(bsrc, (off1_) == OOB ? OOB : (off1_) + S4, 0, 0); \
+    rb[0] = __builtin_amdgcn_raw_buffer_load_b64(bsrc, (off_), 0, 0);                             \
+    rb[1] = __builtin_amdgcn_raw_buffer_load_b64(bsrc, (off_), S4, 0);                            \
   }
 #define UW_LDS_ST(addr_, v_) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(addr_) = (v_);
 #define UW_LDS_ST4(addr_, v_) *(__attribute__((address_space(3))) unsigned*)(uintptr_t)(addr_) = (v_);
@@ -481,8 +480,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 #define UW_V_E1(c_) rq[c_][1]
 #define UW_V_E2(c_) rq[c_][2]
 #define UW_V_E3(c_) rq[c_][3]
-#define UW_V_A0(c_) ra0[c_]
-#define UW_V_A1(c_) ra1[c_]
+#define UW_V_A0(c_) ra[c_][0]
+#define UW_V_A1(c_) ra[c_][1]
 #define UW_YADDR(e_, buf_) (yst0 + (unsigned)(buf_) * UW_YBUF + (unsigned)(((e_) & 1) * 4096 + ((e_) >> 1) * 64))
 #define UW_YCONV(e_, buf_)                                                                        \
   {                                                                                               \
@@ -492,33 +491,32 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     else { UW_CONV_ST(UW_V_E3, dscale, UW_YADDR(3, buf_), UW_YSPLIT) }                            \
   }
 #define UW_ACONV(j_, slot_)                                                                       \
-  {                                                                                               \
-    if constexpr ((j_) == 0) { UW_CONV_ST(UW_V_A0, ascale, ast0 + (slot_), UW_ASPLIT) }           \
-    else { UW_CONV_ST(UW_V_A1, ascale, ast1 + (slot_), UW_ASPLIT) }                               \
+  if (ast[j_] != OOB) {                                                                           \
+    if constexpr ((j_) == 0) { UW_CONV_ST(UW_V_A0, ascale, ast[0] + (slot_), UW_ASPLIT) }         \
+    else { UW_CONV_ST(UW_V_A1, ascale, ast[1] + (slot_), UW_ASPLIT) }                             \
   }
 #define UW_BCONV(slot_)                                                                           \
   if (FUSEB && !(UW_KO & 4)) {                                                                    \
-    unsigned h0_, r0_, h1_, r1_;                                                                  \
-    split_pair_u(__uint_as_float(rb[0]), __uint_as_float(rb[1]), ascale, h0_, r0_);               \
-    split_pair_u(__uint_as_float(rb[2]), __uint_as_float(rb[3]), ascale, h1_, r1_);               \
-    UW_LDS_ST4(bst0 + (slot_), h0_) UW_LDS_ST4(bsy0 + (slot_), h0_)                               \
-    UW_LDS_ST4(bst0 + (slot_) + UW_BSPLIT, r0_) UW_LDS_ST4(bsy0 + (slot_) + UW_BSPLIT, r0_)       \
-    if (tid < 84) {                                                                               \
-      UW_LDS_ST4(bst1 + (slot_), h1_) UW_LDS_ST4(bsy1 + (slot_), h1_)                             \
-      UW_LDS_ST4(bst1 + (slot_) + UW_BSPLIT, r1_) UW_LDS_ST4(bsy1 + (slot_) + UW_BSPLIT, r1_)     \
+    _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                            \
+      unsigned h_, r_;                                                                            \
+      split_pair_u(__uint_as_float(rb[0][e_]), __uint_as_float(rb[1][e_]), ascale, h_, r_);       \
+      if (bst[e_] != OOB) {                                                                       \
+        UW_LDS_ST4(bst[e_] + (slot_), h_) UW_LDS_ST4(bsy[e_] + (slot_), h_)                       \
+        UW_LDS_ST4(bst[e_] + (slot_) + UW_BSPLIT, r_) UW_LDS_ST4(bsy[e_] + (slot_) + UW_BSPLIT, r_) \
+      }                                                                                           \
     }                                                                                             \
   }
-#define UW_YOFFS(P_, ok_) ((ybase != OOB && (ok_)) ? (ybase + (unsigned)(P_) * HW) * 4u : OOB)
-#define UW_AOFFS(ab_, P_, ok_) (((ab_) != OOB && (ok_)) ? ((ab_) + (unsigned)(P_) * HWl) * 4u : OOB)
-#define UW_BOFFS(bb_, P_, ok_) (((bb_) != OOB && (ok_)) ? ((bb_) + (unsigned)(P_) * HW) * 4u : OOB)
+#define UW_YOFFS(P_, ok_) ((ybase != OOB && (ok_)) ? ybase + (unsigned)(P_) * HW * 4u : OOB)
+#define UW_AOFFS(P_, ok_) ((abase != OOB && (ok_)) ? abase + (unsigned)(P_) * HWl * 4u : OOB)
+#define UW_BOFFS(P_, ok_) ((bbase != OOB && (ok_)) ? bbase + (unsigned)(P_) * HW * 4u : OOB)
 
   // One half-step h = (z, PZ_), dY plane P = 2 z + PZ_ (buffer PZ_): 24 groups -- per `a` row R = 0..4 the dY operand
   // of K-block R with the b tiles, then (ix, iz) x the products with rows R (iy = 0) and R - 1 (iy = 1).  Loads and
   // conversions ride in fixed groups: dY plane P + 1 (loaded during the previous half-step) is converted into buffer
   // PZ_ ^ 1 in groups 0-3 and the loads of plane P + 2 follow at once (groups 4-11); `a` plane z + 2 is loaded in groups
-  // 12-19 of PZ_ = 0 and converted in groups 12-13 of PZ_ = 1; b plane P + 2: loads in group 0, conversion in group 23
+  // 12-19 of PZ_ = 0 (8-byte pairs) and converted in groups 12-13 of PZ_ = 1; b plane P + 2: loads in group 0, conversion in group 23
   // (into the ring's free slot).
-#define UW4_HALF(PZ_, sa0_, sa1_, sn_, yoff_, aoff0_, aoff1_, boff0_, boff1_, sbf_)               \
+#define UW4_HALF(PZ_, sa0_, sa1_, sn_, yoff_, aoff_, boff_, sbf_)               \
   {                                                                                               \
     const unsigned bb0_ = bl[0] + (PZ_) * UW_YBUF, bb1_ = bl[1] + (PZ_) * UW_YBUF;                \
     u32x4 B0[2], B1[2], A0[2], A1[2];                                                             \
@@ -547,9 +545,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
       }                                                                                           \
       if constexpr (g_ < 4) { UW_YCONV(g_, (PZ_) ^ 1) }                                           \
       if constexpr (g_ >= 4 && g_ < 12) { UW_YLOAD(g_ - 4, yoff_) }                               \
-      if constexpr ((PZ_) == 0 && g_ >= 12 && g_ < 20) { UW_ALOAD(g_ - 12, aoff0_, aoff1_) }      \
+      if constexpr ((PZ_) == 0 && g_ >= 12 && g_ < 20) { UW_ALOAD(g_ - 12, aoff_) }               \
       if constexpr ((PZ_) == 1 && (g_ == 12 || g_ == 13)) { UW_ACONV(g_ - 12, sn_) }              \
-      if constexpr (g_ == 0) { UW_BLOAD(boff0_, boff1_) }                                         \
+      if constexpr (g_ == 0) { UW_BLOAD(boff_) }                                                  \
       if constexpr (g_ == 23) { UW_BCONV(sbf_) }                                                  \
       if (!(UW_KO & 1)) {                                                                         \
         if constexpr (kk_ == 0) {                                                                 \
@@ -601,13 +599,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     if (FUSEB) bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b + (long long)n * 2 * (S4 >> 2)), 0, 2u * S4, 0x00020000);
     {
       const int gy = 2 * y0 + yr, gx = 2 * x0 + 4 * yq;
-      ybase = (gy < H && gx < W) ? (unsigned)(gy * W + gx) : OOB;
-      const int ay0 = y0 - 1 + ahy0, ax0 = x0 - 1 + ahx0, ay1 = y0 - 1 + ahy1, ax1 = x0 - 1 + ahx1;
-      abase0 = ((unsigned)ay0 < (unsigned)k.Hl && (unsigned)ax0 < (unsigned)k.Wl) ? (unsigned)(ay0 * k.Wl + ax0) : OOB;
-      abase1 = ((unsigned)ay1 < (unsigned)k.Hl && (unsigned)ax1 < (unsigned)k.Wl) ? (unsigned)(ay1 * k.Wl + ax1) : OOB;
-      const int by0 = 2 * y0 - 1 + br0, bx0 = 2 * x0 - 1 + bc0, by1 = 2 * y0 - 1 + br1, bx1 = 2 * x0 - 1 + bc1;
-      bbase0 = ((unsigned)by0 < (unsigned)H && (unsigned)bx0 < (unsigned)W) ? (unsigned)(by0 * W + bx0) : OOB;
-      bbase1 = (tid < 84 && (unsigned)by1 < (unsigned)H && (unsigned)bx1 < (unsigned)W) ? (unsigned)(by1 * W + bx1) : OOB;
+      ybase = (gy < H && gx < W && wid * 8 < k.Cout) ? (unsigned)(gy * W + gx) * 4u : OOB;   // (the scalar offset is not range-checked)
+      const int ay = y0 - 1 + ahy, ax = x0 - 2 + 2 * apr;
+      abase = ((unsigned)ay < (unsigned)k.Hl && (unsigned)ax < (unsigned)k.Wl) ? (unsigned)(ay * k.Wl + ax) * 4u + (unsigned)(acg * 8) * Sl4 : OOB;
+      const int by = 2 * y0 - 1 + brw, bx = 2 * x0 - 2 + 2 * bpr;
+      bbase = ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) ? (unsigned)(by * W + bx) * 4u : OOB;
     }
     // ---- prologue: a planes z0 - 1, z0, z0 + 1 into slots 0, 1, 2; b planes 2 z0 - 1, 2 z0, 2 z0 + 1 into slots 0, 1, 2;
     // dY plane 2 z0 into buffer 0; plane 2 z0 + 1 stays in flight (converted at the head of the first half-step)
@@ -621,16 +617,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
       for (int p = 0; p < 3; ++p) {
         const int P = z0 - 1 + p;
         const bool ok = P >= 0 && P < k.Dl;
-        const unsigned a0 = UW_AOFFS(abase0, P, ok), a1 = UW_AOFFS(abase1, P, ok);
+        const unsigned a0 = UW_AOFFS(P, ok);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { UW_ALOAD(c, a0, a1) }
+        for (int c = 0; c < 8; ++c) { UW_ALOAD(c, a0) }
         UW_ACONV(0, (unsigned)p * UW_ASLOT) UW_ACONV(1, (unsigned)p * UW_ASLOT)
       }
       if constexpr (FUSEB) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const int P = 2 * z0 - 1 + p;
-          UW_BLOAD(UW_BOFFS(bbase0, P, P >= 0), UW_BOFFS(bbase1, P, P >= 0))
+          UW_BLOAD(UW_BOFFS(P, P >= 0))
           UW_BCONV((unsigned)p * UW_BSLOT)
         }
       }
@@ -643,16 +639,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     for (int z = z0; z < z1; ++z) {
       {   // pz = 0: P = 2 z; a planes z - 1 (iz = 0), z (iz = 1); b planes P - 1, P, P + 1 in sb0..2, P + 2 -> sb3
         const unsigned yoff = UW_YOFFS(2 * z + 2, z + 1 < z1);
-        const unsigned ao0 = UW_AOFFS(abase0, z + 2, z + 2 < k.Dl), ao1 = UW_AOFFS(abase1, z + 2, z + 2 < k.Dl);
-        const unsigned bo0 = UW_BOFFS(bbase0, 2 * z + 2, 2 * z + 2 < D), bo1 = UW_BOFFS(bbase1, 2 * z + 2, 2 * z + 2 < D);
-        UW4_HALF(0, so0, so1, 0u, yoff, ao0, ao1, bo0, bo1, sb3)
+        const unsigned aoff = UW_AOFFS(z + 2, z + 2 < k.Dl), boff = UW_BOFFS(2 * z + 2, 2 * z + 2 < D);
+        UW4_HALF(0, so0, so1, 0u, yoff, aoff, boff, sb3)
         __syncthreads();
         const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
       }
       {   // pz = 1: P = 2 z + 1; a planes z (iz = 0), z + 1 (iz = 1); plane z + 2 replaces plane z - 1
         const unsigned yoff = UW_YOFFS(2 * z + 3, z + 1 < z1);
-        const unsigned bo0 = UW_BOFFS(bbase0, 2 * z + 3, 2 * z + 3 < D), bo1 = UW_BOFFS(bbase1, 2 * z + 3, 2 * z + 3 < D);
-        UW4_HALF(1, so1, so2, so0, yoff, OOB, OOB, bo0, bo1, sb3)
+        const unsigned boff = UW_BOFFS(2 * z + 3, 2 * z + 3 < D);
+        UW4_HALF(1, so1, so2, so0, yoff, OOB, boff, sb3)
         __syncthreads();
         const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
       }
