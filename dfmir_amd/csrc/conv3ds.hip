@@ -2528,7 +2528,7 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
                              int dy_n, float* dwt, long long s_tap, float* db, float* ws, int N, int Dl, int Hl, int Wl,
                              int Cout, hipStream_t st);
 static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
-  static DfOptFlag off_o{"DFMIR_CONV3D_NO_UPWGRAD"};
+  static DfOptFlag off_o{"DFMIR_UPWGRAD_DIRECT"};
   return !off_o.get() && !split3d_off() && split3d_wgrad_common_ok(g) && Ca == 32 && g->Cin > Ca && g->Cin - Ca <= 128 &&
          g->Cout >= 8 && g->Cout <= 32 && (g->Cout & 7) == 0 && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7);
 }

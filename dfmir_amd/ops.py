@@ -335,8 +335,11 @@ def _tag_ok(t, tag):
     return tag is not None and tag[-2] == t._version and tag[-1] == t.data_ptr()
 
 
-_UPWGRAD_MIN_VOX = int(os.environ.get("DFMIR_UPWGRAD_MIN_VOX", "400000"))   # low-resolution voxels per image: below, the
-# direct kernel over both parts is faster (profiles/r05_bench_upwgrad.txt: the skip share is 16-32 channels there)
+# dfmir_conv3d_upwgrad below this many low-resolution voxels per image: the direct kernel over both parts.  With MORE than two
+# skip channels their share runs on the direct kernel anyway and the split only pays at the largest volumes
+# (profiles/r05_bench_upwgrad.txt: 48 -> 32 at 80x96x112 0.32 vs 0.29 ms); two skip channels ride in the same launch.
+_UPWGRAD_MIN_VOX = int(os.environ.get("DFMIR_UPWGRAD_MIN_VOX", "400000"))
+_UPWGRAD_MIN_VOX_FUSED = 50000
 _UPWGRAD_WS = {}
 
 
@@ -379,7 +382,8 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             _audit_probe(dy5, dy_amax, "wgrad dY %s" % (tuple(dy5.shape),), plane_max=pm_)
 
     # the up-sampled channels in parity classes (csrc/conv3duw.hip) where the volume fills the chip
-    upw = (parts is not None and parts[0].numel() // parts[0].shape[1] >= _UPWGRAD_MIN_VOX
+    upw = (parts is not None
+           and parts[0][0, 0].numel() >= (min(_UPWGRAD_MIN_VOX, _UPWGRAD_MIN_VOX_FUSED) if parts[1].shape[1] == 2 else _UPWGRAD_MIN_VOX)
            and bool(lib().dfmir_conv3d_upwgrad_ok(ctypes.byref(g), parts[0].shape[1])))
     s2c2 = (parts is None and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and not _NO_TINY3D
             and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))

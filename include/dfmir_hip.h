@@ -49,7 +49,8 @@ const char* dfmir_last_error(void);
  *     DFMIR_CONV3D_NO_PAIR, DFMIR_CONV3D_NO_M16, DFMIR_CONV3D_NO_TINY, DFMIR_CONV3D_NO_VEC,
  *     DFMIR_CONV3D_NO_MULTI, DFMIR_CONV3D_WGS=n, DFMIR_WSPLIT_WGS=n, DFMIR_CONV3D_NO_UPPHASE,
  *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED, DFMIR_CONV3D_NO_MARCH,
- *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (experimental one-wave kernel).
+ *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (experimental one-wave kernel),
+ *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad).
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);
@@ -211,7 +212,11 @@ int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* a, const fl
  * layer, K = the LOW-resolution voxels) holds the whole gradient: 8 / 27 of the direct form's products and one pass over dy
  * with no halo.  The skip channels b run on the direct kernel (which also sums db).  Ca == 32, Cout % 8 == 0, Cout <= 32,
  * D, H even, W % 8 == 0; ws = dfmir_conv3d_upwgrad_ws_floats() floats, owned by the call until the stream has passed it.
- * A/B switch: DFMIR_CONV3D_NO_UPWGRAD=1 (dfmir_conv3d_upwgrad_ok then answers 0); DFMIR_UPWGRAD_NSEG forces the z split. */
+ * Two skip channels (the network's input images at the top level) and db are FUSED into the same launch (rows = (tap,
+ * channel) from x- and y-paired images of b; db as the row of a constant operand); wider skips and db go through the direct
+ * kernel on rows Ca.. of dw_tcc.  A/B switches: DFMIR_UPWGRAD_DIRECT=1 (dfmir_conv3d_upwgrad_ok then answers 0: the direct
+ * kernel over both parts), DFMIR_UPWGRAD_NO_FUSEB=1 (skip share always direct), DFMIR_UPWGRAD_8WAVE=1 (two waves per SIMD, not
+ * fused), DFMIR_UPWGRAD_NSEG=n forces the z split. */
 int dfmir_conv3d_upwgrad_ok(const DfConvGeom* g, int Ca);
 long long dfmir_conv3d_upwgrad_ws_floats(void);
 int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax, int x_amax_n,

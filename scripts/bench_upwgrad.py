@@ -1,6 +1,6 @@
 """GPU box: weight gradient of the ConvBlocks over cat(nearest_up2(a), b) at the decoder's levels -- the parity-class kernel
 (csrc/conv3duw.hip, up-sampled channels; skip channels on the direct kernel) against the direct kernel over both parts
-(DFMIR_CONV3D_NO_UPWGRAD=1 inside this script): HIP-event time per call, and the difference of the two gradients.
+(DFMIR_UPWGRAD_DIRECT=1 inside this script): HIP-event time per call, and the difference of the two gradients.
 DFMIR_HIP_LIB selects a knock-out build."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,14 +41,14 @@ for Ca, Cb, Cout, div in levels:
         da = ops.absmax(dy).clone()
         res = {}
         for tag, off in (("par", ""), ("direct", "1")):
-            set_option("DFMIR_CONV3D_NO_UPWGRAD", off or None)
+            set_option("DFMIR_UPWGRAD_DIRECT", off or None)
             db = torch.zeros(Cout, device=dev)
             dw = ops.conv_wgrad_raw(None, dy, (3, 3, 3), 1, (1, 1, 1), 0, x_amax=xa, dy_amax=da, db=db, parts=(a, b))
             out_ = torch.zeros_like(dw)
             ms = timeit(lambda: ops.conv_wgrad_raw(None, dy, (3, 3, 3), 1, (1, 1, 1), 0, out=out_, x_amax=xa, dy_amax=da,
                                                    db=db, parts=(a, b)))
             res[tag] = (dw, ms)
-        set_option("DFMIR_CONV3D_NO_UPWGRAD", None)
+        set_option("DFMIR_UPWGRAD_DIRECT", None)
         d = (res["par"][0] - res["direct"][0]).double().norm() / res["direct"][0].double().norm()
     out.append("%d+%d->%d @%s par %.3f direct %.3f ms rel %.1e" % (Ca, Cb, Cout, "x".join(map(str, full)), res["par"][1],
                                                                   res["direct"][1], float(d)))

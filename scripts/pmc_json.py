@@ -118,6 +118,9 @@ def main():
                                                  "32 (half res) + 2 -> 32 @160x192x224, one launch (404 GFLOP reference-equivalent)")
             if 'conv3d_up_dgrad_k' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_up_dgrad_k"] = entry(k, d, c[k], 4.0 * (32 * nv + 32 * lo), "d(a): 32 @160x192x224 -> 32 @80x96x112")
+            if 'conv3d_upwgrad4_k' in k and 'FETCH_SIZE' in c[k]:      # csrc/conv3duw.hip: up-sampled channels in parity classes
+                out["conv3d_upwgrad4_k"] = entry(k, d, c[k], 4.0 * (32 * lo + 2 * nv + 32 * nv),
+                                                 "34 -> 32 weight gradient: cat(up2(a), b) in parity classes, skip channels + db fused")
             if 'wgrad_tr_k<3, false, true>' in k and 'FETCH_SIZE' in c[k]:
                 out["conv3d_wgrad_tr_k_upcat"] = entry(k, d, c[k], 4.0 * (32 * lo + 2 * nv + 32 * nv), "34 -> 32 weight gradient, operand cat(up2(a), b) read in place")
     json.dump(out, open(P + tag + "_pmc.json", "w"), indent=1, sort_keys=True)

@@ -14,12 +14,12 @@ import csv, glob, os, collections
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/upconv_prof"
 for f in glob.glob(O + "/kt/**/*kernel_stats.csv", recursive=True):
     for r in list(csv.DictReader(open(f)))[:8]:
-        print(r["Name"][:70], r["Calls"], r["AverageNs"])
+        print(r["Name"].replace("(anonymous namespace)::", "")[:70], r["Calls"], r["AverageNs"])
 for p in ("p1", "p2", "p3", "p4"):
     for f in glob.glob(O + "/%s/**/*counter_collection.csv" % p, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "")[:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
             if "conv3d" in k and "wsplit" not in k:
                 print(p, k, {c: round(sum(v) / len(v)) for c, v in d.items()})

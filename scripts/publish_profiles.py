@@ -13,7 +13,8 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'step_trace_3d.txt': TAG + '_step_trace_3d.txt', 'sustain3d.txt': TAG + '_power_clock_3d.txt', 'pmc_warp.txt': TAG + '_warp_pmc_raw.txt',
       'step_trace_3d_128.txt': TAG + '_step_trace_3d_128.txt', 'bench_upconv3d.txt': TAG + '_bench_upconv3d.txt',
       'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'overlap_trace.txt': TAG + '_overlap_trace.txt', 'bench_in_blurdown.txt': TAG + '_bench_in_blurdown.txt',
-      'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json', 'bench_march.txt': TAG + '_bench_march.txt', 'ab_march_3d.txt': TAG + '_ab_march_3d.txt', 'march_trace.txt': TAG + '_march_trace.txt'}
+      'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json', 'bench_march.txt': TAG + '_bench_march.txt', 'ab_march_3d.txt': TAG + '_ab_march_3d.txt', 'march_trace.txt': TAG + '_march_trace.txt', 'bench_upwgrad.txt': TAG + '_bench_upwgrad.txt', 'upwgrad_ko.txt': TAG + '_upwgrad_ko.txt',
+      'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt'}
 def clean(txt):
     txt = txt.replace("(anonymous namespace)::", "")
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
@@ -70,12 +71,12 @@ open(P + TAG + '_conv3d_pmc.md', 'w').write(md3.replace('{TAG}', TAG))
 if os.path.exists(C + 'pmc_upconv3d.txt'):
     su = clean(open(C + 'pmc_upconv3d.txt').read())
     d, c = parse(su)
-    mdu = ("# PMC counters of the parity-class kernels of the nearest_up2 + cat layers (`csrc/conv3ds.hip`), round 3\n\n"
+    mdu = ("# PMC counters of the parity-class kernels of the nearest_up2 + cat layers (`csrc/conv3ds.hip`, `csrc/conv3duw.hip`)\n\n"
            "Command: `scripts/prof_upconv3d.sh` (`scripts/bench_upconv3d.py`: a [1,32,80,96,112], b [1,2,160,192,224], 34 -> 32 channels, "
            "404.3 GFLOP reference-equivalent per pass; the kernels execute 8/27 of the products of the 32 up-sampled channels).  Raw: `"
            + TAG + "_conv3dup_pmc_raw.txt`.  Rates in the table are REFERENCE-EQUIVALENT FLOP/s.\n\n" + hdr)
     for k in c:
-        if k in d and ('up_phase' in k or 'up_dgrad' in k or 'wgrad_tr' in k) and 'GRBM_GUI_ACTIVE' in c[k] and 'FETCH_SIZE' in c[k] and 'SQ_LDS_IDX_ACTIVE' in c[k]:
+        if k in d and ('up_phase' in k or 'up_dgrad' in k or 'wgrad_tr' in k or 'upwgrad4' in k) and 'GRBM_GUI_ACTIVE' in c[k] and 'FETCH_SIZE' in c[k] and 'SQ_LDS_IDX_ACTIVE' in c[k]:
             gf = 380.5 if 'up_dgrad' in k else 404.29
             mdu += row(k, d[k], c[k], gf) + "\n"
     open(P + TAG + '_conv3dup_pmc.md', 'w').write(mdu)
