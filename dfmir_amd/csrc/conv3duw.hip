@@ -402,21 +402,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     }
   }
   // b operand: tile T = rows 32 T .., this lane supplies quad Q = 8 T + 4 (lane group) + (lane & 3) at voxel sj
-  unsigned qb[2][2], qstep[2];
+  unsigned qb[2], qd[2], qstep[2], qa[2] = {0u, 0u};        // first read, distance to the second (4 voxels on), K-block step; qb + ring slot
   int qdz[2];
 #pragma unroll
   for (int T = 0; T < 2; ++T) {
     const int Q = 8 * T + 4 * ((lane >> 4) & 1) + (lane & 3);   // quad 15: the constant (1, 0, 0, 0) -> row 28 of tile 1 = sum of dY
     const int dxs = 2 - 2 * px, dys = 2 - 2 * py;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int vx = 8 * hi + 4 * i + sj;
+    {
+      const int vx = 8 * hi + sj;
       int o;
       if (Q < 9) o = ((py + Q % 3) * 34 + 2 * vx + 2 * px) * 4;                               // x pair (px, px + 1) of (dz, dy)
       else if (Q < 12) o = (int)UW_BIMG + ((2 * vx + px + dxs) * 10 + 2 * py) * 4;           // y pair (py, py + 1) at dx = dxs
       else if (Q < 15) o = ((py + dys) * 34 + 2 * vx + (px ? 0 : 2)) * 4;                    // single (dys, dxs)
       else o = (int)(UW_LDS4 - UW_BOFF);
-      qb[T][i] = lbase + UW_BOFF + (unsigned)o;
+      qb[T] = lbase + UW_BOFF + (unsigned)o;
+      qd[T] = Q == 15 ? 0u : ((Q >= 9 && Q < 12) ? 320u : 32u);   // 4 voxels on: 8 positions of the x-major / y-major image
     }
     qstep[T] = Q == 15 ? 0u : ((Q >= 9 && Q < 12) ? 8u : 272u);   // K-block Vy -> Vy + 1: two full-resolution rows
     qdz[T] = Q < 9 ? Q / 3 : (Q < 12 ? Q - 9 : (Q < 15 ? Q - 12 : 3));
@@ -513,13 +513,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
   // One half-step h = (z, PZ_), dY plane P = 2 z + PZ_ (buffer PZ_): 24 groups -- per `a` row R = 0..4 the dY operand
   // of K-block R with the b tiles, then (ix, iz) x the products with rows R (iy = 0) and R - 1 (iy = 1).  Loads and
   // conversions ride in fixed groups: dY plane P + 1 (loaded during the previous half-step) is converted into buffer
-  // PZ_ ^ 1 in groups 0-3 and the loads of plane P + 2 follow at once (groups 4-11); `a` plane z + 2 is loaded in groups
-  // 12-19 of PZ_ = 0 (8-byte pairs) and converted in groups 12-13 of PZ_ = 1; b plane P + 2: loads in group 0, conversion in group 23
-  // (into the ring's free slot).
+  // PZ_ ^ 1 in groups 1-4 and the loads of plane P + 2 follow at once (groups 5-12); `a` plane z + 2 is loaded in groups
+  // 13-20 of PZ_ = 0 (8-byte pairs) and converted in groups 13-14 of PZ_ = 1; b plane P + 2: loads in group 2, conversion
+  // in group 17 (into the ring's free slot).
 #define UW4_HALF(PZ_, sa0_, sa1_, sn_, yoff_, aoff_, boff_, sbf_)               \
   {                                                                                               \
     const unsigned bb0_ = bl[0] + (PZ_) * UW_YBUF, bb1_ = bl[1] + (PZ_) * UW_YBUF;                \
     u32x4 B0[2], B1[2], A0[2], A1[2];                                                             \
+    const unsigned qa_[2] = {qa[0], qa[1]};   /* this lane's quads in the ring slots of their dz (set by the previous half-step) */ \
+    unsigned yo_ = OOB, ao_ = OOB;                                                                \
     /* operands of group g (see below) into A buffer g & 1: issued one group ahead of their MFMAs */ \
     auto rd_ = [&](auto gc2_) __attribute__((always_inline)) {                                    \
       constexpr int g2_ = decltype(gc2_)::value, R2_ = g2_ < 20 ? g2_ / 5 : 4, k2_ = g2_ < 20 ? g2_ % 5 : g2_ - 19; \
@@ -543,18 +545,25 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
       if constexpr (!nextb_) {                                    /* one that this group's iy = 1 products still read    */ \
         if (!(UW_KO & 8) || g_ == 0) rd_(std::integral_constant<int, g_ + 1>{});                  \
       }                                                                                           \
-      if constexpr (g_ < 4) { UW_YCONV(g_, (PZ_) ^ 1) }                                           \
-      if constexpr (g_ >= 4 && g_ < 12) { UW_YLOAD(g_ - 4, yoff_) }                               \
-      if constexpr ((PZ_) == 0 && g_ >= 12 && g_ < 20) { UW_ALOAD(g_ - 12, aoff_) }               \
-      if constexpr ((PZ_) == 1 && (g_ == 12 || g_ == 13)) { UW_ACONV(g_ - 12, sn_) }              \
-      if constexpr (g_ == 0) { UW_BLOAD(boff_) }                                                  \
-      if constexpr (g_ == 23) { UW_BCONV(sbf_) }                                                  \
+      /* (the offsets are EXPRESSIONS: evaluated under the MFMAs of the group that first needs them, not in front of the \
+         half-step's first product) */                                                            \
+      if constexpr (g_ >= 1 && g_ < 5) { UW_YCONV(g_ - 1, (PZ_) ^ 1) }                            \
+      if constexpr (g_ == 5) yo_ = (yoff_);                                                       \
+      if constexpr (g_ >= 5 && g_ < 13) { UW_YLOAD(g_ - 5, yo_) }                                 \
+      if constexpr ((PZ_) == 0 && g_ == 13) ao_ = (aoff_);                                        \
+      if constexpr ((PZ_) == 0 && g_ >= 13 && g_ < 21) { UW_ALOAD(g_ - 13, ao_) }                 \
+      if constexpr ((PZ_) == 1 && (g_ == 13 || g_ == 14)) { UW_ACONV(g_ - 13, sn_) }              \
+      if constexpr (g_ == 2) { UW_BLOAD(boff_) }                                                  \
+      if constexpr (g_ == 17) { UW_BCONV(sbf_) }                                                  \
+      if constexpr (FUSEB && g_ == 21) {   /* next half-step's quad addresses: its slots are this one's 1, 2, 3 */ \
+        _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_)                                          \
+          qa[T_] = qb[T_] + (qdz[T_] == 0 ? sb1 : (qdz[T_] == 1 ? sb2 : (qdz[T_] == 2 ? (sbf_) : 0u))); \
+      }                                                                                           \
       if (!(UW_KO & 1)) {                                                                         \
         if constexpr (kk_ == 0) {                                                                 \
           if constexpr (FUSEB) {      /* b tiles: their operands are read here (the A buffer of this group is free) */ \
             _Pragma("unroll") for (int T_ = 0; T_ < 2; ++T_) {                                    \
-              const unsigned so_ = qdz[T_] == 0 ? sb0 : (qdz[T_] == 1 ? sb1 : (qdz[T_] == 2 ? sb2 : 0u)); \
-              const unsigned q0_ = qb[T_][0] + so_ + R_ * qstep[T_], q1_ = qb[T_][1] + so_ + R_ * qstep[T_]; \
+              const unsigned q0_ = qa_[T_] + R_ * qstep[T_], q1_ = q0_ + qd[T_];                  \
               A0[g_ & 1] = tr_pair_u(q0_, q1_);                                                   \
               A1[g_ & 1] = tr_pair_u(q0_ + UW_BSPLIT, q1_ + UW_BSPLIT);                           \
               mma_v(A1[g_ & 1], B0[R_ & 1], accb[T_]);                                            \
@@ -633,21 +642,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
       UW_YCONV(0, 0) UW_YCONV(1, 0) UW_YCONV(2, 0) UW_YCONV(3, 0)
 #pragma unroll
       for (int c = 0; c < 8; ++c) { UW_YLOAD(c, y1off) }
+      if constexpr (FUSEB) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) qa[T] = qb[T] + (qdz[T] == 0 ? sb0 : (qdz[T] == 1 ? sb1 : (qdz[T] == 2 ? sb2 : 0u)));
+      }
     }
     __syncthreads();
 
     for (int z = z0; z < z1; ++z) {
       {   // pz = 0: P = 2 z; a planes z - 1 (iz = 0), z (iz = 1); b planes P - 1, P, P + 1 in sb0..2, P + 2 -> sb3
-        const unsigned yoff = UW_YOFFS(2 * z + 2, z + 1 < z1);
-        const unsigned aoff = UW_AOFFS(z + 2, z + 2 < k.Dl), boff = UW_BOFFS(2 * z + 2, 2 * z + 2 < D);
-        UW4_HALF(0, so0, so1, 0u, yoff, aoff, boff, sb3)
+        UW4_HALF(0, so0, so1, 0u, UW_YOFFS(2 * z + 2, z + 1 < z1), UW_AOFFS(z + 2, z + 2 < k.Dl), UW_BOFFS(2 * z + 2, 2 * z + 2 < D), sb3)
         __syncthreads();
         const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
       }
       {   // pz = 1: P = 2 z + 1; a planes z (iz = 0), z + 1 (iz = 1); plane z + 2 replaces plane z - 1
-        const unsigned yoff = UW_YOFFS(2 * z + 3, z + 1 < z1);
-        const unsigned boff = UW_BOFFS(2 * z + 3, 2 * z + 3 < D);
-        UW4_HALF(1, so1, so2, so0, yoff, OOB, boff, sb3)
+        UW4_HALF(1, so1, so2, so0, UW_YOFFS(2 * z + 3, z + 1 < z1), OOB, UW_BOFFS(2 * z + 3, 2 * z + 3 < D), sb3)
         __syncthreads();
         const unsigned t = sb0; sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = t;
       }
