@@ -247,8 +247,9 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     fw_kinds = ["conv3d_" + z for z in sizes]           # fp32-MFMA kernel (csrc/conv3d.hip): A/B env only
     wg_kinds = ["wgrad3d_" + z for z in ("S", "M", "L")]      # fp32-MFMA wgrad (Cin > 128 layers)
     wgs_kinds = ["wgrad3ds_" + z for z in ("S", "M", "L")]    # split fp16x2 wgrad
+    wgu_kinds = ["wgrad3dup_" + z for z in ("S", "M", "L")]   # ... of cat(up2(a), b) in parity classes (csrc/conv3duw.hip)
     up_kinds = ["conv3dup_" + z for z in sizes]         # parity-class kernels of the nearest_up2 + cat layers
-    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds + up_kinds)
+    timer = KernelTimer(sp_kinds + fw_kinds + wg_kinds + wgs_kinds + wgu_kinds + up_kinds)
     ops.set_conv_profiler(timer)
     for _ in range(max(warmup, 3) if capture else warmup):
         m.set_input({"A": A, "B": B})
@@ -326,7 +327,9 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
     sp_issued = sum(ks[k]["issued"] for k in sp_kinds if k in ks) / (sp_ms * 1e-3) / 1e12 if sp_ms > 0 else 0.0
     fw_tf, fw_n, fw_ms = agg(fw_kinds)
     wg_tf, wg_n, wg_ms = agg(wg_kinds)
-    wgs_tf, wgs_n, wgs_ms = agg(wgs_kinds)
+    wgs_tf, wgs_n, wgs_ms = agg(wgs_kinds + wgu_kinds)
+    wgs_issued = (sum(ks[k]["issued"] for k in wgs_kinds + wgu_kinds if k in ks) / (wgs_ms * 1e-3) / 1e12) if wgs_ms > 0 else 0.0
+    wgu_tf, wgu_n, wgu_ms = agg(wgu_kinds)
     up_tf, up_n, up_ms = agg(up_kinds)
     timed_over = ("%d eager steps right after the timed region (one hipGraph replay per step)" % roofline_steps) if graphed \
         else "the timed region"
@@ -357,7 +360,12 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
                                      "channel-major fp16-pair LDS images of the patch and of dY; plane-pair columns for "
                                      "<= 16 output channels)",
                      "wgrad_achieved": wgs_tf, "wgrad_frac": wgs_tf / FP16_MFMA_PEAK_TFLOPS,
-                     "wgrad_issued_frac": 3.0 * wgs_tf / FP16_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wgs_n})
+                     "wgrad_issued_frac": wgs_issued / FP16_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wgs_n,
+                     "wgrad_note": "achieved = REFERENCE-EQUIVALENT FLOP/s; issued counts the products executed: 3 per MAC x tile "
+                                   "padding, and for the top-level layer over cat(up2(a), b) 8/27 of the up-sampled share "
+                                   "(conv3d_upwgrad4_k: parity classes, skip channels and bias gradient fused)",
+                     "wgrad_upcat": {"kernel": "conv3d_upwgrad4_k", "launches_timed": wgu_n,
+                                     "avg_launch_ms": wgu_ms / max(wgu_n, 1), "reference_equivalent_tflops": wgu_tf}})
     else:
         roof.update({"wgrad_kernel": "conv3d_wgrad16_k (v_mfma_f32_16x16x4_f32)", "wgrad_achieved": wg_tf,
                      "wgrad_frac_of_fp32_peak": wg_tf / FP32_MFMA_PEAK_TFLOPS, "wgrad_launches_timed": wg_n})

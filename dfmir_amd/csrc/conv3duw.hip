@@ -428,19 +428,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 
   // ---- staging roles.  dY: thread = (channel group = wave, row r of 8, aligned quad q of 8): eight 16-byte loads;
   // element e of the quad belongs to class px = e & 1 at Vx = 2 q + (e >> 1), the row to py = r & 1 at Vy = r >> 1.
-  // a: 240 jobs (channel group, halo row of 6, position pair of 10: x0 - 2 + 2 p ..), eight 8-byte loads each; threads
-  // 240 .. 255 repeat jobs 0 .. 15 (same data to the same address).  b: 180 jobs (row of 10, position pair of 18: 2 x0 - 2
-  // + 2 p ..) x both channels; threads 180 .. 255 repeat jobs 0 .. 75.  Pair elements outside the patch are not stored.
+  // a: 240 jobs (channel group, halo row of 6, position pair of 10: x0 - 2 + 2 p ..), eight 8-byte loads each.  b: 180 jobs
+  // (row of 10, position pair of 18: 2 x0 - 2 + 2 p ..) x both channels.  Threads without a job load from out-of-range offsets
+  // (no memory access) and store nothing, like the pair elements outside the patch.
   const int yq = tid & 7, yr = (tid >> 3) & 7;
-  const int ja = tid < 240 ? tid : tid - 240, acg = ja / 60, arr = ja - 60 * acg, ahy = arr / 10, apr = arr - 10 * ahy;
-  const int jb = tid < 180 ? tid : tid - 180, brw = jb / 18, bpr = jb - 18 * brw;
+  const bool ajob = tid < 240, bjob = tid < 180;
+  const int ja = ajob ? tid : 0, acg = ja / 60, arr = ja - 60 * acg, ahy = arr / 10, apr = arr - 10 * ahy;
+  const int jb = bjob ? tid : 0, brw = jb / 18, bpr = jb - 18 * brw;
   const unsigned yst0 = lbase + UW_YOFF + (unsigned)((yr & 1) * 8192 + (yr >> 1) * 1024 + yq * 128 + ((wid ^ ((yq >> 1) & 3)) << 4));
   unsigned ast[2], bst[2], bsy[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int hx = 2 * apr - 1 + e, bc = 2 * bpr - 1 + e;
-    ast[e] = (hx >= 0 && hx <= 17) ? lbase + (unsigned)((ahy * 18 + hx) * 64 + ((acg ^ ((hx >> 2) & 3)) << 4)) : OOB;
-    bst[e] = (bc >= 0 && bc <= 33) ? lbase + UW_BOFF + (unsigned)((brw * 34 + bc) * 4) : OOB;
+    ast[e] = (ajob && hx >= 0 && hx <= 17) ? lbase + (unsigned)((ahy * 18 + hx) * 64 + ((acg ^ ((hx >> 2) & 3)) << 4)) : OOB;
+    bst[e] = (bjob && bc >= 0 && bc <= 33) ? lbase + UW_BOFF + (unsigned)((brw * 34 + bc) * 4) : OOB;
     bsy[e] = lbase + UW_BOFF + UW_BIMG + (unsigned)((bc * 10 + brw) * 4);
   }
 
@@ -593,7 +594,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     });                                                                                           \
   }
 
-  for (int item = blockIdx.x; item < k.nitems; item += gridDim.x) {
+  // Items: workgroup ids go round-robin to the 8 XCDs (one L2 each), so XCD e = id & 7 owns the e-th eighth of the item list
+  // (x fastest, then y: neighbouring columns, whose `a` and b halos and partly used 128-byte lines overlap) and its
+  // workgroups walk it together.
+  const int xcd = blockIdx.x & 7, nslot = ((int)gridDim.x + 7 - xcd) >> 3;
+  const int per_xcd = (k.nitems + 7) >> 3, it_end = (xcd + 1) * per_xcd < k.nitems ? (xcd + 1) * per_xcd : k.nitems;
+  for (int item = xcd * per_xcd + (int)(blockIdx.x >> 3); item < it_end; item += nslot) {
     int q = item;
     const int cx = q % k.ncx; q /= k.ncx;
     const int cy = q % k.ncy; q /= k.ncy;
@@ -610,9 +616,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
       const int gy = 2 * y0 + yr, gx = 2 * x0 + 4 * yq;
       ybase = (gy < H && gx < W && wid * 8 < k.Cout) ? (unsigned)(gy * W + gx) * 4u : OOB;   // (the scalar offset is not range-checked)
       const int ay = y0 - 1 + ahy, ax = x0 - 2 + 2 * apr;
-      abase = ((unsigned)ay < (unsigned)k.Hl && (unsigned)ax < (unsigned)k.Wl) ? (unsigned)(ay * k.Wl + ax) * 4u + (unsigned)(acg * 8) * Sl4 : OOB;
+      abase = (ajob && (unsigned)ay < (unsigned)k.Hl && (unsigned)ax < (unsigned)k.Wl) ? (unsigned)(ay * k.Wl + ax) * 4u + (unsigned)(acg * 8) * Sl4 : OOB;
       const int by = 2 * y0 - 1 + brw, bx = 2 * x0 - 2 + 2 * bpr;
-      bbase = ((unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) ? (unsigned)(by * W + bx) * 4u : OOB;
+      bbase = (bjob && (unsigned)by < (unsigned)H && (unsigned)bx < (unsigned)W) ? (unsigned)(by * W + bx) * 4u : OOB;
     }
     // ---- prologue: a planes z0 - 1, z0, z0 + 1 into slots 0, 1, 2; b planes 2 z0 - 1, 2 z0, 2 z0 + 1 into slots 0, 1, 2;
     // dY plane 2 z0 into buffer 0; plane 2 z0 + 1 stays in flight (converted at the head of the first half-step)

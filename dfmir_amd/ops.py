@@ -422,9 +422,25 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
         size = "L" if Cout > 64 else ("M" if Cout > 32 else "S")
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0 and Cout <= 32
                 and Wi % 4 == 0)                          # csrc/conv3d.hip::df_conv3d_wgrad_try
-        prof("wgrad3dt_S" if s2c2 else
-             ("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size,
-             2.0 * N * Cout * Do * Ho * Wo * Cin * T, launch)
+        flops = 2.0 * N * Cout * Do * Ho * Wo * Cin * T
+        kind = ("wgrad3dt_S" if s2c2 else
+                ("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size)
+        if split3d and is3d and not s2c2 and getattr(prof, "accepts_issued", False):
+            # 16-bit products the kernel ISSUES per algorithmic MAC (cf. conv_raw): 3 x the padding of its tiling
+            if upw:     # parity classes: 8 / 27 of the up-sampled share, 32 columns; fused skip pair: 54 -> 64 rows
+                Ca_, Cb_ = parts[0].shape[1], parts[1].shape[1]
+                skip_ = (64.0 / 54.0) if Cb_ == 2 else (28.0 / 27.0) * (8.0 * ((Cb_ + 7) // 8)) / Cb_
+                pad_ = ((8.0 / 27.0) * Ca_ + skip_ * Cb_) / Cin * (32.0 / Cout)
+                kind = "wgrad3dup_" + size
+            elif Cout < 8:          # the flow head: roles swapped, rows = (tap, co of a chunk of 8), columns = ci of 32
+                pad_ = (28.0 / 27.0) * (8.0 / Cout) * (32.0 / Cin)
+            elif Cout <= 16:        # plane-pair columns: 36 taps' of 27, 16 columns per plane
+                pad_ = (36.0 / 27.0) * (8.0 * ((Cin + 7) // 8)) / Cin * (16.0 / Cout)
+            else:
+                pad_ = (28.0 / 27.0) * (8.0 * ((Cin + 7) // 8)) / Cin * (32.0 / Cout)
+            prof(kind, flops, launch, 3.0 * pad_ * flops)
+        else:
+            prof(kind, flops, launch)
     return dw
 
 
