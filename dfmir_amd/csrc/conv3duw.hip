@@ -820,7 +820,7 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
   k.nseg = (Dl + k.zlen - 1) / k.zlen;
   k.nitems = (int)(cols * k.nseg);
   const unsigned grid = (unsigned)(k.nitems < ncu ? k.nitems : ncu);
-  if (hipMemsetAsync(ws, 0, 72 * 1024 * sizeof(float), st) != hipSuccess) return 2;
+  if (df_zero_async(ws, 72 * 1024, st) != hipSuccess) return 2;   // a kernel, not a memset node (common.h: graph ordering on ROCm 7.2)
   static DfOptFlag v1_o{"DFMIR_UPWGRAD_8WAVE"};             // A/B: the two-waves-per-SIMD form of the up-sampled share
   if (b) conv3d_upwgrad4_k<true><<<grid, 256, 0, st>>>(a, a_amax, b, dy, dy_amax, ws, k);
   else if (v1_o.get()) conv3d_upwgrad_k<<<grid, 512, 0, st>>>(a, a_amax, dy, dy_amax, ws, k);

@@ -276,6 +276,80 @@ __global__ __launch_bounds__(256) void ncc_prod_boxw_x4_k(const float* __restric
 #pragma unroll
   for (int f = 0; f < 5; ++f) *reinterpret_cast<float4*>(o + (long long)f * N + i) = make_float4(s[f][0], s[f][1], s[f][2], s[f][3]);
 }
+// W AND H passes of the 5 product fields in one launch (r = 4): a workgroup owns a 32 x 64 tile of one (b, z) plane, stages
+// I and J over (32 + 8) x (64 + 8) positions (zero outside the image = the zero padding of the reference's box filter),
+// forms the W-window sums of the 5 products for the 40 rows in LDS and sums 9 rows of them per output: the five
+// intermediate fields of the W pass never travel (137 MB out + 137 MB back in at 160x192x224).  Plain 9-term sums, as in the
+// separate passes (no running differences).
+__global__ __launch_bounds__(256) void ncc_prod_boxwh_k(const float* __restrict__ I, const float* __restrict__ J,
+                                                        float* __restrict__ o, long long N, int H, int W, int nty, int ntx) {
+  constexpr int TY = 32, TX = 64, R = 4, PY = TY + 2 * R, PX = TX + 2 * R;
+  __shared__ float sI[PY][PX + 1], sJ[PY][PX + 1];
+  __shared__ float sS[5][PY][TX + 1];
+  const int tid = threadIdx.x;
+  int q = blockIdx.x;
+  const int tx = q % ntx; q /= ntx;
+  const int ty = q % nty;
+  const long long plane = q / nty;
+  const int y0 = ty * TY, x0 = tx * TX;
+  const float* pI = I + plane * H * W;
+  const float* pJ = J + plane * H * W;
+  {   // all loads of the thread in flight before the first LDS store (12 x 2 per thread)
+    constexpr int NE = (PY * PX + 255) / 256;
+    float vi[NE], vj[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, r = e / PX, c = e - r * PX;
+      const int y = y0 - R + r, x = x0 - R + c;
+      const bool in = e < PY * PX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      vi[u] = in ? pI[(long long)y * W + x] : 0.f;
+      vj[u] = in ? pJ[(long long)y * W + x] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, r = e / PX, c = e - r * PX;
+      if (e < PY * PX) { sI[r][c] = vi[u]; sJ[r][c] = vj[u]; }
+    }
+  }
+  __syncthreads();
+  // W sums: job = (row of 40, 16 consecutive columns): 160 jobs
+  if (tid < PY * (TX / 16)) {
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    float a[24], b[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) { a[j] = sI[r][c0 + j]; b[j] = sJ[r][c0 + j]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const float u = a[j + d], v = b[j + d];
+        s0 += u; s1 += v; s2 += u * u; s3 += v * v; s4 += u * v;
+      }
+      sS[0][r][c0 + j] = s0; sS[1][r][c0 + j] = s1; sS[2][r][c0 + j] = s2; sS[3][r][c0 + j] = s3; sS[4][r][c0 + j] = s4;
+    }
+  }
+  __syncthreads();
+  // H sums: thread = (column x, 8 consecutive rows)
+  const int x = tid & 63, yb = (tid >> 6) * 8;
+  if (x0 + x >= W) return;
+#pragma unroll
+  for (int f = 0; f < 5; ++f) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = sS[f][yb + j][x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int y = y0 + yb + j;
+      if (y < H) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) s += v[j + d];
+        o[(long long)f * N + plane * H * W + (long long)y * W + x0 + x] = s;
+      }
+    }
+  }
+}
 static void ncc_prod_boxw_launch(const float* I, const float* J, float* o, long long N, int W, int r, hipStream_t st);
 // out[f][v] = sum_{d} in[f][v + d*stride] over the axis of length `len` (coordinate = (v/stride)%len)
 __global__ __launch_bounds__(256) void box_axis_k(const float* __restrict__ in, float* __restrict__ out,
@@ -429,6 +503,93 @@ __global__ __launch_bounds__(256) void ncc_fields_k(const float* __restrict__ s,
   const float Cq = -A * t.uJ - 2.f * Bq * t.uI;
   fld[i] = A; fld[N + i] = Bq; fld[2 * N + i] = Cq;
 }
+// The three gradient fields AND their W and H box passes in one launch (r = 4), tiled like ncc_prod_boxwh_k: the fields are
+// evaluated from the 5 saved box sums over (32 + 8) x (64 + 8) positions of a (b, z) plane (zero outside the image), summed
+// over 9 columns, then over 9 rows -- the field tensor and its W-summed copy never travel.
+__global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restrict__ s, const float* __restrict__ ws,
+                                                          const float* __restrict__ gout, float* __restrict__ o, long long N,
+                                                          int H, int W, int nty, int ntx, float wn, float eps) {
+  constexpr int TY = 32, TX = 64, R = 4, PY = TY + 2 * R, PX = TX + 2 * R;
+  __shared__ float sF[3][PY][PX + 1];
+  __shared__ float sS[3][PY][TX + 1];
+  const int tid = threadIdx.x;
+  int q = blockIdx.x;
+  const int tx = q % ntx; q /= ntx;
+  const int ty = q % nty;
+  const long long plane = q / nty;
+  const int y0 = ty * TY, x0 = tx * TX;
+  const float m = ws[0] / (float)N;
+  const float kappa = m > 0.f ? gout[0] * (-0.5f / sqrtf(m)) / (float)N : 0.f;
+  {
+    constexpr int NE = (PY * PX + 255) / 256;
+    float v[NE][5];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, r = e / PX, c = e - r * PX;
+      const int y = y0 - R + r, x = x0 - R + c;
+      const bool in = e < PY * PX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+      const long long i = plane * H * W + (long long)y * W + x;
+#pragma unroll
+      for (int f = 0; f < 5; ++f) v[u][f] = in ? s[(long long)f * N + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + 256 * u, r = e / PX, c = e - r * PX;
+      const int y = y0 - R + r, x = x0 - R + c;
+      if (e < PY * PX) {
+        float A = 0.f, Bq = 0.f, Cq = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {      // the same arithmetic as ncc_terms / ncc_fields_k
+          const float Is = v[u][0], Js = v[u][1], I2 = v[u][2], J2 = v[u][3], IJ = v[u][4];
+          const float uI = Is / wn, uJ = Js / wn;
+          const float cross = IJ - uJ * Is - uI * Js + uI * uJ * wn;
+          const float Iv = I2 - 2.f * uI * Is + uI * uI * wn;
+          const float Jv = J2 - 2.f * uJ * Js + uJ * uJ * wn;
+          const float den = Iv * Jv + eps;
+          A = kappa * (2.f * cross / den);
+          Bq = kappa * (-(cross * cross) * Jv / (den * den));
+          Cq = -A * uJ - 2.f * Bq * uI;
+        }
+        sF[0][r][c] = A; sF[1][r][c] = Bq; sF[2][r][c] = Cq;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < PY * (TX / 16)) {
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      float a[24];
+#pragma unroll
+      for (int j = 0; j < 24; ++j) a[j] = sF[f][r][c0 + j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) t += a[j + d];
+        sS[f][r][c0 + j] = t;
+      }
+    }
+  }
+  __syncthreads();
+  const int x = tid & 63, yb = (tid >> 6) * 8;
+  if (x0 + x >= W) return;
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = sS[f][yb + j][x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int y = y0 + yb + j;
+      if (y < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) t += v[j + d];
+        o[(long long)f * N + plane * H * W + (long long)y * W + x0 + x] = t;
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void ncc_combine_k(const float* __restrict__ I, const float* __restrict__ J,
                                                      const float* __restrict__ bx, float* __restrict__ dI,
                                                      long long N) {
@@ -553,10 +714,16 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
   hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   float wn;
+  static DfOptFlag nofuse_o{"DFMIR_NCC_NO_WH_FUSE"};         // A/B: the W and H passes as separate launches
   if (D > 1) {
-    ncc_prod_boxw_launch(I, J, tmp, N, W, r, st);
-    DF_LAUNCH_CHECK();
-    box_axis_launch(tmp, tmp2, 5, N, W, H, r, st);
+    if (r == 4 && !nofuse_o.get()) {
+      const int nty = (H + 31) / 32, ntx = (W + 63) / 64;
+      ncc_prod_boxwh_k<<<(unsigned)((long long)B * D * nty * ntx), 256, 0, st>>>(I, J, tmp2, N, H, W, nty, ntx);
+    } else {
+      ncc_prod_boxw_launch(I, J, tmp, N, W, r, st);
+      DF_LAUNCH_CHECK();
+      box_axis_launch(tmp, tmp2, 5, N, W, H, r, st);
+    }
     DF_LAUNCH_CHECK();
     box_axis_launch(tmp2, tmp, 5, N, (long long)H * W, D, r, st);
     DF_LAUNCH_CHECK();
@@ -584,12 +751,19 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
   const int r = win / 2;
   const unsigned grid = (unsigned)((N + 255) / 256);
   const float wn = (D > 1) ? (float)win * win * win : (float)win * win;
-  ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps);
-  DF_LAUNCH_CHECK();
-  box_axis_launch(tmp, tmp2, 3, N, 1, W, r, st);
-  DF_LAUNCH_CHECK();
-  box_axis_launch(tmp2, tmp, 3, N, W, H, r, st);
-  DF_LAUNCH_CHECK();
+  static DfOptFlag nofuse_o{"DFMIR_NCC_NO_WH_FUSE"};         // A/B: fields, W and H passes as separate launches
+  if (r == 4 && D > 1 && !nofuse_o.get()) {
+    const int nty = (H + 31) / 32, ntx = (W + 63) / 64;
+    ncc_fields_boxwh_k<<<(unsigned)((long long)B * D * nty * ntx), 256, 0, st>>>(sums, ws, gout, tmp, N, H, W, nty, ntx, wn, eps);
+    DF_LAUNCH_CHECK();
+  } else {
+    ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps);
+    DF_LAUNCH_CHECK();
+    box_axis_launch(tmp, tmp2, 3, N, 1, W, r, st);
+    DF_LAUNCH_CHECK();
+    box_axis_launch(tmp2, tmp, 3, N, W, H, r, st);
+    DF_LAUNCH_CHECK();
+  }
   const float* fin = tmp;
   if (D > 1) {
     box_axis_launch(tmp, tmp2, 3, N, (long long)H * W, D, r, st);

@@ -50,7 +50,8 @@ const char* dfmir_last_error(void);
  *     DFMIR_CONV3D_NO_MULTI, DFMIR_CONV3D_WGS=n, DFMIR_WSPLIT_WGS=n, DFMIR_CONV3D_NO_UPPHASE,
  *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED, DFMIR_CONV3D_NO_MARCH,
  *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (experimental one-wave kernel),
- *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad).
+ *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad),
+ *     DFMIR_NCC_NO_WH_FUSE.
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);
@@ -518,7 +519,8 @@ int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, in
                           int H, int W, void* stream);
 /* NCC_Loss (util/losses.py:183-261), mean kernel of `win` per axis (odd), zero padding:
  * out = -sqrt(mean(cross^2/(Ivar*Jvar+eps))).  tmp: 5*numel floats of scratch (box sums, kept for
- * backward). I = prediction, J = target, [B,1,D,H,W]. */
+ * backward). I = prediction, J = target, [B,1,D,H,W].  3-D, win 9: the W and H box passes run in one launch each way
+ * (products / gradient fields formed on a haloed LDS tile); DFMIR_NCC_NO_WH_FUSE=1 = one launch per axis. */
 int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float* ws, float* out,
                   int B, int D, int H, int W, int win, float eps, void* stream);
 int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,

@@ -825,6 +825,28 @@ def test_losses_golden(ops, golden):
         close(l, g["ncc" + tag], what="ncc" + tag); close(I.grad, g["dncc" + tag], rtol=1e-3, what="dncc" + tag)
 
 
+def test_ncc_fused_box_passes_match_the_separate_ones(ops):
+    """NCC[9,9,9] (torchvoxelmorph/losses.py NCC: 5 box-filtered product fields forward, 3 gradient fields backward): the
+    launches that fuse the W and H box passes (with the products / with the field evaluation) through one LDS tile against
+    the separate passes (DFMIR_NCC_NO_WH_FUSE=1, the form the golden vectors pin) on a volume of several ragged tiles and a
+    batch: loss and gradient agree to fp32 summation order."""
+    from dfmir_amd._lib import set_option
+    I = C.rand(171, 2, 1, 6, 70, 150)
+    J = (0.6 * I + 0.4 * C.rand(172, 2, 1, 6, 70, 150)).to(DEV)
+    res = []
+    try:
+        for off in (None, "1"):
+            set_option("DFMIR_NCC_NO_WH_FUSE", off)
+            Ig = I.clone().to(DEV).requires_grad_()
+            l = ops.ncc_loss(Ig, J, 9, 1e-5)
+            l.backward()
+            res.append((l.detach().clone(), Ig.grad.clone()))
+    finally:
+        set_option("DFMIR_NCC_NO_WH_FUSE", None)
+    close(res[0][0], res[1][0], rtol=1e-6, what="ncc fused vs separate")
+    close(res[0][1], res[1][1], rtol=2e-5, what="dncc fused vs separate")
+
+
 def test_adam_matches_torch(ops):
     from dfmir_amd.optim import FlatAdam
     ps = [C.randn(81, 37, 5), C.randn(82, 129)]
