@@ -625,26 +625,42 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
     unsigned so0 = 0, so1 = UW_ASLOT, so2 = 2 * UW_ASLOT;
     unsigned sb0 = 0, sb1 = UW_BSLOT, sb2 = 2 * UW_BSLOT, sb3 = 3 * UW_BSLOT;
     {
+      // every load of the prologue in flight before the first conversion: one round trip per item, not seven
       const unsigned y0off = UW_YOFFS(2 * z0, true), y1off = UW_YOFFS(2 * z0 + 1, true);
 #pragma unroll
       for (int c = 0; c < 8; ++c) { UW_YLOAD(c, y0off) }
+      u32x2w pa[3][8], pb[3][2];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const int P = z0 - 1 + p;
-        const bool ok = P >= 0 && P < k.Dl;
-        const unsigned a0 = UW_AOFFS(P, ok);
+        const unsigned a0 = UW_AOFFS(P, P >= 0 && P < k.Dl);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { UW_ALOAD(c, a0) }
-        UW_ACONV(0, (unsigned)p * UW_ASLOT) UW_ACONV(1, (unsigned)p * UW_ASLOT)
-      }
-      if constexpr (FUSEB) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const int P = 2 * z0 - 1 + p;
-          UW_BLOAD(UW_BOFFS(P, P >= 0))
-          UW_BCONV((unsigned)p * UW_BSLOT)
+        for (int c = 0; c < 8; ++c)
+          if (!(UW_KO & 2)) pa[p][c] = __builtin_amdgcn_raw_buffer_load_b64(asrc, a0, (unsigned)c * Sl4, 0);
+        if constexpr (FUSEB) {
+          const int Pb = 2 * z0 - 1 + p;
+          const unsigned b0 = UW_BOFFS(Pb, Pb >= 0);
+          if (!(UW_KO & 2)) {
+            pb[p][0] = __builtin_amdgcn_raw_buffer_load_b64(bsrc, b0, 0, 0);
+            pb[p][1] = __builtin_amdgcn_raw_buffer_load_b64(bsrc, b0, S4, 0);
+          }
         }
       }
+#define UW_V_PA(c_) pa[p][c_][e]
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (ast[e] != OOB) { UW_CONV_ST(UW_V_PA, ascale, ast[e] + (unsigned)p * UW_ASLOT, UW_ASPLIT) }
+          if (FUSEB && !(UW_KO & 4) && bst[e] != OOB) {
+            unsigned h_, r_;
+            split_pair_u(__uint_as_float(pb[p][0][e]), __uint_as_float(pb[p][1][e]), ascale, h_, r_);
+            const unsigned so_ = (unsigned)p * UW_BSLOT;
+            UW_LDS_ST4(bst[e] + so_, h_) UW_LDS_ST4(bsy[e] + so_, h_)
+            UW_LDS_ST4(bst[e] + so_ + UW_BSPLIT, r_) UW_LDS_ST4(bsy[e] + so_ + UW_BSPLIT, r_)
+          }
+        }
+#undef UW_V_PA
       UW_YCONV(0, 0) UW_YCONV(1, 0) UW_YCONV(2, 0) UW_YCONV(3, 0)
 #pragma unroll
       for (int c = 0; c < 8; ++c) { UW_YLOAD(c, y1off) }
