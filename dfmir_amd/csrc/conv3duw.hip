@@ -10,27 +10,29 @@
 // direct form (conv3d_wgrad_tr_k<., ., UPCAT>, which multiplies every duplicated value again), the same sums in another
 // order.  Zero padding carries over (a[-1] = a[D/2] = 0 are exactly the padded voxels of the up-sampled tensor).
 //
-// Kernel.  G does not depend on the position, so a workgroup keeps ALL of it in registers for its whole life: 512
-// threads = 8 waves = (py, px) x (iz), a wave holds the 2 (pz) x 4 (iy, ix) tiles of 32 x 32 (128 accumulator registers)
-// and the workgroup marches along z over 4 x 16 low-resolution columns: every plane of `a` (6 x 18 positions x 32
-// channels, ring of three) and every plane of dY (8 x 32 voxels x 32 channels, de-interleaved into its four (py, px)
-// sub-lattices as it is written to LDS, two buffers) is staged ONCE, as scaled fp16 pairs (a = (a0 + a1) / s, products
-// a0 b0 + a0 b1 + a1 b0 on v_mfma_f32_32x32x16_f16, fp32 accumulate: conv3ds.hip).  K = 16 low-resolution voxels of an
-// x-row; both operands are K-major reads of channel-minor images through ds_read_b64_tr_b16 (conv3d_wgrad_tr_k has the
-// lane algebra); an `a` row serves the two dY rows it meets (iy = 0 / 1): 56 operand reads per 48 MFMAs.  One barrier per
-// half-step (one dY plane = 48 MFMAs per wave); the next plane's global loads are spread over the MFMA groups.
-// A workgroup walks several (column, z-segment) items and ends with ONE set of atomics into the 64-tile workspace; a small
-// second kernel folds the workspace into the tap-major gradient.  The skip channels b (2 at the top level) keep the
-// direct kernel (conv3ds.hip::dfmir_conv3d_upwgrad).
+// Kernels.  G does not depend on the position, so a workgroup keeps ALL of it in registers for its whole life and marches
+// along z over 4 x 16 low-resolution columns: every plane of `a` (6 x 18 positions x 32 channels, ring of three) and every
+// plane of dY (8 x 32 voxels x 32 channels, de-interleaved into its four (py, px) sub-lattices as it is written to LDS,
+// two buffers) is staged ONCE, as scaled fp16 pairs (a = (a0 + a1) / s, products a0 b0 + a0 b1 + a1 b0 on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate: conv3ds.hip).  K = 16 low-resolution voxels of an x-row; both operands are
+// K-major reads of channel-minor images through ds_read_b64_tr_b16 (conv3d_wgrad_tr_k has the lane algebra); an `a` row
+// serves the two dY rows it meets (iy = 0 / 1).  One barrier per half-step (= one dY plane).  A workgroup walks several
+// (column, z-segment) items and ends with ONE set of atomics into the 72-tile workspace; small kernels fold it into the
+// tap-major gradient.
+//   conv3d_upwgrad4_k<FUSEB>  THE PRODUCT PATH: 256 threads = 4 waves = the (py, px) classes, one wave per SIMD with 512
+//                             registers per lane (16 tiles = the 256 AGPRs); FUSEB: the two skip channels of the top level
+//                             and the bias gradient in the same launch (described at the kernel).  Without FUSEB the skip
+//                             channels keep the direct kernel (conv3ds.hip::dfmir_conv3d_upwgrad).
+//   conv3d_upwgrad_k          the first form, kept as an A/B (DFMIR_UPWGRAD_8WAVE): 512 threads = 8 waves = (py, px) x (iz),
+//                             two waves per SIMD, 8 tiles per wave, never fused.  Same speed on the up-sampled share
+//                             (profiles/r05_bench_upwgrad.txt): these kernels are bound by the sum of their matrix and staging
+//                             work, not by how the waves share it (hardware fact 10).
 #include "conv3x3_common.h"
 #include <type_traits>
 
 typedef _Float16 f16x8_u __attribute__((ext_vector_type(8)));
 typedef short s16x4_u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_u* lds_tr_ptr_u;
-#ifndef UW_LDPOS
-#define UW_LDPOS 0   // staging loads of a half-step: 0 one per MFMA group 1..8, 1 all before the first group, 2 two per group 0..3
-#endif
 #ifndef UW_KO
 #define UW_KO 0      // knock-out builds (timing only): 1 no MFMAs, 2 no staging loads, 4 no conversion + LDS stores, 8 no operand reads,
                      // 16 no epilogue atomics (one store per lane instead), 32 dY loads from a cache-resident 4 KB (4-wave kernel)
