@@ -587,8 +587,12 @@ def test_failed_capture_falls_back_to_a_correct_eager_step(O):
         close(g_[1], r_[1], rtol=1e-6, what="fake_B step %d" % (k + 3))
         close(g_[2], r_[2], rtol=1e-6, what="registered step %d" % (k + 3))
         gscale = max(float(x.norm()) for x in r_[3])
+        # step 4 starts from weights that already differ by the float-atomic round-off of step 3's weight gradients through
+        # Adam (see below): its gradients differ by up to 4e-5 of their norm (2 of 30 runs exceeded the step-3 bound);
+        # a stale packed weight or a garbage probe pool is a 1e-2 .. 1 effect
+        gtol = 2e-5 if k == 0 else 1e-4
         for nm, a, b in zip("GRF", g_[3], r_[3]):
-            assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 2e-6 * gscale, (k, nm)
+            assert float((a - b).norm()) <= gtol * float(b.norm()) + 0.1 * gtol * gscale, (k, nm)
         if k == 0:
             # weights after step 3's Adam update: round-off of the weight gradients' float atomics becomes lr-sized
             # differences on elements whose gradient is at round-off level (0.4 % of the update's norm measured); stale
