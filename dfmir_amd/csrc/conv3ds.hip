@@ -2538,7 +2538,8 @@ extern "C" int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const f
                                     int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                     float* db, float* ws, void* stream) {
   DF_ARG_CHECK(g && a && b && ws && x_amax && x_amax_n > 0 && dy && dy_amax && dy_amax_n > 0 && dw_tcc);
-  DF_ARG_CHECK(upwgrad_geom_ok(g, Ca) && (reinterpret_cast<uintptr_t>(a) & 15) == 0);
+  DF_ARG_CHECK(upwgrad_geom_ok(g, Ca) && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 7) == 0 &&
+               (reinterpret_cast<uintptr_t>(dy) & 15) == 0);   // 8-byte pair loads of a and b, 16-byte quads of dY
   const long long s_tap = (long long)g->Cin * g->Cout;
   // two skip channels (the network's input images at the top level): fused into the same launch, with the bias gradient
   static DfOptFlag nofuse_o{"DFMIR_UPWGRAD_NO_FUSEB"};
