@@ -2527,6 +2527,8 @@ extern "C" int dfmir_conv3d_split_wgrad_upcat(const DfConvGeom* g, const float* 
 int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const float* b, const float* dy, const float* dy_amax,
                              int dy_n, float* dwt, long long s_tap, float* db, float* ws, int N, int Dl, int Hl, int Wl,
                              int Cout, hipStream_t st);
+int df_conv3d_wgrad_march_launch(const float* x, const float* x_amax, int x_n, const float* dy, const float* dy_amax, int dy_n,
+                                 float* dwt, float* db, int N, int D, int H, int W, hipStream_t st);
 static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
   static DfOptFlag off_o{"DFMIR_UPWGRAD_DIRECT"};
   return !off_o.get() && !split3d_off() && split3d_wgrad_common_ok(g) && Ca == 32 && g->Cin > Ca && g->Cin - Ca <= 128 &&
@@ -2572,6 +2574,11 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   const bool rows = s_tap_full > 0 && split3d_wgrad_common_ok(g) && g->Cin >= 1 && g->Cin <= 128 && g->Cout >= 8 && g->Cout <= 32;
   DF_ARG_CHECK(!split3d_off() && (rows || split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
   hipStream_t st = (hipStream_t)stream;
+  // the full-resolution 32 -> 16 layer: all 27 tap matrices resident, z-marching (conv3dwm.hip)
+  static DfOptFlag nomarch_o{"DFMIR_CONV3D_NO_WGRAD_MARCH"};
+  if (!rows && !xa && g->Cin == 32 && g->Cout == 16 && split3d_wgrad_geom_ok(g) && !nomarch_o.get() &&
+      (long long)g->Di * g->Hi * g->Wi >= 4096 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
+    return df_conv3d_wgrad_march_launch(x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, g->N, g->Di, g->Hi, g->Wi, st);
   const bool swapped = !rows && !split3d_wgrad_geom_ok(g);
   W3sP k{};
   k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;

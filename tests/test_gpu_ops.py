@@ -492,6 +492,42 @@ def test_upwgrad_parity_class_kernel(ops, cfg, form, monkeypatch):
         set_option("DFMIR_UPWGRAD_NSEG", None)
 
 
+@pytest.mark.parametrize("cfg", [(1, 9, 37, 72), (2, 5, 13, 40), (1, 12, 8, 32), (1, 3, 20, 68)],
+                         ids=["ragged", "batch2", "z-segments", "three-planes"])
+def test_conv3d_wgrad_march_kernel(ops, cfg):
+    """conv3d_wgrad_march_k (csrc/conv3dwm.hip): weight and bias gradient of the full-resolution 32 -> 16 3x3x3 layer
+    (torchvoxelmorph/networks.py:73-86) with all 27 tap matrices resident in one wave's accumulators, z-marching -- against
+    torch fp64 and against the tiled kernel it replaces (DFMIR_CONV3D_NO_WGRAD_MARCH=1); ragged columns (H % 8, W % 32 != 0),
+    forced z segments, a batch, accumulation into an existing gradient."""
+    from dfmir_amd._lib import set_option
+    N, D, H, W = cfg
+    x = C.randn(221, N, 32, D, H, W)
+    dy = C.randn(222, N, 16, D, H, W) * 1e-3
+    wr = torch.zeros(16, 32, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), wr, None, padding=1).backward(dy.double())
+    ref = wr.grad.permute(2, 3, 4, 1, 0).reshape(27, 32, 16)               # tap-major packing [27][Cin][Cout]
+    dbref = dy.double().sum((0, 2, 3, 4))
+    xg, dyg = x.to(DEV), dy.to(DEV)
+    xa, da = ops.absmax(xg).clone(), ops.absmax(dyg).clone()
+    got = {}
+    try:
+        for tag, off, nseg in (("march", None, None), ("march-3seg", None, 3), ("tiled", "1", None)):
+            set_option("DFMIR_CONV3D_NO_WGRAD_MARCH", off)
+            set_option("DFMIR_WGRAD_MARCH_NSEG", nseg)
+            db = torch.zeros(16, device=DEV)
+            dw = ops.conv_wgrad_raw(xg, dyg, (3, 3, 3), 1, (1, 1, 1), 0, x_amax=xa, dy_amax=da, db=db)
+            close(dw, ref, rtol=1e-4, atol=0, what="dW " + tag)
+            close(db, dbref, rtol=1e-4, atol=0, what="db " + tag)
+            dw2 = ops.conv_wgrad_raw(xg, dyg, (3, 3, 3), 1, (1, 1, 1), 0, out=dw.clone(), x_amax=xa, dy_amax=da, db=db)
+            close(dw2, 2 * ref, rtol=1e-4, atol=0, what="dW accumulated " + tag)
+            close(db, 2 * dbref, rtol=1e-4, atol=0, what="db accumulated " + tag)
+            got[tag] = dw
+    finally:
+        set_option("DFMIR_CONV3D_NO_WGRAD_MARCH", None)
+        set_option("DFMIR_WGRAD_MARCH_NSEG", None)
+    close(got["march"], got["tiled"], rtol=2e-5, atol=0, what="march vs tiled")
+
+
 def test_conv3d_chain_folds_leaky_relu_backward(ops):
     """A chain of LeakyReLU ConvBlocks whose outputs feed only the next conv (conv(sole=True)): the consumer's dgrad
     epilogue applies the activation's derivative (dfmir_conv3d_split_fwd_actgrad), so no act_bwd pass runs between
