@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 10
+#define DFMIR_ABI_VERSION 11
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -51,7 +51,7 @@ const char* dfmir_last_error(void);
  *     DFMIR_CONV3D_WGRAD_COPIES, DFMIR_CONV3D_WGRAD_NO_PAIR, DFMIR_IN_BLUR_BANDED, DFMIR_CONV3D_NO_MARCH,
  *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (experimental one-wave kernel),
  *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad),
- *     DFMIR_NCC_NO_WH_FUSE.
+ *     DFMIR_NCC_NO_WH_FUSE, DFMIR_CONV3D_NO_WGRAD_MARCH, DFMIR_WGRAD_MARCH_NSEG=n.
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);
@@ -228,6 +228,10 @@ int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, in
  * swapped: rows = (tap, co) from shifted dy, columns = ci. */
 int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n, const float* dy,
                                 const float* dy_amax, int dy_amax_n, float* dw_tcc, float* db, void* stream);
+/* 1 when dfmir_conv3d_split_wgrad / _db run this layer on conv3d_wgrad_march_k (csrc/conv3dwm.hip): Cin 32, Cout 16 (the
+ * full-resolution ConvBlock of `extras`, networks.py:73-86) -- all 27 tap matrices resident in one wave's accumulators, the
+ * workgroup marching along z, both operands read once.  A/B: DFMIR_CONV3D_NO_WGRAD_MARCH=1; DFMIR_WGRAD_MARCH_NSEG=n. */
+int dfmir_conv3d_wgrad_is_march(const DfConvGeom* g);
 /* out[0..DFMIR_PROBE_SLOTS) = max(a, b): the probe of cat([nearest_up2(a), b]) from its inputs' probes. */
 int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */

@@ -53,6 +53,7 @@ DFMIR_UPWGRAD_MIN_VOX=0 DFMIR_UPWGRAD_NO_FUSEB=1 TAG=skip-share-on-the-direct-ke
 DFMIR_UPWGRAD_MIN_VOX=0 DFMIR_UPWGRAD_NO_FUSEB=1 DFMIR_UPWGRAD_8WAVE=1 TAG=two-waves-per-SIMD python scripts/bench_upwgrad.py 2>&1 | grep -v amdgpu.ids >> $O/bench_upwgrad.txt
 if [ -f build/ko/libdfmir_hip_uwko14.so ]; then rm -f gpurun_out/upwgrad_ko.txt; bash scripts/gpu_upwgrad_ko.sh - 1 2 32 8 14 15 16 > /dev/null 2>&1; cp gpurun_out/upwgrad_ko.txt $O/upwgrad_ko.txt; fi
 for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_UPWGRAD_DIRECT=1; else unset DFMIR_UPWGRAD_DIRECT; fi; echo "DFMIR_UPWGRAD_DIRECT=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-72; done > $O/ab_upwgrad_3d.txt 2>&1; unset DFMIR_UPWGRAD_DIRECT
+for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_CONV3D_NO_WGRAD_MARCH=1; else unset DFMIR_CONV3D_NO_WGRAD_MARCH; fi; echo "DFMIR_CONV3D_NO_WGRAD_MARCH=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-72; ONLY=32-16 python scripts/bench_conv3d.py 2>/dev/null | tail -1; done > $O/ab_wgrad_march_3d.txt 2>&1; unset DFMIR_CONV3D_NO_WGRAD_MARCH
 for v in 0 2; do DFMIR_CS_XCD_PAIR=$v python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('DFMIR_CS_XCD_PAIR=$v', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step issued_frac', round(r['roofline']['issued_frac'],4))"; done > $O/ab_xcd_order.txt 2>&1
 rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d $R/gpurun_out/upconv_prof
 TAG=${TAG:-r05}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json

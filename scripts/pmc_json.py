@@ -101,6 +101,8 @@ def main():
                 out["conv3d_wgrad_tr_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
             if 'conv3d_march_k' in k and 'FETCH_SIZE' in c[k]:          # the z-marching kernel (csrc/conv3dm.hip)
                 out["conv3d_march_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 @160x192x224" % (cin, cout))
+            if 'conv3d_wgrad_march_k' in k and 'FETCH_SIZE' in c[k]:    # the marching weight gradient (csrc/conv3dwm.hip)
+                out["conv3d_wgrad_march_k_%d_%d" % (cin, cout)] = entry(k, d, c[k], alg, "%d->%d 3x3x3 weight gradient @160x192x224" % (cin, cout))
     if not from_prof and os.path.exists(C + "pmc_conv3d_march.txt"):
         d, c = parse(open(C + "pmc_conv3d_march.txt").read())
         for k in c:

@@ -14,7 +14,7 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'step_trace_3d_128.txt': TAG + '_step_trace_3d_128.txt', 'bench_upconv3d.txt': TAG + '_bench_upconv3d.txt',
       'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'overlap_trace.txt': TAG + '_overlap_trace.txt', 'bench_in_blurdown.txt': TAG + '_bench_in_blurdown.txt',
       'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json', 'bench_march.txt': TAG + '_bench_march.txt', 'ab_march_3d.txt': TAG + '_ab_march_3d.txt', 'march_trace.txt': TAG + '_march_trace.txt', 'bench_upwgrad.txt': TAG + '_bench_upwgrad.txt', 'upwgrad_ko.txt': TAG + '_upwgrad_ko.txt',
-      'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt'}
+      'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt', 'ab_wgrad_march_3d.txt': TAG + '_ab_wgrad_march_3d.txt'}
 def clean(txt):
     txt = txt.replace("(anonymous namespace)::", "")
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
@@ -62,7 +62,7 @@ def gf_of(k, gf):
 for sec, gf in ((s1, 404.29), (s2, 190.25), (s3, 95.13)):
     d, c = parse(sec)
     for k in c:
-        if k in d and ('conv3d_split_k' in k or 'wgrad_tr' in k or 'conv3d_march_k' in k or 'split_m16' in k) and 'FETCH_SIZE' in c[k] and 'SQ_LDS_IDX_ACTIVE' in c[k] and 'GRBM_GUI_ACTIVE' in c[k]:
+        if k in d and ('conv3d_split_k' in k or 'wgrad_tr' in k or 'conv3d_march_k' in k or 'split_m16' in k or 'wgrad_march' in k) and 'FETCH_SIZE' in c[k] and 'SQ_LDS_IDX_ACTIVE' in c[k] and 'GRBM_GUI_ACTIVE' in c[k]:
             if sec is s3 and 'conv3d_march_k' not in k:
                 continue
             md3 += row(k, d[k], c[k], gf_of(k, gf), "z-marching kernel (csrc/conv3dm.hip)" if 'march' in k else "") + "\n"
