@@ -65,7 +65,7 @@ for sec, gf in ((s1, 404.29), (s2, 190.25), (s3, 95.13)):
         if k in d and ('conv3d_split_k' in k or 'wgrad_tr' in k or 'conv3d_march_k' in k or 'split_m16' in k or 'wgrad_march' in k) and 'FETCH_SIZE' in c[k] and 'SQ_LDS_IDX_ACTIVE' in c[k] and 'GRBM_GUI_ACTIVE' in c[k]:
             if sec is s3 and 'conv3d_march_k' not in k:
                 continue
-            md3 += row(k, d[k], c[k], gf_of(k, gf), "z-marching kernel (csrc/conv3dm.hip)" if 'march' in k else "") + "\n"
+            md3 += row(k, d[k], c[k], gf_of(k, gf), ("marching weight gradient, 27 tap matrices resident (csrc/conv3dwm.hip)" if 'wgrad_march' in k else ("z-marching kernel (csrc/conv3dm.hip)" if 'march' in k else ""))) + "\n"
 md3 += ("\nSustained clocks / package power with each kernel running back to back (`scripts/sustain_clock3d.py`, `{TAG}_power_clock_3d.txt`): the weight-gradient kernel holds the package AT its 1 400 W cap (1.72–1.81 GHz), the forward kernel just under it (1 377–1 392 W at 1.98–2.04 GHz).  On the cap only energy per useful FLOP buys speed: skipping the padding row tile (1/8 of the reads and MFMAs of the 7-tile form) took 34→32 from 1.815 to 1.715 ms although no wave finishes earlier; making the forward kernel persistent, prefetching across tiles or staggering the two workgroups of a CU changed nothing.\n")
 open(P + TAG + '_conv3d_pmc.md', 'w').write(md3.replace('{TAG}', TAG))
 if os.path.exists(C + 'pmc_upconv3d.txt'):
