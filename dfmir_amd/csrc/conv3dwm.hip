@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_march_k(const float* __re
   // columns of the patch are not stored.
   const int fq = tid & 7, fr = (tid >> 3) & 7;
   const bool sjob = tid < 200;
-  const int js = sjob ? tid : 0, scg = js / 100, srr = js - 100 * scg, shy = srr / 10, sqq = srr - 10 * shy;
+  // (channel group in the lowest bit: the 8 lanes of a ds_write_b128 group then cover 4 of the 8 possible 16-byte slots of
+  // the 256-byte bank window twice instead of 2 of them four times)
+  const int js = sjob ? tid : 0, scg = js & 1, srr = js >> 1, shy = srr / 10, sqq = srr - 10 * shy;
   const unsigned fst0 = lbase + (unsigned)(((fr * 32 + 4 * fq) * 4 + (wid ^ (fq & 3))) * 16);     // element e: + e * 64
   unsigned sst[4];
 #pragma unroll
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_march_k(const float* __re
       }
     });
   }
-  if (k.db) {   // threads 0 .. 99: channels 0-7, 100 .. 199: channels 8-15
+  if (k.db) {   // even threads below 200: channels 0-7, odd ones: channels 8-15
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float v0 = wave_sum((sjob && scg == 0) ? bacc[c] : 0.f), v1 = wave_sum((sjob && scg == 1) ? bacc[c] : 0.f);
