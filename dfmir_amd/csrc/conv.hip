@@ -291,6 +291,64 @@ __global__ __launch_bounds__(256) void conv_small_k(const float* __restrict__ x,
   }
 }
 
+// Few output voxels (the deepest U-Net levels of the 6-level 3-D plugin network: 8^3, 4^3 and 2^3 volumes, forward and the
+// dgrads of the stride-2 convs): ONE WORKGROUP PER OUTPUT VOXEL, thread = (output channel co, tap share kp): the taps are
+// dealt round-robin to the 256 / COP shares, weights [tap][ci][co] are read coalesced along co, the input value is a
+// broadcast, fp32 FMAs; the shares meet in LDS.  conv_mfma_k walks K = taps x Cin = 864 .. 1728 serially in one or two
+// workgroups for these shapes (70 us per launch, 0.62 of the 3.6 ms step at 128^3); a thread per output element still walks it
+// serially behind its load latencies (49 us); here a thread sees 3-4 taps (8 us).
+// (Eight voxels per workgroup for 16^3, sharing each weight value, measured slower than conv_mfma_k there: not kept.)
+template <int COP>
+__global__ __launch_bounds__(256) void conv_tinyvol_k(const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, float* __restrict__ y, DfConvGeom g) {
+  constexpr int KP = 256 / COP;
+  __shared__ float sm[KP][COP];
+  const long long DHWi = (long long)g.Di * g.Hi * g.Wi;
+  const long long DHWo = (long long)g.Do * g.Ho * g.Wo;
+  const int co = threadIdx.x % COP, kp = threadIdx.x / COP;
+  long long t = blockIdx.x;
+  const long long pp = t;
+  const int ox = (int)(t % g.Wo); t /= g.Wo;
+  const int oy = (int)(t % g.Ho); t /= g.Ho;
+  const int oz = (int)(t % g.Do);
+  const int n = (int)(t / g.Do);
+  const float* xin = x + (long long)n * g.Cin * DHWi;
+  const int T = g.KD * g.KH * g.KW;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (co < g.Cout) {
+    for (int tap = kp; tap < T; tap += KP) {
+      const int kw = tap % g.KW, kh = (tap / g.KW) % g.KH, kd = tap / (g.KW * g.KH);
+      int iz, iy, ix;
+      const bool v = df_in_coord(oz, kd, g.stride, g.pd, g.dil, g.Di, g.pad_mode, iz) &
+                     df_in_coord(oy, kh, g.stride, g.ph, g.dil, g.Hi, g.pad_mode, iy) &
+                     df_in_coord(ox, kw, g.stride, g.pw, g.dil, g.Wi, g.pad_mode, ix);
+      if (!v) continue;
+      const float* xp = xin + ((long long)iz * g.Hi + iy) * g.Wi + ix;
+      const float* wp = wt + (long long)tap * g.Cin * g.Cout + co;
+      int ci = 0;
+      for (; ci + 8 <= g.Cin; ci += 8) {
+        float xv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xv[u] = xp[(long long)(ci + u) * DHWi]; wv[u] = wp[(long long)(ci + u) * g.Cout]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { acc0 = fmaf(xv[u], wv[u], acc0); acc1 = fmaf(xv[u + 1], wv[u + 1], acc1); }
+      }
+      for (; ci < g.Cin; ++ci) acc0 = fmaf(xp[(long long)ci * DHWi], wp[(long long)ci * g.Cout], acc0);
+    }
+  }
+  sm[kp][co] = acc0 + acc1;
+  __syncthreads();
+  if (kp == 0 && co < g.Cout) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) v += sm[j][co];
+    v += bias ? bias[co] : 0.f;
+    if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+    else if (g.act == 2) v = tanhf(v);
+    y[((long long)n * g.Cout + co) * DHWo + (pp - (long long)n * DHWo)] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient:  dWt[j][co] += sum_p Xg[j][p] * dY[co][p],  j = tap*Cin + ci
 // MFMA A operand = gathered input (rows = j), B operand = dY (cols = co): lanes 0..31 of one
@@ -672,6 +730,15 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     if (g->Cout == 1) conv_small_k<1><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else if (g->Cout == 2) conv_small_k<2><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else conv_small_k<4><<<grid, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
+  static DfOptFlag tinyvol_o{"DFMIR_NO_TINYVOL"};             // A/B: the deepest levels on conv_mfma_k
+  if (P <= 512 && g->Cout <= 64 && !tinyvol_o.get()) {
+    if (g->Cout <= 8) conv_tinyvol_k<8><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    else if (g->Cout <= 16) conv_tinyvol_k<16><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    else if (g->Cout <= 32) conv_tinyvol_k<32><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
+    else conv_tinyvol_k<64><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     DF_LAUNCH_CHECK();
     return 0;
   }

@@ -528,6 +528,38 @@ def test_conv3d_wgrad_march_kernel(ops, cfg):
     close(got["march"], got["tiled"], rtol=2e-5, atol=0, what="march vs tiled")
 
 
+@pytest.mark.parametrize("cfg", [(32, 32, 4, 1, 1), (32, 32, 2, 1, 1), (32, 48, 8, 1, 1), (16, 32, 8, 2, 1), (32, 16, 4, 1, 2), (64, 20, 4, 1, 1)],
+                         ids=["4^3", "2^3", "8^3-48out", "8^3-stride2", "4^3-dgrad-of-stride2", "4^3-20out"])
+def test_conv_tiny_volume_kernel(ops, cfg):
+    """conv_tinyvol_k (csrc/conv.hip): the convolutions of the deepest U-Net levels (<= 512 output voxels; the 6-level 3-D
+    plugin network at 128^3: torchvoxelmorph/networks.py:66-86) -- one workgroup per output voxel, taps dealt over the threads --
+    against torch fp64 through the autograd Function (forward, dx incl. the zero-dilated dgrad of a stride-2 conv, dW, db) and
+    against the generic MFMA kernel (DFMIR_NO_TINYVOL=1)."""
+    from dfmir_amd._lib import set_option
+    Cin, Cout, S, stride, batch = cfg
+    x = C.randn(231, batch, Cin, S, S, S)
+    w = C.randn(232, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5
+    b = C.randn(233, Cout) * 0.1
+    xr, wr, br = (t.double().clone().requires_grad_() for t in (x, w, b))
+    yr = F.leaky_relu(F.conv3d(xr, wr, br, stride=stride, padding=1), 0.2)
+    cot = C.randn(234, *yr.shape)
+    (yr * cot.double()).sum().backward()
+    outs = []
+    try:
+        for off in (None, "1"):
+            set_option("DFMIR_NO_TINYVOL", off)
+            xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+            yg = ops.conv(xg, wg, bg, None, stride, 1, 0, 1, 0.2)
+            (yg * cot.to(DEV)).sum().backward()
+            close(yg, yr, what="y"); close(xg.grad, xr.grad, rtol=3e-4, what="dx")
+            close(wg.grad, wr.grad, rtol=1e-3, what="dw"); close(bg.grad, br.grad, rtol=1e-3, what="db")
+            outs.append((yg.detach(), xg.grad))
+    finally:
+        set_option("DFMIR_NO_TINYVOL", None)
+    close(outs[0][0], outs[1][0], rtol=2e-6, what="y tiny-volume vs MFMA kernel")
+    close(outs[0][1], outs[1][1], rtol=2e-5, what="dx tiny-volume vs MFMA kernel")
+
+
 def test_conv3d_chain_folds_leaky_relu_backward(ops):
     """A chain of LeakyReLU ConvBlocks whose outputs feed only the next conv (conv(sole=True)): the consumer's dgrad
     epilogue applies the activation's derivative (dfmir_conv3d_split_fwd_actgrad), so no act_bwd pass runs between
