@@ -1166,9 +1166,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
   const int l31 = lane & 31, hi = lane >> 5;
   const long long S = (long long)k.D * k.H * k.W;
   // tiles: XCD-contiguous eighths, x fastest, then z, then y (as conv3d_split_k); one tile per workgroup
+  // The four (pz, py) instances of a tile sit in neighbouring workgroup ids of the SAME XCD (round 5): as the outermost grid
+  // dimension they were four passes over the volume, each re-reading the patch of `a` from memory (fetch 887 MB for 165 MB
+  // of inputs).
   const long long per_xcd = (k.ntile + 7) / 8;
-  const long long tile = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((long long)(blockIdx.x >> 3) >= per_xcd || tile >= k.ntile) return;
+  const unsigned rid = blockIdx.x >> 3;
+  const long long tile = (long long)(blockIdx.x & 7) * per_xcd + (rid >> 2);
+  if ((long long)(rid >> 2) >= per_xcd || tile >= k.ntile) return;
   int n, z0, y0, x0;
   {
     long long pid = tile;
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_up_phase_k(const float* __restr
     n = (int)(pid / k.ny);
     z0 = bz * TZ; y0 = by * TY; x0 = bx * TX;
   }
-  const int mt = blockIdx.y, pzy = blockIdx.z, pz = pzy >> 1, py = pzy & 1;
+  const int mt = blockIdx.y, pzy = (int)(rid & 3), pz = pzy >> 1, py = pzy & 1;
 
   const float amax = reduce_absmax(x_amax, k.x_n, red);
   const int ex = scale_exp3(amax);
@@ -1518,7 +1522,7 @@ static int conv3d_up_launch(const float* a, const float* a_amax, int a_amax_n, c
   C3uP k{N, Ca, Cout, D, H, W, (D + 3) / 4, (H + 7) / 8, (W + 15) / 16, nchunk, a_amax_n, 0,
          b, b_amax, b_n, Cb, bias, act, slope, y_amax};
   k.ntile = (long long)N * k.nz * k.ny * k.nx;
-  const dim3 grid((unsigned)(8 * ((k.ntile + 7) / 8)), (unsigned)nmt, 4);
+  const dim3 grid((unsigned)(32 * ((k.ntile + 7) / 8)), (unsigned)nmt, 1);
   if (Cb > 0) conv3d_up_phase_k<true><<<grid, 256, 0, st>>>(a, a_amax, reinterpret_cast<const u32x4*>(ws), trailer, y, k);
   else conv3d_up_phase_k<false><<<grid, 256, 0, st>>>(a, a_amax, reinterpret_cast<const u32x4*>(ws), trailer, y, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
