@@ -126,6 +126,11 @@ _SIGS = {
     "dfmir_masked_l1_bwd": [P, P, P, c_float, P, P, P, P, c_longlong, P],
     "dfmir_flow_smooth_fwd": [P, P, P] + [c_int] * 5 + [P],
     "dfmir_flow_smooth_bwd": [P, P, P] + [c_int] * 5 + [P],
+    "dfmir_flow_smooth_fwd_p": [P, P, P] + [c_int] * 6 + [P],
+    "dfmir_flow_smooth_bwd_p": [P, P, P] + [c_int] * 6 + [P],
+    "dfmir_mul": [P, P, P, c_longlong, P],
+    "dfmir_ncc_fwd_m": [P, P, P, c_int, P, P, P, P] + [c_int] * 5 + [c_float, P],
+    "dfmir_ncc_bwd_m": [P, P, P, c_int, P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_ncc_fwd": [P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_ncc_bwd": [P, P, P, P, P, P, P, P] + [c_int] * 5 + [c_float, P],
     "dfmir_patch_gather_fwd_multi": [P, c_int, P, P, c_int, c_int, c_longlong, c_int, P],

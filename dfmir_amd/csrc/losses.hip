@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void masked_l1_bwd_k(const float* __restrict__
 // One workgroup = RB consecutive rows (a row = W values at fixed plane, z, y): the row's coordinates are decoded once per
 // row with wave-uniform arithmetic, lanes run along x -- no per-element divisions (they used to cost more than the
 // memory traffic), every load a contiguous run.  <= 2048 workgroups: each ends in three same-address atomics.
+// L1: sum |d| instead of sum d^2 (Grad_Loss / vxm Grad with penalty 'l1': util/losses.py:92-117, torchvoxelmorph/losses.py:102-112)
+template <bool L1>
 __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict__ f, float* __restrict__ ws,
                                                          long long planes, int D, int H, int W, int RB) {
   __shared__ float sm[17];
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict
       if (row < rows) {
         const float* p = f + row * W;
         const float v = p[x];
-        if (x + 1 < W) { const float d = p[x + 1] - v; sw += d * d; }
-        if (yy + 1 < H) { const float d = p[x + W] - v; sh += d * d; }
-        if (zz + 1 < D) { const float d = p[x + HW] - v; sd += d * d; }
+        if (x + 1 < W) { const float d = p[x + 1] - v; sw += L1 ? fabsf(d) : d * d; }
+        if (yy + 1 < H) { const float d = p[x + W] - v; sh += L1 ? fabsf(d) : d * d; }
+        if (zz + 1 < D) { const float d = p[x + HW] - v; sd += L1 ? fabsf(d) : d * d; }
       }
       if (++yy == H) { yy = 0; if (++zz == D) zz = 0; }
     }
@@ -179,7 +181,8 @@ __global__ void flow_smooth_fin_k(const float* ws, float* out, float cd, float c
   if (cw > 0.f) s += ws[2] / cw;
   out[0] = s / nd;
 }
-template <typename IDX>
+__device__ __forceinline__ float df_sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+template <typename IDX, bool L1 = false>
 __global__ __launch_bounds__(256) void flow_smooth_bwd_k(const float* __restrict__ f,
                                                          const float* __restrict__ gout,
                                                          float* __restrict__ df, long long planes, int D,
@@ -196,20 +199,20 @@ __global__ __launch_bounds__(256) void flow_smooth_bwd_k(const float* __restrict
     float acc = 0.f;
     if (W > 1) {
       float t = 0.f;
-      if (x > 0) t += v - f[i - 1];
-      if (x + 1 < W) t -= f[i + 1] - v;
+      if (x > 0) t += L1 ? df_sgn(v - f[i - 1]) : v - f[i - 1];
+      if (x + 1 < W) t -= L1 ? df_sgn(f[i + 1] - v) : f[i + 1] - v;
       acc += kw * t;
     }
     if (H > 1) {
       float t = 0.f;
-      if (y > 0) t += v - f[i - W];
-      if (y + 1 < H) t -= f[i + W] - v;
+      if (y > 0) t += L1 ? df_sgn(v - f[i - W]) : v - f[i - W];
+      if (y + 1 < H) t -= L1 ? df_sgn(f[i + W] - v) : f[i + W] - v;
       acc += kh * t;
     }
     if (D > 1) {
       float t = 0.f;
-      if (z > 0) t += v - f[i - HW];
-      if (z + 1 < D) t -= f[i + HW] - v;
+      if (z > 0) t += L1 ? df_sgn(v - f[i - HW]) : v - f[i - HW];
+      if (z + 1 < D) t -= L1 ? df_sgn(f[i + HW] - v) : f[i + HW] - v;
       acc += kd * t;
     }
     df[i] = g * acc;
@@ -477,26 +480,49 @@ __device__ __forceinline__ NccTerms ncc_terms(const float* s, long long N, long 
   t.den = t.Iv * t.Jv + eps;
   return t;
 }
-__global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__ s, float* __restrict__ ws,
-                                                       long long N, float wn, float eps) {
+// mask (optional, N floats): ws[0] = sum cc * mask, ws[1] = sum mask (util/losses.py:257-261)
+__global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__ s, const float* __restrict__ mask,
+                                                       float* __restrict__ ws, long long N, float wn, float eps) {
   __shared__ float sm[17];
-  float acc = 0.f;
+  float acc = 0.f, msum = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
     const NccTerms t = ncc_terms(s, N, i, wn, eps);
-    acc += t.cross * t.cross / t.den;
+    const float cc = t.cross * t.cross / t.den;
+    if (mask) { const float m = mask[i]; acc += cc * m; msum += m; }
+    else acc += cc;
   }
   acc = block_sum(acc, sm);
-  if (threadIdx.x == 0) atomicAdd(&ws[0], acc);
+  if (mask) msum = block_sum(msum, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[0], acc);
+    if (mask) atomicAdd(&ws[1], msum);
+  }
 }
-__global__ void ncc_fin_k(const float* ws, float* out, float n) { out[0] = -sqrtf(ws[0] / n); }
+// mode 0: -sqrt(S / n) (NCC_Loss.forward, util/losses.py:248-261; 0 when the mask is empty), mode 1: -S / n
+// (torchvoxelmorph/losses.py:67); n = sum(mask) with a mask, else the element count
+__device__ __forceinline__ float ncc_norm(const float* ws, float n, int masked) { return masked ? ws[1] : n; }
+__global__ void ncc_fin_k(const float* ws, float* out, float n, int mode, int masked) {
+  const float ne = ncc_norm(ws, n, masked);
+  if (!(ne > 0.f)) { out[0] = 0.f; return; }
+  out[0] = mode == 0 ? -sqrtf(ws[0] / ne) : -(ws[0] / ne);
+}
+// d loss / d cc_i = ncc_kappa(...) * mask_i
+__device__ __forceinline__ float ncc_kappa(const float* ws, const float* gout, float n, int mode, int masked) {
+  const float ne = ncc_norm(ws, n, masked);
+  if (!(ne > 0.f)) return 0.f;
+  if (mode == 1) return -gout[0] / ne;
+  const float m = ws[0] / ne;
+  return m > 0.f ? gout[0] * (-0.5f / sqrtf(m)) / ne : 0.f;
+}
 // fields: A = dL/dIJsum, Bq = dL/dI2sum, Cq = dL/dIsum
 __global__ __launch_bounds__(256) void ncc_fields_k(const float* __restrict__ s, const float* __restrict__ ws,
                                                     const float* __restrict__ gout, float* __restrict__ fld,
-                                                    long long N, float wn, float eps) {
+                                                    long long N, float wn, float eps, const float* __restrict__ mask,
+                                                    int mode) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const float m = ws[0] / (float)N;
-  const float kappa = m > 0.f ? gout[0] * (-0.5f / sqrtf(m)) / (float)N : 0.f;
+  float kappa = ncc_kappa(ws, gout, (float)N, mode, mask != nullptr);
+  if (mask) kappa *= mask[i];
   const NccTerms t = ncc_terms(s, N, i, wn, eps);
   const float A = kappa * (2.f * t.cross / t.den);
   const float Bq = kappa * (-(t.cross * t.cross) * t.Jv / (t.den * t.den));
@@ -508,7 +534,8 @@ __global__ __launch_bounds__(256) void ncc_fields_k(const float* __restrict__ s,
 // over 9 columns, then over 9 rows -- the field tensor and its W-summed copy never travel.
 __global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restrict__ s, const float* __restrict__ ws,
                                                           const float* __restrict__ gout, float* __restrict__ o, long long N,
-                                                          int H, int W, int nty, int ntx, float wn, float eps) {
+                                                          int H, int W, int nty, int ntx, float wn, float eps,
+                                                          const float* __restrict__ mask, int mode) {
   constexpr int TY = 32, TX = 64, R = 4, PY = TY + 2 * R, PX = TX + 2 * R;
   __shared__ float sF[3][PY][PX + 1];
   __shared__ float sS[3][PY][TX + 1];
@@ -518,8 +545,7 @@ __global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restric
   const int ty = q % nty;
   const long long plane = q / nty;
   const int y0 = ty * TY, x0 = tx * TX;
-  const float m = ws[0] / (float)N;
-  const float kappa = m > 0.f ? gout[0] * (-0.5f / sqrtf(m)) / (float)N : 0.f;
+  const float kappa0 = ncc_kappa(ws, gout, (float)N, mode, mask != nullptr);
   {
     constexpr int NE = (PY * PX + 255) / 256;
     float v[NE][5];
@@ -545,6 +571,7 @@ __global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restric
           const float Iv = I2 - 2.f * uI * Is + uI * uI * wn;
           const float Jv = J2 - 2.f * uJ * Js + uJ * uJ * wn;
           const float den = Iv * Jv + eps;
+          const float kappa = mask ? kappa0 * mask[plane * H * W + (long long)y * W + x] : kappa0;
           A = kappa * (2.f * cross / den);
           Bq = kappa * (-(cross * cross) * Jv / (den * den));
           Cq = -A * uJ - 2.f * Bq * uI;
@@ -650,15 +677,19 @@ extern "C" int dfmir_masked_l1_bwd(const float* a, const float* b, const unsigne
   DF_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C, int D, int H,
-                                     int W, void* stream) {
-  DF_ARG_CHECK(flow && ws && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+extern "C" int dfmir_flow_smooth_fwd_p(const float* flow, float* ws, float* out, int B, int C, int D, int H,
+                                       int W, int penalty, void* stream) {
+  DF_ARG_CHECK(flow && ws && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (penalty == 1 || penalty == 2));
+  const bool l1 = penalty == 1;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = df_zero_async(ws, 8, st);
   if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   const long long planes = (long long)B * C;
   const long long nrow = planes * D * H;
-  if ((W & 3) == 0 && W <= 256 && nrow < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(flow) & 15) == 0) {
+  if (l1) {
+    const int rb = (int)((nrow + 2047) / 2048);
+    flow_smooth_fwd_k<true><<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
+  } else if ((W & 3) == 0 && W <= 256 && nrow < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(flow) & 15) == 0) {
     const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);
     const unsigned grid = 8 * ((df_grid(nrow * tpr, 8 * 1024, 512) + 7) / 8);      // >= 8 rows per thread: few workgroups, few atomics
     if (tpr == 16) flow_smooth_fwd_v4_k<16><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
@@ -666,7 +697,7 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
     else flow_smooth_fwd_v4_k<64><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
   } else {
     const int rb = (int)((nrow + 2047) / 2048);
-    flow_smooth_fwd_k<<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
+    flow_smooth_fwd_k<false><<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
   }
   DF_LAUNCH_CHECK();
   const float cd = (float)((double)planes * (D - 1) * H * W), ch = (float)((double)planes * D * (H - 1) * W),
@@ -676,16 +707,28 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
   DF_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,
-                                     int H, int W, void* stream) {
-  DF_ARG_CHECK(flow && gout && dflow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0);
+extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C, int D, int H,
+                                     int W, void* stream) {
+  return dfmir_flow_smooth_fwd_p(flow, ws, out, B, C, D, H, W, 2, stream);
+}
+extern "C" int dfmir_flow_smooth_bwd_p(const float* flow, const float* gout, float* dflow, int B, int C, int D,
+                                       int H, int W, int penalty, void* stream) {
+  DF_ARG_CHECK(flow && gout && dflow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (penalty == 1 || penalty == 2));
   const long long planes = (long long)B * C;
   const double cd = (double)planes * (D - 1) * H * W, ch = (double)planes * D * (H - 1) * W,
                cw = (double)planes * D * H * (W - 1);
   const double nd = (D > 1) ? 3.0 : 2.0;
-  const float kd = cd > 0 ? (float)(2.0 / (cd * nd)) : 0.f, kh = ch > 0 ? (float)(2.0 / (ch * nd)) : 0.f,
-              kw = cw > 0 ? (float)(2.0 / (cw * nd)) : 0.f;
-  if ((W & 3) == 0 && W <= 256 && planes * D * H < 0x7FFFFFFFLL &&
+  const double two = penalty == 1 ? 1.0 : 2.0;          // d|d| = sgn(d), d(d^2) = 2 d
+  const float kd = cd > 0 ? (float)(two / (cd * nd)) : 0.f, kh = ch > 0 ? (float)(two / (ch * nd)) : 0.f,
+              kw = cw > 0 ? (float)(two / (cw * nd)) : 0.f;
+  if (penalty == 1) {
+    if (planes * D * H * W < 0x7FFFFFFFLL)
+      flow_smooth_bwd_k<unsigned, true><<<df_grid(planes * D * H * W, 256, 1 << 16), 256, 0, (hipStream_t)stream>>>(
+          flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+    else
+      flow_smooth_bwd_k<long long, true><<<df_grid(planes * D * H * W, 256, 4096), 256, 0, (hipStream_t)stream>>>(
+          flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  } else if ((W & 3) == 0 && W <= 256 && planes * D * H < 0x7FFFFFFFLL &&
       ((reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(dflow)) & 15) == 0) {
     const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);
     const unsigned grid = 8 * ((df_grid(planes * D * H * tpr, 256, 1 << 15) + 7) / 8);
@@ -702,11 +745,15 @@ extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float
   DF_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,
+                                     int H, int W, void* stream) {
+  return dfmir_flow_smooth_bwd_p(flow, gout, dflow, B, C, D, H, W, 2, stream);
+}
 
 // fwd: final 5 box sums are left in `tmp`.
-extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float* ws, float* out,
-                             int B, int D, int H, int W, int win, float eps, void* stream) {
-  DF_ARG_CHECK(I && J && tmp && tmp2 && ws && out && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1));
+extern "C" int dfmir_ncc_fwd_m(const float* I, const float* J, const float* mask, int mode, float* tmp, float* tmp2,
+                               float* ws, float* out, int B, int D, int H, int W, int win, float eps, void* stream) {
+  DF_ARG_CHECK(I && J && tmp && tmp2 && ws && out && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1) && (mode == 0 || mode == 1));
   hipStream_t st = (hipStream_t)stream;
   const long long N = (long long)B * D * H * W;
   const int r = win / 2;
@@ -735,17 +782,22 @@ extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* 
     DF_LAUNCH_CHECK();
     wn = (float)win * win;
   }
-  ncc_cc_reduce_k<<<df_grid(N, 256, 1024), 256, 0, st>>>(tmp, ws, N, wn, eps);
+  ncc_cc_reduce_k<<<df_grid(N, 256, 1024), 256, 0, st>>>(tmp, mask, ws, N, wn, eps);
   DF_LAUNCH_CHECK();
-  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N);
+  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N, mode, mask != nullptr);
   DF_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float* ws, float* out,
+                             int B, int D, int H, int W, int win, float eps, void* stream) {
+  return dfmir_ncc_fwd_m(I, J, nullptr, 0, tmp, tmp2, ws, out, B, D, H, W, win, eps, stream);
+}
 // bwd: sums = the 5N box sums of the forward; tmp, tmp2 = 3N floats of scratch each.
-extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
-                             const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
-                             int win, float eps, void* stream) {
-  DF_ARG_CHECK(I && J && sums && tmp && tmp2 && ws && gout && dI && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1));
+extern "C" int dfmir_ncc_bwd_m(const float* I, const float* J, const float* mask, int mode, const float* sums,
+                               float* tmp, float* tmp2, const float* ws, const float* gout, float* dI, int B, int D,
+                               int H, int W, int win, float eps, void* stream) {
+  DF_ARG_CHECK(I && J && sums && tmp && tmp2 && ws && gout && dI && B > 0 && D > 0 && H > 0 && W > 0 && (win & 1) &&
+               (mode == 0 || mode == 1));
   hipStream_t st = (hipStream_t)stream;
   const long long N = (long long)B * D * H * W;
   const int r = win / 2;
@@ -754,10 +806,10 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
   static DfOptFlag nofuse_o{"DFMIR_NCC_NO_WH_FUSE"};         // A/B: fields, W and H passes as separate launches
   if (r == 4 && D > 1 && !nofuse_o.get()) {
     const int nty = (H + 31) / 32, ntx = (W + 63) / 64;
-    ncc_fields_boxwh_k<<<(unsigned)((long long)B * D * nty * ntx), 256, 0, st>>>(sums, ws, gout, tmp, N, H, W, nty, ntx, wn, eps);
+    ncc_fields_boxwh_k<<<(unsigned)((long long)B * D * nty * ntx), 256, 0, st>>>(sums, ws, gout, tmp, N, H, W, nty, ntx, wn, eps, mask, mode);
     DF_LAUNCH_CHECK();
   } else {
-    ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps);
+    ncc_fields_k<<<grid, 256, 0, st>>>(sums, ws, gout, tmp, N, wn, eps, mask, mode);
     DF_LAUNCH_CHECK();
     box_axis_launch(tmp, tmp2, 3, N, 1, W, r, st);
     DF_LAUNCH_CHECK();
@@ -771,6 +823,22 @@ extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, 
     fin = tmp2;
   }
   ncc_combine_k<<<grid, 256, 0, st>>>(I, J, fin, dI, N);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
+                             const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
+                             int win, float eps, void* stream) {
+  return dfmir_ncc_bwd_m(I, J, nullptr, 0, sums, tmp, tmp2, ws, gout, dI, B, D, H, W, win, eps, stream);
+}
+// out = a * b, element-wise (the `prediction * mask` of Grad_Loss.forward, util/losses.py:120-121, and its gradient)
+__global__ __launch_bounds__(256) void mul_k(const float* __restrict__ a, const float* __restrict__ b,
+                                             float* __restrict__ o, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = a[i] * b[i];
+}
+extern "C" int dfmir_mul(const float* a, const float* b, float* out, long long n, void* stream) {
+  DF_ARG_CHECK(a && b && out && n > 0);
+  mul_k<<<df_grid(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(a, b, out, n);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -2145,7 +2145,7 @@ def masked_l1(a, b, mask=None, thr=-0.95):
 
 class FlowSmoothFn(Function):
     @staticmethod
-    def forward(ctx, flow):
+    def forward(ctx, flow, penalty=2):
         _need(flow)
         flow = _c(flow)
         nd = flow.dim() - 2
@@ -2153,36 +2153,82 @@ class FlowSmoothFn(Function):
         D, H, W = flow.shape[2:] if nd == 3 else (1,) + tuple(flow.shape[2:])
         ws = torch.empty(8, device=flow.device, dtype=torch.float32)
         out = torch.empty((), device=flow.device, dtype=torch.float32)
-        check(lib().dfmir_flow_smooth_fwd(_p(flow), _p(ws), _p(out), B, C, D, H, W, _st()))
+        if penalty == 2:
+            check(lib().dfmir_flow_smooth_fwd(_p(flow), _p(ws), _p(out), B, C, D, H, W, _st()))
+        else:
+            check(lib().dfmir_flow_smooth_fwd_p(_p(flow), _p(ws), _p(out), B, C, D, H, W, int(penalty), _st()))
         ctx.save_for_backward(flow)
-        ctx.meta = (B, C, D, H, W)
+        ctx.meta = (B, C, D, H, W, int(penalty))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         (flow,) = ctx.saved_tensors
-        B, C, D, H, W = ctx.meta
+        B, C, D, H, W, penalty = ctx.meta
         g = _c(g)
         df = torch.empty_like(flow)
-        check(lib().dfmir_flow_smooth_bwd(_p(flow), _p(g), _p(df), B, C, D, H, W, _st()))
-        return df
+        if penalty == 2:
+            check(lib().dfmir_flow_smooth_bwd(_p(flow), _p(g), _p(df), B, C, D, H, W, _st()))
+        else:
+            check(lib().dfmir_flow_smooth_bwd_p(_p(flow), _p(g), _p(df), B, C, D, H, W, penalty, _st()))
+        return df, None
 
 
-def flow_smoothness(flow):
-    return FlowSmoothFn.apply(flow)
+def flow_smoothness(flow, penalty='l2'):
+    """mean over axes of mean(|forward difference|^p): smooothing_loss (registration_model.py:25-32), Grad_Loss
+    (util/losses.py:81-130) and vxm Grad (torchvoxelmorph/losses.py:93-117); penalty 'l2' (p = 2) or 'l1' (p = 1)."""
+    if penalty not in ('l1', 'l2'):
+        raise DfmirHipError("gradient penalty must be 'l1' or 'l2', got %r" % (penalty,))
+    return FlowSmoothFn.apply(flow, 2 if penalty == 'l2' else 1)
+
+
+class MulFn(Function):
+    """a * b element-wise, same shapes (`prediction * mask`, util/losses.py:120-121)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need(a, b)
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+            raise DfmirHipError("ops.mul: fp32 tensors of one shape (got %s, %s)" % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty_like(a)
+        check(lib().dfmir_mul(_p(a), _p(b), _p(out), a.numel(), _st()))
+        ctx.save_for_backward(a if ctx.needs_input_grad[1] else None, b if ctx.needs_input_grad[0] else None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(g)
+            check(lib().dfmir_mul(_p(g), _p(b), _p(da), g.numel(), _st()))
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(g)
+            check(lib().dfmir_mul(_p(g), _p(a), _p(db), g.numel(), _st()))
+        return da, db
+
+
+def mul(a, b):
+    return MulFn.apply(a, b)
 
 
 class NCCFn(Function):
-    """-sqrt(mean(cc)) with a win^nd mean window (util/losses.py:248-256); gradient w.r.t. the
-    prediction I only (J is the fixed target)."""
+    """Windowed NCC with a win^nd mean window; gradient w.r.t. the prediction I only (J is the fixed target).
+    mode 0: -sqrt(mean(cc)) (NCC_Loss, util/losses.py:248-256), with a mask -sqrt(sum(cc * mask) / sum(mask)) and 0 for
+    an empty mask (:257-261); mode 1: -mean(cc) (vxm NCC.loss, torchvoxelmorph/losses.py:67)."""
 
     @staticmethod
-    def forward(ctx, I, J, win, eps):
-        _need(I, J)
+    def forward(ctx, I, J, win, eps, mask=None, mode=0):
+        _need(I, J, mask)
         I, J = _c(I), _c(J)
         if I.shape[1] != 1:
             raise DfmirHipError("NCC expects single-channel volumes")
+        if mask is not None and (mask.dtype != torch.float32 or mask.shape != I.shape or not mask.is_contiguous()):
+            raise DfmirHipError("NCC mask: a contiguous fp32 tensor of the volumes' shape")
         nd = I.dim() - 2
         B = I.shape[0]
         D, H, W = I.shape[2:] if nd == 3 else (1,) + tuple(I.shape[2:])
@@ -2191,29 +2237,41 @@ class NCCFn(Function):
         tmp2 = torch.empty(5 * N, device=I.device, dtype=torch.float32)
         ws = torch.empty(8, device=I.device, dtype=torch.float32)
         out = torch.empty((), device=I.device, dtype=torch.float32)
-        check(lib().dfmir_ncc_fwd(_p(I), _p(J), _p(sums), _p(tmp2), _p(ws), _p(out), B, D, H, W, int(win),
-                                  float(eps), _st()))
-        ctx.save_for_backward(I, J, sums, ws)
-        ctx.meta = (B, D, H, W, int(win), float(eps))
+        if mask is None and mode == 0:
+            check(lib().dfmir_ncc_fwd(_p(I), _p(J), _p(sums), _p(tmp2), _p(ws), _p(out), B, D, H, W, int(win),
+                                      float(eps), _st()))
+        else:
+            check(lib().dfmir_ncc_fwd_m(_p(I), _p(J), _p(mask), int(mode), _p(sums), _p(tmp2), _p(ws), _p(out), B, D, H, W,
+                                        int(win), float(eps), _st()))
+        ctx.save_for_backward(I, J, sums, ws, mask)
+        ctx.meta = (B, D, H, W, int(win), float(eps), int(mode))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        I, J, sums, ws = ctx.saved_tensors
-        B, D, H, W, win, eps = ctx.meta
+        I, J, sums, ws, mask = ctx.saved_tensors
+        B, D, H, W, win, eps, mode = ctx.meta
         g = _c(g)
         N = I.numel()
         t1 = torch.empty(3 * N, device=I.device, dtype=torch.float32)
         t2 = torch.empty(3 * N, device=I.device, dtype=torch.float32)
         dI = torch.empty_like(I)
-        check(lib().dfmir_ncc_bwd(_p(I), _p(J), _p(sums), _p(t1), _p(t2), _p(ws), _p(g), _p(dI), B, D, H, W,
-                                  win, eps, _st()))
-        return dI, None, None, None
+        if mask is None and mode == 0:
+            check(lib().dfmir_ncc_bwd(_p(I), _p(J), _p(sums), _p(t1), _p(t2), _p(ws), _p(g), _p(dI), B, D, H, W,
+                                      win, eps, _st()))
+        else:
+            check(lib().dfmir_ncc_bwd_m(_p(I), _p(J), _p(mask), mode, _p(sums), _p(t1), _p(t2), _p(ws), _p(g), _p(dI),
+                                        B, D, H, W, win, eps, _st()))
+        return dI, None, None, None, None, None
 
 
-def ncc_loss(I, J, win=9, eps=1e-5):
-    return NCCFn.apply(I, J, win, eps)
+def ncc_loss(I, J, win=9, eps=1e-5, mask=None, reduction='neg_sqrt_mean'):
+    """reduction 'neg_sqrt_mean' (NCC_Loss) or 'neg_mean' (vxm NCC); mask: any tensor that broadcasts to I's shape
+    (bool / byte / float: the reference multiplies cc by it, util/losses.py:261)."""
+    if mask is not None:
+        mask = mask.to(device=I.device, dtype=torch.float32).expand_as(I).contiguous()
+    return NCCFn.apply(I, J, win, eps, mask, {'neg_sqrt_mean': 0, 'neg_mean': 1}[reduction])
 
 
 class MeanFn(Function):

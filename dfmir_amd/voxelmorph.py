@@ -221,3 +221,13 @@ layers = _Namespace()
 layers.SpatialTransformer = SpatialTransformer
 layers.VecInt = VecInt
 layers.ResizeTransform = ResizeTransform
+
+
+def _losses_namespace():
+    from . import losses as _l               # (losses imports ops only: no cycle)
+    ns = _Namespace()
+    ns.NCC, ns.Grad = _l.NCC, _l.Grad        # torchvoxelmorph/losses.py:7-67,93-117
+    return ns
+
+
+losses = _losses_namespace()

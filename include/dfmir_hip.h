@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 11
+#define DFMIR_ABI_VERSION 12
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -521,6 +521,14 @@ int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C
                           int W, void* stream);
 int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,
                           int H, int W, void* stream);
+/* The same with the penalty chosen: 1 = 'l1' (mean |forward difference|), 2 = 'l2' -- Grad_Loss(penalty=...)
+ * (util/losses.py:81-130) and vxm Grad(penalty).loss (models/voxelmorph/torchvoxelmorph/losses.py:93-117). */
+int dfmir_flow_smooth_fwd_p(const float* flow, float* ws, float* out, int B, int C, int D, int H,
+                            int W, int penalty, void* stream);
+int dfmir_flow_smooth_bwd_p(const float* flow, const float* gout, float* dflow, int B, int C, int D,
+                            int H, int W, int penalty, void* stream);
+/* out = a * b element-wise: `prediction * mask` of Grad_Loss.forward (util/losses.py:120-121). */
+int dfmir_mul(const float* a, const float* b, float* out, long long n, void* stream);
 /* NCC_Loss (util/losses.py:183-261), mean kernel of `win` per axis (odd), zero padding:
  * out = -sqrt(mean(cross^2/(Ivar*Jvar+eps))).  tmp: 5*numel floats of scratch (box sums, kept for
  * backward). I = prediction, J = target, [B,1,D,H,W].  3-D, win 9: the W and H box passes run in one launch each way
@@ -530,6 +538,15 @@ int dfmir_ncc_fwd(const float* I, const float* J, float* tmp, float* tmp2, float
 int dfmir_ncc_bwd(const float* I, const float* J, const float* sums, float* tmp, float* tmp2,
                   const float* ws, const float* gout, float* dI, int B, int D, int H, int W,
                   int win, float eps, void* stream);
+/* The same with a weight per voxel and the reduction chosen.  mask (numel floats, may be NULL): the masked branch of
+ * NCC_Loss.forward (util/losses.py:257-261): out = -sqrt(sum(cc * mask) / sum(mask)), 0 when sum(mask) == 0.
+ * mode 0 = that form; mode 1 = -sum(cc [* mask]) / n, n = numel (or sum(mask)): vxm NCC(win).loss = -mean(cc)
+ * (models/voxelmorph/torchvoxelmorph/losses.py:15-67).  ws[0] = sum(cc * mask), ws[1] = sum(mask) (kept for backward). */
+int dfmir_ncc_fwd_m(const float* I, const float* J, const float* mask, int mode, float* tmp, float* tmp2,
+                    float* ws, float* out, int B, int D, int H, int W, int win, float eps, void* stream);
+int dfmir_ncc_bwd_m(const float* I, const float* J, const float* mask, int mode, const float* sums,
+                    float* tmp, float* tmp2, const float* ws, const float* gout, float* dI, int B, int D,
+                    int H, int W, int win, float eps, void* stream);
 /* out[t] = scale * sum_l mean(rows[l][t*seg..(t+1)*seg)), rows [L][T*seg]: the per-term
  * `total_nce_loss += loss.mean() * lambda_NCE` ... `/ n_layers` of calculate_NCE_loss (registration_model.py:247-253)
  * for T terms and L layers at once (scale = lambda_NCE / n_layers); bwd fills drows from gout[T]. */

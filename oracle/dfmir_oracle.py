@@ -147,9 +147,12 @@ class PatchSampler(nn.Module):
         return out, ids
 
 
-def patchnce_loss(feat_q, feat_k, batch_size, T=0.07):
-    """models/patchnce.py:14-55 (negatives from the same image; reduction 'none')."""
+def patchnce_loss(feat_q, feat_k, batch_size, T=0.07, all_negatives=False):
+    """models/patchnce.py:14-55 (negatives from the same image; reduction 'none').  all_negatives =
+    opt.nce_includes_all_negatives_from_minibatch (:32-38): the whole minibatch as ONE group of negatives."""
     n, dim = feat_q.shape
+    if all_negatives:
+        batch_size = 1
     feat_k = feat_k.detach()
     l_pos = (feat_q * feat_k).sum(1, keepdim=True)
     q = feat_q.view(batch_size, -1, dim)
@@ -287,14 +290,24 @@ def smoothing_loss(flow):
     return ((dx * dx).mean() + (dy * dy).mean()) / 2.0
 
 
-def grad_loss_l2(flow):
-    """util/losses.py:92-115 Grad_Loss._grad2d/_grad3d, penalty 'l2'."""
+def grad_loss(flow, penalty='l2', mask=None, loss_mult=None):
+    """util/losses.py:92-130 Grad_Loss._grad2d/_grad3d + forward: |forward differences| (squared for 'l2'), mean per axis,
+    mean over axes; `mask` multiplies the field first (:119-121), `loss_mult` the result (:127-128).  The vxm `Grad.loss`
+    (models/voxelmorph/torchvoxelmorph/losses.py:102-117) is the same arithmetic on a 3-D field."""
+    if mask is not None:
+        flow = flow * mask
     nd = flow.dim() - 2
     tot = 0.0
     for ax in range(2, 2 + nd):
-        d = flow.narrow(ax, 1, flow.shape[ax] - 1) - flow.narrow(ax, 0, flow.shape[ax] - 1)
-        tot = tot + (d * d).mean()
-    return tot / float(nd)
+        d = torch.abs(flow.narrow(ax, 1, flow.shape[ax] - 1) - flow.narrow(ax, 0, flow.shape[ax] - 1))
+        tot = tot + ((d * d) if penalty == 'l2' else d).mean()
+    tot = tot / float(nd)
+    return tot if loss_mult is None else tot * loss_mult
+
+
+def grad_loss_l2(flow):
+    """util/losses.py:92-115 Grad_Loss._grad2d/_grad3d, penalty 'l2'."""
+    return grad_loss(flow, 'l2')
 
 
 def masked_l1(src, tgt, mask):
@@ -307,8 +320,9 @@ def masked_l1(src, tgt, mask):
     return (1 / mask.sum()) * (diff * mask).sum()
 
 
-def ncc_loss(pred, target, win=9, eps=1e-5):
-    """util/losses.py:183-256 NCC_Loss(kernel_type='mean').forward without mask."""
+def ncc_map(pred, target, win=9, eps=1e-5):
+    """cc of util/losses.py:183-246 (NCC_Loss._compute_local_sums + ncc, 'mean' kernel) = the same map in
+    models/voxelmorph/torchvoxelmorph/losses.py:15-65."""
     nd = pred.dim() - 2
     filt = torch.ones([1, 1] + [win] * nd)
     conv = F.conv2d if nd == 2 else F.conv3d
@@ -321,8 +335,23 @@ def ncc_loss(pred, target, win=9, eps=1e-5):
     cross = IJs - uJ * Is - uI * Js + uI * uJ * wn
     Iv = I2s - 2 * uI * Is + uI * uI * wn
     Jv = J2s - 2 * uJ * Js + uJ * uJ * wn
-    cc = cross * cross / (Iv * Jv + eps)
-    return -1.0 * torch.sqrt(cc.mean())
+    return cross * cross / (Iv * Jv + eps)
+
+
+def ncc_loss(pred, target, win=9, eps=1e-5, mask=None):
+    """util/losses.py:248-261 NCC_Loss(kernel_type='mean').forward: -sqrt(mean(cc)); with a mask
+    -sqrt(sum(cc * mask) / sum(mask)), and 0 when the mask is empty."""
+    cc = ncc_map(pred, target, win, eps)
+    if mask is None:
+        return -1.0 * torch.sqrt(cc.mean())
+    if torch.sum(mask) == 0:
+        return torch.tensor(0)
+    return -1.0 * torch.sqrt((1 / torch.sum(mask)) * torch.sum(cc * mask))
+
+
+def vxm_ncc_loss(y_true, y_pred, win=9):
+    """models/voxelmorph/torchvoxelmorph/losses.py:7-67 NCC(win).loss = -mean(cc), eps 1e-5."""
+    return -torch.mean(ncc_map(y_true, y_pred, win, 1e-5))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -336,8 +365,9 @@ class RegistrationStep(object):
 
     def __init__(self, size, batch_size, ngf=64, n_blocks=9, lr=2e-4, betas=(0.5, 0.999), num_patches=256,
                  nce_T=0.07, lambda_NCE=0.25, nce_layers=(0, 4, 8, 12, 16), netF_nc=256, nce_idt=True,
-                 flip_equivariance=False):
+                 flip_equivariance=False, nce_all_negatives=False):
         self.bs, self.size = batch_size, size
+        self.nce_all_negatives = nce_all_negatives         # opt.nce_includes_all_negatives_from_minibatch (patchnce.py:32-38)
         # FastCUT (registration_model.py:63-67): nce_idt False, lambda_NCE 10, flip_equivariance True.  `flip_draw()` ->
         # bool stands in for `np.random.random() < 0.5` (registration_model.py:189) so that tests can force the flip.
         self.nce_idt, self.flip_equivariance, self.flipped = nce_idt, flip_equivariance, False
@@ -379,7 +409,7 @@ class RegistrationStep(object):
         fq_pool, _ = self.netF(fq, self.num_patches, ids)
         tot = 0.0
         for q, k in zip(fq_pool, fk_pool):
-            tot = tot + (patchnce_loss(q, k, self.bs, self.nce_T) * self.lambda_NCE).mean()
+            tot = tot + (patchnce_loss(q, k, self.bs, self.nce_T, self.nce_all_negatives) * self.lambda_NCE).mean()
         return tot / len(self.nce_layers)
 
     def g_loss(self):

@@ -37,6 +37,24 @@ def patch_ids(call, layer, S, P):
     return torch.randperm(S, generator=gen(1000003 * (call + 1) + 7919 * layer))[:min(P, S)]
 
 
+def edge_inputs():
+    """Seeded inputs of fixture edges.npz (make_golden_edges.py), shared with tests/test_oracle_golden.py and tests/test_gpu_ops.py."""
+    d = {}
+    for tag, shp in (("2d", (2, 1, 24, 28)), ("3d", (1, 1, 12, 14, 16))):
+        I = rand(175, *shp)
+        J = 0.6 * I + 0.4 * rand(176, *shp)
+        d["I" + tag], d["J" + tag] = I, J
+        d["mask" + tag] = (rand(177, *shp) > 0.35)
+    d["field3"] = randn(178, 1, 3, 7, 9, 11) * 1.5
+    d["field2"] = randn(179, 2, 2, 18, 22)
+    d["fmask2"] = (rand(180, 2, 1, 18, 22) > 0.3).float()
+    return d
+
+
+def edge_sample_feats():
+    return [randn(162, 2, 1, 14, 14), randn(163, 2, 16, 12, 12), randn(164, 2, 32, 8, 8)]
+
+
 def checksum(tensors):
     h = hashlib.sha256()
     for t in tensors:

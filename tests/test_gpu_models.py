@@ -232,6 +232,61 @@ def test_fastcut_step_vs_oracle(O, flip, stacked):
         assert float((model.fake_B - torch.flip(model.fake_B, [3])).abs().max()) > 1e-3
 
 
+def test_all_negatives_step_vs_oracle_and_netF_sample(O, golden):
+    """opt.nce_includes_all_negatives_from_minibatch (models/patchnce.py:32-38: the whole minibatch is ONE group of
+    negatives) through the model's default stacked path -- two whole steps against the oracle (losses, outputs, gradient
+    arenas) -- and `--netF sample` (models/networks.py:280-281): the reference builds `torch.optim.Adam` over PatchSampleF's
+    empty parameter list in data_dependent_initialize (registration_model.py:134-135) and raises; the mirror raises the same
+    error (fixture edges.npz records the reference's message)."""
+    size, B, ngf = 64, 2, 8
+    torch.manual_seed(6)
+    st = O.RegistrationStep(size, B, ngf=ngf, nce_all_negatives=True)
+    with torch.no_grad():
+        st.netR.flow.weight.mul_(1e5)
+    st.ids_hook = lambda c, feats: [C.patch_ids(c, i, f.shape[2] * f.shape[3], 256) for i, f in enumerate(feats)]
+    A0, B0 = C.image_pair(9, B, size, size)
+    st.data_dependent_initialize(A0, B0)
+    with torch.no_grad():
+        for p in st.netF.parameters():
+            if p.dim() == 1:
+                p.add_(0.01)
+    model, opt = _hip_model_from_oracle(st, size, B, ngf, nce_includes_all_negatives_from_minibatch=True)
+    model.patch_id_source = PinnedIds()
+    data = {"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B}
+    model.data_dependent_initialize(data)
+    _load(model.netF, st.netF)
+    model.setup(opt)
+    model.parallelize()
+    for it in range(2):
+        A_, B_ = C.image_pair(30 + 2 * it, B, size, size)
+        ref = st.step(A_, B_)
+        model.set_input({"A": A_, "B": B_, "A_paths": [""] * B, "B_paths": [""] * B})
+        model.optimize_parameters()
+        assert model._nce_on_device
+        ls = model.get_current_losses()
+        for k, v in ref.items():
+            assert abs(ls[k] - v) <= 3e-4 * (it + 1) * max(abs(v), 1e-6), (it, k, ls[k], v)
+        if it == 0:
+            close(model.fake_B, st.fake_B, what="fake_B"); close(model.registered, st.registered, what="registered")
+            close(model.pos_flow, st.flow, what="pos_flow")
+            for nm, o_, net in (("G", model.optimizer_G, st.netG), ("F", model.optimizer_F, st.netF), ("R", model.optimizer_R, st.netR)):
+                # (the oracle's .grad after its step: Adam does not modify them)
+                ref_g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+                got_g = o_.flat_g.cpu()
+                rel = float((got_g - ref_g).norm() / ref_g.norm())
+                assert rel <= 1e-3, (nm, rel)
+    # --netF sample
+    g = golden("edges.npz")
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    opt2 = default_options(batch_size=B, crop_size=size, load_size=size, ngf=ngf, gpu_ids=[0], netF='sample',
+                           checkpoints_dir="/tmp/dfmir_ckpt", name="t")
+    m2 = REGISTRATIONModel(opt2)
+    with pytest.raises(ValueError) as ei:
+        m2.data_dependent_initialize(data)
+    assert "ValueError: %s" % ei.value == str(g["netF_sample_optimizer_error"])
+
+
 @pytest.mark.parametrize("capture", [False, True])
 def test_whole_step_golden_default_path(golden, O, capture):
     """Fixture S1 (the reference's own three train steps) through the DEFAULT production path -- device-side batched

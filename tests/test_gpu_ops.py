@@ -893,6 +893,74 @@ def test_losses_golden(ops, golden):
         close(l, g["ncc" + tag], what="ncc" + tag); close(I.grad, g["dncc" + tag], rtol=1e-3, what="dncc" + tag)
 
 
+def test_edge_branches_golden(ops, golden):
+    """Fixture E1-E6 (tests/golden/make_golden_edges.py, the reference's own outputs): NCC_Loss with a mask
+    (util/losses.py:257-261) incl. the empty mask, vxm NCC(win).loss = -mean(cc) and vxm Grad('l1' | 'l2', loss_mult)
+    (torchvoxelmorph/losses.py:7-67,93-117), Grad_Loss 'l1' / `mask=` (util/losses.py:81-130), PatchNCELoss over all negatives
+    of the minibatch (patchnce.py:32-38) and PatchSampleF without the MLP (--netF sample, networks.py:280-281) -- through the
+    mirror's classes (dfmir_amd.losses / voxelmorph.losses / patchnce / networks)."""
+    from dfmir_amd import losses as L
+    from dfmir_amd import networks as N
+    from dfmir_amd import voxelmorph as V
+    from dfmir_amd.options import default_options
+    from dfmir_amd.patchnce import PatchNCELoss
+    g = golden("edges.npz")
+    d = {k: v.to(DEV) for k, v in C.edge_inputs().items()}
+    for tag, kv in (("2d", [9, 9]), ("3d", [9, 9, 9])):
+        I = d["I" + tag].clone().requires_grad_()
+        l = L.NCC_Loss(DEV, kernel_var=kv, kernel_type='mean')(I, d["J" + tag], mask=d["mask" + tag])
+        l.backward()
+        close(l, g["ncc_masked_" + tag], what="masked ncc " + tag)
+        close(I.grad, g["dncc_masked_" + tag], rtol=1e-3, what="d masked ncc " + tag)
+    I = d["I2d"].clone().requires_grad_()
+    l = L.NCC_Loss(DEV, kernel_var=[9, 9])(I, d["J2d"], mask=torch.zeros_like(I, dtype=torch.bool))
+    l.backward()
+    assert float(l) == float(g["ncc_empty_mask"]) == 0.0 and float(I.grad.abs().max()) == 0.0
+    assert V.losses.NCC is L.NCC and V.losses.Grad is L.Grad
+    for tag, win in (("2d", [5, 5]), ("3d", None)):
+        yp = d["I" + tag].clone().requires_grad_()
+        l = V.losses.NCC(win).loss(d["J" + tag], yp)
+        l.backward()
+        close(l, g["vxm_ncc_" + tag], what="vxm ncc " + tag)
+        close(yp.grad, g["dvxm_ncc_" + tag], rtol=1e-3, what="d vxm ncc " + tag)
+    for tag, pen, mult in (("l1", 'l1', None), ("l2m", 'l2', 2.5)):
+        f = d["field3"].clone().requires_grad_()
+        l = V.losses.Grad(pen, loss_mult=mult).loss(None, f)
+        l.backward()
+        close(l, g["vxm_grad_" + tag], what="vxm grad " + tag); close(f.grad, g["dvxm_grad_" + tag], what="d vxm grad " + tag)
+    with pytest.raises(IndexError):
+        V.losses.Grad('l1').loss(None, d["field2"])           # the reference indexes five axes
+    f = d["field3"].clone().requires_grad_()
+    l = L.Grad_Loss(dim=3, penalty='l1')(f); l.backward()
+    close(l, g["grad3d_l1"], what="grad3d l1"); close(f.grad, g["dgrad3d_l1"], what="d grad3d l1")
+    for key, pen, mult in (("grad2d_l1_masked", 'l1', 0.5), ("grad2d_l2_masked", 'l2', None)):
+        f = d["field2"].clone().requires_grad_()
+        l = L.Grad_Loss(dim=2, penalty=pen, loss_mult=mult)(f, mask=d["fmask2"]); l.backward()
+        close(l, g[key], what=key); close(f.grad, g["d" + key], what="d " + key)
+    # --netF sample + all negatives of the minibatch
+    feats = [f.to(DEV) for f in C.edge_sample_feats()]
+    hpf = N.define_F(1, 'sample', 'instance', False, 'xavier', 0.02, False, [0], default_options(netF_nc=32))
+    assert len(list(hpf.parameters())) == 0 and not hpf.use_mlp
+    ids = [C.patch_ids(40, i, f.shape[2] * f.shape[3], 48).to(DEV) for i, f in enumerate(feats)]
+    fq = [f.clone().requires_grad_() for f in feats]
+    fk = [C.randn(165 + i, *f.shape).to(DEV) for i, f in enumerate(feats)]
+    kpool, _ = hpf(fk, 48, ids)
+    qpool, _ = hpf(fq, 48, ids)
+    for name, allneg in (("all", True), ("own", False)):
+        crit = PatchNCELoss(default_options(batch_size=2, nce_includes_all_negatives_from_minibatch=allneg))
+        for f in fq:
+            f.grad = None
+        tot = 0
+        for i, (q, k) in enumerate(zip(qpool, kpool)):
+            l = crit(q, k)
+            close(l, g["sample_%s_loss%d" % (name, i)], what="%s-negatives loss %d" % (name, i))
+            close(q, g["sample_q%d" % i], what="sampled q%d" % i)
+            tot = tot + ops.mean(l)
+        tot.backward(retain_graph=True)
+        for i, f in enumerate(fq):
+            close(f.grad, g["sample_%s_dfeat%d" % (name, i)], rtol=1e-3, what="%s-negatives dfeat%d" % (name, i))
+
+
 def test_ncc_fused_box_passes_match_the_separate_ones(ops):
     """NCC[9,9,9] (torchvoxelmorph/losses.py NCC: 5 box-filtered product fields forward, 3 gradient fields backward): the
     launches that fuse the W and H box passes (with the products / with the field evaluation) through one LDS tile against

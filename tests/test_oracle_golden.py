@@ -167,6 +167,55 @@ def test_losses(golden):
         close(l, g["ncc" + tag]); close(I.grad, g["dncc" + tag], rtol=1e-3)
 
 
+def test_edges(golden):
+    """Fixture E1-E6 (tests/golden/make_golden_edges.py): the masked NCC_Loss, vxm NCC / Grad, Grad_Loss l1 / masked,
+    PatchNCELoss over all negatives of the minibatch and PatchSampleF without the MLP -- the oracle against the
+    reference's own outputs."""
+    g = golden("edges.npz")
+    d = C.edge_inputs()
+    for tag in ("2d", "3d"):
+        I = d["I" + tag].clone().requires_grad_()
+        l = O.ncc_loss(I, d["J" + tag], 9, mask=d["mask" + tag]); l.backward()
+        close(l, g["ncc_masked_" + tag]); close(I.grad, g["dncc_masked_" + tag], rtol=1e-3)
+    assert float(O.ncc_loss(d["I2d"], d["J2d"], 9, mask=torch.zeros_like(d["I2d"], dtype=torch.bool))) == float(g["ncc_empty_mask"]) == 0.0
+    for tag, win in (("2d", 5), ("3d", 9)):
+        yp = d["I" + tag].clone().requires_grad_()
+        l = O.vxm_ncc_loss(d["J" + tag], yp, win); l.backward()
+        close(l, g["vxm_ncc_" + tag]); close(yp.grad, g["dvxm_ncc_" + tag], rtol=1e-3)
+    for tag, pen, mult in (("l1", 'l1', None), ("l2m", 'l2', 2.5)):
+        f = d["field3"].clone().requires_grad_()
+        l = O.grad_loss(f, pen, loss_mult=mult); l.backward()
+        close(l, g["vxm_grad_" + tag]); close(f.grad, g["dvxm_grad_" + tag])
+    f = d["field3"].clone().requires_grad_()
+    l = O.grad_loss(f, 'l1'); l.backward()
+    close(l, g["grad3d_l1"]); close(f.grad, g["dgrad3d_l1"])
+    for key, pen, mult in (("grad2d_l1_masked", 'l1', 0.5), ("grad2d_l2_masked", 'l2', None)):
+        f = d["field2"].clone().requires_grad_()
+        l = O.grad_loss(f, pen, mask=d["fmask2"], loss_mult=mult); l.backward()
+        close(l, g[key]); close(f.grad, g["d" + key])
+    feats = C.edge_sample_feats()
+    opf = O.PatchSampler(32, False)
+    assert len(list(opf.parameters())) == 0
+    ids = [C.patch_ids(40, i, f.shape[2] * f.shape[3], 48) for i, f in enumerate(feats)]
+    fq = [f.clone().requires_grad_() for f in feats]
+    fk = [C.randn(165 + i, *f.shape) for i, f in enumerate(feats)]
+    kpool, _ = opf(fk, 48, ids)
+    qpool, _ = opf(fq, 48, ids)
+    for name, allneg in (("all", True), ("own", False)):
+        for f in fq:
+            f.grad = None
+        tot = 0
+        for i, (q, k) in enumerate(zip(qpool, kpool)):
+            l = O.patchnce_loss(q, k, 2, 0.07, all_negatives=allneg)
+            close(l, g["sample_%s_loss%d" % (name, i)], what="%s loss %d" % (name, i))
+            close(q, g["sample_q%d" % i])
+            tot = tot + l.mean()
+        tot.backward(retain_graph=True)
+        for i, f in enumerate(fq):
+            close(f.grad, g["sample_%s_dfeat%d" % (name, i)], rtol=1e-3, what="%s dfeat%d" % (name, i))
+    assert str(g["netF_sample_optimizer_error"]) == "ValueError: optimizer got an empty parameter list"
+
+
 def make_vxm(tag):
     shp, feats_ = ((64, 64), O.PLUGIN_UNET_FEATURES) if tag == "2d" else ((32, 32, 32), None)
     torch.manual_seed(81)
