@@ -70,6 +70,7 @@ _SIGS = {
     "dfmir_conv3d_split_wgrad_upcat": [_GP, P, P, c_int, P, c_int, P, P, c_int, P, P, P],
     "dfmir_conv3d_upwgrad_ok": [_GP, c_int],
     "dfmir_conv3d_wgrad_is_march": [_GP],
+    "dfmir_conv3d_wgrad_is_march_at": [_GP, P, P],
     "dfmir_conv3d_upwgrad_ws_floats": [],
     "dfmir_conv3d_upwgrad": [_GP, P, P, c_int, P, c_int, P, P, c_int, P, P, P, P],
     "dfmir_conv3d_split_wgrad_db": [_GP, P, P, c_int, P, P, c_int, P, P, P],

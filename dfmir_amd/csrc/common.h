@@ -64,6 +64,19 @@ static inline unsigned df_grid(long long n, int bs, long long cap = 1LL << 20) {
   return (unsigned)b;
 }
 
+// Compute units of the CURRENT device (persistent kernels launch one workgroup per CU); cached per device ordinal, so a
+// process that drives several (possibly different) devices gets each one's own count.
+static inline int df_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 // Zero a few floats on the stream with a KERNEL.  Not hipMemsetAsync: a captured step turns that into a hipGraph
 // memset node, and on ROCm 7.2 such nodes are not reliably ordered with the kernel nodes around them -- the third of
 // four identical masked-L1 calls in one captured graph read a stale workspace at every replay

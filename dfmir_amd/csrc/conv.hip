@@ -736,7 +736,7 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
   static DfOptFlag tinyvol_o{"DFMIR_NO_TINYVOL"};             // A/B: the deepest levels on conv_mfma_k
   // chosen by the PER-IMAGE volume, 3-D only: the kernel a sample runs on must not depend on the batch it arrives in
   // (tests/test_gpu_models.py::test_batch16_equals_per_sample_runs), and the 2-D deep levels keep their tuned path
-  if (g->Do > 1 && (long long)g->Do * g->Ho * g->Wo <= 512 && P <= 8192 && g->Cout <= 64 && !tinyvol_o.get()) {
+  if (!use_generic_only() && g->Do > 1 && (long long)g->Do * g->Ho * g->Wo <= 512 && P <= 8192 && g->Cout <= 64 && !tinyvol_o.get()) {
     if (g->Cout <= 8) conv_tinyvol_k<8><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else if (g->Cout <= 16) conv_tinyvol_k<16><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else if (g->Cout <= 32) conv_tinyvol_k<32><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);

@@ -2538,8 +2538,16 @@ static bool wgrad_march_geom_ok(const DfConvGeom* g) {
   return g->Cin == 32 && g->Cout == 16 && !split3d_off() && split3d_wgrad_geom_ok(g) && !nomarch_o.get() &&
          (long long)g->Di * g->Hi * g->Wi >= 4096;
 }
-// 1 when dfmir_conv3d_split_wgrad / _db take the marching kernel for this layer (csrc/conv3dwm.hip)
+// what the launcher decides: the geometry AND 16-byte aligned operands (x, dy are read as quads)
+static bool wgrad_march_takes(const DfConvGeom* g, const float* x, const float* dy) {
+  return wgrad_march_geom_ok(g) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+}
+// 1 when dfmir_conv3d_split_wgrad / _db take the marching kernel for this layer (csrc/conv3dwm.hip): _is_march answers
+// for 16-byte aligned operands, _is_march_at for the operands given (the SAME predicate the launcher applies)
 extern "C" int dfmir_conv3d_wgrad_is_march(const DfConvGeom* g) { return (g && wgrad_march_geom_ok(g)) ? 1 : 0; }
+extern "C" int dfmir_conv3d_wgrad_is_march_at(const DfConvGeom* g, const float* x, const float* dy) {
+  return (g && wgrad_march_takes(g, x, dy)) ? 1 : 0;
+}
 static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
   static DfOptFlag off_o{"DFMIR_UPWGRAD_DIRECT"};
   return !off_o.get() && !split3d_off() && split3d_wgrad_common_ok(g) && Ca == 32 && g->Cin > Ca && g->Cin - Ca <= 128 &&
@@ -2586,7 +2594,7 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   DF_ARG_CHECK(!split3d_off() && (rows || split3d_wgrad_geom_ok(g) || split3d_wgrad_swapped_ok(g)));
   hipStream_t st = (hipStream_t)stream;
   // the full-resolution 32 -> 16 layer: all 27 tap matrices resident, z-marching (conv3dwm.hip)
-  if (!rows && !xa && wgrad_march_geom_ok(g) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
+  if (!rows && !xa && wgrad_march_takes(g, x, dy))
     return df_conv3d_wgrad_march_launch(x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, g->N, g->Di, g->Hi, g->Wi, st);
   const bool swapped = !rows && !split3d_wgrad_geom_ok(g);
   W3sP k{};

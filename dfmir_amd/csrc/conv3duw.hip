@@ -814,10 +814,7 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
   k.N = N; k.Dl = Dl; k.Hl = Hl; k.Wl = Wl; k.Cout = Cout;
   k.a_n = a_n; k.dy_n = dy_n;
   k.ncy = (Hl + 3) / 4; k.ncx = (Wl + 15) / 16;
-  static const int ncu = [] {
-    int dev = 0, v = 0;
-    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }();
+  const int ncu = df_cu_count();
   // z segments: a workgroup (one per CU) walks ceil(items / CUs) items of zlen planes, each with a prologue worth ~2 planes
   const long long cols = (long long)N * k.ncy * k.ncx;
   static DfOptInt nseg_o{"DFMIR_UPWGRAD_NSEG", 0};

@@ -338,10 +338,7 @@ int df_conv3d_wgrad_march_launch(const float* x, const float* x_amax, int x_n, c
   k.ncy = (H + 7) / 8; k.ncx = (W + 31) / 32;
   k.s_tap = 32LL * 16;
   k.db = db;
-  static const int ncu = [] {
-    int dev = 0, v = 0;
-    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }();
+  const int ncu = df_cu_count();
   const long long cols = (long long)N * k.ncy * k.ncx;
   static DfOptInt nseg_o{"DFMIR_WGRAD_MARCH_NSEG", 0};
   int best = 1;

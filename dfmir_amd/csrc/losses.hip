@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void ncc_prod_boxw_x4_k(const float* __restric
 __global__ __launch_bounds__(256) void ncc_prod_boxwh_k(const float* __restrict__ I, const float* __restrict__ J,
                                                         float* __restrict__ o, long long N, int H, int W, int nty, int ntx) {
   constexpr int TY = 32, TX = 64, R = 4, PY = TY + 2 * R, PX = TX + 2 * R;
+  // 75 KB of static LDS: above the 64 KB most parts allow, within gfx950's 160 KB per CU (this library builds for gfx950 only)
+  static_assert((2 * PY * (PX + 1) + 5 * PY * (TX + 1)) * sizeof(float) <= 160 * 1024, "LDS tile exceeds gfx950's 160 KB");
   __shared__ float sI[PY][PX + 1], sJ[PY][PX + 1];
   __shared__ float sS[5][PY][TX + 1];
   const int tid = threadIdx.x;
@@ -537,6 +539,8 @@ __global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restric
                                                           int H, int W, int nty, int ntx, float wn, float eps,
                                                           const float* __restrict__ mask, int mode) {
   constexpr int TY = 32, TX = 64, R = 4, PY = TY + 2 * R, PX = TX + 2 * R;
+  // 66 KB of static LDS (gfx950: 160 KB per CU; see ncc_prod_boxwh_k)
+  static_assert((3 * PY * (PX + 1) + 3 * PY * (TX + 1)) * sizeof(float) <= 160 * 1024, "LDS tile exceeds gfx950's 160 KB");
   __shared__ float sF[3][PY][PX + 1];
   __shared__ float sS[3][PY][TX + 1];
   const int tid = threadIdx.x;

@@ -35,7 +35,7 @@ def init_from_env(default_backend="nccl"):
 # DFMIR_FORCE_DIST=1: treat a world of ONE rank as distributed (process group created, weights broadcast, every arena
 # all-reduced through the backend).  On a 1-GPU box this is the only way to run the RCCL code path itself -- communicator
 # creation with device_id, the watchdog thread next to a hipGraph capture, async work handles -- before an 8-GPU node does.
-_FORCE = bool(os.environ.get("DFMIR_FORCE_DIST"))
+_FORCE = os.environ.get("DFMIR_FORCE_DIST") not in (None, "", "0")     # flag semantics of include/dfmir_hip.h "Options"
 
 
 def is_distributed():

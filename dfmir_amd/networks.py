@@ -225,8 +225,8 @@ def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[], debug=False, i
 # ------------------------------------------------------------------------------------------------
 # generator
 # ------------------------------------------------------------------------------------------------
-_NO_SHARE_TAP = bool(os.environ.get("DFMIR_NO_SHARE_TAP"))   # A/B switch: dense gradients of the sampled features
-_NO_SKIP_FOLD = bool(os.environ.get("DFMIR_NO_SKIP_FOLD"))   # A/B switch: skip gradient summed by autograd's add
+_NO_SHARE_TAP = ops._env_on("DFMIR_NO_SHARE_TAP")   # A/B switch: dense gradients of the sampled features
+_NO_SKIP_FOLD = ops._env_on("DFMIR_NO_SKIP_FOLD")   # A/B switch: skip gradient summed by autograd's add
 
 
 class ResnetBlock(nn.Module):

@@ -434,7 +434,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
                 kind = "wgrad3dup_" + size
             elif Cout < 8:          # the flow head: roles swapped, rows = (tap, co of a chunk of 8), columns = ci of 32
                 pad_ = (28.0 / 27.0) * (8.0 / Cout) * (32.0 / Cin)
-            elif parts is None and lib().dfmir_conv3d_wgrad_is_march(ctypes.byref(g)):   # 14 tiles of two taps for 27
+            elif parts is None and lib().dfmir_conv3d_wgrad_is_march_at(ctypes.byref(g), _p(x5), _p(dy5)):   # 14 tiles of two taps for 27
                 pad_ = 28.0 / 27.0
             elif Cout <= 16:        # plane-pair columns: 36 taps' of 27, 16 columns per plane
                 pad_ = (36.0 / 27.0) * (8.0 * ((Cin + 7) // 8)) / Cin * (16.0 / Cout)
@@ -565,7 +565,7 @@ _DEFER = {"on": False, "pending": {}}
 
 class deferred_weight_grads:
     def __enter__(self):
-        _DEFER["on"] = os.environ.get("DFMIR_NO_DEFER") is None   # A/B switch
+        _DEFER["on"] = not _env_on("DFMIR_NO_DEFER")   # A/B switch
         return self
 
     def __exit__(self, *exc):

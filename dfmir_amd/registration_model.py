@@ -284,7 +284,7 @@ class REGISTRATIONModel(BaseModel):
 
     def _overlap_registration(self):
         return (self.isTrain and self.device.type == 'cuda' and getattr(self.opt, 'overlap_registration', True)
-                and not os.environ.get('DFMIR_NO_OVERLAP_R'))
+                and not ops._env_on('DFMIR_NO_OVERLAP_R'))
 
     # -- data-parallel gradient buckets (build-defined; replaces nothing in the reference, whose DataParallel reduces on
     # device 0, base_model.py:103-107).  opt.bucket_allreduce: G's arena leaves in two depth buckets.  The query pass of the
@@ -320,8 +320,12 @@ class REGISTRATIONModel(BaseModel):
         b = self._bucket
         if b is None or id(self.optimizer_G) in self._early:
             return
-        if torch.cuda.is_current_stream_capturing() and not os.environ.get('DFMIR_BUCKET_IN_GRAPH'):
-            return                                         # a captured step keeps its exchange behind the replay
+        if getattr(self.opt, 'capture_step', False) and not ops._env_on('DFMIR_BUCKET_IN_GRAPH'):
+            # A model that captures its step keeps the whole exchange behind the replay -- in the eager warm-up steps and
+            # after a failed capture as well: an early flush there would build the deferred-gradient job tables for a
+            # different item set than the capture flushes (a table upload inside the capture), and a rank whose capture
+            # failed would issue tail + head all-reduces against its peers' single one.
+            return
         from . import distributed as dfdist
         ops.flush_deferred_subset(b['owners'], 'late')
         works = dfdist.allreduce_arenas([self.optimizer_G.flat_g[b['off']:]], async_op=True)
@@ -334,6 +338,16 @@ class REGISTRATIONModel(BaseModel):
                                                    'stream': torch.cuda.Stream(device=self.device)})
 
     def _forward_backward(self):
+        if getattr(self, '_early', None):
+            # a previous backward fired the bucket hook and never reached sync_gradients (it raised, or the caller ran
+            # _forward_backward twice): finish those exchanges and forget them, or this step's hook would see a stale entry
+            # and the arena's tail would never be reduced
+            for _, w in self._early.values():
+                if w is not None:
+                    w.wait()
+            self._early.clear()
+        if getattr(self, '_bucket', None) is not None:
+            self._bucket['in_graph'] = False
         if self._overlap_registration():
             # netR reads only the two input images (registration_model.py:146): its forward runs on a second stream beside
             # the generator's, and autograd then runs its backward there as well, beside the generator's backward -- a
@@ -374,7 +388,7 @@ class REGISTRATIONModel(BaseModel):
             return l1_reg, l1_idt, smooothing_loss(y_pred[1])
 
         # ... which follow netR on ITS stream, beside the NCE query pass (not when the masked-L1 normalisation is a collective)
-        side_losses = (rs is not None and not os.environ.get('DFMIR_NO_SIDE_LOSSES')
+        side_losses = (rs is not None and not ops._env_on('DFMIR_NO_SIDE_LOSSES')
                        and not (getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False)))
         if side_losses:
             rs.wait_stream(cur)                            # fake_B / idt_B exist
@@ -394,7 +408,7 @@ class REGISTRATIONModel(BaseModel):
 
         self._nce_terms = None
         idt = bool(self.opt.nce_idt)
-        if (getattr(self.opt, 'batch_query_passes', True) and not os.environ.get('DFMIR_NO_STACKED_Q')
+        if (getattr(self.opt, 'batch_query_passes', True) and not ops._env_on('DFMIR_NO_STACKED_Q')
                 and self.opt.lambda_NCE > 0.0 and self.opt.lambda_GAN <= 0.0):
             # The three NCE terms each run G's encoder on their own query batch (fake_B, idt_B, regA) with the same
             # weights: one pass over the three stacked along the batch instead (per-sample kernels; same random
@@ -571,7 +585,7 @@ class REGISTRATIONModel(BaseModel):
         # reference's call order with host-drawn ids (torch.randperm).  A netF.forward replaced on the instance (how older
         # tests pin ids) implies it; `model.patch_id_source` is the hook that pins ids on the default path.
         sequential = (getattr(self.opt, 'nce_sequential_keys', False) or 'forward' in vars(self.netF)
-                      or os.environ.get('DFMIR_NCE_SEQUENTIAL_KEYS'))
+                      or ops._env_on('DFMIR_NCE_SEQUENTIAL_KEYS'))
         if not sequential and self.opt.netF == 'mlp_sample' and all(S >= 2 * P or P <= S <= 4096 for S in sizes):
             id_src = getattr(self, 'patch_id_source', None)
             # a captured step may hold the ids only by device address: the device generator, or a source that declares

@@ -232,6 +232,9 @@ int dfmir_conv3d_split_wgrad_db(const DfConvGeom* g, const float* x, const float
  * full-resolution ConvBlock of `extras`, networks.py:73-86) -- all 27 tap matrices resident in one wave's accumulators, the
  * workgroup marching along z, both operands read once.  A/B: DFMIR_CONV3D_NO_WGRAD_MARCH=1; DFMIR_WGRAD_MARCH_NSEG=n. */
 int dfmir_conv3d_wgrad_is_march(const DfConvGeom* g);
+/* The launcher's own predicate: the geometry above AND x, dy 16-byte aligned (they are read as quads; unaligned operands
+ * run on the tiled kernel).  _is_march(g) answers for aligned operands. */
+int dfmir_conv3d_wgrad_is_march_at(const DfConvGeom* g, const float* x, const float* dy);
 /* out[0..DFMIR_PROBE_SLOTS) = max(a, b): the probe of cat([nearest_up2(a), b]) from its inputs' probes. */
 int dfmir_probe_merge(const float* a, const float* b, float* out, void* stream);
 /* dw_tcc[tap][Cin][Cout] += sum_{n,o} x(gathered) * dy      (accumulates; same packing as w_tcc). */

@@ -64,7 +64,7 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
         model.parallelize()
         assert model._ddp and all(o.grad_scale == 0.5 for o in model.optimizers)
         w_after_bcast = [o.flat_p.cpu() for o in model.optimizers]
-        if bucket:                                           # the arena's tail leaves INSIDE backward
+        if bucket and not capture:                           # the arena's tail leaves INSIDE backward
             model.set_input(data)
             model._forward_backward()
             assert model._bucket['fired'] == 1 and len(model._early) == 1
@@ -100,6 +100,8 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
         losses = model.get_current_losses()
         w_end = [o.flat_p.cpu() for o in model.optimizers]
         graphed = bool(getattr(model, '_graph', {}).get('graph') is not None)
+        if bucket:                                           # a capturing model keeps the whole exchange behind the replay
+            assert model._bucket is not None and model._bucket['fired'] == 0 and not model._early
         if big:
             import hashlib
             dig = lambda ts: [hashlib.sha1(t.numpy().tobytes()).hexdigest() for t in ts]
@@ -152,6 +154,20 @@ def test_gradient_buckets_change_nothing():
         assert float(np.abs(a - b).max()) <= 2 * 5 * 2e-4 and float(np.linalg.norm(a - b)) <= 5e-3 * float(np.linalg.norm(b))
     for k in b0[5]:
         assert abs(b0[5][k] - p0[5][k]) <= 2e-2 * max(abs(p0[5][k]), 1e-6), (k, b0[5][k], p0[5][k])
+
+
+def test_gradient_buckets_with_a_captured_step():
+    """opt.bucket_allreduce together with opt.capture_step (what `bench.py --bucket-allreduce` runs): the depth-bucket hook
+    stays off for a model that captures its step -- in the eager warm-up steps too, so the deferred-gradient job table the
+    capture needs exists before it (no table upload inside the capture) and every rank issues the same collectives whether
+    or not its capture succeeded.  Two ranks: the later steps ARE graph replays, the hook never fired, the reduced arenas
+    are the sums of the local gradients and the replicas stay bit-identical."""
+    r0, r1 = _run_two_ranks_2d(True, "gloo", bucket=True)
+    for s0, s1, g0 in zip(r0[2], r1[2], r0[3]):
+        assert np.array_equal(s0, s1) and np.allclose(s0, g0, rtol=1e-6, atol=1e-12) and float(np.abs(s0).sum()) > 0
+    for a, b in zip(r0[4], r1[4]):
+        assert np.array_equal(a, b), "replicas stay bit-identical through the optimizer steps"
+    assert r0[6] and r1[6], "the later steps must have been hipGraph replays (the capture did not fall back)"
 
 
 def test_registration_model_two_ranks_full_geometry():

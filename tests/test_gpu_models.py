@@ -752,7 +752,8 @@ def test_full_size_step_vs_oracle(O, default_path, capsys):
     model.optimize_parameters()
     ls = model.get_current_losses()
     # the three outputs north_star names -- translated image, deformation field, warped moving image -- norm-wise AND
-    # element-wise (every element within ELEM_RTOL of max(|ref_i|, 1e-6 max|ref|)); the other tensors norm-wise
+    # element-wise (99.9 % of the elements within ELEM_RTOL of max(|ref_i|, 1e-6 max|ref|), every element within 1: see
+    # tests/test_gpu_ops.py::close); the other tensors norm-wise
     close(model.fake_B, st.fake_B, what="fake_B", elem_rtol=ELEM_RTOL); close(model.regA, st.regA, what="regA")
     close(model.registered, st.registered, what="registered", elem_rtol=ELEM_RTOL); close(model.idt_B, st.idt_B, what="idt_B")
     close(model.pos_flow, st.flow, what="pos_flow", elem_rtol=ELEM_RTOL)
@@ -879,7 +880,8 @@ def test_batch16_step_vs_oracle(O, capsys):
     model.optimize_parameters()
     ls = model.get_current_losses()
     # the three outputs north_star names -- translated image, deformation field, warped moving image -- norm-wise AND
-    # element-wise (every element within ELEM_RTOL of max(|ref_i|, 1e-6 max|ref|)); the other tensors norm-wise
+    # element-wise (99.9 % of the elements within ELEM_RTOL of max(|ref_i|, 1e-6 max|ref|), every element within 1: see
+    # tests/test_gpu_ops.py::close); the other tensors norm-wise
     close(model.fake_B, st.fake_B, what="fake_B", elem_rtol=ELEM_RTOL); close(model.regA, st.regA, what="regA")
     close(model.registered, st.registered, what="registered", elem_rtol=ELEM_RTOL); close(model.idt_B, st.idt_B, what="idt_B")
     close(model.pos_flow, st.flow, what="pos_flow", elem_rtol=ELEM_RTOL)
