@@ -381,7 +381,8 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
                         % (tuple(shape) + ("default" if feats is None else "plugin 6-level", label)),
             "value": 1.0 / dt, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
             "step_submission": "hipGraph replay + eager Adam" if graphed else "eager",
-            "conv_tflops": gflop_step / dt / 1e3, "conv_gflop_per_step": gflop_step, "dtype": "f32",
+            "conv_tflops": gflop_step / dt / 1e3, "conv_gflop_per_step": gflop_step,
+            "dtype": "f32 (fp32 MFMA)" if (os.environ.get("DFMIR_CONV3D_FP32") or os.environ.get("DFMIR_CONV_FP32")) else "f32 (fp16x2-split MFMA, fp32 accumulate)",
             "losses": {k: round(v, 6) for k, v in losses.items()}, "roofline": roof,
             "field_note": "timed on freshly initialised weights: flow head N(0, 1e-5), i.e. a near-identity field (SURVEY section 8 "
                           "D2 keeps the headline on init weights); `rough_field` is the same step on a deformation of a few voxels",
@@ -697,7 +698,10 @@ def main():
             "value_host_inputs": host_rate,
             "value_pil_loader": pil_rate,       # fed by dfmir_amd.data's DataLoader (PNG decode + transforms in worker processes)
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (fp16x2-split MFMA, fp32 accumulate)" if (split and nprod == 3.0) else
+                      ("f32 (bf16x3-split MFMA, fp32 accumulate)" if split else "f32 (fp32 MFMA)")),
+            "data": "synthetic",
             "config": {"workload": "2-D %dx%d T1<->T2-shaped synthetic slice pairs, batch %d per GPU, ngf %d: "
                                    "REGISTRATIONModel.set_input+optimize_parameters (ResnetGenerator-9 + PatchNCE + 2-D "
                                    "VoxelMorph + bilinear warps, fwd+bwd+Adam), BASELINE configs[1]" % (S, S, B, args.ngf),

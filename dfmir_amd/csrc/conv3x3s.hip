@@ -1058,293 +1058,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
   WGT(3)
 }
 
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENT (round 4, DFMIR_CONV_W1=1): the same convolution with ONE wave per SIMD and the whole register file behind it.
-// The shared-tile kernel above reads 54 LDS operand units per 108 MFMAs, and its knock-outs put those reads at a quarter
-// of its time.  Here a 256-thread workgroup (launch bound 1 wave per SIMD: 512 registers per lane) owns 16 x 32 pixels x 128
-// output channels; a wave = 64 couts x 8 tile rows = 16 accumulator tiles (256 registers), so that per kx stage it reads
-// 10 patch rows + 6 weight blocks (x 2 split terms = 32 units) for 144 MFMAs: 0.22 reads per MFMA instead of 0.5.  There
-// is no partner wave to hide the staging behind: the next chunk's patch (3 positions x 16 channels per thread) is loaded
-// in stage kx = 0 and converted + stored between the MFMAs of stage 1; the pre-split weights never touch a register --
-// `buffer_load ... lds` copies the [split][ky][half][128 couts] slab of stage s + 2 into the LDS region stage s - 1 has
-// just released.  One barrier per stage (3 per 16-channel chunk).  Cin % 16 == 0, fp16x2 mode only.
-constexpr int W1_XP = 640;                               // 18 x 34 = 612 patch positions, padded
-#ifdef W1_TRACE
-__device__ unsigned g_w1_trace[4 * 64 * 4];
-extern "C" int dfmir_w1_trace_dump(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w1_trace), sizeof(g_w1_trace)); }
-#define W1T(slot_) { if (trace_blk && lane == 0 && stage_no < 64) g_w1_trace[(wid * 64 + stage_no) * 4 + (slot_)] = (unsigned)__builtin_readcyclecounter(); }
-#else
-#define W1T(slot_)
+// (The one-wave-per-SIMD experiment of round 4, conv3x3_split_w1_k, lives in scripts/ubench/conv3x3_split_w1.inc: a lab
+// build with -DDFMIR_BUILD_W1 includes it and DFMIR_CONV_W1=1 selects it; the product library does not carry it.)
+#ifdef DFMIR_BUILD_W1
+#include "../../scripts/ubench/conv3x3_split_w1.inc"
 #endif
-template <int DUMMY>
-__global__ __launch_bounds__(256, 1) void conv3x3_split_w1_k(const float* __restrict__ x, const u32x4* __restrict__ ws,
-                                                             const float* __restrict__ bias, float* __restrict__ y,
-                                                             ConvCsP k, SplitScale sc) {
-  constexpr int NSP = 2, XP = W1_XP, PW = CS_PW, NPOS = 18 * PW, WR = NSP * 3 * 2 * 128;
-  __shared__ __attribute__((aligned(16))) u32x4 Wr[3][WR];
-  __shared__ __attribute__((aligned(16))) u32x4 Xs[2][NSP * 2 * XP];
-  __shared__ float bs[128];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int ch_ = wid & 1, rh = wid >> 1;                 // this wave: couts 64 ch_ .. + 63, tile rows 8 rh .. + 7
-  const int HWo = k.Ho * k.Wo, HWi = k.Hi * k.Wi;
-  int bt = blockIdx.x, bm = blockIdx.y;
-  if (k.xcd_pair >= 2) {
-    const int ny = k.xcd_pair - 1, per = (int)(gridDim.x >> 3) / ny, j = bt >> 3;
-    bm = j % ny;
-    bt = (bt & 7) * per + j / ny;
-  }
-  const int tx = bt % k.tiles_x; bt /= k.tiles_x;
-  const int ty = bt % k.tiles_y;
-  const int n = bt / k.tiles_y;
-  const int oy0 = ty * 16, ox0 = tx * CS_TW;
-  const int m0 = bm * 128;
-  constexpr unsigned OOB = 0x80000000u;
-
-  // patch positions of this thread (3 of 612) and the first loads
-  unsigned gvo[3];
-#pragma unroll
-  for (int s2 = 0; s2 < 3; ++s2) {
-    const int pos = tid + 256 * s2;
-    int off = -1;
-    if (pos < NPOS) {
-      const int r = pos / PW, c = pos - r * PW;
-      off = halo_offset(oy0 - k.pad + r, ox0 - k.pad + c, k.Hi, k.Wi, k.pad_mode);
-    }
-    gvo[s2] = off < 0 ? OOB : (unsigned)off * 4u;
-  }
-  const float* xn = x + (long long)n * k.Cin * HWi;
-  const int chunks = k.Cin >> 4;
-  const unsigned hw4 = (unsigned)HWi * 4u;
-  unsigned rx[3][16];
-#define W1_GLOADX(c_)                                                                            \
-  {                                                                                              \
-    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(                        \
-        const_cast<float*>(xn + (long long)(16 * (c_)) * HWi), 0,                                \
-        (c_) < chunks ? 16u * hw4 : 0u, 0x00020000);                                             \
-    _Pragma("unroll") for (int s2 = 0; s2 < 3; ++s2)                                             \
-      _Pragma("unroll") for (int c2 = 0; c2 < 16; ++c2)                                          \
-        rx[s2][c2] = __builtin_amdgcn_raw_buffer_load_b32(rx_, gvo[s2], (unsigned)c2 * hw4, 0);  \
-  }
-  // weight slab of (chunk c_, kx_): unit u = tid + 256 j -> (split u / 768, ky (u / 256) % 3, half (u / 128) % 2, cout u % 128)
-  unsigned wvo[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int u = tid + 256 * j;
-    const int sp_ = u / 768, ky = (u >> 8) % 3, hf = (u >> 7) & 1, co = m0 + (u & 127);
-    wvo[j] = co < k.Cout ? (unsigned)(((hf * NSP * 9 + sp_ * 9 + ky * 3) * k.Cout + co) * 16) : OOB;
-  }
-  const unsigned wchunk16 = (unsigned)(2 * NSP * 9 * k.Cout);   // 16-B units of one 16-channel chunk in the packed section
-#define W1_DMA(c_, kx_)                                                                          \
-  {                                                                                              \
-    const bool live_ = (c_) < chunks;                                                            \
-    const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc(                        \
-        const_cast<u32x4*>(ws + (long long)(live_ ? (c_) : 0) * wchunk16 + (long long)(kx_) * k.Cout), 0, \
-        live_ ? (unsigned)(wchunk16 - (kx_) * k.Cout) * 16u : 0u, 0x00020000);                   \
-    _Pragma("unroll") for (int j = 0; j < 6; ++j)                                                \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_, (__attribute__((address_space(3))) void*)&Wr[kx_][256 * j + 64 * wid], \
-                                               16, wvo[j], 0, 0, 0);                             \
-  }
-  W1_GLOADX(0);
-  W1_DMA(0, 0);
-  W1_DMA(0, 1);
-  const int ex = scale_exp(reduce_absmax(sc.x_amax, sc.x_n, bs));
-  __syncthreads();
-  const int ew = (int)sc.w_trailer[1];
-  const float xscale = pow2f(ex), osc = pow2f(-ex) * pow2f(-ew);
-  if (tid < 128) bs[tid] = (bias && (m0 + tid) < k.Cout) ? bias[m0 + tid] : 0.f;
-  // positions past the patch (tid + 512 >= 612) convert into the padding units 612 .. 639: no branch around the conversion, so
-  // that it can sit between the MFMAs of a row block
-#define W1_POS(s2_) ((tid + 256 * (s2_)) < NPOS ? (tid + 256 * (s2_)) : NPOS + (tid & 15))
-#define W1_CONVPAIR(s2_, p_)                                                                     \
-  { unsigned pr_[2];                                                                             \
-    split_pair_scaled(__uint_as_float(rx[s2_][2 * (p_)]), __uint_as_float(rx[s2_][2 * (p_) + 1]), xscale, pr_); \
-    cvh[((p_) >> 2)][(p_) & 3] = pr_[0]; cvl[((p_) >> 2)][(p_) & 3] = pr_[1]; }
-#define W1_CONVSTORE(buf_, s2_, hf_)                                                             \
-  { Xs[buf_][(0 * 2 + (hf_)) * XP + W1_POS(s2_)] = cvh[hf_]; Xs[buf_][(1 * 2 + (hf_)) * XP + W1_POS(s2_)] = cvl[hf_]; }
-#define W1_LSTOREX(buf_, s2_)                                                                    \
-  { _Pragma("unroll") for (int p = 0; p < 8; ++p) W1_CONVPAIR(s2_, p)                            \
-    W1_CONVSTORE(buf_, s2_, 0) W1_CONVSTORE(buf_, s2_, 1) }
-  u32x4 cvh[2], cvl[2];
-  W1_LSTOREX(0, 0) W1_LSTOREX(0, 1) W1_LSTOREX(0, 2)
-
-  f32x16 acc[2][8];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[cb][j][r] = 0.f;
-  using P = Prod<2>;
-  const int abase = lhi * 128 + 64 * ch_ + l31;          // + ((split * 3 + ky) * 2) * 128 + 32 cb
-  const int xbase = lhi * XP + (8 * rh) * PW + l31;      // + split * 2 XP + r * PW + kx
-
-  // One stage = one kx: 10 patch rows x (up to) 3 ky x 2 cout blocks x 3 products = 144 MFMAs.  Software pipeline (there is no
-  // second wave on the SIMD to cover a wait): patch rows are read two rows ahead; the barrier sits in the MIDDLE of a stage --
-  // behind it the slab of stage s + 1 (requested one stage earlier) is visible to every wave and the region of stage s - 1 is
-  // free -- and is followed by the request for stage s + 2's slab, the reads of stage s + 1's weight operands (second register
-  // set) and, in stage kx = 1, the conversion of the next chunk's patch, all between the MFMAs of rows 5-9.
-#define W1_LDX(dst_, buf_, r_, kx2_) { _Pragma("unroll") for (int q = 0; q < NSP; ++q) dst_[q] = (buf_)[q * 2 * XP + xbase + (r_) * PW + (kx2_)]; }
-#define W1_LDA1(dst_, kx2_, ky_)                                                                 \
-  { _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                             \
-      _Pragma("unroll") for (int q = 0; q < NSP; ++q)                                            \
-        dst_[ky_][cb][q] = Wr[kx2_][((q * 3 + (ky_)) * 2) * 128 + abase + 32 * cb]; }
-#define W1_LDA(dst_, kx2_) { W1_LDA1(dst_, kx2_, 0) W1_LDA1(dst_, kx2_, 1) W1_LDA1(dst_, kx2_, 2) }
-  // pin the issue order of a row block: nm MFMAs, each followed by one of the block's nds LDS reads / nvm buffer loads /
-  // (conversion rows) 2 VALU, and an LDS store after every fourth
-#define W1_SCHED(nm_, nds_, nvm_, conv_)                                                         \
-  { _Pragma("unroll") for (int i = 0; i < (nm_); ++i) {                                          \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
-      if (i < (nds_)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                         \
-      if (i < (nvm_)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
-      if (conv_) { __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); } \
-    }                                                                                            \
-    __builtin_amdgcn_sched_barrier(0); }
-#define W1_ROW(r_)                                                                               \
-  { _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                           \
-      const int j = (r_) - ky;                                                                   \
-      if (j >= 0 && j < 8) {                                                                     \
-        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                         \
-          _Pragma("unroll") for (int q = 0; q < P::N; ++q)                                       \
-            acc[cb][j] = mma16<2>(xr[((r_) + KXO) % 3][P::B[q]], a[ky][cb][P::A[q]], acc[cb][j]); \
-      } } }
-  // MFMA number m of row r: ky = m / 6, cout block (m / 3) % 2, product m % 3
-#define W1_MMA1(r_, m_)                                                                          \
-  { constexpr int ky_ = (m_) / 6, cb_ = ((m_) / 3) % 2, q_ = (m_) % 3, j_ = (r_) - ky_;          \
-    if (j_ >= 0 && j_ < 8) acc[cb_][j_] = mma16<2>(xr[((r_) + KXO) % 3][P::B[q_]], a[ky_][cb_][P::A[q_]], acc[cb_][j_]); }
-  // a row block that also converts one patch position of the next chunk: two MFMAs, one pair of values, fenced so that the
-  // inline-asm conversion stays where it is put
-#define W1_ROWC(r_, buf_, s2_)                                                                   \
-  { __builtin_amdgcn_sched_barrier(0);                                                           \
-    W1_MMA1(r_, 0) W1_MMA1(r_, 1) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 0) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 2) W1_MMA1(r_, 3) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 1) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 4) W1_MMA1(r_, 5) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 2) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 6) W1_MMA1(r_, 7) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 3) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 8) W1_MMA1(r_, 9) __builtin_amdgcn_sched_barrier(0); W1_CONVSTORE(buf_, s2_, 0) W1_CONVPAIR(s2_, 4) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 10) W1_MMA1(r_, 11) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 5) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 12) W1_MMA1(r_, 13) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 6) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 14) W1_MMA1(r_, 15) __builtin_amdgcn_sched_barrier(0); W1_CONVPAIR(s2_, 7) __builtin_amdgcn_sched_barrier(0); \
-    W1_MMA1(r_, 16) W1_MMA1(r_, 17) __builtin_amdgcn_sched_barrier(0); W1_CONVSTORE(buf_, s2_, 1) __builtin_amdgcn_sched_barrier(0); }
-#define W1_STAGE(c_, kx_)                                                                        \
-  {                                                                                              \
-    const u32x4* Xb = Xs[(c_) & 1];                                                              \
-    const u32x4* Xn = (kx_) == 2 ? Xs[((c_) + 1) & 1] : Xb;     /* rows 0, 1 of the NEXT stage */ \
-    constexpr int KXO = (kx_);                            /* row r lives in register slot (r + kx) % 3: 10 rows per stage */ \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    W1T(0)                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 5; ++r) {                                              \
-      W1_LDX(xr[(r + 2 + KXO) % 3], Xb, r + 2, kx_)                                              \
-      W1_ROW(r)                                                                                  \
-      W1_SCHED(r == 0 ? 6 : (r == 1 ? 12 : 18), 2, 0, false)                                     \
-    }                                                                                            \
-    W1T(1)                                                                                       \
-    __builtin_amdgcn_s_waitcnt(0x0f70);                   /* vmcnt(0): my pieces of the next slab, my patch loads */ \
-    W1T(2)                                                                                       \
-    __syncthreads();                                                                             \
-    W1T(3)                                                                                       \
-    W1_DMA((c_) + ((kx_) + 2) / 3, ((kx_) + 2) % 3)                                              \
-    if ((kx_) == 0) W1_GLOADX((c_) + 1)                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    _Pragma("unroll") for (int r = 5; r < 10; ++r) {                                             \
-      if (r + 2 < 10) W1_LDX(xr[(r + 2 + KXO) % 3], Xb, r + 2, kx_)                              \
-      else W1_LDX(xr[(r + 2 + KXO) % 3], Xn, r + 2 - 10, ((kx_) + 1) % 3)                        \
-      if (r == 5) W1_LDA1(an, ((kx_) + 1) % 3, 0)                                                \
-      if (r == 6) W1_LDA1(an, ((kx_) + 1) % 3, 1)                                                \
-      if (r == 7) W1_LDA1(an, ((kx_) + 1) % 3, 2)                                                \
-      if ((kx_) == 1 && r >= 5 && r <= 7) {                                                      \
-        if (r == 5) W1_ROWC(5, ((c_) + 1) & 1, 0)                                                \
-        if (r == 6) W1_ROWC(6, ((c_) + 1) & 1, 1)                                                \
-        if (r == 7) W1_ROWC(7, ((c_) + 1) & 1, 2)                                                \
-      } else {                                                                                   \
-        W1_ROW(r)                                                                                \
-        /* VMEM of this half: 6 slab pieces (every stage), + the 48 patch loads of the next chunk in stage kx = 0 */ \
-        W1_SCHED(r == 9 ? 6 : (r == 8 ? 12 : 18), (r >= 5 && r <= 7) ? 6 : 2,                    \
-                 (kx_) == 0 ? (r <= 7 ? 14 : (r == 8 ? 12 : 0)) : (r == 5 ? 6 : 0), false)       \
-      }                                                                                          \
-    }                                                                                            \
-    _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                             \
-      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                           \
-        _Pragma("unroll") for (int q = 0; q < NSP; ++q) a[ky][cb][q] = an[ky][cb][q];            \
-    ++stage_no;                                                                                  \
-  }
-  u32x4 a[3][2][NSP], an[3][2][NSP], xr[3][NSP];
-  int stage_no = 0;
-#ifdef W1_TRACE
-  const bool trace_blk = blockIdx.x == 40 && blockIdx.y == 0;
-#endif
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-  __syncthreads();                                        // chunk 0's patch and the slabs of stages 0 and 1 are in place
-  W1_LDA(a, 0)
-  W1_LDX(xr[0], Xs[0], 0, 0)
-  W1_LDX(xr[1], Xs[0], 1, 0)
-  for (int c = 0; c < chunks; ++c) {
-    W1_STAGE(c, 0)
-    W1_STAGE(c, 1)
-    W1_STAGE(c, 2)
-  }
-#undef W1_LDX
-#undef W1_LDA
-#undef W1_LDA1
-#undef W1_SCHED
-#undef W1_ROW
-#undef W1_ROWC
-#undef W1_MMA1
-#undef W1_CONVPAIR
-#undef W1_CONVSTORE
-#undef W1_POS
-#undef W1_STAGE
-#undef W1_LSTOREX
-#undef W1_DMA
-#undef W1_GLOADX
-
-  // ---- epilogue (rows = pixels, columns = couts; float4 only: the host takes this kernel when k.vec4 holds)
-  float* yb = y + (long long)n * k.Cout * HWo;
-  const long long ss = (long long)k.Cout * k.ring_rl;
-#pragma unroll 16
-  for (int t = 0; t < 16; ++t) {
-    const int cb = t >> 3, j = t & 7;
-    const int cc = 64 * ch_ + 32 * cb + l31, co = m0 + cc;
-    const int oy = oy0 + 8 * rh + j;
-    const bool live = co < k.Cout && oy < k.Ho;
-    const float bv = bs[cc];
-    const long long rowoff = (long long)(live ? co : 0) * HWo + (long long)(live ? oy : 0) * k.Wo;
-    const float* rg = (k.ring && live) ? k.ring + ((long long)n * 4 * k.Cout + co) * k.ring_rl : nullptr;
-    float4 rv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ox = ox0 + 8 * q + 4 * lhi;
-      rv[q] = (k.res && live && ox < k.Wo) ? *reinterpret_cast<const float4*>(k.res + (long long)n * k.Cout * HWo + rowoff + ox)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ox = ox0 + 8 * q + 4 * lhi;
-      float v[4];
-      const float r4[4] = {rv[q].x, rv[q].y, rv[q].z, rv[q].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float tv = acc[cb][j][4 * q + e] * osc + bv;
-        if (k.act == 1) tv = tv > 0.f ? tv : tv * k.slope;      // (tanh layers stay on the shared-tile kernel)
-        v[e] = tv + r4[e];
-      }
-      if (rg) {
-        const bool border = oy == 1 || oy == k.Ho - 2 || ox == 0 || ox + 4 == k.Wo;
-        if (border) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int xx = ox + e;
-            if (oy == 1) v[e] += rg[xx + 1] + (xx == 1 ? rg[0] : 0.f) + (xx == k.Wo - 2 ? rg[k.Wo + 1] : 0.f);
-            if (oy == k.Ho - 2) v[e] += rg[ss + xx + 1] + (xx == 1 ? rg[ss] : 0.f) + (xx == k.Wo - 2 ? rg[ss + k.Wo + 1] : 0.f);
-            if (xx == 1) v[e] += rg[2 * ss + oy + 1];
-            if (xx == k.Wo - 2) v[e] += rg[3 * ss + oy + 1];
-          }
-        }
-      }
-      if (live && ox < k.Wo) *reinterpret_cast<float4*>(yb + rowoff + ox) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // res != NULL (y = act(conv + bias) + res): only the shared-tile kernel has that epilogue -- df_conv3x3_split_res_ok(g)
@@ -1419,6 +1137,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
       // group's compute half-step -- was built and measured in round 4: bit-identical, 16 % SLOWER (0.404 vs 0.348 ms at
       // n = 32).  The epilogue is a 33 MB burst of stores issued by all 256 CUs in lockstep, i.e. HBM-write-bound wherever
       // it is placed, and the extra state cost the main loop its registers)
+#ifdef DFMIR_BUILD_W1
       static DfOptFlag w1_o{"DFMIR_CONV_W1"};
       if (w1_o.get() && rr && kc.vec4 && g->act != 2 && (g->Cin % 16) == 0 && (g->Ho % 16) == 0 && (g->Wo % 32) == 0) {
         // experiment: one wave per SIMD, 16 x 32 x 128 tiles (conv3x3_split_w1_k)
@@ -1431,6 +1150,7 @@ bool df_conv3x3_split_fwd_try(const DfConvGeom* g, const float* x, const float* 
         if ((nbw & 7) == 0 && gyw <= 2) { kw.xcd_pair = (int)gyw + 1; gw = dim3((unsigned)(gyw * nbw), 1u); }
         conv3x3_split_w1_k<0><<<gw, 256, 0, st>>>(x, ws, bias, y, kw, sc);
       } else
+#endif
       if (rr) conv3x3_split_cs_k<true, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
       else conv3x3_split_cs_k<false, 64, 8><<<grid, 512, 0, st>>>(x, ws, bias, y, kc, sc);
     } else {

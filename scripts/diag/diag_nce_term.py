@@ -1,5 +1,5 @@
 """GPU box: ONE NCE term in isolation through the model's own calculate_NCE_loss: d(term)/d(query image), HIP vs fp32 oracle,
-both against the fp64 oracle.  python scripts/diag_nce_term.py   (NCE_LAYERS=16, SRC=B|A, TGT=idt|fake|rand)"""
+both against the fp64 oracle.  python scripts/diag/diag_nce_term.py   (NCE_LAYERS=16, SRC=B|A, TGT=idt|fake|rand)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -3,8 +3,8 @@ fp32 CPU oracle's own error -- the table `test_full_size_gradients_vs_fp64_oracl
 switches the environment carries.  The two CPU runs are cached in a file so that several switch settings can be
 compared in one gpurun call:
 
-    python scripts/diag_wgrad_precision.py /tmp/g.pt            # default path
-    DFMIR_CONV_FP32=1 python scripts/diag_wgrad_precision.py /tmp/g.pt
+    python scripts/diag/diag_wgrad_precision.py /tmp/g.pt            # default path
+    DFMIR_CONV_FP32=1 python scripts/diag/diag_wgrad_precision.py /tmp/g.pt
 """
 import os
 import sys

@@ -62,7 +62,7 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
         model.data_dependent_initialize(data)
         model.setup(opt)
         model.parallelize()
-        assert model._ddp and all(o.grad_scale == 0.5 for o in model.optimizers)
+        assert model._ddp and all(o.grad_scale == 1.0 / world for o in model.optimizers)
         w_after_bcast = [o.flat_p.cpu() for o in model.optimizers]
         if bucket and not capture:                           # the arena's tail leaves INSIDE backward
             model.set_input(data)
@@ -79,9 +79,13 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
             q.put((rank, [w.numpy() for w in w_after_bcast], summed, model._bucket['off'],
                    [o.flat_p.cpu().numpy() for o in model.optimizers], dict(model.get_current_losses()), False))
             return
-        # one step by hand: local gradients, then the exchange
+        # one step by hand: local gradients, then the exchange (the patch ids this rank draws are recorded on the way)
+        drawn = []
+        orig_sets = model._patch_id_sets
+        model._patch_id_sets = lambda *a, **k: (lambda out: (drawn.append([t.cpu().numpy() for t in out]), out)[1])(orig_sets(*a, **k))
         model.set_input(data)
         model._forward_backward()
+        del model._patch_id_sets                                 # (back to the class's method before anything is captured)
         local = [o.flat_g.cpu() for o in model.optimizers]
         model.sync_gradients()
         summed = [o.flat_g.cpu() for o in model.optimizers]
@@ -107,10 +111,10 @@ def _worker_2d(rank, world, port, q, capture, backend="gloo", cfg=(64, 2, 8), bu
             dig = lambda ts: [hashlib.sha1(t.numpy().tobytes()).hexdigest() for t in ts]
             sum_ok = [bool(np.allclose(s_.numpy(), g_.numpy(), rtol=1e-6, atol=1e-12)) and float(s_.abs().sum()) > 0
                       for s_, g_ in zip(summed, gathered)]
-            q.put((rank, dig(w_after_bcast), dig(summed), sum_ok, dig(w_end), dict(losses), graphed))
+            q.put((rank, dig(w_after_bcast), dig(summed), sum_ok, dig(w_end), dict(losses), graphed, drawn))
         else:
             q.put((rank, [w.numpy() for w in w_after_bcast], [s.numpy() for s in summed], [g.numpy() for g in gathered],
-                   [w.numpy() for w in w_end], dict(losses), graphed))
+                   [w.numpy() for w in w_end], dict(losses), graphed, drawn))
     finally:
         dist.destroy_process_group()
 
@@ -170,6 +174,53 @@ def test_gradient_buckets_with_a_captured_step():
     assert r0[6] and r1[6], "the later steps must have been hipGraph replays (the capture did not fall back)"
 
 
+@pytest.mark.parametrize("capture,bucket", [(False, False), (True, False), (True, True)], ids=["eager", "graph", "graph+bucket-option"])
+def test_registration_model_eight_ranks_rehearsal(capture, bucket):
+    """The 8-GPU protocol of BASELINE configs[2] rehearsed with EIGHT processes on the one GPU (gloo, device tensors staged
+    through the host; 64 x 64, ngf 8, batch 2 per rank): every rank holds rank 0's weights after parallelize(), draws the
+    SAME patch ids, flat_g after sync_gradients() is the sum of the eight local gradients on every rank, and after the
+    manual step + four optimize_parameters() calls (eager, or captured + replayed, with and without opt.bucket_allreduce)
+    the eight replicas are bit-identical.  What the first SCALE run on a real 8-GPU node adds is RCCL itself."""
+    res = _run_two_ranks_2d(capture, "gloo", bucket=bucket, world=8)
+    assert [r[0] for r in res] == list(range(8))
+    r0 = res[0]
+    assert r0[7] and all(len(r[7]) == len(r0[7]) for r in res)
+    for r in res[1:]:
+        for a, b in zip(r0[1], r[1]):
+            assert np.array_equal(a, b), "weights must be identical after the rank-0 broadcast in parallelize()"
+        for s0, s1 in zip(r0[2], r[2]):
+            assert np.array_equal(s0, s1), "every rank holds the same reduced arena"
+        for a, b in zip(r0[4], r[4]):
+            assert np.array_equal(a, b), "replicas stay bit-identical through the optimizer steps"
+        for call0, call in zip(r0[7], r[7]):
+            for i0, i1 in zip(call0, call):
+                assert np.array_equal(i0, i1), "every rank draws the same patch ids (same generator seed)"
+        assert r[6] == capture
+    for s0, g0 in zip(r0[2], r0[3]):
+        assert np.allclose(s0, g0, rtol=1e-6, atol=1e-12) and float(np.abs(s0).sum()) > 0, "flat_g = sum of the 8 local gradients"
+    assert len({tuple(sorted(r[5].items())) for r in res}) == 8, "eight different shards: eight different per-rank losses"
+
+
+def test_bench_eight_ranks_as_the_driver_launches_it():
+    """The driver's N = 8 command line (torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...) on a small geometry,
+    the eight ranks sharing the one GPU over gloo: ONE JSON line, n_gpus 8, global batch 16, the all-reduce of ones saw eight
+    ranks, eight per-rank step times."""
+    env = dict(os.environ, DFMIR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "3",
+           "--batch", "2", "--size", "64", "--ngf", "8"]
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["global_batch"] == 16 and r["config"]["parallelism"] == "dp8"
+    assert r["collective"]["rccl_ranks_seen"] == 8 and len(r["collective"]["step_ms_by_rank"]) == 8
+    assert all(t > 0 for t in r["collective"]["step_ms_by_rank"])
+    assert r["value"] > 0 and r["scaling"] == "weak" and r["step_submission"].startswith("hipGraph")
+    assert all(np.isfinite(v) for v in r["losses"].values())
+
+
 def test_registration_model_two_ranks_full_geometry():
     """BASELINE configs[2]'s per-GPU shard as quoted -- batch 16 per rank, 256 x 256, ngf 64, the step captured into a
     hipGraph -- on two ranks (sharing the one GPU over gloo): identical weights after the broadcast, flat_g after the
@@ -184,15 +235,15 @@ def test_registration_model_two_ranks_full_geometry():
     assert r0[6] and r1[6], "the later steps must have been hipGraph replays"
 
 
-def _run_two_ranks_2d(capture, backend, cfg=(64, 2, 8), bucket=False):
+def _run_two_ranks_2d(capture, backend, cfg=(64, 2, 8), bucket=False, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_2d, args=(r, 2, port, q, capture, backend, cfg, bucket)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_2d, args=(r, world, port, q, capture, backend, cfg, bucket)) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0

@@ -333,11 +333,11 @@ def test_trajectory_drift_vs_fp64_oracle(O):
     Adam updates per step; steps 3.. are replays of one captured hipGraph) of the default production path, next to the CPU
     oracle in fp32 AND in fp64 from the same weights.  Early training with Adam is a sensitive system (updates of size lr
     whatever the gradient's size, and every ReLU / mask decision that sits on a rounding boundary changes one image's
-    gradient by 0.1-3 %: scripts/diag_dfake.py shows such flips in the fp32 oracle as well as in the HIP path, in different
+    gradient by 0.1-3 %: scripts/diag/diag_dfake.py shows such flips in the fp32 oracle as well as in the HIP path, in different
     images): the fp32 oracle itself leaves the fp64 trajectory -- 1e-4 relative at step 3, 1.4 % at the loss spike of step 5.
     So the bound is the sum of the drift the reference-generated three-step fixture S1 allows (3e-4 x (step + 1) relative) and
     12x the fp32 oracle's own distance from the fp64 trajectory at that step (measured: HIP 1.0e-3 at step 3 where fp32 has
-    1.4e-4, 5 % at step 5 where fp32 has 1.4 %; scripts/diag_first_update.py, diag_gen_grads.py, diag_nce_precision.py and
+    1.4e-4, 5 % at step 5 where fp32 has 1.4 %; scripts/diag/diag_first_update.py, diag_gen_grads.py, diag_nce_precision.py and
     diag_nce_term.py put the generator, the NCE head and a single NCE term in isolation at 1.2-2x fp32 PyTorch's error)."""
     size, B, steps = 64, 2, 5          # up to, not into, the oracle's own loss spike at step 5 (fp32 vs fp64: 1.4 % there)
 

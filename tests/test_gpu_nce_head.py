@@ -158,7 +158,7 @@ def test_batched_key_path_matches_term_by_term():
     # netF's weight gradients are sums of per-row terms orthogonal to the (L2-normalised) rows: they cancel to ~1e-5
     # of the gradient that flows through the head (|g_F| ~ 5e-3 vs |g_G| ~ 8 here), so the 1e-7 relative difference
     # between the keys of the two paths (same math, different GEMM tile walk) is visible in them.  Bound the
-    # difference by fp32 round-off of the flow they are taken from (scripts/diag_keypath.py prints the breakdown;
+    # difference by fp32 round-off of the flow they are taken from (scripts/diag/diag_keypath.py prints the breakdown;
     # the batched path reproduces itself to 1e-6).
     a, b = arenas["F"]
     assert float((a - b).norm()) <= 2e-6 * float(arenas["G"][1].norm()), float((a - b).norm())
