@@ -1,6 +1,6 @@
 """GPU box: d(loss)/d(fake_B), d(idt_B) of ONE train step (64x64, batch 2, ngf 8), HIP vs fp32 oracle, both against the fp64 oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import dfmir_oracle as O
 from tests.golden import common as C

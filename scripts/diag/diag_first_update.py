@@ -2,7 +2,7 @@
 different Adam update (|dw| > lr / 2, i.e. the sign of a noise-level gradient flipped) in the HIP path / in the fp32 CPU oracle,
 both against the fp64 CPU oracle, and the relative L2 error of the gradient itself."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import dfmir_oracle as O
 from tests.golden import common as C

@@ -4,7 +4,7 @@ output (reference module indices, models/networks.py:982-1024)."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from oracle import dfmir_oracle as O

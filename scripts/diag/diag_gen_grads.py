@@ -2,7 +2,7 @@
 relative L2 error of the output, the input gradient and every parameter gradient against an fp64 run of the oracle's generator,
 for the HIP path and for the fp32 oracle.  python scripts/diag/diag_gen_grads.py [ngf] [size] [batch]"""
 import os, sys, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import dfmir_oracle as O
 from tests.golden import common as C

@@ -1,7 +1,7 @@
 """GPU box: PatchSampleF + PatchNCELoss ALONE on given feature maps (the five tapped layers' shapes at ngf 8, 64x64, batch 2):
 relative L2 error of d(feature) and of the MLP gradients against an fp64 run of the oracle, HIP vs fp32 oracle."""
 import os, sys, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import dfmir_oracle as O
 from tests.golden import common as C

@@ -1,7 +1,7 @@
 """GPU box: ONE NCE term in isolation through the model's own calculate_NCE_loss: d(term)/d(query image), HIP vs fp32 oracle,
 both against the fp64 oracle.  python scripts/diag/diag_nce_term.py   (NCE_LAYERS=16, SRC=B|A, TGT=idt|fake|rand)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import dfmir_oracle as O
 from tests.golden import common as C

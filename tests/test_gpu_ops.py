@@ -16,6 +16,8 @@ DEV = "cuda"
 
 
 ELEMENTWISE = []      # (what, norm-wise rel, element-wise max / 99.9 % / median rel) of every close(..., elem_rtol=...) call
+MARGINS = []          # (test id, what, measured rel. error, bound) of every close() call: tests/conftest.py writes them to
+#                       $DFMIR_MARGINS_OUT at session end (profiles/rNN_parity_margins.txt is such a file)
 
 
 def close(got, ref, rtol=1e-4, atol=1e-6, what="", elem_rtol=None, elem_floor=1e-6):
@@ -31,6 +33,8 @@ def close(got, ref, rtol=1e-4, atol=1e-6, what="", elem_rtol=None, elem_floor=1e
     assert np.isfinite(got).all(), "%s: non-finite values" % what
     scale = max(float(np.abs(ref).max()), 1e-30)
     err = float(np.abs(got - ref).max())
+    import os
+    MARGINS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, err / scale, rtol + atol / scale))
     assert err <= atol + rtol * scale, "%s: max abs err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
     if elem_rtol is not None:
         rel = np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), elem_floor * scale)
