@@ -581,6 +581,25 @@ class deferred_weight_grads:
         return False
 
 
+def begin_deferred():
+    """deferred_weight_grads as two calls, for a backward that runs in several pieces (registration_model's staged step:
+    the pieces are separate autograd calls on two streams, captured into separate hipGraphs): begin_deferred() before the
+    first piece, end_deferred() -- the one flush -- after the last, on a stream that has waited for all of them."""
+    _DEFER["on"] = not _env_on("DFMIR_NO_DEFER")
+
+
+def end_deferred(failed=False):
+    _DEFER["on"] = False
+    pending, _DEFER["pending"] = _DEFER["pending"], {}
+    if not pending:
+        return
+    if failed:
+        for _, buf, _ in pending.values():
+            zero_(buf)
+    else:
+        _flush_deferred(list(pending.values()))
+
+
 _JOBS = {"key": None, "dev": None, "max": 0}
 _JOBS_BY_GROUP = {"all": _JOBS}
 

@@ -254,9 +254,13 @@ class REGISTRATIONModel(BaseModel):
             # Under a process group other threads of this process (RCCL's watchdog) may touch the HIP runtime while the
             # capture is open: "thread_local" keeps their calls legal; single-process runs keep the strict default.
             mode = "thread_local" if getattr(self, '_ddp', False) else "global"
+            staged = self._staged_ok()
             try:
-                with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
-                    self._forward_backward()
+                if staged:
+                    graph = self._capture_staged(side, mode)
+                else:
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode=mode):
+                        self._forward_backward()
             except Exception as exc:                                   # noqa: BLE001 -- keep training, eagerly
                 # nothing of a failed capture has executed: weights, moments and the id counter are where the last
                 # eager step left them -- but the host-side caches believe the recorded re-pack / pool zero-fill ran:
@@ -279,7 +283,10 @@ class REGISTRATIONModel(BaseModel):
                 st['in_B'].copy_(self.real_B, non_blocking=True)
             vars(self).update(st['outputs'])
             self.real_A, self.real_B = st['in_A'], st['in_B']
-        st['graph'].replay()
+        if isinstance(st['graph'], list):
+            self._replay_staged(st['graph'])                 # eight single-stream graphs, event edges between the launches
+        else:
+            st['graph'].replay()
         self._apply_updates()
 
     def _overlap_registration(self):
@@ -348,6 +355,8 @@ class REGISTRATIONModel(BaseModel):
             self._early.clear()
         if getattr(self, '_bucket', None) is not None:
             self._bucket['in_graph'] = False
+        if self._staged_ok():
+            return self._run_staged_eager()
         if self._overlap_registration():
             # netR reads only the two input images (registration_model.py:146): its forward runs on a second stream beside
             # the generator's, and autograd then runs its backward there as well, beside the generator's backward -- a
@@ -462,6 +471,177 @@ class REGISTRATIONModel(BaseModel):
                 # stream autograd bound netR's AccumulateGrad nodes to
                 cur.wait_stream(rs)
 
+    # -- the two-stream step in single-stream PIECES (build-defined; opt.staged_step, default on).  With netR on a second
+    # stream the captured step used to be ONE hipGraph with parallel branches, and hipGraphLaunch (ROCm 7.2) returns from
+    # such a graph only when its second branch has been handed to the GPU -- 39 ms into a 74 ms step, a host core per rank
+    # doing nothing.  Here the same kernels are issued as eight pieces, each on ONE stream, with every cross-stream
+    # dependency BETWEEN pieces: captured, each piece is a linear hipGraph whose launch returns at once, and the edges are
+    # event waits between the launches.  What makes the pieces separable is a backward in four autograd calls instead of
+    # one: the generator's output and netR's outputs enter the losses through detached leaves, each loss group is
+    # back-propagated on the stream it was computed on with its coefficient of registration_model.py:163-166,230-234 as the
+    # seed, and the leaves' gradients are handed to `fake.backward` / netR's backward -- the same sums in the same order
+    # (every leaf collects exactly two contributions, and a + b = b + a).
+    #
+    #   generator stream:  prep | g_fwd ........ | q_pass (NCE query pass, fwd + bwd) | g_bwd ............ | finish
+    #   netR's stream:          | r_fwd | r_loss (warp, masked L1, smoothness: fwd + bwd) |  r_bwd        |
+    #   edges: prep -> r_fwd;  g_fwd -> r_loss;  r_fwd -> q_pass;  q_pass -> r_bwd;  r_loss -> g_bwd;  r_bwd -> finish
+    def _staged_ok(self):
+        gmn = getattr(self.opt, 'global_mask_norm', False) and getattr(self, '_ddp', False)
+        return (getattr(self.opt, 'staged_step', True) and not ops._env_on('DFMIR_NO_STAGED') and self._overlap_registration()
+                and not ops._env_on('DFMIR_NO_SIDE_LOSSES') and not ops._env_on('DFMIR_BUCKET_IN_GRAPH') and not gmn
+                and getattr(self.opt, 'batch_query_passes', True) and not ops._env_on('DFMIR_NO_STACKED_Q')
+                and self.opt.lambda_NCE > 0.0 and self.opt.lambda_GAN <= 0.0 and self.opt.netF == 'mlp_sample')
+
+    def _loss_seeds(self, idt):
+        """d total / d (NCE terms..., l1_reg, l1_idt, smooth): the last row of the step's scalar algebra, as device scalars
+        (made once, outside any capture)."""
+        key = (bool(idt), float(self.opt.lambda_NCE))
+        c = self.__dict__.setdefault('_seed_cache', {})
+        if key not in c:
+            vals = [0.5, 0.5, 0.25, 1.0, 1.0, 0.20] if idt else [1.0, 0.25, 1.0, 1.0, 0.20]
+            c[key] = list(torch.tensor(vals, dtype=torch.float32).to(self.device).unbind(0))
+        return c[key]
+
+    def _step_pieces(self):
+        """[(name, stream 'g' | 'r', fn, names of the pieces on the OTHER stream it waits for)] -- see the comment above."""
+        idt = bool(self.opt.nce_idt)
+        seeds = self._loss_seeds(idt)                       # (built before anything is captured)
+        n_nce = 3 if idt else 2
+        S = self.__dict__.setdefault('_stage', {})
+        S.clear()
+
+        def prep():
+            ops.prepare_step(self.device)
+            self.optimizer_G.zero_grad()
+            self.optimizer_R.zero_grad()
+            self.optimizer_F.zero_grad()
+
+        def r_fwd():
+            y = self.netR(self.real_A, self.real_B)
+            S['y'] = y
+            self.regA, self.pos_flow = y[0], y[2]
+            S['regA_q'] = y[0].detach().requires_grad_()     # the NCE query pass reads regA through this leaf ...
+            S['flow_l'] = y[2].detach().requires_grad_()     # ... the warp of fake_B and the smoothness term the field
+
+        def g_fwd():
+            self.forward()
+            S['fake_q'] = self.fake.detach().requires_grad_()
+            S['fake_l'] = self.fake.detach().requires_grad_()
+
+        def r_loss():
+            nb = self.real_A.size(0)
+            fl = S['fake_l']
+            self.registered = self.spatialTransformer(fl[:nb], S['flow_l'])
+            with torch.no_grad():
+                self.dvf = self.spatialTransformer(self._checkerboard(nb), S['flow_l'].detach())
+            l1_reg = self.calculate_L1_loss(self.registered, self.real_B, mask='threshold')
+            l1_idt = self.calculate_L1_loss(fl[nb:], self.registered, mask='threshold')
+            smooth = smooothing_loss(S['flow_l'])
+            self._loss_inputs = (l1_reg, l1_idt, smooth)
+            torch.autograd.backward([l1_reg, l1_idt, smooth], seeds[n_nce:])
+
+        def q_pass():
+            nb = self.real_A.size(0)
+            fq = S['fake_q']
+            if idt:
+                terms = ((self.real_A, None), (self.real_B, None), (self.real_B, S['regA_q']))
+                tgt = ops.cat_batch(fq, S['regA_q'])
+            else:
+                terms = ((self.real_A, fq[:nb]), (self.real_B, S['regA_q']))
+                tgt = ops.cat_batch(fq[:nb], S['regA_q'])
+            nce = self.calculate_NCE_losses_stacked(terms, tgt=tgt)
+            S['nce'] = nce
+            torch.autograd.backward(list(nce), seeds[:n_nce])
+
+        def r_bwd():
+            y = S['y']
+            torch.autograd.backward([y[0], y[2]], [S['regA_q'].grad, S['flow_l'].grad])
+
+        def g_bwd():
+            # (FastCUT: the query pass saw fake_B only -- the slice's backward leaves zeros in idt_B's half)
+            self.fake.backward(S['fake_q'].grad + S['fake_l'].grad)
+
+        def finish():
+            ops.end_deferred()
+            with torch.no_grad():
+                l1_reg, l1_idt, smooth = (t.detach() for t in self._loss_inputs)
+                nce = [t.detach() for t in S['nce']]
+                self.loss_G_GAN = 0.0
+                if idt:
+                    self.loss_NCE, self.loss_NCE_Y, nce_local = nce
+                    out = ops.scalar_combine(
+                        [[0.5, 0.5, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.0, 0.25, 0.0, 0.0, 0.0],
+                         [0.0, 0.0, 0.0, 0.0, 0.0, 0.20]], [self.loss_NCE, self.loss_NCE_Y, nce_local, l1_reg, l1_idt, smooth])
+                else:
+                    (self.loss_NCE, nce_local), self.loss_NCE_Y = nce, 0.0
+                    out = ops.scalar_combine(
+                        [[1.0, 0.0, 0.0, 0.0, 0.0], [0.0, 0.25, 1.0, 1.0, 0.0], [0.0, 0.25, 0.0, 0.0, 0.0],
+                         [0.0, 0.0, 0.0, 0.0, 0.20]], [self.loss_NCE, nce_local, l1_reg, l1_idt, smooth])
+                self.loss_G, self.loss_R, self.loss_local, self.loss_smooth = out.unbind(0)
+
+        return [('prep', 'g', prep, ()), ('r_fwd', 'r', r_fwd, ('prep',)), ('g_fwd', 'g', g_fwd, ()),
+                ('r_loss', 'r', r_loss, ('g_fwd',)), ('q_pass', 'g', q_pass, ('r_fwd',)), ('r_bwd', 'r', r_bwd, ('q_pass',)),
+                ('g_bwd', 'g', g_bwd, ('r_loss',)), ('finish', 'g', finish, ('r_bwd',))]
+
+    def _r_stream(self):
+        return self._graph_state().setdefault('r_stream', torch.cuda.Stream(device=self.device))
+
+    def _run_staged_eager(self):
+        """The pieces enqueued one after the other on the current stream ('g') and netR's stream ('r')."""
+        cur, rs = torch.cuda.current_stream(), self._r_stream()
+        streams = {'g': cur, 'r': rs}
+        done = {}
+        ops.begin_deferred()
+        try:
+            for name, sk, fn, after in self._step_pieces():
+                for dep in after:
+                    streams[sk].wait_event(done[dep])
+                with torch.cuda.stream(streams[sk]):
+                    fn()
+                done[name] = torch.cuda.Event()
+                done[name].record(streams[sk])
+        except BaseException:
+            cur.wait_stream(rs)
+            ops.end_deferred(failed=True)
+            raise
+        # tensors that crossed streams stay referenced in self._stage until the next step (no record_stream bookkeeping)
+
+    def _capture_staged(self, side, mode):
+        """Every piece into its own hipGraph (nothing executes); one private memory pool per stream."""
+        rs = self._r_stream()
+        streams = {'g': side, 'r': rs}
+        pools = {'g': torch.cuda.graph_pool_handle(), 'r': torch.cuda.graph_pool_handle()}
+        graphs = []
+        ops.begin_deferred()
+        try:
+            for name, sk, fn, after in self._step_pieces():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pools[sk], stream=streams[sk], capture_error_mode=mode):
+                    fn()
+                graphs.append((name, sk, g, after))
+        except BaseException:
+            ops._DEFER["on"] = False
+            ops._DEFER["pending"] = {}
+            raise
+        return graphs
+
+    def _replay_staged(self, graphs):
+        cur, rs = torch.cuda.current_stream(), self._r_stream()
+        streams = {'g': cur, 'r': rs}
+        evs = self._graph_state().setdefault('events', {})
+        for name, sk, g, after in graphs:
+            s = streams[sk]
+            for dep in after:
+                s.wait_event(evs[dep])
+            if s is cur:
+                g.replay()
+            else:
+                with torch.cuda.stream(s):
+                    g.replay()
+            if name not in evs:
+                evs[name] = torch.cuda.Event()
+            evs[name].record(s)
+
     def _global_mask_norm(self, *terms):
         """opt.global_mask_norm (build-defined, data-parallel runs only): the reference's DataParallel evaluates
         calculate_L1_loss on the gathered GLOBAL batch, i.e. sum_ranks(S_r) / sum_ranks(M_r) with S = sum |a-b| m and
@@ -561,7 +741,7 @@ class REGISTRATIONModel(BaseModel):
             total_nce_loss += ops.mean(loss) * self.opt.lambda_NCE
         return total_nce_loss / n_layers
 
-    def calculate_NCE_losses_stacked(self, terms):
+    def calculate_NCE_losses_stacked(self, terms, tgt=None):
         """calculate_NCE_loss(real_A, fake_B), (real_B, idt_B), (real_B, regA) with ONE query-side encoder pass over
         cat(fake (= [fake_B; idt_B]), regA).  terms = ((src, tgt or None), ...): the first two targets are the halves
         of self.fake.
@@ -574,7 +754,8 @@ class REGISTRATIONModel(BaseModel):
         reference's order, as before."""
         T = len(terms)
         n_layers = len(self.nce_layers)
-        tgt = ops.cat_batch(self.fake, terms[2][1]) if T == 3 else ops.cat_batch(terms[0][1], terms[1][1])
+        if tgt is None:                                     # (the staged step hands in the stack of its detached leaves)
+            tgt = ops.cat_batch(self.fake, terms[2][1]) if T == 3 else ops.cat_batch(terms[0][1], terms[1][1])
         feat_q = self.netG(tgt, self.nce_layers, encode_only=True)
         if self.opt.flip_equivariance and self.flipped_for_equivariance:     # registration_model.py:241-242, every term
             feat_q = [torch.flip(fq, [3]) for fq in feat_q]

@@ -197,7 +197,9 @@ def test_registration_model_eight_ranks_rehearsal(capture, bucket):
                 assert np.array_equal(i0, i1), "every rank draws the same patch ids (same generator seed)"
         assert r[6] == capture
     for s0, g0 in zip(r0[2], r0[3]):
-        assert np.allclose(s0, g0, rtol=1e-6, atol=1e-12) and float(np.abs(s0).sum()) > 0, "flat_g = sum of the 8 local gradients"
+        # (eight addends: the ring's summation order is not the test's; norm-wise)
+        assert float(np.linalg.norm(s0 - g0)) <= 1e-6 * float(np.linalg.norm(g0)) and float(np.abs(s0).sum()) > 0, \
+            "flat_g = sum of the 8 local gradients"
     assert len({tuple(sorted(r[5].items())) for r in res}) == 8, "eight different shards: eight different per-rank losses"
 
 

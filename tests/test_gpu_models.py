@@ -631,6 +631,18 @@ def test_failed_capture_falls_back_to_a_correct_eager_step(O):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("injected capture failure")
     model._forward_backward = failing_fb
+    real_pieces = model._step_pieces                     # the staged step (default): its last piece raises while it is captured
+
+    def failing_pieces():
+        ps = real_pieces()
+        name, sk, fn, after = ps[-1]
+
+        def fin():
+            fn()
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure")
+        return ps[:-1] + [(name, sk, fin, after)]
+    model._step_pieces = failing_pieces
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = [run(batches[2])]
@@ -830,20 +842,22 @@ def test_full_size_gradients_vs_fp64_oracle(O, capsys):
 
 def test_registration_net_on_a_second_stream_changes_nothing(O):
     """opt.overlap_registration (build-defined, default on): netR's forward and backward run on a second HIP stream beside
-    the generator's.  Two steps with and without it from identical states: same losses, outputs and gradient arenas (up to
-    the summation order of the weight gradients' float atomics)."""
+    the generator's -- as single-stream pieces with one autograd call per loss group and stream (opt.staged_step, default
+    on: registration_model._step_pieces) or as one two-stream forward / one backward.  Two steps each way and on ONE stream
+    from identical states: same losses, outputs and gradient arenas (up to the summation order of the weight gradients'
+    float atomics)."""
     from tests.test_oracle_golden import make_step
     res = []
-    for overlap in (True, False):
+    for overlap, staged in ((True, True), (True, False), (False, False)):
         st, size, B = make_step()
         model, opt = _hip_model_from_oracle(st, size, B, 8)
-        opt.overlap_registration = overlap
+        opt.overlap_registration, opt.staged_step = overlap, staged
         model.patch_id_source = PinnedIds()
         A0, B0 = C.image_pair(93, B, size, size)
         model.data_dependent_initialize({"A": A0, "B": B0, "A_paths": [""] * B, "B_paths": [""] * B})
         _load(model.netF, st.netF)
         model.setup(opt)
-        assert model._overlap_registration() == overlap
+        assert model._overlap_registration() == overlap and model._staged_ok() == staged
         out = []
         for it in range(2):
             A_, B_ = C.image_pair(100 + it, B, size, size)
@@ -853,17 +867,18 @@ def test_registration_net_on_a_second_stream_changes_nothing(O):
             out.append(([v for v in model.get_current_losses().values()], model.fake_B.clone(), model.registered.clone(),
                         model.regA.clone(), [o_.flat_g.clone() for o_ in model.optimizers]))
         res.append(out)
-    for it, (a, b) in enumerate(zip(*res)):
-        # step 0 starts from identical weights; step 1 from weights one Adam update apart by at most lr wherever a gradient
-        # element sits at round-off level (Adam's first update is lr * g / |g|)
-        tol = 1e-6 if it == 0 else 2e-4
-        np.testing.assert_allclose(a[0], b[0], rtol=1e-5 if it == 0 else 2e-3, atol=1e-9)
-        for x, y in zip(a[1:4], b[1:4]):
-            close(x, y, rtol=tol, what="outputs, step %d" % it)
-        if it == 0:
-            gscale = max(float(g.norm()) for g in b[4])
-            for nm, x, y in zip("GRF", a[4], b[4]):
-                assert float((x - y).norm()) <= 2e-5 * float(y.norm()) + 2e-6 * gscale, nm
+    for which in (0, 1):
+        for it, (a, b) in enumerate(zip(res[which], res[2])):
+            # step 0 starts from identical weights; step 1 from weights one Adam update apart by at most lr wherever a gradient
+            # element sits at round-off level (Adam's first update is lr * g / |g|)
+            tol = 1e-6 if it == 0 else 2e-4
+            np.testing.assert_allclose(a[0], b[0], rtol=1e-5 if it == 0 else 2e-3, atol=1e-9)
+            for x, y in zip(a[1:4], b[1:4]):
+                close(x, y, rtol=tol, what="outputs, step %d" % it)
+            if it == 0:
+                gscale = max(float(g.norm()) for g in b[4])
+                for nm, x, y in zip("GRF", a[4], b[4]):
+                    assert float((x - y).norm()) <= 2e-5 * float(y.norm()) + 2e-6 * gscale, (which, nm)
 
 
 def test_batch16_step_vs_oracle(O, capsys):
