@@ -656,6 +656,11 @@ def main():
         torch.cuda.synchronize()
         pil_rate = B * world * n_done / (time.perf_counter() - th) if n_done else None
         del it
+    pil_by_rank = None
+    if distributed and world > 1:
+        # every rank's own loader-fed rate (x world, i.e. comparable with `value`): 8 ranks x (1 training process + pil_workers
+        # loader processes) share the host's cores
+        pil_by_rank = dfdist.allgather_float(float(pil_rate or 0.0), dev)
 
     ks = ks_overlapped if graphed else timer.summary()
     ks1 = ks_single if graphed else {}
@@ -690,13 +695,17 @@ def main():
                         "note": "rank 0's device time between HIP events recorded after every step of the timed region (no host "
                                 "wait between steps); ms_per_step / value are the barrier-to-barrier wall clock, max over ranks"},
             "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
-            "step_submission": "hipGraph replay + eager all-reduce/Adam" if graphed else "eager",
-            "host_enqueue_note": ("time the host spends inside the submission calls of a step.  With opt.overlap_registration "
-                                  "(default) the captured graph has two parallel branches and hipGraphLaunch (ROCm 7.2) returns "
-                                  "only when the second branch has been handed to the GPU, ~60 % into the step; "
-                                  "DFMIR_NO_OVERLAP_R=1: one chain, 0.5 ms of host time and a 1.3 ms longer step"),
+            "step_submission": (("hipGraph replay (%d single-stream graphs) + eager all-reduce/Adam" % len(model._graph['graph'])
+                                 if isinstance(model._graph['graph'], list) else "hipGraph replay + eager all-reduce/Adam")
+                                if graphed else "eager"),
+            "host_enqueue_note": ("time the host spends inside the submission calls of a step.  The two-stream step is submitted as "
+                                  "eight single-stream hipGraphs with event edges between the launches (opt.staged_step, "
+                                  "registration_model._step_pieces): every launch returns at once.  DFMIR_NO_STAGED=1 = ONE graph "
+                                  "with parallel branches, whose hipGraphLaunch (ROCm 7.2) returns only when the second branch has "
+                                  "been handed to the GPU: ~39 ms of a 74 ms step (profiles/r06_ab_staged.txt)"),
             "value_host_inputs": host_rate,
             "value_pil_loader": pil_rate,       # fed by dfmir_amd.data's DataLoader (PNG decode + transforms in worker processes)
+            "value_pil_loader_by_rank": pil_by_rank,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (fp16x2-split MFMA, fp32 accumulate)" if (split and nprod == 3.0) else

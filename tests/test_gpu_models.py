@@ -274,7 +274,9 @@ def test_all_negatives_step_vs_oracle_and_netF_sample(O, golden):
                 ref_g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
                 got_g = o_.flat_g.cpu()
                 rel = float((got_g - ref_g).norm() / ref_g.norm())
-                assert rel <= 1e-3, (nm, rel)
+                # (F: sums behind the L2 normalisation, cancellation-dominated -- 1.6e-3 measured here; at full size the
+                # fp32 CPU oracle itself is 2.8e-3 from an fp64 run on the same rows, test_full_size_gradients_vs_fp64_oracle)
+                assert rel <= (4e-3 if nm == "F" else 1e-3), (nm, rel)
     # --netF sample
     g = golden("edges.npz")
     from dfmir_amd.options import default_options
@@ -336,8 +338,10 @@ def test_trajectory_drift_vs_fp64_oracle(O):
     gradient by 0.1-3 %: scripts/diag/diag_dfake.py shows such flips in the fp32 oracle as well as in the HIP path, in different
     images): the fp32 oracle itself leaves the fp64 trajectory -- 1e-4 relative at step 3, 1.4 % at the loss spike of step 5.
     So the bound is the sum of the drift the reference-generated three-step fixture S1 allows (3e-4 x (step + 1) relative) and
-    12x the fp32 oracle's own distance from the fp64 trajectory at that step (measured: HIP 1.0e-3 at step 3 where fp32 has
-    1.4e-4, 5 % at step 5 where fp32 has 1.4 %; scripts/diag/diag_first_update.py, diag_gen_grads.py, diag_nce_precision.py and
+    3x the fp32 oracle's own distance from the fp64 trajectory at that step (round 6, five runs: every loss of every step
+    inside the S1 floor alone, worst |HIP - fp64| = 0.75 of it at step 5 -- the second term is head-room for the run-to-run
+    noise of the weight gradients' float atomics through Adam; it was 12x until round 5.  Round 4 had measured HIP 1.0e-3 at
+    step 3 where fp32 has 1.4e-4, 5 % at step 5 where fp32 has 1.4 %; scripts/diag/diag_first_update.py, diag_gen_grads.py, diag_nce_precision.py and
     diag_nce_term.py put the generator, the NCE head and a single NCE term in isolation at 1.2-2x fp32 PyTorch's error)."""
     size, B, steps = 64, 2, 5          # up to, not into, the oracle's own loss spike at step 5 (fp32 vs fp64: 1.4 % there)
 
@@ -367,7 +371,7 @@ def test_trajectory_drift_vs_fp64_oracle(O):
     _load(model.netF, st.netF)
     model.setup(opt)
     model.parallelize()
-    worst, rows = 0.0, []
+    worst, worst_floor, rows = 0.0, 0.0, []
     for it in range(steps):
         A_, B_ = C.image_pair(300 + 2 * it, B, size, size)
         r32 = st.step(A_, B_)
@@ -380,10 +384,12 @@ def test_trajectory_drift_vs_fp64_oracle(O):
             e_hip, e_32 = abs(got[k] - v), abs(r32[k] - v)
             floor = 3e-4 * (it + 1) * max(abs(v), 1e-3)
             worst = max(worst, (e_hip - floor) / max(e_32, 1e-12) if e_hip > floor else 0.0)
+            worst_floor = max(worst_floor, e_hip / floor)
             rows.append((it, k, got[k], r32[k], v))
-            assert e_hip <= 12.0 * e_32 + floor, "step %d loss %s: HIP %.6f fp32 oracle %.6f fp64 oracle %.6f" % (it, k, got[k], r32[k], v)
+            assert e_hip <= 3.0 * e_32 + floor, "step %d loss %s: HIP %.6f fp32 oracle %.6f fp64 oracle %.6f" % (it, k, got[k], r32[k], v)
     assert model._graph['graph'] is not None, "steps 3.. must have been hipGraph replays"
-    print("\n  trajectory: worst (|HIP - fp64| - floor) / |fp32 - fp64| over %d steps x 6 losses = %.1f" % (steps, worst))
+    print("\n  trajectory: worst (|HIP - fp64| - floor) / |fp32 - fp64| over %d steps x 6 losses = %.1f; worst |HIP - fp64| / floor = %.2f"
+          % (steps, worst, worst_floor))
     for it, k, a, b, c in rows:
         if k in ("G", "R"):
             print("    step %d %-3s HIP %.6f  fp32 %.6f  fp64 %.6f" % (it, k, a, b, c))
