@@ -8,13 +8,15 @@ import pytest
 import torch
 
 from tests.golden import common as C
-from tests.test_gpu_ops import DEV, close
+from tests.test_gpu_ops import DEV, close, near
 
 pytestmark = pytest.mark.gpu
 
 # element-wise bound on the three north_star outputs at full size (floor: 1e-6 of the tensor's maximum); measured values are
 # printed by the tests that use it and kept in profiles/r05_elementwise_error.txt
-ELEM_RTOL = 1e-2
+ELEM_RTOL = 8e-3
+# the six losses of a full-size (256 x 256, ngf 64) step against the fp32 CPU oracle; measured values: profiles/r06_parity_margins.txt
+LOSS_RTOL_FULL = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -224,7 +226,7 @@ def test_fastcut_step_vs_oracle(O, flip, stacked):
         assert model.flipped_for_equivariance == flip and st.flipped == flip
         ls = model.get_current_losses()
         for k in ("G", "NCE", "R", "smooth", "local"):
-            assert abs(ls[k] - ref[k]) <= 3e-4 * (it + 1) * max(abs(ref[k]), 1e-6), (it, k, ls[k], ref[k])
+            near(ls[k], ref[k], 3e-4 * (it + 1), "loss %s step %d" % (k, it))
         if it == 0:
             close(model.fake_B, st.fake_B, what="fake_B"); close(model.registered, st.registered, what="registered")
             close(model.pos_flow, st.flow, what="pos_flow"); close(model.regA, st.regA, what="regA")
@@ -265,7 +267,7 @@ def test_all_negatives_step_vs_oracle_and_netF_sample(O, golden):
         assert model._nce_on_device
         ls = model.get_current_losses()
         for k, v in ref.items():
-            assert abs(ls[k] - v) <= 3e-4 * (it + 1) * max(abs(v), 1e-6), (it, k, ls[k], v)
+            near(ls[k], v, 3e-4 * (it + 1), "loss %s step %d" % (k, it))
         if it == 0:
             close(model.fake_B, st.fake_B, what="fake_B"); close(model.registered, st.registered, what="registered")
             close(model.pos_flow, st.flow, what="pos_flow")
@@ -753,7 +755,7 @@ def test_config0_geometry_at_full_width(O):
     close(model.fake_B, st.fake_B, what="fake_B"); close(model.regA, st.regA, what="regA")
     close(model.registered, st.registered, what="registered"); close(model.pos_flow, st.flow, what="pos_flow")
     for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
-        assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
+        near(ls[k], ref[k], LOSS_RTOL_FULL, "loss " + k)
 
 
 @pytest.mark.parametrize("default_path", [False, True], ids=["per-term-keys", "default-batched-head"])
@@ -780,7 +782,7 @@ def test_full_size_step_vs_oracle(O, default_path, capsys):
         for row in ELEMENTWISE[-3:]:
             print("\n  %-10s norm-wise %.2e   element-wise max %.2e  99.9%% %.2e  median %.2e" % row, end="")
     for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
-        assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
+        near(ls[k], ref[k], LOSS_RTOL_FULL, "loss " + k)
     moved = (model.netG.state_dict()["model.12.conv_block.1.weight"].cpu() - st.netG.state_dict()["model.12.conv_block.1.weight"]).abs().max()
     assert float(moved) <= 2.0 * 2e-4 * 1.001   # both took one Adam step of size <= lr
 
@@ -827,14 +829,14 @@ def test_full_size_gradients_vs_fp64_oracle(O, capsys):
     # model.14.conv_block.1: 0 vs 3 -> 0.5x), and it does NOT depend on the operand split: DFMIR_CONV_FP32=1 (exact fp32
     # products) and DFMIR_NO_CH_SCALE give the same table.  What is systematic is a factor ~2 in the forward activations'
     # distance to fp64 (one fp32 accumulation chain over K = 2304 per output: 5e-7 per conv against mkldnn's blocked
-    # 1.7e-7), hence ~1.5x the flips.  Bounds: the GEOMETRIC MEAN of the ratio over G's layers within 2.5x of fp32
+    # 1.7e-7), hence ~1.5x the flips.  Bounds: the GEOMETRIC MEAN of the ratio over G's layers within 2.2x of fp32
     # PyTorch (measured 1.8), every single layer within 6x (its lottery) and within 3x of the worst error fp32 PyTorch
     # itself shows on any layer of the same network (HIP's worst: 2.7e-3, PyTorch's: 2.8e-3).
     g_rows = [(e_hip, e_cpu) for e_hip, e_cpu, k in rows if k.startswith("G.")]
     gmean = float(np.exp(np.mean([np.log((eh + 1e-12) / (ec + 1e-12)) for eh, ec in g_rows])))
     with capsys.disabled():
         print("    geometric mean of HIP : fp32-CPU over G's layers: %.2f" % gmean)
-    assert gmean <= 2.5, gmean
+    assert gmean <= 2.2, gmean          # measured 1.6 (round 6) .. 1.8 (round 4)
     worst_cpu = {t: max(ec for eh, ec, k in rows if k.startswith(t)) for t in ("G.", "R.", "F.")}
     for e_hip, e_cpu, k in rows:
         assert e_hip <= 6.0 * e_cpu + 2e-5, "%s: HIP %.3e vs fp64, fp32 CPU oracle %.3e" % (k, e_hip, e_cpu)
@@ -911,7 +913,7 @@ def test_batch16_step_vs_oracle(O, capsys):
         for row in ELEMENTWISE[-3:]:
             print("\n  %-10s norm-wise %.2e   element-wise max %.2e  99.9%% %.2e  median %.2e" % row, end="")
     for k in ("G", "NCE", "R", "smooth", "local", "NCE_Y"):
-        assert abs(ls[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-6), (k, ls[k], ref[k])
+        near(ls[k], ref[k], LOSS_RTOL_FULL, "loss " + k)
     rows = []
     for tag, n32, nh in (("G", st.netG, model.netG), ("R", st.netR, model.netR)):
         for (k, p32), (k2, ph) in zip(n32.named_parameters(), nh.named_parameters()):
@@ -924,8 +926,10 @@ def test_batch16_step_vs_oracle(O, capsys):
         print("\n  batch 16: rel. L2 distance of the HIP gradients to the fp32 CPU oracle's, worst 6")
         for e, k in sorted(rows, reverse=True)[:6]:
             print("    %-44s %.2e" % (k, e))
-    for e, k in rows:      # measured (MI355X, rounds 3 / 4): worst 2.8e-4 .. 2.95e-4 (G.model.1.weight, the deepest backward)
-        assert e <= 5e-4, "%s: %.3e" % (k, e)
+    for e, k in rows:      # measured (MI355X, rounds 3 - 6): worst 2.8e-4 .. 2.95e-4 (G.model.1.weight, the deepest backward)
+        from tests.test_gpu_ops import MARGINS
+        MARGINS.append(("tests/test_gpu_models.py::test_batch16_step_vs_oracle", "grad " + k, e, 4e-4))
+        assert e <= 4e-4, "%s: %.3e" % (k, e)
 
 
 def test_batch16_equals_per_sample_runs(O):
@@ -979,9 +983,9 @@ def test_registration3d_step_vs_oracle(O, shape, plugin):
         if it == 0:
             close(model.flow, st.flow, what="flow"); close(model.regA, st.ys, what="warped")
             for (k, po), (k2, ph) in zip(st.netR.named_parameters(), model.netR.named_parameters()):
-                close(ph.grad, po.grad, rtol=3e-3, atol=1e-9, what="grad " + k)
+                close(ph.grad, po.grad, rtol=2e-3, atol=1e-9, what="grad " + k)    # measured worst 9.0e-4 (profiles/r06_parity_margins.txt)
         for k in ("ncc", "grad"):
-            assert abs(got[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-7), (it, k, got[k], ref[k])
+            near(got[k], ref[k], 1e-3, "3-D loss %s step %d" % (k, it), floor=1e-7)
 
 
 def test_skipping_the_unused_target_branch_changes_nothing(O):

@@ -44,6 +44,14 @@ def close(got, ref, rtol=1e-4, atol=1e-6, what="", elem_rtol=None, elem_floor=1e
                 what, ELEMENTWISE[-1][3], ELEMENTWISE[-1][2], elem_floor, elem_rtol)
 
 
+def near(got, ref, rtol, what="", floor=1e-6):
+    """Scalar comparison |got - ref| <= rtol * max(|ref|, floor), recorded in MARGINS like close()."""
+    import os
+    err, scale = abs(float(got) - float(ref)), max(abs(float(ref)), floor)
+    MARGINS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], what, err / scale, rtol))
+    assert err <= rtol * scale, "%s: %r vs %r (rel %.2e > %.1e)" % (what, float(got), float(ref), err / scale, rtol)
+
+
 @pytest.fixture(scope="module")
 def ops():
     assert torch.cuda.is_available(), "these tests need the MI355X"
