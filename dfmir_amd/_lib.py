@@ -141,6 +141,9 @@ _SIGS = {
     "dfmir_segment_means_bwd": [P, P, c_int, c_int, c_longlong, c_float, P],
     "dfmir_scalar_combine_fwd": [P, c_int, P, c_int, P, P],
     "dfmir_scalar_combine_bwd": [P, c_int, P, c_int, P, P],
+    "dfmir_det_head_floats": [],
+    "dfmir_det_begin": [P, c_longlong, P, c_longlong, P, c_int, P, c_longlong, P, c_int, ctypes.c_double, P],
+    "dfmir_det_end": [P, P, c_longlong, P, c_longlong, P],
     "dfmir_fill_zero": [P, c_longlong, P],
     "dfmir_sum_scaled": [P, P, c_longlong, c_float, P],
     "dfmir_fill_from_scalar": [P, P, c_longlong, c_float, P],

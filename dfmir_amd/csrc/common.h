@@ -77,6 +77,18 @@ static inline int df_cu_count() {
   return v;
 }
 
+// ---- deterministic accumulation (dfmir_det_begin / dfmir_det_end: include/dfmir_hip.h, "Deterministic weight gradients").
+// Between the two calls every weight- / bias-gradient kernel launched by THIS host thread adds its partial sums as 64-bit
+// FIXED-POINT integers into the scratch the caller handed over: integer addition is associative, so the result does not
+// depend on the order in which workgroups finish (fp32 atomics make every weight gradient run-to-run different in its
+// last bits).  fx = device pointer to {scale, 1 / scale} (a power of two such that the bound count * max|x| * max|dy| maps
+// below 2^61), nullptr outside a begin / end pair -- the kernels then add floats as before.
+const float* df_det_fx();
+__device__ __forceinline__ void df_acc(float* base, long long idx, float v, const float* fx) {
+  if (fx) atomicAdd(reinterpret_cast<unsigned long long*>(base) + idx, (unsigned long long)__float2ll_rn(v * fx[0]));
+  else atomicAdd(base + idx, v);
+}
+
 // Zero a few floats on the stream with a KERNEL.  Not hipMemsetAsync: a captured step turns that into a hipGraph
 // memset node, and on ROCm 7.2 such nodes are not reliably ordered with the kernel nodes around them -- the third of
 // four identical masked-L1 calls in one captured graph read a stale workspace at every replay

@@ -359,7 +359,7 @@ template <int WJ, int WC, int TJ, int TC, int BP>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict__ x,
                                                          const float* __restrict__ dy,
                                                          float* __restrict__ dwt, DfConvGeom g,
-                                                         long long pchunk) {
+                                                         long long pchunk, const float* __restrict__ fx) {
   constexpr int BJ = WJ * TJ * 32, BC = WC * TC * 32;
   constexpr int RS = 256 / BP;
   constexpr int NA = BJ / RS, NB = (BC + RS - 1) / RS;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jr = jb + (r & 3) + 8 * (r >> 2);
-        if (jr < J) atomicAdd(&dwt[(long long)jr * g.Cout + co], acc[i][j][r]);
+        if (jr < J) df_acc(dwt, (long long)jr * g.Cout + co, acc[i][j][r], fx);
       }
     }
   }
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------
 __global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
-                            long long S, int nsplit) {
+                            long long S, int nsplit, const float* __restrict__ fx) {
   // one (n, c) plane segment per workgroup: contiguous float4 stream, one atomic per workgroup
   __shared__ float sm[17];
   const int c = blockIdx.x, n = blockIdx.y, part = blockIdx.z;
@@ -518,7 +518,7 @@ __global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db
     for (long long i = beg + threadIdx.x; i < end; i += blockDim.x) s += p[i];
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0 && beg < S) atomicAdd(&db[c], s);
+  if (threadIdx.x == 0 && beg < S) df_acc(db, c, s, fx);
 }
 
 // part (may be NULL): part[blockIdx.x] <- this block's max |w| -- the range probe of the fp16x2 split, taken
@@ -881,13 +881,13 @@ static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_a
     dim3 grid;
     if (g->Cout > 64) {
       plan(128, 128, 16, nP, pchunk, grid);
-      conv_wgrad_mfma_k<2, 2, 2, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+      conv_wgrad_mfma_k<2, 2, 2, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk, df_det_fx());
     } else if (g->Cout > 32) {
       plan(128, 64, 16, nP, pchunk, grid);
-      conv_wgrad_mfma_k<4, 1, 1, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+      conv_wgrad_mfma_k<4, 1, 1, 2, 16><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk, df_det_fx());
     } else {
       plan(128, 32, 32, nP, pchunk, grid);
-      conv_wgrad_mfma_k<4, 1, 1, 1, 32><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk);
+      conv_wgrad_mfma_k<4, 1, 1, 1, 32><<<grid, 256, 0, st>>>(xs, ds, dw_tcc, gs, pchunk, df_det_fx());
     }
     DF_LAUNCH_CHECK();
   }
@@ -899,7 +899,7 @@ static int bias_grad_launch(const float* dy, float* db, int N, int C, long long 
   if (nsplit > 64) nsplit = 64;
   if (nsplit < 1) nsplit = 1;
   DF_ARG_CHECK(N <= 65535);
-  bias_grad_k<<<dim3(C, N, nsplit), S >= 4096 ? 256 : 64, 0, st>>>(dy, db, N, C, S, nsplit);
+  bias_grad_k<<<dim3(C, N, nsplit), S >= 4096 ? 256 : 64, 0, st>>>(dy, db, N, C, S, nsplit, df_det_fx());
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -206,6 +206,7 @@ struct W3dP {
   int cg, ngroups;               // channels per group, number of groups (blockIdx.y)
   int ny, nx;                    // patches per axis (nz == D)
   long long npatch, per_block;   // total patches (N*D*ny*nx) and patches per block
+  const float* fx;               // deterministic mode (common.h df_acc)
 };
 
 template <int NCT, int RT>
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad16_k(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
           const int co = c * 16 + l15;
-          if (co < k.Cout) atomicAdd(&dwt[((long long)tap * k.Cin + c0 + ci) * k.Cout + co], acc[r][c][e]);
+          if (co < k.Cout) df_acc(dwt, ((long long)tap * k.Cin + c0 + ci) * k.Cout + co, acc[r][c][e], k.fx);
         }
       }
     }
@@ -399,6 +400,7 @@ bool df_conv3d_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, f
   if ((long long)g->Cin * S * 4 >= 0x7FFFFFFFLL || (long long)g->Cout * S * 4 >= 0x7FFFFFFFLL) return false;
   if ((g->Wi & 3) != 0) return false;                       // float4 dY loads
   W3dP k{};
+  k.fx = df_det_fx();
   k.N = g->N; k.Cin = g->Cin; k.Cout = g->Cout; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
   k.ngroups = (g->Cin + 31) / 32;
   k.cg = (g->Cin + k.ngroups - 1) / k.ngroups;

@@ -1905,6 +1905,7 @@ struct W3sP {
   // tensor xa [N, Ca, D/2, H/2, W/2] at (z >> 1, y >> 1, x >> 1), the remaining Cin - Ca from x [N, Cin - Ca, D, H, W]
   const float* xa;
   int Ca;
+  const float* fx;               // deterministic mode (common.h df_acc): dwt holds 64-bit fixed-point sums, db is NULL
 };
 
 template <int NCH>
@@ -2088,7 +2089,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_split_k(const float* __restr
         const int rho = tile * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
         const int tap = rho >> 3, ci = (c_base + c) * 8 + (rho & 7);
         const int to = k.flip ? 26 - tap : tap;
-        if (rho < 216 && ci < k.Cin) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + l31 * k.s_col], acc[c][s][r] * sc);
+        if (rho < 216 && ci < k.Cin) df_acc(dwt, to * k.s_tap + ci * k.s_row + l31 * k.s_col, acc[c][s][r] * sc, k.fx);
       }
     }
   if (db_y && yco < k.Cout) atomicAdd(&k.db[yco], bacc);
@@ -2478,7 +2479,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_tr_k(const float* __restr
           ok = ok && rho < 216;
         }
         const int to = k.flip ? 26 - tap : tap;
-        if (ok) atomicAdd(&dwt[to * k.s_tap + ci * k.s_row + co * k.s_col], acc[c][s][r] * sc);
+        if (ok) df_acc(dwt, to * k.s_tap + ci * k.s_row + co * k.s_col, acc[c][s][r] * sc, k.fx);
       }
     }
   if (k.db) {                                              // wave-uniform: every lane of a wave holds the same 8 channels
@@ -2554,7 +2555,7 @@ static bool upwgrad_geom_ok(const DfConvGeom* g, int Ca) {
          g->Cout >= 8 && g->Cout <= 32 && (g->Cout & 7) == 0 && !(g->Di & 1) && !(g->Hi & 1) && !(g->Wi & 7);
 }
 extern "C" int dfmir_conv3d_upwgrad_ok(const DfConvGeom* g, int Ca) { return (g && upwgrad_geom_ok(g, Ca)) ? 1 : 0; }
-extern "C" long long dfmir_conv3d_upwgrad_ws_floats(void) { return 72LL * 1024; }
+extern "C" long long dfmir_conv3d_upwgrad_ws_floats(void) { return 2 * 72LL * 1024; }   // (64-bit slots in deterministic mode)
 extern "C" int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const float* b, int Ca, const float* x_amax,
                                     int x_amax_n, const float* dy, const float* dy_amax, int dy_amax_n, float* dw_tcc,
                                     float* db, float* ws, void* stream) {
@@ -2571,7 +2572,7 @@ extern "C" int dfmir_conv3d_upwgrad(const DfConvGeom* g, const float* a, const f
   if (rc || fuse) return rc;
   DfConvGeom gb = *g;
   gb.Cin = g->Cin - Ca;
-  return conv3d_split_wgrad_impl(&gb, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc + (long long)Ca * g->Cout, db,
+  return conv3d_split_wgrad_impl(&gb, b, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc + (df_det_fx() ? 2LL : 1LL) * Ca * g->Cout, db,   // (deterministic mode: 8-byte slots)
                                  stream, nullptr, 0, s_tap);
 }
 extern "C" int dfmir_conv3d_split_wgrad(const DfConvGeom* g, const float* x, const float* x_amax, int x_amax_n,
@@ -2598,6 +2599,7 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
     return df_conv3d_wgrad_march_launch(x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, g->N, g->Di, g->Hi, g->Wi, st);
   const bool swapped = !rows && !split3d_wgrad_geom_ok(g);
   W3sP k{};
+  k.fx = df_det_fx();
   k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;
   k.xa = xa; k.Ca = xa ? Ca : 0;
   if (swapped) {

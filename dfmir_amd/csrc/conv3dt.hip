@@ -360,7 +360,7 @@ __global__ __launch_bounds__(128) void conv3d_s2c2_fwd_k(const float* __restrict
 
 typedef float s2_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void conv3d_s2c2_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dwt, C3s2P k) {
+                                                           float* __restrict__ dwt, C3s2P k, const float* __restrict__ fx) {
   constexpr int COUT = 16, NV = S2_TZ * S2_TY * S2_TX;     // 512 output voxels per tile
   constexpr int DP = NV + 4;                               // dY row stride: 16 channels x 4 voxels of a B read on 64 banks
   __shared__ __attribute__((aligned(16))) float Xs[2 * S2_PZ * S2_PY * S2_PITCH];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_s2c2_wgrad_k(const float* __res
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 16 * wid + 4 * (lane >> 4) + r;
-    if (row < 54) atomicAdd(&dwt[row * COUT + (lane & 15)], acc[r]);
+    if (row < 54) df_acc(dwt, row * COUT + (lane & 15), acc[r], fx);
   }
 }
 }  // namespace
@@ -445,7 +445,7 @@ extern "C" int dfmir_conv3d_s2c2_wgrad(const DfConvGeom* g, const float* x, cons
   const C3s2P k = s2_params(g);
   DF_ARG_CHECK(k.ntile < (1LL << 30));
   const unsigned grid = (unsigned)(k.ntile < 512 ? k.ntile : 512);
-  conv3d_s2c2_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw_tcc, k);
+  conv3d_s2c2_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw_tcc, k, df_det_fx());
   DF_LAUNCH_CHECK();
   return 0;
 }

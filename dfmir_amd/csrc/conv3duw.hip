@@ -86,6 +86,7 @@ struct UwP {
   int a_n, dy_n;                 // floats of the two range probes
   int ncy, ncx, nseg, zlen;      // 4 x 16 columns per low-resolution plane, z segments of zlen planes
   int nitems;                    // N * nseg * ncy * ncx
+  const float* fx;               // deterministic mode (common.h df_acc): the workspace holds 64-bit fixed-point sums
 };
 
 constexpr unsigned UW_ASPLIT = 108u * 64u;          // one split of an `a` plane slot: 6 x 18 positions x 32 channels x fp16
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_upwgrad_k(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ci = (r >> 2) * 8 + hi * 4 + (r & 3);
-          atomicAdd(&gws[tile * 1024 + ci * 32 + l31], acc[p][s][r] * osc_a * osc_d);
+          df_acc(gws, tile * 1024 + ci * 32 + l31, acc[p][s][r] * osc_a * osc_d, k.fx);
         }
       }
   }
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ci = (r >> 2) * 8 + hi * 4 + (r & 3);
-            atomicAdd(&gws[tile * 1024 + ci * 32 + l31], acc[p][iz][s][r] * sc);
+            df_acc(gws, tile * 1024 + ci * 32 + l31, acc[p][iz][s][r] * sc, k.fx);
           }
         }
     if constexpr (FUSEB) {
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r >> 2) * 8 + hi * 4 + (r & 3);          // row 28 of tile 1: sum of dY (ones operand, unscaled)
-          atomicAdd(&gws[(64 + (py * 2 + px) * 2 + T) * 1024 + row * 32 + l31], accb[T][r] * ((T == 1 && row == 28) ? osc_d : sc));
+          df_acc(gws, (64 + (py * 2 + px) * 2 + T) * 1024 + row * 32 + l31, accb[T][r] * ((T == 1 && row == 28) ? osc_d : sc), k.fx);
         }
     }
   }
@@ -752,20 +753,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_upwgrad4_k(const float* __restr
 
 // dWb[tap][cb][co] += the rows of the 8 b tiles (class (py, px), T) that hold (tap, cb): see conv3d_upwgrad4_k
 __global__ __launch_bounds__(256) void conv3d_upwgrad_foldb_k(const float* __restrict__ gws, float* __restrict__ dwt, int Cout,
-                                                               long long s_tap, int total, float* __restrict__ db) {
+                                                               long long s_tap, int total, float* __restrict__ db,
+                                                               const float* __restrict__ fx) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total + Cout) return;
+  const long long* g64 = reinterpret_cast<const long long*>(gws);   // deterministic mode: integer sums in, integer sum out
   if (idx >= total) {                                       // bias gradient: row 28 of the classes' second tiles
     const int co = idx - total;
     float s = 0.f;
 #pragma unroll
     for (int cls = 0; cls < 4; ++cls) s += gws[(64 + cls * 2 + 1) * 1024 + 28 * 32 + co];
-    if (db) db[co] += s;
+    if (db && !fx) db[co] += s;                             // (deterministic mode: db comes from dfmir_bias_grad)
     return;
   }
   const int co = idx % Cout, cb = (idx / Cout) & 1, tap = idx / (Cout * 2);
   const int dz = tap / 9, dyy = (tap / 3) % 3, dx = tap % 3;
   float s = 0.f;
+  long long s64 = 0;
 #pragma unroll
   for (int cls = 0; cls < 4; ++cls) {
     const int py = cls >> 1, px = cls & 1;
@@ -773,17 +777,21 @@ __global__ __launch_bounds__(256) void conv3d_upwgrad_foldb_k(const float* __res
     if (dx == px || dx == px + 1) { Q = dz * 3 + dyy; pos = (dx - px) * 2 + cb; }
     else if (dyy == py || dyy == py + 1) { Q = 9 + dz; pos = (dyy - py) * 2 + cb; }
     else { Q = 12 + dz; pos = (px ? 2 : 0) + cb; }
-    s += gws[(64 + cls * 2 + (Q >> 3)) * 1024 + ((Q & 7) * 4 + pos) * 32 + co];
+    if (fx) s64 += g64[(64 + cls * 2 + (Q >> 3)) * 1024 + ((Q & 7) * 4 + pos) * 32 + co];
+    else s += gws[(64 + cls * 2 + (Q >> 3)) * 1024 + ((Q & 7) * 4 + pos) * 32 + co];
   }
-  dwt[tap * s_tap + (long long)cb * Cout + co] += s;
+  if (fx) reinterpret_cast<long long*>(dwt)[tap * s_tap + (long long)cb * Cout + co] += s64;
+  else dwt[tap * s_tap + (long long)cb * Cout + co] += s;
 }
 
 // dW[tap][ci][co] += the 8 tiles of the workspace that contain tap = (dz, dy, dx): per axis d = 0: (p, i) = (0,0), (1,0);
 // d = 1: (0,1), (1,0);  d = 2: (0,1), (1,1)
 __global__ __launch_bounds__(256) void conv3d_upwgrad_fold_k(const float* __restrict__ gws, float* __restrict__ dwt, int Cout,
-                                                              long long s_tap, int total) {
+                                                              long long s_tap, int total, const float* __restrict__ fx) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
+  const long long* g64 = reinterpret_cast<const long long*>(gws);
+  long long s64 = 0;
   const int co = idx % Cout, ci = (idx / Cout) & 31, tap = idx / (Cout * 32);
   const int d[3] = {tap / 9, (tap / 3) % 3, tap % 3};
   int pi[3][2];                                             // the two (p * 2 + i) codes of each axis
@@ -797,9 +805,11 @@ __global__ __launch_bounds__(256) void conv3d_upwgrad_fold_k(const float* __rest
   for (int m = 0; m < 8; ++m) {
     const int cz = pi[0][m >> 2], cy = pi[1][(m >> 1) & 1], cx = pi[2][m & 1];
     const int tile = (((((cz >> 1) * 2 + (cy >> 1)) * 2 + (cx >> 1)) * 2 + (cz & 1)) * 2 + (cy & 1)) * 2 + (cx & 1);
-    s += gws[tile * 1024 + ci * 32 + co];
+    if (fx) s64 += g64[tile * 1024 + ci * 32 + co];
+    else s += gws[tile * 1024 + ci * 32 + co];
   }
-  dwt[tap * s_tap + (long long)ci * Cout + co] += s;
+  if (fx) reinterpret_cast<long long*>(dwt)[tap * s_tap + (long long)ci * Cout + co] += s64;
+  else dwt[tap * s_tap + (long long)ci * Cout + co] += s;
 }
 
 }  // namespace
@@ -832,15 +842,18 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
   k.zlen = (Dl + best - 1) / best;
   k.nseg = (Dl + k.zlen - 1) / k.zlen;
   k.nitems = (int)(cols * k.nseg);
+  k.fx = df_det_fx();
   const unsigned grid = (unsigned)(k.nitems < ncu ? k.nitems : ncu);
-  if (df_zero_async(ws, 72 * 1024, st) != hipSuccess) return 2;   // a kernel, not a memset node (common.h: graph ordering on ROCm 7.2)
+  if (df_zero_async(ws, (k.fx ? 2 : 1) * 72 * 1024, st) != hipSuccess) return 2;   // a kernel, not a memset node (common.h: graph ordering on ROCm 7.2)
   static DfOptFlag v1_o{"DFMIR_UPWGRAD_8WAVE"};             // A/B: the two-waves-per-SIMD form of the up-sampled share
   if (b) conv3d_upwgrad4_k<true><<<grid, 256, 0, st>>>(a, a_amax, b, dy, dy_amax, ws, k);
   else if (v1_o.get()) conv3d_upwgrad_k<<<grid, 512, 0, st>>>(a, a_amax, dy, dy_amax, ws, k);
   else conv3d_upwgrad4_k<false><<<grid, 256, 0, st>>>(a, a_amax, nullptr, dy, dy_amax, ws, k);
   const int total = 27 * 32 * Cout;
-  conv3d_upwgrad_fold_k<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, dwt, Cout, s_tap, total);
-  if (b) conv3d_upwgrad_foldb_k<<<(unsigned)((27 * 2 * Cout + Cout + 255) / 256), 256, 0, st>>>(ws, dwt + 32LL * Cout, Cout, s_tap, 27 * 2 * Cout, db);
+  conv3d_upwgrad_fold_k<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, dwt, Cout, s_tap, total, k.fx);
+  // (deterministic mode: dwt counts 8-byte slots, so the skip rows start 32 * Cout SLOTS = 64 * Cout floats further on)
+  if (b) conv3d_upwgrad_foldb_k<<<(unsigned)((27 * 2 * Cout + Cout + 255) / 256), 256, 0, st>>>(
+      ws, dwt + (k.fx ? 64LL : 32LL) * Cout, Cout, s_tap, 27 * 2 * Cout, db, k.fx);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -64,6 +64,7 @@ struct WmP {
   int nitems;                    // N * nseg * ncy * ncx
   long long s_tap;               // dwt index = tap * s_tap + ci * 16 + co
   float* db;                     // optional: db[co] += sum of dY
+  const float* fx;               // deterministic mode (common.h df_acc): dwt holds 64-bit fixed-point sums, db is NULL
 };
 
 constexpr unsigned WM_FSPLIT = 8u * 32u * 64u;      // one split of an x plane: 8 x 32 voxels x 32 channels x fp16 = 16 KB
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_march_k(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ci = (r >> 2) * 8 + hi * 4 + (r & 3);
-          atomicAdd(&dwt[tap * k.s_tap + ci * 16 + co], acc[T][r] * sc);
+          df_acc(dwt, tap * k.s_tap + ci * 16 + co, acc[T][r] * sc, k.fx);
         }
       }
     });
@@ -338,6 +339,7 @@ int df_conv3d_wgrad_march_launch(const float* x, const float* x_amax, int x_n, c
   k.ncy = (H + 7) / 8; k.ncx = (W + 31) / 32;
   k.s_tap = 32LL * 16;
   k.db = db;
+  k.fx = df_det_fx();
   const int ncu = df_cu_count();
   const long long cols = (long long)N * k.ncy * k.ncx;
   static DfOptInt nseg_o{"DFMIR_WGRAD_MARCH_NSEG", 0};

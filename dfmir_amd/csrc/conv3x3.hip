@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_k(const float* __restrict__ 
 struct W3P {
   int N, Cin, Cout, H, W, pad_mode;
   int runs_per_img, runs_total, runs_per_block;
+  const float* fx;        // deterministic mode (common.h df_acc): dwt holds 64-bit fixed-point sums
 };
 
 template <int WI, int WC>
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_k(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r]);
+        if (ci < k.Cin) df_acc(dwt, ((long long)t * k.Cin + ci) * k.Cout + co, acc[t][r], k.fx);
       }
     }
   }
@@ -395,7 +396,7 @@ bool df_conv3x3_wgrad_try(const DfConvGeom* g, const float* x, const float* dy, 
   if (!((W % BP == 0) || (W < BP && BP % W == 0))) return false;
   const int npos = (W >= BP) ? 3 * (BP + 2) : (BP / W + 2) * (W + 2);
   if (npos > 105) return false;
-  W3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, (int)(HW / BP), 0, 0};
+  W3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, (int)(HW / BP), 0, 0, df_det_fx()};
   k.runs_total = g->N * k.runs_per_img;
   const bool wide = g->Cout >= 128;
   const int CT = wide ? 32 : 64, BC = wide ? 128 : 64;
@@ -457,7 +458,8 @@ __device__ __forceinline__ void sw_tile(const float* __restrict__ patch, const f
 template <int NCT>   // 16-wide output-channel blocks (1: Cout <= 16, 2: Cout <= 32)
 __global__ __launch_bounds__(512, 1) void conv3x3_small_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 float* __restrict__ dwt, int N, int Cin, int Cout,
-                                                                int H, int W, int pad_mode, int tiles_x, int tiles_y) {
+                                                                int H, int W, int pad_mode, int tiles_x, int tiles_y,
+                                                                const float* __restrict__ fx) {
   __shared__ float patch[SW_CIN * SW_PP];
   __shared__ float dyt[16 * NCT * SW_DS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_small_wgrad_k(const float* __r
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
           const int co = c * 16 + l15;
-          if (co < Cout) atomicAdd(&dwt[(long long)jj * Cout + co], acc[r][c][e]);
+          if (co < Cout) df_acc(dwt, (long long)jj * Cout + co, acc[r][c][e], fx);
         }
       }
     }
@@ -576,7 +578,7 @@ bool df_conv3x3_small_wgrad_try(const DfConvGeom* g, const float* x, const float
   const long long ntile = (long long)g->N * tx * ty;
   if (ntile >= (1LL << 31) || ntile < 32) return false;                  // tiny layers: the generic kernel is as good
   const unsigned grid = (unsigned)(ntile < 256 ? ntile : 256);
-  conv3x3_small_wgrad_k<1><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty);
+  conv3x3_small_wgrad_k<1><<<grid, 512, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, tx, ty, df_det_fx());
   hipError_t e = hipGetLastError();
   *rc = (e == hipSuccess) ? 0 : df_set_error((int)e, __FILE__, __LINE__);
   return true;

@@ -1214,6 +1214,7 @@ struct WS3P {
   // layer fills it completely.
   int swap;
   float* dbx;             // swapped roles: the bias gradient is the pixel sum of the kernel's X operand (= dY), interior rows of a run
+  const float* fx;        // deterministic mode (common.h df_acc): dwt is then an array of 64-bit fixed-point sums; db / dbx are NULL
 };
 
 // BC = 128: 8 waves = 2 ci tiles x 4 co tiles, each wave both k-steps of a run.
@@ -1397,8 +1398,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split_k(const float* __r
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
         if (ci < k.Cin)
-          atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co],
-                    NSP == 2 ? acc[t][r] * oscale * oscale2 : acc[t][r]);
+          df_acc(dwt, ((long long)t * k.Cin + ci) * k.Cout + co, NSP == 2 ? acc[t][r] * oscale * oscale2 : acc[t][r], k.fx);
       }
     }
   }
@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
         const int col = 4 * lhi + (r & 3) + 8 * (r >> 2);
         const int co = co0 + wc * 32 + col;
         const float v = T[l31 * 33 + col];
-        if (ci < k.Cin && co < k.Cout) atomicAdd(&dwt[((long long)(8 - t) * k.Cout + co) * k.Cin + ci], v);
+        if (ci < k.Cin && co < k.Cout) df_acc(dwt, ((long long)(8 - t) * k.Cout + co) * k.Cin + ci, v, k.fx);
       }
       __syncthreads();
     }
@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wi * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
-        if (ci < k.Cin) atomicAdd(&dwt[((long long)t * k.Cin + ci) * k.Cout + co], acc[t][r] * oscale * oscale2);
+        if (ci < k.Cin) df_acc(dwt, ((long long)t * k.Cin + ci) * k.Cout + co, acc[t][r] * oscale * oscale2, k.fx);
       }
     }
   }
@@ -1919,7 +1919,7 @@ bool df_conv3x3_split_wgrad_try(const DfConvGeom* g, const float* x, const float
   const long long HW = (long long)g->Hi * g->Wi;
   if (HW * g->Cin * 4 >= (1LL << 31) || HW * g->Cout * 4 >= (1LL << 31)) return false;
   const bool swap = mode == 2 && x_amax && dy_amax && df_conv3x3_split_wgrad_swaps(g);
-  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax, 0, nullptr};
+  WS3P k{g->N, g->Cin, g->Cout, g->Hi, g->Wi, g->pad_mode, g->Wi / 16, 0, 0, 0, x_amax, dy_amax, x_n, dy_n, db, dy_pmax, 0, nullptr, df_det_fx()};
   if (swap) {
     k.Cin = g->Cout; k.Cout = g->Cin;
     k.x_amax = dy_amax; k.dy_amax = x_amax; k.x_n = dy_n; k.dy_n = x_n;

@@ -483,8 +483,11 @@ __device__ __forceinline__ NccTerms ncc_terms(const float* s, long long N, long 
   return t;
 }
 // mask (optional, N floats): ws[0] = sum cc * mask, ws[1] = sum mask (util/losses.py:257-261)
+// part (optional, 2 * gridDim.x floats): per-workgroup partial sums instead of atomics -- ncc_fin_k adds them in index
+// order, so the loss and (through ws[0]) its gradient do not depend on the order in which workgroups finish
 __global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__ s, const float* __restrict__ mask,
-                                                       float* __restrict__ ws, long long N, float wn, float eps) {
+                                                       float* __restrict__ ws, long long N, float wn, float eps,
+                                                       float* __restrict__ part) {
   __shared__ float sm[17];
   float acc = 0.f, msum = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)gridDim.x * 256) {
@@ -496,14 +499,25 @@ __global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__
   acc = block_sum(acc, sm);
   if (mask) msum = block_sum(msum, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(&ws[0], acc);
-    if (mask) atomicAdd(&ws[1], msum);
+    if (part) {
+      part[blockIdx.x] = acc;
+      part[gridDim.x + blockIdx.x] = mask ? msum : 0.f;
+    } else {
+      atomicAdd(&ws[0], acc);
+      if (mask) atomicAdd(&ws[1], msum);
+    }
   }
 }
 // mode 0: -sqrt(S / n) (NCC_Loss.forward, util/losses.py:248-261; 0 when the mask is empty), mode 1: -S / n
 // (torchvoxelmorph/losses.py:67); n = sum(mask) with a mask, else the element count
 __device__ __forceinline__ float ncc_norm(const float* ws, float n, int masked) { return masked ? ws[1] : n; }
-__global__ void ncc_fin_k(const float* ws, float* out, float n, int mode, int masked) {
+__global__ void ncc_fin_k(float* ws, float* out, float n, int mode, int masked, const float* part, int nparts) {
+  if (part) {
+    float a = 0.f, m = 0.f;
+    for (int i = 0; i < nparts; ++i) { a += part[i]; m += part[nparts + i]; }
+    ws[0] = a;
+    ws[1] = m;
+  }
   const float ne = ncc_norm(ws, n, masked);
   if (!(ne > 0.f)) { out[0] = 0.f; return; }
   out[0] = mode == 0 ? -sqrtf(ws[0] / ne) : -(ws[0] / ne);
@@ -786,9 +800,12 @@ extern "C" int dfmir_ncc_fwd_m(const float* I, const float* J, const float* mask
     DF_LAUNCH_CHECK();
     wn = (float)win * win;
   }
-  ncc_cc_reduce_k<<<df_grid(N, 256, 1024), 256, 0, st>>>(tmp, mask, ws, N, wn, eps);
+  // tmp2 is free again after the box passes: its head takes the per-workgroup partials (volumes of >= 2048 / 5 voxels)
+  const unsigned ng = df_grid(N, 256, 1024);
+  float* part = (5 * N >= 2LL * ng) ? tmp2 : nullptr;
+  ncc_cc_reduce_k<<<ng, 256, 0, st>>>(tmp, mask, ws, N, wn, eps, part);
   DF_LAUNCH_CHECK();
-  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N, mode, mask != nullptr);
+  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N, mode, mask != nullptr, part, (int)ng);
   DF_LAUNCH_CHECK();
   return 0;
 }
@@ -843,6 +860,70 @@ __global__ __launch_bounds__(256) void mul_k(const float* __restrict__ a, const 
 extern "C" int dfmir_mul(const float* a, const float* b, float* out, long long n, void* stream) {
   DF_ARG_CHECK(a && b && out && n > 0);
   mul_k<<<df_grid(n, 256, 8192), 256, 0, (hipStream_t)stream>>>(a, b, out, n);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
+// ---------------------------------------------------------------------------------------------
+// Deterministic weight gradients (include/dfmir_hip.h).  fx lives at the head of the caller's scratch; the 8-byte sum
+// slots follow at float offset DF_DET_HEAD.
+static thread_local const float* tl_det_fx = nullptr;
+const float* df_det_fx() { return tl_det_fx; }
+constexpr int DF_DET_HEAD = 8;
+__global__ __launch_bounds__(256) void det_scale_k(const float* __restrict__ x_amax, int xn, const float* __restrict__ dy_amax,
+                                                   int dyn, float count, float* __restrict__ fx) {
+  __shared__ float sm[17];
+  const float ax = reduce_absmax(x_amax, xn, sm);
+  __syncthreads();
+  const float ay = reduce_absmax(dy_amax, dyn, sm);
+  if (threadIdx.x) return;
+  // every sum the kernels form -- dW[.] = sum x * dy over `count` positions, db[.] = sum dy -- is bounded by B
+  const float B = count * fmaxf(ax, 1.f) * ay;
+  int e = 0;
+  if (B > 0.f && B < 3.0e38f) frexpf(B, &e);               // B < 2^e
+  int sh = 61 - e;
+  sh = sh > 120 ? 120 : (sh < -120 ? -120 : sh);
+  fx[0] = ldexpf(1.f, sh);
+  fx[1] = ldexpf(1.f, -sh);
+}
+__global__ __launch_bounds__(256) void det_final_k(const long long* __restrict__ slots, const float* __restrict__ fx,
+                                                   float* __restrict__ out, long long n) {
+  const double inv = (double)fx[1];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] += (float)((double)slots[i] * inv);
+}
+extern "C" int dfmir_det_head_floats(void) { return DF_DET_HEAD; }
+extern "C" int dfmir_det_begin(float* scratch, long long slots, const float* x, long long nx, const float* x_amax, int x_amax_n,
+                               const float* dy, long long ndy, const float* dy_amax, int dy_amax_n, double count,
+                               void* stream) {
+  DF_ARG_CHECK(scratch && slots > 0 && count > 0 && (x_amax || (x && nx > 0)) && (dy_amax || (dy && ndy > 0)) &&
+               (reinterpret_cast<uintptr_t>(scratch) & 15) == 0 && tl_det_fx == nullptr);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = dfmir_fill_zero(scratch, DF_DET_HEAD + 2 * slots, stream);
+    if (rc) return rc;
+  }
+  if (!x_amax) {                                           // no range probe came with the operand: measure it
+    const int rc = dfmir_absmax(x, nx, scratch + 4, stream);
+    if (rc) return rc;
+    x_amax = scratch + 4; x_amax_n = 1;
+  }
+  if (!dy_amax) {
+    const int rc = dfmir_absmax(dy, ndy, scratch + 5, stream);
+    if (rc) return rc;
+    dy_amax = scratch + 5; dy_amax_n = 1;
+  }
+  det_scale_k<<<1, 256, 0, st>>>(x_amax, x_amax_n, dy_amax, dy_amax_n, (float)count, scratch);
+  DF_LAUNCH_CHECK();
+  tl_det_fx = scratch;
+  return 0;
+}
+extern "C" int dfmir_det_end(const float* scratch, float* dw_out, long long n_dw, float* db_out, long long n_db, void* stream) {
+  tl_det_fx = nullptr;
+  DF_ARG_CHECK(scratch && n_dw >= 0 && n_db >= 0 && (n_dw == 0 || dw_out) && (n_db == 0 || db_out));
+  hipStream_t st = (hipStream_t)stream;
+  const long long* slots = reinterpret_cast<const long long*>(scratch + DF_DET_HEAD);
+  if (n_dw) det_final_k<<<df_grid(n_dw, 256, 2048), 256, 0, st>>>(slots, scratch, dw_out, n_dw);
+  if (n_db) det_final_k<<<df_grid(n_db, 256, 64), 256, 0, st>>>(slots + n_dw, scratch, db_out, n_db);
   DF_LAUNCH_CHECK();
   return 0;
 }

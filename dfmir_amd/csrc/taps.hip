@@ -279,7 +279,7 @@ constexpr int S7W_TH = 8, S7W_PH = S7W_TH + 6;
 __global__ __launch_bounds__(256) void conv7x7_c1_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dw, float* __restrict__ db,
                                                           int N, int H, int W, int Cout, int pad_mode,
-                                                          int tiles_x, int tiles_y) {
+                                                          int tiles_x, int tiles_y, const float* __restrict__ fx) {
   __shared__ float patch[S7W_PH * S7_PW];
   __shared__ float dyt[64 * (S7W_TH * S7_TW + 1)];        // [co][px], row stride 257: conflict-free column reads
   constexpr int DS = S7W_TH * S7_TW + 1;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void conv7x7_c1_wgrad_k(const float* __restric
     for (int r = 0; r < 16; ++r) {
       const int c = mb * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
       if (c < Cout) {
-        if (t < S7_T) atomicAdd(&dw[c * S7_T + t], acc[r]);
-        else if (db) atomicAdd(&db[c], acc[r]);
+        if (t < S7_T) df_acc(dw, c * S7_T + t, acc[r], fx);
+        else if (db) df_acc(db, c, acc[r], fx);
       }
     }
   }
@@ -382,7 +382,7 @@ extern "C" int dfmir_conv7x7_c1_wgrad(const float* x, const float* dy, float* dw
   // persistent workgroups, two per CU (68 KB of LDS each); every one ends with 3 200 atomic adds onto the same
   // gradient, so more workgroups than that only add contention (1024: +70 us)
   const unsigned grid = (unsigned)(ntile < 512 ? ntile : 512);
-  conv7x7_c1_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, N, H, W, Cout, pad_mode, tx, ty);
+  conv7x7_c1_wgrad_k<<<grid, 256, 0, (hipStream_t)stream>>>(x, dy, dw, db, N, H, W, Cout, pad_mode, tx, ty, df_det_fx());
   DF_LAUNCH_CHECK();
   return 0;
 }

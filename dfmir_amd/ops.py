@@ -353,6 +353,54 @@ def _upwgrad_ws(device):
     return ws
 
 
+# Deterministic weight gradients (opt.deterministic_wgrad -> set_deterministic_wgrad; build-defined).  The weight- and
+# bias-gradient kernels split their reduction over workgroups and meet in fp32 atomics: every run rounds in a different
+# order (2 of 30 runs of one test exceeded a 4e-5 bound on step 4's gradients because of it).  In this mode each
+# gradient launch accumulates 64-bit fixed-point integers into a per-call scratch (include/dfmir_hip.h "Deterministic
+# weight gradients") -- integer addition is associative -- and a finaliser adds the converted sums to the real target: two
+# runs of a step from the same state give bit-identical gradient arenas.  Cost: one zero-fill, one scale launch and one
+# finaliser per gradient launch, and the bias gradients as their own pass over dY.
+_DET = {"on": _env_on("DFMIR_DETERMINISTIC_WGRAD")}
+
+
+def set_deterministic_wgrad(on):
+    _DET["on"] = bool(on)
+
+
+class _DetAcc(object):
+    def __init__(self, n_dw, n_db, count, x, x_amax, dy, dy_amax):
+        head = int(lib().dfmir_det_head_floats())
+        self.n_dw, self.n_db = int(n_dw), int(n_db)
+        self.scr = torch.empty(head + 2 * (self.n_dw + self.n_db), device=dy.device, dtype=torch.float32)
+        check(lib().dfmir_det_begin(_p(self.scr), self.n_dw + self.n_db, _p(x), 0 if x is None else x.numel(), _p(x_amax),
+                                    0 if x_amax is None else x_amax.numel(), _p(dy), dy.numel(), _p(dy_amax),
+                                    0 if dy_amax is None else dy_amax.numel(), float(count), _st()))
+        self.dw = self.scr[head:head + 2 * self.n_dw]              # the entry points see 8-byte slots behind this pointer
+        self.db = self.scr[head + 2 * self.n_dw:] if self.n_db else None
+
+    def end(self, dw_out, db_out):
+        check(lib().dfmir_det_end(_p(self.scr), _p(dw_out), self.n_dw, _p(db_out), self.n_db if db_out is not None else 0, _st()))
+
+    def abort(self):
+        check(lib().dfmir_det_end(_p(self.scr), None, 0, None, 0, _st()))
+
+
+def bias_grad(dy5, db):
+    """db[c] += sum over (n, voxels) of dy5[n, c] (accumulates); deterministic mode: through the fixed-point scratch."""
+    N, C = dy5.shape[0], dy5.shape[1]
+    S = dy5.numel() // (N * C)
+    if not _DET["on"]:
+        check(lib().dfmir_bias_grad(_p(dy5), _p(db), N, C, S, _st()))
+        return
+    acc = _DetAcc(0, C, N * S, dy5, None, dy5, None)         # (x plays no part: the bound is count * max|dy|)
+    try:
+        check(lib().dfmir_bias_grad(_p(dy5), _p(acc.db), N, C, S, _st()))
+    except BaseException:
+        acc.abort()
+        raise
+    acc.end(None, db)
+
+
 def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_amax=None, db=None, dy_pmax=None,
                    parts=None):
     """dW in the tap-major packing; `out` (same packing) is accumulated into when given.  parts = (a, b): the operand is
@@ -387,6 +435,12 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
            and bool(lib().dfmir_conv3d_upwgrad_ok(ctypes.byref(g), parts[0].shape[1])))
     s2c2 = (parts is None and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and not _NO_TINY3D
             and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
+    # deterministic mode: the kernels add 64-bit fixed-point sums into a scratch, never a bias gradient (its own pass below)
+    det = _DetAcc(dw.numel(), Cout if db is not None else 0, N * Do * Ho * Wo, x5 if parts is None else None, x_amax,
+                  dy5, dy_amax) if _DET["on"] else None
+    dw_real, db_real = dw, db
+    if det is not None:
+        dw, db = det.dw, None
 
     def launch():
         if s2c2:
@@ -413,6 +467,16 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
                                                0 if x_amax is None else x_amax.numel(), _p(dy5), _p(dy_amax),
                                                0 if dy_amax is None else dy_amax.numel(), _p(pm), _p(dw), _p(db), _st()))
 
+    if det is not None:
+        try:
+            launch()
+            if db_real is not None:
+                check(lib().dfmir_bias_grad(_p(dy5), _p(det.db), dy5.shape[0], Cout, Do * Ho * Wo, _st()))
+        except BaseException:
+            det.abort()
+            raise
+        det.end(dw_real, db_real)
+        return dw_real
     prof = _CONV_PROFILER[0]
     if prof is None:
         launch()
@@ -807,8 +871,7 @@ def _conv_backward_impl(ctx, dy, dskip, x5, weight, y5):
                                      dy_pmax=dy_pmax, parts=parts)
                 dw = weight_unpack(dwt, tuple(weight.shape))
         elif db_buf is not None:
-            S = dy5.shape[2] * dy5.shape[3] * dy5.shape[4]
-            check(lib().dfmir_bias_grad(_p(dy5), _p(db_buf), dy5.shape[0], Cout, S, _st()))   # accumulates
+            bias_grad(dy5, db_buf)                                                           # accumulates
         return dx, dw, db
 
 
@@ -885,7 +948,7 @@ class TapSumFn(Function):
             check(lib().dfmir_tapsum_bwd(_p(dy), _p(dz), N, C, H, W, H, W, K, pad, pad_mode, _st()))
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = zeros(C, dy.device)
-            check(lib().dfmir_bias_grad(_p(dy), _p(db), N, C, H * W, _st()))
+            bias_grad(dy.view(N, C, H * W), db)
         return dz, db, None, None, None, None, None, None
 
 
@@ -918,7 +981,18 @@ class Stem7Fn(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dwb = zeros(Cout * 49 + Cout, dy.device)
             dbp = dwb[Cout * 49:] if ctx.has_bias else None
-            check(lib().dfmir_conv7x7_c1_wgrad(_p(x), _p(dy), _p(dwb), _p(dbp), N, H, W, Cout, ctx.pad_mode, _st()))
+            if _DET["on"]:
+                det = _DetAcc(Cout * 49, Cout if ctx.has_bias else 0, N * H * W, x, None, dy, None)
+                try:
+                    check(lib().dfmir_conv7x7_c1_wgrad(_p(x), _p(dy), _p(det.dw), None, N, H, W, Cout, ctx.pad_mode, _st()))
+                    if ctx.has_bias:
+                        check(lib().dfmir_bias_grad(_p(dy), _p(det.db), N, Cout, H * W, _st()))
+                except BaseException:
+                    det.abort()
+                    raise
+                det.end(dwb, dbp)
+            else:
+                check(lib().dfmir_conv7x7_c1_wgrad(_p(x), _p(dy), _p(dwb), _p(dbp), N, H, W, Cout, ctx.pad_mode, _st()))
             dw = dwb[:Cout * 49].view(Cout, 1, 7, 7)
             db = dbp if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if ctx.needs_input_grad[0]:

@@ -26,6 +26,7 @@ def default_options(**overrides):
         skip_unused_target=True,   # build-defined: do not compute VxmDense's discarded warp(target, -flow) output
         global_mask_norm=False,    # build-defined, DDP: masked-L1 normalised by the GLOBAL batch's mask sums (DataParallel semantics)
         overlap_registration=True,  # build-defined: netR's forward / backward on a second HIP stream beside the generator's
+        deterministic_wgrad=False,  # build-defined: weight / bias gradients by 64-bit fixed-point accumulation (bit-reproducible)
         staged_step=True,          # build-defined: the two-stream step as single-stream pieces (one linear hipGraph each when captured)
         capture_step=False)        # build-defined: replay the steady-state step as one hipGraph (REGISTRATIONModel)
     for k, v in overrides.items():

@@ -18,11 +18,13 @@ from .voxelmorph import VxmDense
 
 class Registration3DModel(object):
     def __init__(self, shape, features=None, lam=1.0, lr=2e-4, betas=(0.5, 0.999), win=9, device="cuda",
-                 capture_step=False):
+                 capture_step=False, deterministic_wgrad=None):
         """capture_step (build-defined, as REGISTRATIONModel's opt.capture_step): after two eager steps forward +
         losses + backward are captured into ONE hipGraph and replayed; Adam and the gradient all-reduce stay eager.
         Small volumes are host-bound otherwise (128^3: 3.7 ms of Python / autograd / ctypes per 5.2 ms step)."""
         self.device = torch.device(device)
+        if deterministic_wgrad is not None:     # (process-global switch of dfmir_amd.ops, as REGISTRATIONModel's opt.deterministic_wgrad)
+            ops.set_deterministic_wgrad(deterministic_wgrad)
         self.netR = VxmDense(tuple(shape), features, int_steps=7, bidir=True).to(self.device)
         self.netR.skip_unused_target = True      # the step reads (y_source, flow) only
         self.optimizer_R = FlatAdam(self.netR.parameters(), lr=lr, betas=betas)

@@ -86,6 +86,9 @@ class REGISTRATIONModel(BaseModel):
 
     def __init__(self, opt):
         BaseModel.__init__(self, opt)
+        # opt.deterministic_wgrad (build-defined, default False): weight / bias gradients through 64-bit fixed-point
+        # accumulation -- bit-identical arenas from run to run (a PROCESS-global switch of dfmir_amd.ops)
+        ops.set_deterministic_wgrad(bool(getattr(opt, 'deterministic_wgrad', False)) or ops._env_on('DFMIR_DETERMINISTIC_WGRAD'))
         self.loss_names = ['G', 'NCE', 'R', 'smooth', 'local']
         self.visual_names = ['real_A', 'fake_B', 'real_B', 'dvf', 'registered', 'regA']
         self.nce_layers = [int(i) for i in self.opt.nce_layers.split(',')]

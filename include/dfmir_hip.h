@@ -570,6 +570,26 @@ int dfmir_sum_scaled(const float* x, float* out, long long n, float scale, void*
 int dfmir_fill_from_scalar(const float* gout, float* dx, long long n, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Deterministic weight gradients (build-defined, opt.deterministic_wgrad; the reference's cuDNN backward is not
+ * deterministic either, models/base_model.py:37-38 sets cudnn.benchmark).  The weight- and bias-gradient kernels split
+ * their reduction over workgroups and add the partial sums with fp32 atomics: every run rounds in a different order.
+ * Between dfmir_det_begin and dfmir_det_end EVERY gradient entry point called by this host thread (dfmir_conv_wgrad*,
+ * dfmir_conv3d_split_wgrad*, dfmir_conv3d_upwgrad, dfmir_conv3d_s2c2_wgrad, dfmir_conv7x7_c1_wgrad, dfmir_bias_grad) adds
+ * 64-bit FIXED-POINT integers instead -- associative, hence bit-reproducible -- into `scratch`:
+ *   scratch: dfmir_det_head_floats() + 2 * slots floats, 16-byte aligned; the call zeroes it.  The caller passes
+ *     scratch + dfmir_det_head_floats() as the entry point's dw_tcc (8 bytes per element: element i of the gradient is
+ *     slot i) and NULL as its db; a bias gradient is taken with dfmir_bias_grad into slots n_dw .. n_dw + n_db - 1
+ *     (pointer scratch + head + 2 * n_dw).
+ *   scale: a power of two chosen on the device such that count * max(max|x|, 1) * max|dy| -- a bound of every sum formed --
+ *     maps below 2^61.  x_amax / dy_amax: range probes as for the split kernels, or NULL with x / dy given (measured here).
+ *   dfmir_det_end: dw_out[i] += slot[i] / scale (i < n_dw), db_out[j] += slot[n_dw + j] / scale, and ends the mode.
+ * ---------------------------------------------------------------------------------------- */
+int dfmir_det_head_floats(void);
+int dfmir_det_begin(float* scratch, long long slots, const float* x, long long nx, const float* x_amax, int x_amax_n,
+                    const float* dy, long long ndy, const float* dy_amax, int dy_amax_n, double count, void* stream);
+int dfmir_det_end(const float* scratch, float* dw_out, long long n_dw, float* db_out, long long n_db, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * torch.optim.Adam(lr, betas) step over one flat parameter arena
  * (registration_model.py:114-117,135,168-171).  grad is pre-scaled by grad_scale (1/world under DDP).
  * ---------------------------------------------------------------------------------------- */

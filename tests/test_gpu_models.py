@@ -676,6 +676,92 @@ def test_failed_capture_falls_back_to_a_correct_eager_step(O):
                 assert float((a - b).norm()) <= 2e-3 * float(b.norm()), (k, nm)
 
 
+class FixedIds(object):
+    """model.patch_id_source that returns the SAME id sets at every call (the device generator advances per draw)."""
+    graph_safe = False
+    distinct = True
+
+    def __call__(self, sizes, n_sets, P):
+        return torch.stack([torch.stack([C.patch_ids(7 + t, l, S, P) for t in range(n_sets)]) for l, S in enumerate(sizes)]).to(DEV)
+
+
+@pytest.mark.parametrize("cfg", [(64, 2, 8), (256, 16, 64)], ids=["64-b2-ngf8", "256-b16-ngf64(configs[1])"])
+def test_deterministic_weight_gradients(cfg):
+    """opt.deterministic_wgrad (build-defined): every weight / bias gradient accumulated as 64-bit fixed-point integers
+    (include/dfmir_hip.h "Deterministic weight gradients").  Forward + backward twice from the same weights, inputs and
+    patch ids: the three gradient arenas are BIT-identical (SHA-1), and within round-off of the default float-atomic path."""
+    import hashlib
+    from dfmir_amd import ops
+    from dfmir_amd.options import default_options
+    from dfmir_amd.registration_model import REGISTRATIONModel
+    size, B, ngf = cfg
+    res = {}
+    try:
+        for det in (True, False):
+            torch.manual_seed(17)
+            opt = default_options(batch_size=B, crop_size=size, load_size=size, ngf=ngf, gpu_ids=[0], deterministic_wgrad=det,
+                                  checkpoints_dir="/tmp/dfmir_ckpt", name="det")
+            model = REGISTRATIONModel(opt)
+            assert ops._DET["on"] == det
+            with torch.no_grad():
+                model.netR.flow.weight.mul_(1e5)
+            model.patch_id_source = FixedIds()
+            A0, B0 = C.image_pair(61, B, size, size)
+            data = {"A": A0.to(DEV), "B": B0.to(DEV), "A_paths": [""] * B, "B_paths": [""] * B}
+            model.data_dependent_initialize(data)
+            model.setup(opt)
+            model.parallelize()
+            runs = []
+            for _ in range(2):
+                model.set_input(data)
+                model._forward_backward()
+                torch.cuda.synchronize()
+                runs.append([o_.flat_g.clone() for o_ in model.optimizers])
+            res[det] = runs
+            del model
+    finally:
+        ops.set_deterministic_wgrad(False)
+    sha = lambda t: hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()
+    for nm, a, b in zip("GRF", res[True][0], res[True][1]):
+        assert float(a.abs().sum()) > 0
+        assert sha(a) == sha(b), "arena %s differs between two deterministic runs" % nm
+    for nm, a, b in zip("GRF", res[True][0], res[False][0]):
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()), (nm, float((a - b).norm() / b.norm()))
+
+
+def test_deterministic_weight_gradients_3d():
+    """The same for the 3-D step (every 3-D weight-gradient kernel: tiled, plane-pair, marching, parity-class, first level,
+    flow head; NCC's reduction in index order): two backward passes from one state give bit-identical arenas."""
+    import hashlib
+    from dfmir_amd import ops
+    from dfmir_amd.registration3d import Registration3DModel
+    res = {}
+    try:
+        for shape, feats in (((32, 64, 64), None), ((64, 64, 64), "plugin")):
+            from oracle import dfmir_oracle as O_
+            for det in (True, False):
+                torch.manual_seed(23)
+                m = Registration3DModel(shape, O_.PLUGIN_UNET_FEATURES if feats else None, device=DEV, deterministic_wgrad=det)
+                with torch.no_grad():
+                    m.netR.flow.weight.mul_(3e4)
+                A = C.rand(31, 1, 1, *shape).to(DEV)
+                B = (0.5 * A + 0.5 * C.rand(41, 1, 1, *shape).to(DEV))
+                runs = []
+                for _ in range(2):
+                    m.set_input({"A": A, "B": B})
+                    m._forward_backward()
+                    torch.cuda.synchronize()
+                    runs.append(m.optimizer_R.flat_g.clone())
+                res[(shape, det)] = runs
+            a, b = res[(shape, True)]
+            assert float(a.abs().sum()) > 0
+            assert hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest() == hashlib.sha1(b.cpu().numpy().tobytes()).hexdigest(), shape
+            c = res[(shape, False)][0]
+            assert float((a - c).norm()) <= 2e-5 * float(c.norm()), (shape, float((a - c).norm() / c.norm()))
+    finally:
+        ops.set_deterministic_wgrad(False)
+
+
 def _full_size_oracle(O, B, double=False):
     """256x256, ngf 64 oracle step state with seeded weights, pinned ids, a non-vacuous flow head; optionally fp64."""
     size = 256
