@@ -496,6 +496,84 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 1x1(x1) convolutions' weight gradient as a streaming NT GEMM (round 6): dW[ci][co] += sum_{n,q} X[n][ci][q] dY[n][co][q].
+// No taps, no padding, no gather: both operands are read as 16-byte quads of consecutive voxels (the generic kernel above
+// decodes a coordinate and issues a 4-byte load per ELEMENT: 20 TFLOP/s on the 64 -> 49 tap GEMM of the generator's 7x7
+// head, 0.66 ms for 13 GFLOP over 0.95 GB).  Workgroup = 64 ci x 64 co (4 waves = 2 x 2 tiles of 32 x 32 on
+// v_mfma_f32_32x32x2_f32), K = the voxels of its share of 64-voxel chunks, staged channel-major into LDS (row stride 65:
+// a wave's 32 channel rows of one voxel sit in 32 banks) one chunk ahead through registers; split-K over blockIdx.x, the
+// partial tiles meet in df_acc (fp32 atomics, or 64-bit fixed point in deterministic mode).
+//   users: the head's tap GEMM (models/networks.py:1022-1023 as tap-sum, csrc/taps.hip) and the stem's input gradient,
+//   PatchSampleF's two Linear layers (models/networks.py:587-595).   Requires S % 4 == 0 and 16-byte aligned operands.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1x1_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dwt, int N, int Cin, int Cout, long long S,
+                                                       long long chunks_per_img, long long chunks_per_block,
+                                                       const float* __restrict__ fx) {
+  constexpr int BK = 64, LD = BK + 1;
+  __shared__ float Xs[64 * LD];
+  __shared__ float Ds[64 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5, wm = wid >> 1, wn = wid & 1;
+  const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const long long total = (long long)N * chunks_per_img;
+  const long long cbeg = (long long)blockIdx.x * chunks_per_block;
+  long long cend = cbeg + chunks_per_block;
+  if (cend > total) cend = total;
+  // staging: thread -> (row r of the 64-channel tile, 16 voxels of the chunk) = four quads
+  const int r = tid >> 2, q16 = (tid & 3) * 16;
+  const bool xrow = ci0 + r < Cin, drow = co0 + r < Cout;
+  float4 rx[4], rd[4];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define G1_GLOAD(c_)                                                                                         \
+  {                                                                                                          \
+    const long long n_ = (c_) / chunks_per_img, q0_ = ((c_) - n_ * chunks_per_img) * BK + q16;               \
+    const float* xp_ = x + ((long long)n_ * Cin + ci0 + r) * S + q0_;                                        \
+    const float* dp_ = dy + ((long long)n_ * Cout + co0 + r) * S + q0_;                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+      const bool in_ = q0_ + 4 * j < S;                                                                      \
+      rx[j] = (xrow && in_) ? *reinterpret_cast<const float4*>(xp_ + 4 * j) : z4;                            \
+      rd[j] = (drow && in_) ? *reinterpret_cast<const float4*>(dp_ + 4 * j) : z4;                            \
+    }                                                                                                        \
+  }
+#define G1_LSTORE()                                                                                          \
+  {                                                                                                          \
+    float* xs_ = &Xs[r * LD + q16];                                                                          \
+    float* ds_ = &Ds[r * LD + q16];                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+      xs_[4 * j] = rx[j].x; xs_[4 * j + 1] = rx[j].y; xs_[4 * j + 2] = rx[j].z; xs_[4 * j + 3] = rx[j].w;    \
+      ds_[4 * j] = rd[j].x; ds_[4 * j + 1] = rd[j].y; ds_[4 * j + 2] = rd[j].z; ds_[4 * j + 3] = rd[j].w;    \
+    }                                                                                                        \
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (cbeg < cend) G1_GLOAD(cbeg)
+  for (long long c = cbeg; c < cend; ++c) {
+    __syncthreads();                                        // the previous chunk's readers are done
+    G1_LSTORE()
+    __syncthreads();
+    if (c + 1 < cend) G1_GLOAD(c + 1)
+    const float* ap = &Xs[(wm * 32 + l31) * LD + lhi];
+    const float* bp = &Ds[(wn * 32 + l31) * LD + lhi];
+#pragma unroll 8
+    for (int ks = 0; ks < BK / 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+  }
+#undef G1_GLOAD
+#undef G1_LSTORE
+  const int co = co0 + wn * 32 + l31;
+  if (co < Cout && cbeg < cend) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = ci0 + wm * 32 + 4 * lhi + (i & 3) + 8 * (i >> 2);
+      if (ci < Cin) df_acc(dwt, (long long)ci * Cout + co, acc[i], fx);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void bias_grad_k(const float* __restrict__ dy, float* __restrict__ db, int N, int C,
                             long long S, int nsplit, const float* __restrict__ fx) {
@@ -848,6 +926,27 @@ static int conv_wgrad_impl(const DfConvGeom* g, const float* x, const float* x_a
     if (df_conv3x3_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3x3_small_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
     if (df_conv3d_wgrad_try(g, x, dy, dw_tcc, st, &rc)) return rc;
+  }
+  {
+    // 1x1x1, stride 1, no padding: the streaming NT GEMM (A/B: DFMIR_NO_1X1_WGRAD=1 = the generic gather kernel)
+    static DfOptFlag no1x1_o{"DFMIR_NO_1X1_WGRAD"};
+    const long long S1 = (long long)g->Di * g->Hi * g->Wi;
+    if (!use_generic_only() && !no1x1_o.get() && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->stride == 1 && g->pd == 0 &&
+        g->ph == 0 && g->pw == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && (S1 & 3) == 0 && S1 >= 64 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && g->Cin >= 8 && g->Cout >= 8) {
+      const long long cpi = (S1 + 63) / 64, total = (long long)g->N * cpi;
+      const unsigned ny = (unsigned)((g->Cin + 63) / 64), nz = (unsigned)((g->Cout + 63) / 64);
+      long long want = 1024 / ((long long)ny * nz);          // ~4 workgroups per CU in all
+      if (want < 1) want = 1;
+      long long maxs = (total + 7) / 8;                        // >= 8 chunks per workgroup
+      if (maxs < 1) maxs = 1;
+      if (want > maxs) want = maxs;
+      const long long cpb = (total + want - 1) / want;
+      const unsigned nx = (unsigned)((total + cpb - 1) / cpb);
+      conv1x1_wgrad_k<<<dim3(nx, ny, nz), 256, 0, st>>>(x, dy, dw_tcc, g->N, g->Cin, g->Cout, S1, cpi, cpb, df_det_fx());
+      DF_LAUNCH_CHECK();
+      return 0;
+    }
   }
   long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
   const int J = g->KD * g->KH * g->KW * g->Cin;

@@ -76,6 +76,10 @@ CONV2D = [
     (48, 32, 3, 1, 1, False, 1, 1, 11, 7),
     (33, 3, 1, 1, 0, False, 0, 1, 6, 50),
     (256, 256, 1, 1, 0, False, 1, 1, 1, 512),
+    # 1x1 weight gradients on the streaming NT-GEMM kernel (conv1x1_wgrad_k): ragged channel tiles, a last chunk of 32 of 64
+    # voxels, three images (split-K across image boundaries), exactly one chunk
+    (72, 49, 1, 1, 0, False, 0, 3, 20, 24),
+    (8, 136, 1, 1, 0, False, 1, 1, 4, 16),
     # geometries that take the LDS-resident 3x3 kernels (conv3x3.hip): aligned / unaligned pixel runs,
     # padded-frame dgrad of reflect convs, W >= tile, partial channel chunks, both wgrad tilings
     (64, 128, 3, 1, 1, False, 0, 2, 32, 32),
