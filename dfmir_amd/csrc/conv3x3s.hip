@@ -894,6 +894,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
       if (pos < NPOS) {                                                                          \
         float v[8];                                                                              \
         _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = __uint_as_float(rx[s][c]);          \
+        CS_NORM_PROBE_OPS()                                                                      \
         u32x4 sp[NSP];                                                                           \
         split8_s<NSP>(v, xscale, sp);                                                                      \
         _Pragma("unroll") for (int q = 0; q < NSP; ++q) Xs[buf_][(q * 2 + grp) * XP + pos] = sp[q]; \
@@ -901,6 +902,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
     }                                                                                            \
   }
 
+  // CS_NORM_PROBE (lab builds, scripts/build_var.sh): what an InstanceNorm + ReLU applied while the patch is staged would
+  // cost the converting wave group -- one fma and one max per value with run-time operands that happen to be the identity
+  // (x * 1 + 0, max with -3e38: results unchanged, instructions real; profiles/r06_cs_norm_probe.txt)
+#ifdef CS_NORM_PROBE
+  const float np_r = fmaf(oscale2, 0.f, 1.f), np_m = oscale2 * 0.f, np_lo = fmaf(oscale2, 0.f, -3.0e38f);
+#define CS_NORM_PROBE_OPS() _Pragma("unroll") for (int c = 0; c < 8; ++c) v[c] = fmaxf(fmaf(v[c], np_r, np_m), np_lo);
+#else
+#define CS_NORM_PROBE_OPS()
+#endif
   // prologue: X(0) (each group its channel half) and W_A(0) in place; B holds W_B(0), X-half-1(1) in registers
   CS_GLOADX(0);
   if (grp == 0) CS_GLOADW(0);
@@ -973,6 +983,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_split_cs_k(const float* __rest
 #undef CS_GLOADX
 #undef CS_LSTOREW
 #undef CS_LSTOREX
+#undef CS_NORM_PROBE_OPS
 
   // Epilogue.  The MFMAs ran with rows = the 32 pixels of a tile row and columns = 32 output channels, so a lane holds
   // ONE output channel (l31) and, per accumulator quad q, the 4 consecutive pixels 8q + 4 lhi .. + 3 of each of its 4 tile
