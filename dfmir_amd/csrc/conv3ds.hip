@@ -2534,6 +2534,9 @@ int df_conv3d_upwgrad_launch(const float* a, const float* a_amax, int a_n, const
                              int Cout, hipStream_t st);
 int df_conv3d_wgrad_march_launch(const float* x, const float* x_amax, int x_n, const float* dy, const float* dy_amax, int dy_n,
                                  float* dwt, float* db, int N, int D, int H, int W, hipStream_t st);
+int df_conv3d_flow_wgrad_ok(const DfConvGeom* g, const float* x, const float* dy);
+int df_conv3d_flow_wgrad_launch(const float* x, const float* x_amax, int x_n, const float* dy, const float* dy_amax, int dy_n,
+                                float* dwt, float* db, int N, int D, int H, int W, int Cout, hipStream_t st);
 static bool wgrad_march_geom_ok(const DfConvGeom* g) {
   static DfOptFlag nomarch_o{"DFMIR_CONV3D_NO_WGRAD_MARCH"};
   return g->Cin == 32 && g->Cout == 16 && !split3d_off() && split3d_wgrad_geom_ok(g) && !nomarch_o.get() &&
@@ -2598,6 +2601,9 @@ static int conv3d_split_wgrad_impl(const DfConvGeom* g, const float* x, const fl
   if (!rows && !xa && wgrad_march_takes(g, x, dy))
     return df_conv3d_wgrad_march_launch(x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, g->N, g->Di, g->Hi, g->Wi, st);
   const bool swapped = !rows && !split3d_wgrad_geom_ok(g);
+  // the flow head 16 -> 3: (co, dx) pairs as MFMA columns, z-marching (conv3dt.hip)
+  if (swapped && !xa && df_conv3d_flow_wgrad_ok(g, x, dy))
+    return df_conv3d_flow_wgrad_launch(x, x_amax, x_amax_n, dy, dy_amax, dy_amax_n, dw_tcc, db, g->N, g->Di, g->Hi, g->Wi, g->Cout, st);
   W3sP k{};
   k.fx = df_det_fx();
   k.N = g->N; k.D = g->Di; k.H = g->Hi; k.W = g->Wi;

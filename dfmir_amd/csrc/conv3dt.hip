@@ -409,7 +409,252 @@ __global__ __launch_bounds__(256, 2) void conv3d_s2c2_wgrad_k(const float* __res
     if (row < 54) df_acc(dwt, row * COUT + (lane & 15), acc[r], fx);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// conv3d_flow_wgrad_k (round 6): weight + bias gradient of the flow head Conv3d(16, Cout <= 4, 3, padding 1)
+// (torchvoxelmorph/networks.py:1076-1080) as a z-marching streaming kernel.
+//   dW[dz][dy][dx][ci][co] = sum_u x[ci][u] * dY[co][u - (dz - 1, dy - 1, dx - 1)]
+// With the (co, dx) pairs as the MFMA COLUMNS (3 Cout <= 12 of 16) and the x-row of 32 voxels as K, one
+// v_mfma_f32_16x16x32_f16 per (dz, dy) and split product turns an x-row of all 16 input channels into its share of nine
+// [16 ci x (co, dx)] tiles: 27 MFMAs per 32 voxels (the swapped-role tiled kernel this replaces walked 28 tap rows x 8
+// padded channels against 32 columns: 0.33 ms for 0.52 GB).  A operand = 8 consecutive voxels of one channel: one 16-byte
+// read of a channel-major fp16 image, no transposing read.  The dx shift of the B operand would be a 2-byte misalignment:
+// the three shifted copies of every dY row are made when the row is staged (3 channels: cheap).  A workgroup owns an
+// 8 x 32 column and marches along z: every x plane and every dY plane (ring of three: the taps dz reach z - 1 .. z + 1) is
+// staged once as scaled fp16 pairs, in-plane halo of the 3-channel operand only.  The four waves (two rows each) meet in
+// LDS in wave order, then one set of df_acc adds per workgroup; the bias gradient is summed from the staged dY.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_pair_t(float x0, float x1, float s, unsigned& h, unsigned& r) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+}
+__device__ __forceinline__ void split8_t(const float* v, float s, u32x4_t& h, u32x4_t& r) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned hh, rr;
+    split_pair_t(v[2 * q], v[2 * q + 1], s, hh, rr);
+    h[q] = hh; r[q] = rr;
+  }
+}
+__device__ __forceinline__ f32x4_t mma16t(u32x4_t a, u32x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int scale_exp_t(float amax) {
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  int e = (amax > 0.f) ? 14 - be : 0;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+struct FwP {
+  int N, D, H, W, Cout;
+  int x_n, dy_n;                 // floats of the two range probes
+  int ncy, ncx, nseg, zlen;      // 8 x 32 columns per plane, z segments of zlen planes
+  float* db;                     // optional bias gradient
+  const float* fx;               // deterministic mode (common.h df_acc)
+};
+constexpr int FW_XCS = 33;                       // 16-byte units per channel of an x plane slot: 8 rows x 4 + 1 (bank spread)
+constexpr int FW_XSLOT = 2 * 16 * FW_XCS;        // [split][ci]
+constexpr int FW_DCS = 41;                       // units per (co, dx) column of a dY plane slot: 10 rows x 4 + 1
+// CO = the most output channels the instance holds: 3 (the flow head; 69 KB of LDS: two workgroups per CU) or 4
+template <int CO>
+__global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+                                                              const float* __restrict__ dy, const float* __restrict__ dy_amax,
+                                                              float* __restrict__ dwt, FwP k) {
+  constexpr int FW_NCOL = 3 * CO;                  // (co, dx) columns held
+  constexpr int FW_DSLOT = 2 * FW_NCOL * FW_DCS;   // [split][col]
+  __shared__ __attribute__((aligned(16))) u32x4_t Xa[2 * FW_XSLOT];      // 33.8 KB
+  __shared__ __attribute__((aligned(16))) u32x4_t Dsh[3 * FW_DSLOT];     // 35.4 KB for CO = 3 (also the epilogue's reduction buffer)
+  __shared__ float red[17];
+  __shared__ float bsum[160];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  int it = blockIdx.x;
+  const int cx = it % k.ncx; it /= k.ncx;
+  const int cy = it % k.ncy; it /= k.ncy;
+  const int seg = it % k.nseg;
+  const int n = it / k.nseg;
+  const int y0 = cy * 8, x0 = cx * 32, zs = seg * k.zlen;
+  int ze = zs + k.zlen;
+  if (ze > k.D) ze = k.D;
+  const long long HW = (long long)k.H * k.W, S = HW * k.D;
+  const float* xn = x + (long long)n * 16 * S;
+  const float* dn = dy + (long long)n * k.Cout * S;
+  const int ex = scale_exp_t(reduce_absmax(x_amax, k.x_n, red));
+  __syncthreads();
+  const int ed = scale_exp_t(reduce_absmax(dy_amax, k.dy_n, red));
+  const float xscale = __uint_as_float((unsigned)(ex + 127) << 23), dscale = __uint_as_float((unsigned)(ed + 127) << 23);
+  const float osc = __uint_as_float((unsigned)(-ex + 127) << 23) * __uint_as_float((unsigned)(-ed + 127) << 23);
+  const int ncol = 3 * k.Cout;
+
+  // x staging: two items per thread, item = (ci, row, 8 voxels)
+  float4 rx[2][2];
+  // dY staging: threads 0 .. Cout * 40 - 1, item = (co, patch row 0 .. 9 <-> y0 - 1 .. y0 + 8, 8-voxel group): voxels
+  // x0 + 8 g - 1 .. x0 + 8 g + 8
+  const int d_co = tid / 40, d_row = (tid % 40) >> 2, d_g = tid & 3;
+  const bool d_act = tid < k.Cout * 40;
+  float4 rd[2];
+  float rdl = 0.f, rdr = 0.f;
+  float bacc = 0.f;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define FW_GLOAD_X(z_)                                                                                     \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+      const int i_ = tid + 256 * j, ci_ = i_ >> 5, row_ = (i_ >> 2) & 7, g_ = i_ & 3;                      \
+      const int yy_ = y0 + row_, xx_ = x0 + 8 * g_;                                                        \
+      const bool ok_ = (z_) < k.D && yy_ < k.H;                                                            \
+      const float* p_ = xn + (long long)ci_ * S + (long long)(z_) * HW + (long long)yy_ * k.W + xx_;       \
+      rx[j][0] = (ok_ && xx_ < k.W) ? *reinterpret_cast<const float4*>(p_) : z4;                           \
+      rx[j][1] = (ok_ && xx_ + 4 < k.W) ? *reinterpret_cast<const float4*>(p_ + 4) : z4;                   \
+    }                                                                                                      \
+  }
+#define FW_LSTORE_X(buf_)                                                                                  \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+      const int i_ = tid + 256 * j, ci_ = i_ >> 5, row_ = (i_ >> 2) & 7, g_ = i_ & 3;                      \
+      const float v_[8] = {rx[j][0].x, rx[j][0].y, rx[j][0].z, rx[j][0].w, rx[j][1].x, rx[j][1].y, rx[j][1].z, rx[j][1].w}; \
+      u32x4_t h_, r_;                                                                                      \
+      split8_t(v_, xscale, h_, r_);                                                                        \
+      Xa[(buf_) * FW_XSLOT + ci_ * FW_XCS + row_ * 4 + g_] = h_;                                           \
+      Xa[(buf_) * FW_XSLOT + (16 + ci_) * FW_XCS + row_ * 4 + g_] = r_;                                    \
+    }                                                                                                      \
+  }
+#define FW_GLOAD_D(z_)                                                                                     \
+  {                                                                                                        \
+    rd[0] = z4; rd[1] = z4; rdl = 0.f; rdr = 0.f;                                                          \
+    const int yy_ = y0 - 1 + d_row, xx_ = x0 + 8 * d_g;                                                    \
+    if (d_act && (z_) >= 0 && (z_) < k.D && yy_ >= 0 && yy_ < k.H) {                                       \
+      const float* p_ = dn + (long long)d_co * S + (long long)(z_) * HW + (long long)yy_ * k.W + xx_;      \
+      if (xx_ < k.W) rd[0] = *reinterpret_cast<const float4*>(p_);                                         \
+      if (xx_ + 4 < k.W) rd[1] = *reinterpret_cast<const float4*>(p_ + 4);                                 \
+      if (xx_ > 0 && xx_ - 1 < k.W) rdl = p_[-1];                                                          \
+      if (xx_ + 8 < k.W) rdr = p_[8];                                                                      \
+    }                                                                                                      \
+  }
+  // the three shifted copies: column (co, dx) element x' = dY[x' - dx + 1]  ->  dx 0: +1 .. +8, dx 1: 0 .. 7, dx 2: -1 .. 6
+#define FW_LSTORE_D(slot_, own_)                                                                           \
+  if (d_act) {                                                                                             \
+    const float w_[10] = {rdl, rd[0].x, rd[0].y, rd[0].z, rd[0].w, rd[1].x, rd[1].y, rd[1].z, rd[1].w, rdr}; \
+    if ((own_) && d_row >= 1 && d_row <= 8)                                                                \
+      bacc += ((w_[1] + w_[2]) + (w_[3] + w_[4])) + ((w_[5] + w_[6]) + (w_[7] + w_[8]));                   \
+    _Pragma("unroll") for (int dx_ = 0; dx_ < 3; ++dx_) {                                                  \
+      u32x4_t h_, r_;                                                                                      \
+      split8_t(&w_[2 - dx_], dscale, h_, r_);                                                              \
+      const int u_ = (slot_) * FW_DSLOT + (d_co * 3 + dx_) * FW_DCS + d_row * 4 + d_g;                     \
+      Dsh[u_] = h_;                                                                                        \
+      Dsh[u_ + FW_NCOL * FW_DCS] = r_;                                                                     \
+    }                                                                                                      \
+  }
+
+  f32x4_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: dY planes zs - 1, zs, zs + 1 -> slots (z + 3) % 3; x plane zs -> buffer 0
+  FW_GLOAD_D(zs - 1) FW_LSTORE_D((zs + 2) % 3, false)
+  FW_GLOAD_D(zs) FW_LSTORE_D(zs % 3, true)
+  FW_GLOAD_D(zs + 1) FW_LSTORE_D((zs + 1) % 3, zs + 1 < ze)
+  FW_GLOAD_X(zs) FW_LSTORE_X(0)
+  const int bcol = l15 < ncol ? l15 : 0;                    // padding columns read column 0 (their results are dropped)
+  for (int z = zs; z < ze; ++z) {
+    const int buf = (z - zs) & 1;
+    __syncthreads();                                        // x plane z and dY plane z + 1 are in place
+    const bool more = z + 1 < ze;
+    if (more) FW_GLOAD_X(z + 1)
+    FW_GLOAD_D(z + 2)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wid + rr;
+      const u32x4_t ah = Xa[buf * FW_XSLOT + l15 * FW_XCS + row * 4 + kg];
+      const u32x4_t ar = Xa[buf * FW_XSLOT + (16 + l15) * FW_XCS + row * 4 + kg];
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const int slot = (z - dz + 1 + 3) % 3;
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy) {
+          const int u = slot * FW_DSLOT + bcol * FW_DCS + (row - dyy + 2) * 4 + kg;
+          const u32x4_t bh = Dsh[u], br = Dsh[u + FW_NCOL * FW_DCS];
+          f32x4_t a_ = acc[dz * 3 + dyy];
+          a_ = mma16t(ah, bh, a_);
+          a_ = mma16t(ah, br, a_);
+          a_ = mma16t(ar, bh, a_);
+          acc[dz * 3 + dyy] = a_;
+        }
+      }
+    }
+    __syncthreads();                                        // the readers of x buffer buf ^ 1 (step z - 1) and of dY plane z - 1 are done
+    if (more) FW_LSTORE_X(buf ^ 1)
+    FW_LSTORE_D((z + 2) % 3, z + 2 < ze)
+  }
+#undef FW_GLOAD_X
+#undef FW_LSTORE_X
+#undef FW_GLOAD_D
+#undef FW_LSTORE_D
+
+  // the four waves' tiles meet in LDS, in wave order (a fixed summation order: deterministic mode relies on it)
+  __syncthreads();
+  float* redw = reinterpret_cast<float*>(Dsh);              // [9][16 rows][16 cols]
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i_ = t * 256 + (4 * kg + r) * 16 + l15;
+          redw[i_] = (w == 0 ? 0.f : redw[i_]) + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 9 * 16 * ncol; i += 256) {
+    const int col = i % ncol, ci = (i / ncol) & 15, t9 = i / (ncol * 16);
+    const int co = col / 3, dx = col - 3 * co;
+    const int tap = t9 * 3 + dx;                            // (dz * 3 + dy) * 3 + dx
+    df_acc(dwt, (long long)tap * (16 * k.Cout) + ci * k.Cout + co, redw[t9 * 256 + ci * 16 + col] * osc, k.fx);
+  }
+  if (k.db) {
+    if (tid < 160) bsum[tid] = d_act ? bacc : 0.f;
+    __syncthreads();
+    if (tid < k.Cout) {
+      float s_ = 0.f;
+      for (int j = 0; j < 40; ++j) s_ += bsum[tid * 40 + j];
+      df_acc(k.db, tid, s_, k.fx);
+    }
+  }
+}
 }  // namespace
+
+// Host side (conv3ds.hip::conv3d_split_wgrad_impl calls this for the 16 -> Cout <= 4 flow head).  dwt: tap-major [27][16][Cout].
+int df_conv3d_flow_wgrad_ok(const DfConvGeom* g, const float* x, const float* dy) {
+  static DfOptFlag off_o{"DFMIR_CONV3D_NO_FLOW_WGRAD"};     // A/B: the swapped-role tiled kernel
+  return !off_o.get() && g->Cin == 16 && g->Cout >= 1 && g->Cout <= 4 && (g->Wi & 3) == 0 && g->Di >= 2 &&
+         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 &&
+         (long long)g->Di * g->Hi * g->Wi >= 1024;
+}
+int df_conv3d_flow_wgrad_launch(const float* x, const float* x_amax, int x_n, const float* dy, const float* dy_amax, int dy_n,
+                                float* dwt, float* db, int N, int D, int H, int W, int Cout, hipStream_t st) {
+  FwP k{};
+  k.N = N; k.D = D; k.H = H; k.W = W; k.Cout = Cout;
+  k.x_n = x_n; k.dy_n = dy_n;
+  k.ncy = (H + 7) / 8; k.ncx = (W + 31) / 32;
+  k.db = db;
+  k.fx = df_det_fx();
+  // z segments: about two workgroups per CU in all, at least 8 planes each (a segment's prologue stages three dY planes)
+  const long long cols = (long long)N * k.ncy * k.ncx;
+  long long ns = (2LL * df_cu_count() + cols - 1) / cols;
+  if (ns > D / 8) ns = D / 8;
+  if (ns < 1) ns = 1;
+  k.zlen = (int)((D + ns - 1) / ns);
+  k.nseg = (D + k.zlen - 1) / k.zlen;
+  const long long items = cols * k.nseg;
+  if (items >= (1LL << 31)) return 1;
+  if (Cout <= 3) conv3d_flow_wgrad_k<3><<<(unsigned)items, 256, 0, st>>>(x, x_amax, dy, dy_amax, dwt, k);
+  else conv3d_flow_wgrad_k<4><<<(unsigned)items, 256, 0, st>>>(x, x_amax, dy, dy_amax, dwt, k);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dfmir_conv3d_s2c2_ok(const DfConvGeom* g) {
   if (!g || tiny_off()) return 0;

@@ -293,6 +293,11 @@ CONV3D = [
     # the flow head on the fp32-FMA kernel (conv3dt.hip; W % 4 == 0): ragged tiles in every axis with batch 2, several x tiles
     (16, 3, 3, 1, 1, 2, 5, 9, 36),
     (16, 3, 3, 1, 1, 1, 9, 17, 68),
+    # the flow head's weight gradient on conv3d_flow_wgrad_k ((co, dx) pairs as MFMA columns, z-marching): several z segments,
+    # four output channels (the 12-column instance), one 8 x 32 column
+    (16, 3, 3, 1, 1, 1, 40, 24, 64),
+    (16, 4, 3, 1, 1, 1, 24, 16, 32),
+    (16, 2, 3, 1, 1, 2, 16, 8, 32),
     # the first encoder level (2 -> 16, stride 2) from an LDS-staged patch, weight gradient on fp32 MFMA (conv3dt.hip): one
     # tile, ragged tiles in every axis with batch 2, odd input sizes
     (2, 16, 3, 2, 1, 1, 12, 10, 16),
