@@ -85,6 +85,8 @@ _SIGS = {
     "dfmir_tapsum_fwd": [P, P, P] + [c_int] * 10 + [c_float, P],
     "dfmir_tapsum_bwd": [P, P] + [c_int] * 9 + [P],
     "dfmir_instnorm_fwd": [P, P, P, P, P, c_int, c_longlong, c_float, c_int, P, P],
+    "dfmir_instnorm_stats_ok": [c_longlong],
+    "dfmir_instnorm_stats": [P, P, P, c_int, c_longlong, c_float, c_int, P, P],
     "dfmir_instnorm_bwd": [P, P, P, P, P, c_int, c_longlong, c_int, P, P],
     "dfmir_instnorm_bwd_cols_ok": [c_longlong, c_int],
     "dfmir_instnorm_bwd_cols": [P, P, P, P, P, c_int, c_longlong, c_int, P, P, c_int, P],

@@ -1726,6 +1726,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     rda = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_, 0, 0);                                 \
     rdb = __builtin_amdgcn_raw_buffer_load_b128(bd_, db_ == OOB ? OOB : db_ + 16u, 0, 0);        \
   }
+  // W2_NORM_PROBE (lab builds): the cost of an InstanceNorm + ReLU applied while the X operand is converted -- (x - m) * r and a
+  // max per value with run-time operands that happen to be the identity (profiles/r06_cs_norm_probe.txt)
+#ifdef W2_NORM_PROBE
+  const float np_r = fmaf(oscale, 0.f, 1.f), np_m = oscale * 0.f, np_lo = fmaf(oscale, 0.f, -3.0e38f);
+#define W2_NORM_PROBE_OPS() _Pragma("unroll") for (int i = 0; i < 10; ++i) r[i] = fmaxf((r[i] - np_m) * np_r, np_lo);
+#else
+#define W2_NORM_PROBE_OPS()
+#endif
   // X: r[0] = left neighbour, r[1..8] = the group, r[9] = right neighbour; pairs (0,1)..(8,9) make the units
   // dx=0 (cols -1..6) and dx=2 (cols 1..8), the odd pairing dx=1 is the even one shifted by a half
 #define W2_LSTORE(buf_)                                                                          \
@@ -1733,6 +1741,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_split2_k(const float* __
     float r[10];                                                                                 \
     r[0] = __uint_as_float(rxl); r[9] = __uint_as_float(rxr);                                    \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) { r[1 + e] = __uint_as_float(rxa[e]); r[5 + e] = __uint_as_float(rxb[e]); } \
+    W2_NORM_PROBE_OPS()                                                                          \
     baccx += xin ? ((r[1] + r[2]) + (r[3] + r[4])) + ((r[5] + r[6]) + (r[7] + r[8])) : 0.f;      \
     unsigned pa[5][NSP], pb[4][NSP];                                                             \
     if (W2_KO & 4) { _Pragma("unroll") for (int i = 0; i < 5; ++i) { pa[i][0] = __float_as_uint(r[2 * i]); pa[i][1] = __float_as_uint(r[2 * i + 1]); } } \

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_reg_k(const float* __restrict
       const float4 r = r4[threadIdx.x + NT * i];
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    y4[threadIdx.x + NT * i] = o;
+    if (y) y4[threadIdx.x + NT * i] = o;                    // y == NULL: statistics + range probe only (dfmir_instnorm_stats)
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
   if (amax) publish_block_absmax_acc(am, &smax, amax);   // range probe for the next conv's fp16x2 split
@@ -928,6 +928,19 @@ int df_absmax_launch(const float* x, long long n, float* out, hipStream_t st, bo
 // to max |output| -- the range
 // probe the fp16x2 conv kernels need for their next input, produced while the output is still in registers (one
 // conditional atomic per workgroup, common.h publish_block_absmax_acc).
+// Statistics only: mean / rstd of every plane and the range probe of relu?(IN(x)), nothing written back -- the consumer
+// normalises while it stages its operand (dfmir_conv3x3_fwd_norm).  Plane sizes of the register-resident kernels only.
+extern "C" int dfmir_instnorm_stats_ok(long long S) { return (S == 4096 || S == 16384 || S == 65536) ? 1 : 0; }
+extern "C" int dfmir_instnorm_stats(const float* x, float* mean, float* rstd, int planes, long long S, float eps, int relu,
+                                    float* y_amax, void* stream) {
+  DF_ARG_CHECK(x && mean && rstd && planes > 0 && dfmir_instnorm_stats_ok(S));
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 4096) instnorm_fwd_reg_k<256, 4><<<planes, 256, 0, st>>>(x, nullptr, nullptr, mean, rstd, eps, relu, y_amax);
+  else if (S == 16384) instnorm_fwd_reg_k<256, 16><<<planes, 256, 0, st>>>(x, nullptr, nullptr, mean, rstd, eps, relu, y_amax);
+  else instnorm_fwd_reg_k<1024, 16><<<planes, 1024, 0, st>>>(x, nullptr, nullptr, mean, rstd, eps, relu, y_amax);
+  DF_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
                                   int planes, long long S, float eps, int relu, float* y_amax, void* stream) {
   DF_ARG_CHECK(x && y && mean && rstd && planes > 0 && S > 0);

@@ -335,6 +335,11 @@ int dfmir_tapsum_bwd(const float* dy, float* dz, int N, int C, int Hz, int Wz, i
  * 984-985, 1190-1221 (x + conv_block(x)).  One (n,c) plane of S elements per workgroup.
  * y = res + relu?((x-mean)*rstd) ; mean/rstd [planes] are saved for backward.
  * ---------------------------------------------------------------------------------------- */
+/* Statistics of InstanceNorm only (round 6): mean / rstd per plane and the range probe of relu?(IN(x)); y is NOT written --
+ * a consumer that normalises while it stages its operand follows.  S in {4096, 16384, 65536} (dfmir_instnorm_stats_ok). */
+int dfmir_instnorm_stats_ok(long long S);
+int dfmir_instnorm_stats(const float* x, float* mean, float* rstd, int planes, long long S, float eps, int relu,
+                         float* y_amax, void* stream);
 int dfmir_instnorm_fwd(const float* x, const float* res, float* y, float* mean, float* rstd,
                        int planes, long long S, float eps, int relu, float* y_amax, void* stream);
 int dfmir_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
