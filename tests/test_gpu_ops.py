@@ -674,6 +674,25 @@ def test_instnorm(ops, shape, relu, res):
         close(rg.grad, rr.grad, what="dres")
 
 
+@pytest.mark.parametrize("hw", [64, 128, 256])
+def test_instnorm_statistics_only_pass(ops, hw):
+    """dfmir_instnorm_stats (the statistics + range probe of InstanceNorm without the normalised tensor; the measurement
+    behind profiles/r06_in_fusion_probes.txt): mean / rstd bit-identical to dfmir_instnorm_fwd's, the probe covers
+    max relu(IN(x)), nothing else is written."""
+    from dfmir_amd.ops import _p, _st, check, lib
+    x = (C.randn(8, 2, 3, hw, hw) * 1.7 - 0.4).to(DEV)
+    planes, S = 6, hw * hw
+    assert lib().dfmir_instnorm_stats_ok(S) == 1 and lib().dfmir_instnorm_stats_ok(100) == 0
+    y = torch.empty_like(x)
+    m0, r0, m1, r1 = (torch.empty(planes, device=DEV) for _ in range(4))
+    p0, p1 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    check(lib().dfmir_instnorm_fwd(_p(x), None, _p(y), _p(m0), _p(r0), planes, S, 1e-5, 1, _p(p0), _st()))
+    check(lib().dfmir_instnorm_stats(_p(x), _p(m1), _p(r1), planes, S, 1e-5, 1, _p(p1), _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(m0, m1) and torch.equal(r0, r1) and torch.equal(p0, p1)
+    assert float(p1.max()) == float(y.max()) > 0
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 2, 64, 64), (1, 1, 8, 8), (1, 2, 4, 8), (1, 2, 6, 12)])
 def test_blur_vectorised_vs_oracle(ops, shape):
     """Shapes that take the 4-outputs-per-thread resampling kernels (norm_resample.hip *_v4_k), against the
