@@ -56,4 +56,12 @@ for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_UPWGRAD_DIRECT=1; else u
 for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_CONV3D_NO_WGRAD_MARCH=1; else unset DFMIR_CONV3D_NO_WGRAD_MARCH; fi; echo "DFMIR_CONV3D_NO_WGRAD_MARCH=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-72; ONLY=32-16 python scripts/bench_conv3d.py 2>/dev/null | tail -1; done > $O/ab_wgrad_march_3d.txt 2>&1; unset DFMIR_CONV3D_NO_WGRAD_MARCH
 for v in 0 2; do DFMIR_CS_XCD_PAIR=$v python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('DFMIR_CS_XCD_PAIR=$v', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step issued_frac', round(r['roofline']['issued_frac'],4))"; done > $O/ab_xcd_order.txt 2>&1
 rm -rf $R/gpurun_out/conv_prof $R/gpurun_out/warp_prof $R/gpurun_out/conv3d_prof $R/gpurun_out/kt3d $R/gpurun_out/upconv_prof
-TAG=${TAG:-r05}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json
+TAG=${TAG:-r06}; python scripts/pmc_json.py $TAG > $O/pmc_json.log 2>&1; cp profiles/${TAG}_pmc.json $O/pmc.json
+# ---- round 6: the A/Bs of this round's switches, the parity margins, the staged-step probe
+for sw in NONE DFMIR_NO_STAGED NONE DFMIR_NO_STAGED; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step  host enqueue', round(r['host_enqueue_ms_per_step'],2), 'ms  loader-fed', round(r['value_pil_loader'] or 0, 1), r['step_submission'])"; done > $O/ab_staged.txt 2>&1
+for sw in NONE DFMIR_NO_1X1_WGRAD NONE DFMIR_NO_1X1_WGRAD; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; done > $O/ab_1x1_wgrad.txt 2>&1
+for sw in NONE DFMIR_DETERMINISTIC_WGRAD; do env $sw=1 python bench.py --steps 20 --warmup 5 --no-3d --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', round(r['value'],1), 'pairs/s', round(r['ms_per_step'],2), 'ms/step')"; echo $sw; env $sw=1 python scripts/bench_3d.py 2>/dev/null | cut -c1-100; done > $O/ab_deterministic.txt 2>&1
+for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_CONV3D_NO_FLOW_WGRAD=1; else unset DFMIR_CONV3D_NO_FLOW_WGRAD; fi; echo "DFMIR_CONV3D_NO_FLOW_WGRAD=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-100; ONLY=16-3 python scripts/bench_conv3d.py 2>/dev/null | tail -n 1; done > $O/ab_flow_wgrad.txt 2>&1; unset DFMIR_CONV3D_NO_FLOW_WGRAD
+python scripts/graph_split_probe.py 2>&1 | grep -v amdgpu.ids > $O/graph_split_probe.txt
+DFMIR_MARGINS_OUT=$O/parity_margins.txt timeout 1500 python -m pytest tests -m gpu -q -s > $O/pytest_margins.txt 2>&1; tail -n 3 $O/pytest_margins.txt
+

@@ -50,7 +50,7 @@ def entry(name, dur, c, alg_bytes, shape):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     from_prof = "--from-profiles" in sys.argv
     P = R + "/profiles/"
     C = R + "/gpurun_out/collect/"

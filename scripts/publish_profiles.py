@@ -2,7 +2,7 @@
 PMC summaries (<TAG>_conv3x3s_pmc.md, <TAG>_conv3d_pmc.md, <TAG>_conv3dup_pmc.md) from the raw counter output.
 usage: python scripts/publish_profiles.py [r04]"""
 import ast, os, re, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C, P = R + '/gpurun_out/collect/', R + '/profiles/'
 cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b16_eager.json', 'bench_kernel_stats.csv': TAG + '_bench_b16_kernel_stats.csv',
@@ -14,7 +14,9 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'step_trace_3d_128.txt': TAG + '_step_trace_3d_128.txt', 'bench_upconv3d.txt': TAG + '_bench_upconv3d.txt',
       'ab_xcd_order.txt': TAG + '_ab_xcd_order.txt', 'overlap_trace.txt': TAG + '_overlap_trace.txt', 'bench_in_blurdown.txt': TAG + '_bench_in_blurdown.txt',
       'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json', 'bench_march.txt': TAG + '_bench_march.txt', 'ab_march_3d.txt': TAG + '_ab_march_3d.txt', 'march_trace.txt': TAG + '_march_trace.txt', 'bench_upwgrad.txt': TAG + '_bench_upwgrad.txt', 'upwgrad_ko.txt': TAG + '_upwgrad_ko.txt',
-      'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt', 'ab_wgrad_march_3d.txt': TAG + '_ab_wgrad_march_3d.txt'}
+      'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt', 'ab_wgrad_march_3d.txt': TAG + '_ab_wgrad_march_3d.txt',
+      'ab_staged.txt': TAG + '_ab_staged.txt', 'ab_1x1_wgrad.txt': TAG + '_ab_1x1_wgrad.txt', 'ab_deterministic.txt': TAG + '_ab_deterministic.txt',
+      'ab_flow_wgrad.txt': TAG + '_ab_flow_wgrad.txt', 'graph_split_probe.txt': TAG + '_graph_split_probe.txt', 'parity_margins.txt': TAG + '_parity_margins.txt'}
 def clean(txt):
     txt = txt.replace("(anonymous namespace)::", "")
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
