@@ -511,13 +511,20 @@ __global__ __launch_bounds__(256) void ncc_cc_reduce_k(const float* __restrict__
 // mode 0: -sqrt(S / n) (NCC_Loss.forward, util/losses.py:248-261; 0 when the mask is empty), mode 1: -S / n
 // (torchvoxelmorph/losses.py:67); n = sum(mask) with a mask, else the element count
 __device__ __forceinline__ float ncc_norm(const float* ws, float n, int masked) { return masked ? ws[1] : n; }
-__global__ void ncc_fin_k(float* ws, float* out, float n, int mode, int masked, const float* part, int nparts) {
+__global__ __launch_bounds__(256) void ncc_fin_k(float* ws, float* out, float n, int mode, int masked, const float* part,
+                                                 int nparts) {
+  // the partials in a FIXED order: thread t adds part[t], part[t + 256], ... and the block tree is the same every run
+  // (one thread walking 2 x 1024 partials took 44 us)
+  __shared__ float sm[17];
   if (part) {
     float a = 0.f, m = 0.f;
-    for (int i = 0; i < nparts; ++i) { a += part[i]; m += part[nparts + i]; }
-    ws[0] = a;
-    ws[1] = m;
+    for (int i = threadIdx.x; i < nparts; i += 256) { a += part[i]; m += part[nparts + i]; }
+    a = block_sum(a, sm);
+    m = block_sum(m, sm);
+    if (threadIdx.x == 0) { ws[0] = a; ws[1] = m; }
+    __syncthreads();
   }
+  if (threadIdx.x) return;
   const float ne = ncc_norm(ws, n, masked);
   if (!(ne > 0.f)) { out[0] = 0.f; return; }
   out[0] = mode == 0 ? -sqrtf(ws[0] / ne) : -(ws[0] / ne);
@@ -805,7 +812,7 @@ extern "C" int dfmir_ncc_fwd_m(const float* I, const float* J, const float* mask
   float* part = (5 * N >= 2LL * ng) ? tmp2 : nullptr;
   ncc_cc_reduce_k<<<ng, 256, 0, st>>>(tmp, mask, ws, N, wn, eps, part);
   DF_LAUNCH_CHECK();
-  ncc_fin_k<<<1, 1, 0, st>>>(ws, out, (float)N, mode, mask != nullptr, part, (int)ng);
+  ncc_fin_k<<<1, 256, 0, st>>>(ws, out, (float)N, mode, mask != nullptr, part, (int)ng);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,7 @@ def pytest_sessionfinish(session, exitstatus):
         return
     worst = {}
     for test, what, err, bound in mod.MARGINS:
+        bound = max(bound, 1e-300)                       # (bit-exact comparisons: rtol = atol = 0)
         k = (test.split("[")[0], what)
         if k not in worst or err / bound > worst[k][0] / worst[k][1]:
             worst[k] = (err, bound, test)
