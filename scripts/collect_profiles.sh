@@ -64,4 +64,8 @@ for sw in NONE DFMIR_DETERMINISTIC_WGRAD; do env $sw=1 python bench.py --steps 2
 for sw in 0 1 0 1; do if [ $sw = 1 ]; then export DFMIR_CONV3D_NO_FLOW_WGRAD=1; else unset DFMIR_CONV3D_NO_FLOW_WGRAD; fi; echo "DFMIR_CONV3D_NO_FLOW_WGRAD=$sw"; python scripts/bench_3d.py 2>/dev/null | cut -c1-100; ONLY=16-3 python scripts/bench_conv3d.py 2>/dev/null | tail -n 1; done > $O/ab_flow_wgrad.txt 2>&1; unset DFMIR_CONV3D_NO_FLOW_WGRAD
 python scripts/graph_split_probe.py 2>&1 | grep -v amdgpu.ids > $O/graph_split_probe.txt
 DFMIR_MARGINS_OUT=$O/parity_margins.txt timeout 1500 python -m pytest tests -m gpu -q -s > $O/pytest_margins.txt 2>&1; tail -n 3 $O/pytest_margins.txt
+python scripts/bench_conv1x1.py 2>&1 | grep -v amdgpu.ids > $O/bench_conv1x1.txt; DFMIR_NO_1X1_WGRAD=1 python scripts/bench_conv1x1.py 2>&1 | grep -v amdgpu.ids | sed 's/^/generic kernel: /' >> $O/bench_conv1x1.txt
+bash scripts/prof_cmd.sh "python $R/scripts/bench_conv1x1.py" conv1x1_wgrad_k conv1x1 > $O/pmc_conv1x1.txt 2>&1
+ONLY=16-3 bash scripts/prof_cmd.sh "python $R/scripts/bench_conv3d.py" conv3d_flow_wgrad_k flow > $O/pmc_flow_wgrad.txt 2>&1
+rm -rf $R/gpurun_out/prof_conv1x1 $R/gpurun_out/prof_flow
 

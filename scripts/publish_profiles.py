@@ -16,7 +16,8 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'conv2d_layer_census.txt': TAG + '_conv2d_layer_census.txt', 'conv3d_step_census.txt': TAG + '_conv3d_step_census.txt', 'ab_round3_switches.txt': TAG + '_ab_round3_switches.txt', 'ab_switches.txt': TAG + '_ab_switches.txt', 'pmc_upconv3d.txt': TAG + '_conv3dup_pmc_raw.txt', 'pmc.json': TAG + '_pmc.json', 'bench_march.txt': TAG + '_bench_march.txt', 'ab_march_3d.txt': TAG + '_ab_march_3d.txt', 'march_trace.txt': TAG + '_march_trace.txt', 'bench_upwgrad.txt': TAG + '_bench_upwgrad.txt', 'upwgrad_ko.txt': TAG + '_upwgrad_ko.txt',
       'ab_upwgrad_3d.txt': TAG + '_ab_upwgrad_3d.txt', 'ab_wgrad_march_3d.txt': TAG + '_ab_wgrad_march_3d.txt',
       'ab_staged.txt': TAG + '_ab_staged.txt', 'ab_1x1_wgrad.txt': TAG + '_ab_1x1_wgrad.txt', 'ab_deterministic.txt': TAG + '_ab_deterministic.txt',
-      'ab_flow_wgrad.txt': TAG + '_ab_flow_wgrad.txt', 'graph_split_probe.txt': TAG + '_graph_split_probe.txt', 'parity_margins.txt': TAG + '_parity_margins.txt'}
+      'ab_flow_wgrad.txt': TAG + '_ab_flow_wgrad.txt', 'graph_split_probe.txt': TAG + '_graph_split_probe.txt', 'parity_margins.txt': TAG + '_parity_margins.txt', 'bench_conv1x1.txt': TAG + '_bench_conv1x1.txt',
+      'pmc_conv1x1.txt': TAG + '_conv1x1_pmc_raw.txt', 'pmc_flow_wgrad.txt': TAG + '_flow_wgrad_pmc_raw.txt'}
 def clean(txt):
     txt = txt.replace("(anonymous namespace)::", "")
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
