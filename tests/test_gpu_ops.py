@@ -333,6 +333,55 @@ def test_conv3d(ops, cfg):
     close(bg.grad, br.grad.float(), rtol=3e-4, what="db")
 
 
+def test_round6_weight_gradient_kernels_on_seeded_random_geometries(ops):
+    """conv1x1_wgrad_k (1x1 weight gradients as a streaming NT GEMM) and conv3d_flow_wgrad_k (the flow head's weight + bias
+    gradient, (co, dx) pairs as MFMA columns) on a dozen seeded random geometries each -- ragged channel tiles, chunks and
+    columns that end inside the volume, batches, z segments -- against an fp64 contraction; the A/B kernels they replace
+    (DFMIR_NO_1X1_WGRAD / DFMIR_CONV3D_NO_FLOW_WGRAD) must agree with them to fp32 round-off of the same sums."""
+    import random
+    from dfmir_amd._lib import set_option
+    rnd = random.Random(606)
+    for case in range(12):
+        n, cin, cout = rnd.choice([1, 2, 3]), rnd.choice([8, 17, 49, 64, 72, 130]), rnd.choice([8, 33, 49, 64, 100])
+        h, w = rnd.choice([4, 9, 16, 31]), 4 * rnd.choice([4, 5, 16, 33])
+        x = C.randn(700 + case, n, cin, 1, h, w).to(DEV)
+        dy = (C.randn(720 + case, n, cout, 1, h, w) * 1e-2).to(DEV)
+        ref = torch.einsum("ncp,ndp->cd", x.flatten(2).double(), dy.flatten(2).double())
+        got = ops.conv_wgrad_raw(x, dy, (1, 1, 1), 1, (0, 0, 0), 0).reshape(cin, cout)
+        close(got, ref.float(), rtol=2e-5, what="1x1 dW, case %d (%d x %d -> %d @%dx%d)" % (case, n, cin, cout, h, w))
+        set_option("DFMIR_NO_1X1_WGRAD", "1")
+        try:
+            old = ops.conv_wgrad_raw(x, dy, (1, 1, 1), 1, (0, 0, 0), 0).reshape(cin, cout)
+        finally:
+            set_option("DFMIR_NO_1X1_WGRAD", None)
+        close(got, old, rtol=2e-5, what="1x1 dW vs the generic kernel, case %d" % case)
+    for case in range(12):
+        n, cout = rnd.choice([1, 2]), rnd.choice([1, 2, 3, 4])
+        d, h, w = rnd.choice([2, 5, 9, 24, 41]), rnd.choice([3, 8, 13, 20]), 4 * rnd.choice([2, 8, 9, 17])
+        if d * h * w < 1024:
+            d = 1024 // (h * w) + 2
+        x = C.randn(740 + case, n, 16, d, h, w).to(DEV)
+        dy = (C.randn(760 + case, n, cout, d, h, w) * 1e-2).to(DEV)
+        xr = x.double().cpu()
+        wr = torch.zeros(cout, 16, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        (F.conv3d(xr, wr, br, padding=1) * dy.double().cpu()).sum().backward()
+        xa, da = ops.absmax(x), ops.absmax(dy)
+        res = []
+        for off in (None, "1"):
+            set_option("DFMIR_CONV3D_NO_FLOW_WGRAD", off)
+            try:
+                db = ops.zeros(cout, DEV)
+                dwt = ops.conv_wgrad_raw(x, dy, (3, 3, 3), 1, (1, 1, 1), 0, x_amax=xa, dy_amax=da, db=db)
+                res.append((ops.weight_unpack(dwt, (cout, 16, 3, 3, 3)), db))
+            finally:
+                set_option("DFMIR_CONV3D_NO_FLOW_WGRAD", None)
+        tag = "case %d (%d x 16 -> %d @%dx%dx%d)" % (case, n, cout, d, h, w)
+        close(res[0][0], wr.grad.float(), rtol=3e-5, what="flow dW, " + tag)
+        close(res[0][1], br.grad.float(), rtol=3e-5, what="flow db, " + tag)
+        close(res[0][0], res[1][0], rtol=3e-5, what="flow dW vs the tiled kernel, " + tag)
+
+
 @pytest.mark.parametrize("cfg", [(32, 16, 1, 11, 24, 64), (16, 16, 2, 7, 16, 32), (16, 32, 1, 10, 33, 48)],
                          ids=["32to16", "16to16-batch2", "16to32"])
 @pytest.mark.parametrize("nseg", [1, 3])
