@@ -505,6 +505,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_k(const float* __restrict
 // v_mfma_f32_32x32x2_f32), K = the voxels of its share of 64-voxel chunks, staged channel-major into LDS (row stride 65:
 // a wave's 32 channel rows of one voxel sit in 32 banks) one chunk ahead through registers; split-K over blockIdx.x, the
 // partial tiles meet in df_acc (fp32 atomics, or 64-bit fixed point in deterministic mode).
+// (The FORWARD / data-gradient counterpart was built too -- persistent workgroups, weights resident, 128-voxel tiles -- and
+// measured 1.5x SLOWER than conv_mfma_k on the same GEMMs (0.47 vs 0.30 ms at n = 32, 24 % matrix-pipe busy, 2 TB/s:
+// profiles/r06_ab_1x1_fwd.txt); it is not in the tree.)
 //   users: the head's tap GEMM (models/networks.py:1022-1023 as tap-sum, csrc/taps.hip) and the stem's input gradient,
 //   PatchSampleF's two Linear layers (models/networks.py:587-595).   Requires S % 4 == 0 and 16-byte aligned operands.
 // ---------------------------------------------------------------------------------------------

@@ -76,10 +76,13 @@ CONV2D = [
     (48, 32, 3, 1, 1, False, 1, 1, 11, 7),
     (33, 3, 1, 1, 0, False, 0, 1, 6, 50),
     (256, 256, 1, 1, 0, False, 1, 1, 1, 512),
-    # 1x1 weight gradients on the streaming NT-GEMM kernel (conv1x1_wgrad_k): ragged channel tiles, a last chunk of 32 of 64
-    # voxels, three images (split-K across image boundaries), exactly one chunk
+    # 1x1 convolutions (weight gradients on the streaming NT-GEMM kernel conv1x1_wgrad_k): ragged channel tiles, a last chunk of
+    # 32 of 64 voxels, three images (split-K across image boundaries), exactly two chunks, tanh epilogue
     (72, 49, 1, 1, 0, False, 0, 3, 20, 24),
-    (8, 136, 1, 1, 0, False, 1, 1, 4, 16),
+    (8, 136, 1, 1, 0, False, 1, 1, 8, 16),
+    (40, 72, 1, 1, 0, False, 2, 2, 12, 20),
+    (40, 49, 1, 1, 0, False, 2, 3, 20, 24),
+    (64, 64, 1, 1, 0, False, 1, 2, 16, 32),
     # geometries that take the LDS-resident 3x3 kernels (conv3x3.hip): aligned / unaligned pixel runs,
     # padded-frame dgrad of reflect convs, W >= tile, partial channel chunks, both wgrad tilings
     (64, 128, 3, 1, 1, False, 0, 2, 32, 32),
@@ -355,6 +358,19 @@ def test_round6_weight_gradient_kernels_on_seeded_random_geometries(ops):
         finally:
             set_option("DFMIR_NO_1X1_WGRAD", None)
         close(got, old, rtol=2e-5, what="1x1 dW vs the generic kernel, case %d" % case)
+        # the same geometry forward with bias + LeakyReLU, and its data gradient
+        wt = (C.randn(780 + case, cout, cin, 1, 1) / cin ** 0.5)
+        bt = C.randn(790 + case, cout) * 0.1
+        x4 = x[:, :, 0].cpu()
+        xr = x4.double().requires_grad_()
+        yr = F.leaky_relu(F.conv2d(xr, wt.double(), bt.double()), 0.2)
+        cot = C.randn(795 + case, *yr.shape)
+        (yr * cot.double()).sum().backward()
+        xg = x4.clone().to(DEV).requires_grad_()
+        yg = ops.conv(xg, wt.to(DEV), bt.to(DEV), None, 1, 0, 0, 1, 0.2)
+        (yg * cot.to(DEV)).sum().backward()
+        close(yg, yr.float(), rtol=2e-5, what="1x1 y, case %d" % case)
+        close(xg.grad, xr.grad.float(), rtol=2e-5, what="1x1 dx, case %d" % case)
     for case in range(12):
         n, cout = rnd.choice([1, 2]), rnd.choice([1, 2, 3, 4])
         d, h, w = rnd.choice([2, 5, 9, 24, 41]), rnd.choice([3, 8, 13, 20]), 4 * rnd.choice([2, 8, 9, 17])
