@@ -1063,7 +1063,9 @@ def test_edge_branches_golden(ops, golden):
             tot = tot + ops.mean(l)
         tot.backward(retain_graph=True)
         for i, f in enumerate(fq):
-            close(f.grad, g["sample_%s_dfeat%d" % (name, i)], rtol=1e-3, what="%s-negatives dfeat%d" % (name, i))
+            # (layer 0 has ONE channel: x / (|x| + 1e-7) is +-1 and its true gradient 0 -- 4e-5 of round-off on both sides)
+            close(f.grad, g["sample_%s_dfeat%d" % (name, i)], rtol=1e-3, atol=1e-5 if i == 0 else 1e-6,
+                  what="%s-negatives dfeat%d" % (name, i))
 
 
 def test_ncc_fused_box_passes_match_the_separate_ones(ops):
