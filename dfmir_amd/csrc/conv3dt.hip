@@ -461,12 +461,13 @@ constexpr int FW_XSLOT = 2 * 16 * FW_XCS;        // [split][ci]
 constexpr int FW_DCS = 41;                       // units per (co, dx) column of a dY plane slot: 10 rows x 4 + 1
 // CO = the most output channels the instance holds: 3 (the flow head; 69 KB of LDS: two workgroups per CU) or 4
 template <int CO>
-__global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(const float* __restrict__ x, const float* __restrict__ x_amax,
+__global__ __launch_bounds__(256, CO <= 3 ? 3 : 2) void conv3d_flow_wgrad_k(const float* __restrict__ x, const float* __restrict__ x_amax,
                                                               const float* __restrict__ dy, const float* __restrict__ dy_amax,
                                                               float* __restrict__ dwt, FwP k) {
   constexpr int FW_NCOL = 3 * CO;                  // (co, dx) columns held
   constexpr int FW_DSLOT = 2 * FW_NCOL * FW_DCS;   // [split][col]
-  __shared__ __attribute__((aligned(16))) u32x4_t Xa[2 * FW_XSLOT];      // 33.8 KB
+  // ONE x slot: plane z + 1 is written after the barrier that ends the reads of plane z (16.9 KB + 35.4 KB: three workgroups per CU)
+  __shared__ __attribute__((aligned(16))) u32x4_t Xa[FW_XSLOT];
   __shared__ __attribute__((aligned(16))) u32x4_t Dsh[3 * FW_DSLOT];     // 35.4 KB for CO = 3 (also the epilogue's reduction buffer)
   __shared__ float red[17];
   __shared__ float bsum[160];
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(cons
       const float v_[8] = {rx[j][0].x, rx[j][0].y, rx[j][0].z, rx[j][0].w, rx[j][1].x, rx[j][1].y, rx[j][1].z, rx[j][1].w}; \
       u32x4_t h_, r_;                                                                                      \
       split8_t(v_, xscale, h_, r_);                                                                        \
-      Xa[(buf_) * FW_XSLOT + ci_ * FW_XCS + row_ * 4 + g_] = h_;                                           \
-      Xa[(buf_) * FW_XSLOT + (16 + ci_) * FW_XCS + row_ * 4 + g_] = r_;                                    \
+      Xa[ci_ * FW_XCS + row_ * 4 + g_] = h_;                                                               \
+      Xa[(16 + ci_) * FW_XCS + row_ * 4 + g_] = r_;                                                        \
     }                                                                                                      \
   }
 #define FW_GLOAD_D(z_)                                                                                     \
@@ -559,7 +560,6 @@ __global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(cons
   FW_GLOAD_X(zs) FW_LSTORE_X(0)
   const int bcol = l15 < ncol ? l15 : 0;                    // padding columns read column 0 (their results are dropped)
   for (int z = zs; z < ze; ++z) {
-    const int buf = (z - zs) & 1;
     __syncthreads();                                        // x plane z and dY plane z + 1 are in place
     const bool more = z + 1 < ze;
     if (more) FW_GLOAD_X(z + 1)
@@ -567,8 +567,8 @@ __global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(cons
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wid + rr;
-      const u32x4_t ah = Xa[buf * FW_XSLOT + l15 * FW_XCS + row * 4 + kg];
-      const u32x4_t ar = Xa[buf * FW_XSLOT + (16 + l15) * FW_XCS + row * 4 + kg];
+      const u32x4_t ah = Xa[l15 * FW_XCS + row * 4 + kg];
+      const u32x4_t ar = Xa[(16 + l15) * FW_XCS + row * 4 + kg];
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz) {
         const int slot = (z - dz + 1 + 3) % 3;
@@ -584,8 +584,8 @@ __global__ __launch_bounds__(256, CO <= 3 ? 2 : 1) void conv3d_flow_wgrad_k(cons
         }
       }
     }
-    __syncthreads();                                        // the readers of x buffer buf ^ 1 (step z - 1) and of dY plane z - 1 are done
-    if (more) FW_LSTORE_X(buf ^ 1)
+    __syncthreads();                                        // the readers of x plane z and of dY plane z - 1 are done
+    if (more) FW_LSTORE_X(0)
     FW_LSTORE_D((z + 2) % 3, z + 2 < ze)
   }
 #undef FW_GLOAD_X
@@ -633,6 +633,7 @@ int df_conv3d_flow_wgrad_ok(const DfConvGeom* g, const float* x, const float* dy
          ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 &&
          (long long)g->Di * g->Hi * g->Wi >= 1024;
 }
+static inline int CoutMaxWgs(int Cout) { return Cout <= 3 ? 3 : 2; }     // workgroups per CU (LDS)
 int df_conv3d_flow_wgrad_launch(const float* x, const float* x_amax, int x_n, const float* dy, const float* dy_amax, int dy_n,
                                 float* dwt, float* db, int N, int D, int H, int W, int Cout, hipStream_t st) {
   FwP k{};
@@ -641,9 +642,9 @@ int df_conv3d_flow_wgrad_launch(const float* x, const float* x_amax, int x_n, co
   k.ncy = (H + 7) / 8; k.ncx = (W + 31) / 32;
   k.db = db;
   k.fx = df_det_fx();
-  // z segments: about two workgroups per CU in all, at least 8 planes each (a segment's prologue stages three dY planes)
+  // z segments: one round of resident workgroups in all, at least 8 planes each (a segment's prologue stages three dY planes)
   const long long cols = (long long)N * k.ncy * k.ncx;
-  long long ns = (2LL * df_cu_count() + cols - 1) / cols;
+  long long ns = ((CoutMaxWgs(Cout)) * (long long)df_cu_count() + cols - 1) / cols;
   if (ns > D / 8) ns = D / 8;
   if (ns < 1) ns = 1;
   k.zlen = (int)((D + ns - 1) / ns);
