@@ -25,6 +25,15 @@
 // v_mfma_f32_32x32x16_f16, rows = the 32 voxels of a tile row, K = 16 = one tap.  A wave owns two tile rows x three
 // planes; the voxel operands of a tap column are read once per patch row and serve the (dy, dz) products that use them
 // (0.26-0.48 LDS operand reads per MFMA).  MFMA rows = voxels, so a lane ends with 4 consecutive voxels of one channel.
+//
+// The flow head (16 -> 3, torchvoxelmorph/networks.py:1076-1080) in the same march -- "FLOW" form, Cout = 3.  Three
+// output channels fill 3 of 16 MFMA columns, and the three open output planes of the march are three separate
+// accumulator sets above: here the COLUMNS are (open plane, channel) = 3 x 4 (one zero column per plane), so ONE
+// accumulator set serves the three planes and a plane step issues 60 MFMAs per wave instead of 180.  Column group g
+// holds the output plane whose index is = g modulo 3 for as long as it is open; the weight operand of a step is the
+// tap matrix with its dz blocks rotated to match (three pre-rotated copies in LDS, one per phase of the march), and when
+// input plane P has been consumed the lanes of group (P - 1) mod 3 store their plane and clear their columns.  The
+// fp32-FMA kernel this replaces (csrc/conv3dt.hip) ran at the vector rate: 0.32 ms at 160 x 192 x 224 for 0.52 GB.
 #include "conv3x3_common.h"
 #include <type_traits>
 
@@ -110,8 +119,10 @@ struct MarchP {
 
 template <int CIN, int COUT>
 struct MarchCfg {
-  static_assert((CIN == 32 && COUT == 16) || (CIN == 16 && (COUT == 16 || COUT == 32)), "layer shapes of the march kernel");
+  static_assert((CIN == 32 && COUT == 16) || (CIN == 16 && (COUT == 16 || COUT == 32 || COUT == 3)), "layer shapes of the march kernel");
   static constexpr bool B32 = COUT == 32;                       // 32x32x16 MFMAs (one tap per k-step)
+  static constexpr bool FLOW = COUT == 3;                       // columns = (open plane, channel): one accumulator set
+  static constexpr int NDZ = FLOW ? 1 : 3;                      // weight blocks walked per k-step and plane step
   static constexpr int NO = CIN / 8;                            // channel octets
   static constexpr int NSTEP = (CIN == 32 || B32) ? 9 : 5;      // k-steps per dz
   static constexpr int NH = B32 ? 1 : 2;                        // voxel operands per tile row (32 / 16 voxels each)
@@ -147,7 +158,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
                                                          const float* __restrict__ w_tcc, const float* __restrict__ bias,
                                                          float* __restrict__ y, float* __restrict__ y_amax, MarchP k) {
   using C = MarchCfg<CIN, COUT>;
-  constexpr bool B32 = C::B32;
+  constexpr bool B32 = C::B32, FLOW = C::FLOW;
+  static_assert(!(FLOW && ACTG), "the flow head is never a data gradient");
+  constexpr int NDZ = C::NDZ;
   constexpr int NO = C::NO, NSTEP = C::NSTEP, NH = C::NH, WU = C::WU, SLOTS = C::SLOTS, RS = C::RS, OP = C::OP, SU = C::SU;
   constexpr int NQ = C::NQ, NJ = C::NJ, NR = C::NR;
   constexpr unsigned OOB = 0x80000000u;
@@ -198,7 +211,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   for (int u = tid; u < NSTEP * 3 * 64; u += 512) {
     const int ln = u & 63, jd = u >> 6, j = jd / 3, dz = jd % 3;
     int co, tap, c0;                                         // tap < 0: zero unit
-    if constexpr (B32) {
+    if constexpr (FLOW) {
+      // unit (k-step j, phase ph = jd % 3): column group g = the open plane = g (mod 3), which input plane P0 + i with
+      // i = ph (mod 3) reaches through tap plane (ph + 1 - g) mod 3
+      const int col = ln & 15, g = col >> 2, kgp = ln >> 4, t2 = kgp >> 1;
+      co = col & 3;
+      c0 = 8 * (kgp & 1);
+      int dy, dx;
+      if (j < 3) { dy = j; dx = t2; }
+      else if (j == 3) { dy = t2; dx = 2; }
+      else { dy = 2; dx = 2; }
+      const int dzr = (dz + 1 - g + 3) % 3;
+      tap = (g == 3 || co == 3 || (j == 4 && t2 == 1)) ? -1 : dzr * 9 + dy * 3 + dx;
+      if (tap < 0) co = 0;
+    } else if constexpr (B32) {
       co = ln & 31; c0 = 8 * (ln >> 5);
       tap = dz * 9 + (j % 3) * 3 + j / 3;
     } else if constexpr (CIN == 32) {
@@ -225,13 +251,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
 
   // ---- staging jobs of this thread (the same for every plane): job < NQ = the 16-byte quad xq of patch row q, octet o
   // (8 buffer_load_dwordx4, one per channel -> 4 positions x 2 split units), else one halo column position (8 dword loads)
+  // FLOW: a halo column is loaded as the aligned quad that contains it (component jhe = 3 left, 0 right; the rest of the
+  // quad is a neighbour column's interior: L2 hits) -- ONE kind of load, issued by every lane with an out-of-range offset
+  // where there is no job, so that the loads are straight-line code: with the loads under lane- and plane-dependent
+  // branches the compiler's s_waitcnt placement assumed the worst path and drained the other register set's loads (the
+  // prefetch of two planes ahead) before every conversion
   unsigned jvo[NR];            // byte offset of (channel 8 o, plane 0, row, column) or OOB
   int jpos[NR];                // LDS unit of the (first) position within a split section; < 0: no job
+  int jhe[NR];                 // FLOW: the one quad component a halo job stores, -1 = all four
   bool jquad[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int job = tid + 512 * r;
-    jvo[r] = OOB; jpos[r] = -1; jquad[r] = job < NQ;
+    jvo[r] = OOB; jpos[r] = -1; jquad[r] = FLOW || job < NQ; jhe[r] = -1;
     if (job < NJ) {
       int o, q, col, gx;
       if (job < NQ) {
@@ -240,7 +272,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
         const int xq = (job & 3) | (((job >> 3) & 1) << 2), q2 = (job >> 4) % 9;
         q = 2 * q2 + ((job >> 2) & 1); o = (job >> 4) / 9; col = 1 + 4 * xq; gx = x0 + 4 * xq;
       }
-      else { const int s_ = job - NQ, side = s_ & 1; q = (s_ >> 1) % 18; o = (s_ >> 1) / 18; col = side ? 33 : 0; gx = side ? x0 + 32 : x0 - 1; }
+      else {
+        const int s_ = job - NQ, side = s_ & 1; q = (s_ >> 1) % 18; o = (s_ >> 1) / 18; col = side ? 33 : 0; gx = side ? x0 + 32 : x0 - 1;
+        if constexpr (FLOW) { jhe[r] = side ? 0 : 3; gx = side ? x0 + 32 : x0 - 4; }
+      }
       const int gy = y0 - 1 + q;
       jpos[r] = o * OP + q * RS + col;
       if ((unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W)
@@ -249,9 +284,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   }
   const __amdgpu_buffer_rsrc_t x_src = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (long long)n * CIN * S), 0, (unsigned)((long long)CIN * S * 4), 0x00020000);
-  u32x4 rq[NR][8];
+  // FLOW: TWO register sets (plane index & 1) -- a plane step is 60 MFMAs per wave, a third of the other forms', and with one
+  // set (loads issued half a step before their conversion) every step waited out the memory latency: 3.9 us per plane
+  constexpr int NRQ = FLOW ? 2 : NR;
+  u32x4 rq[NRQ][8];
   bool ko_st = true;                                         // (knock-out builds switch the staging stores off after the prologue)
-#define M3_GLOAD(z_)                                                                              \
+#define M3_GLOAD(z_) M3_GLOAD_S(z_, 0)
+#define M3_GLOAD_S(z_, set_)               /* set_: register set of the FLOW form (its one job round), else 0 */ \
   {                                                                                               \
     const int zz_ = (z_);                                                                         \
     const bool zok_ = (unsigned)zz_ < (unsigned)k.D;                                              \
@@ -260,29 +299,32 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       const unsigned vo_ = (zok_ && !((M3_KO & 2) && k.D > 0)) ? jvo[r] : OOB;                    \
       if (jquad[r]) {                                                                             \
         _Pragma("unroll") for (int c = 0; c < 8; ++c)                                             \
-          rq[r][c] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
+          rq[r + (set_)][c] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
       } else if (jpos[r] >= 0) {                                                                  \
         _Pragma("unroll") for (int c = 0; c < 8; ++c)                                             \
-          rq[r][c][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
+          rq[r + (set_)][c][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)c * s4, 0); \
       }                                                                                           \
     }                                                                                             \
   }
-#define M3_LSTORE(sl_)                                                                            \
+#define M3_LSTORE(sl_) M3_LSTORE_S(sl_, 0)
+#define M3_LSTORE_S(sl_, set_)                                                                    \
   if (ko_st) {                                                                                    \
     u32x4* Xd_ = Xs + (sl_) * SU;                                                                 \
     _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                              \
       if (jquad[r]) {                                                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
           float v_[8];                                                                            \
-          _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r][c][e]);     \
+          _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r + (set_)][c][e]); \
           u32x4 h_, r_;                                                                           \
           split8_m(v_, xscale, h_, r_);                                                           \
-          Xd_[jpos[r] + e] = h_;                                                                  \
-          Xd_[NO * OP + jpos[r] + e] = r_;                                                        \
+          if (jpos[r] >= 0 && (jhe[r] < 0 || jhe[r] == e)) {                                      \
+            Xd_[jpos[r] + (jhe[r] < 0 ? e : 0)] = h_;                                             \
+            Xd_[NO * OP + jpos[r] + (jhe[r] < 0 ? e : 0)] = r_;                                   \
+          }                                                                                       \
         }                                                                                         \
       } else if (jpos[r] >= 0) {                                                                  \
         float v_[8];                                                                              \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r][c][0]);       \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) v_[c] = __uint_as_float(rq[r + (set_)][c][0]); \
         u32x4 h_, r_;                                                                             \
         split8_m(v_, xscale, h_, r_);                                                             \
         Xd_[jpos[r]] = h_;                                                                        \
@@ -311,10 +353,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   // NSETS = 4 (16 -> 16): the finished plane keeps its set for one more step, during which its epilogue rides between
   // the MFMA groups like the staging atoms (10-13 % of a step was an epilogue with nothing on the matrix pipe); the
   // 32-column form has no registers for a fourth set (96 + 32) and finishes its plane at the end of the step
-  constexpr int NSETS = (B32 || CIN == 32) ? 3 : 4;      // (32 input channels: two job rounds of staging registers)
-  acc_t acc[NSETS][2][NH];
+  constexpr int NSETS = (B32 || CIN == 32 || FLOW) ? 3 : 4;      // (32 input channels: two job rounds of staging registers)
+  constexpr int NACC = FLOW ? 1 : NSETS;                  // FLOW: the three open planes are column groups of one set
+  acc_t acc[NACC][2][NH];
 #pragma unroll
-  for (int a = 0; a < NSETS; ++a)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -323,8 +366,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
         for (int i = 0; i < (B32 ? 16 : 4); ++i) acc[a][r][h][i] = 0.f;
 
   // epilogue constants: lane = one output channel, 4 consecutive voxels per accumulator quad
-  const int co = B32 ? l31 : l15;
-  const float bv = bias ? bias[co] : 0.f;
+  const int co = FLOW ? (l15 & 3) : (B32 ? l31 : l15);
+  const bool col_ok = !FLOW || (l15 < 12 && co < 3);         // FLOW: column 4 g + 3 and group 3 are padding
+  const float bv = (bias && co < COUT) ? bias[co] : 0.f;
   const __amdgpu_buffer_rsrc_t y_dst = __builtin_amdgcn_make_buffer_rsrc(
       y + (long long)n * COUT * S, 0, (unsigned)((long long)COUT * S * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     const int gy = y0 + 2 * wid + r;
     const int gx = RC ? (x0 + l31) : (B32 ? (x0 + 8 * (e & 3) + 4 * lhi) : (x0 + 16 * (e & 1) + 4 * kg));
     // RC: element i of group e = (row, q) is channel 8 q + 4 lhi + i at voxel x0 + l31 (channel step in the soffset)
-    evo[e] = (gy < k.H && gx < k.W) ? (unsigned)(gy * k.W + gx) * 4u + (unsigned)(RC ? 8 * (e & 3) + 4 * lhi : co) * s4 : OOB;
+    evo[e] = (gy < k.H && gx < k.W && col_ok) ? (unsigned)(gy * k.W + gx) * 4u + (unsigned)(RC ? 8 * (e & 3) + 4 * lhi : co) * s4 : OOB;
   }
   float pm = 0.f;
 
@@ -349,6 +393,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
         Bu[q_][h][s] = Xc[s * NO * OP + vb[kind_] + (q_) * RS + 16 * h];                          \
   }
+#define M3_WU(jd_, PH_) (FLOW ? (jd_) * 3 + (PH_) : (jd_))     /* weight unit of block jd_: FLOW keeps one per (k-step, phase) */
 #define M3_AREAD(buf_, jd_)                                                                       \
   if (M3_KO_RD) { Aw[buf_][0] = Ws[((jd_) * 2 + 0) * 64 + lane]; Aw[buf_][1] = Ws[((jd_) * 2 + 1) * 64 + lane]; }
 #if M3_KO & 32
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   //               two barriers (converting in place during the MFMA phase costs a second register set: a position's unit
   //               needs one component of eight 4-register load results);   t = 45, 47, ..   the activation-source quads
   u32x4 cvh, cvr;                                                   // two slots: the unit being converted
-#define M3_CONV_HALF(r_, e_, half_, H_, R_)     /* (every lane converts: no predicate, no merge with old register contents) */ \
+#define M3_CONV_HALF(r_, e_, half_, H_, R_)     /* (every lane converts: no predicate, no merge with old register contents); r_ = register set */ \
   {                                                                                               \
     _Pragma("unroll") for (int q = 2 * (half_); q < 2 * (half_) + 2; ++q) {                       \
       unsigned hh_, rr_;                                                                          \
@@ -377,14 +422,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       H_[q] = hh_; R_[q] = rr_;                                                                   \
     }                                                                                             \
   }
-#define M3_LOAD1(r_, c_, z_)                                                                      \
+#define M3_LOAD1(r_, c_, z_) M3_LOAD1S(r_, r_, c_, z_)
+#define M3_LOAD1S(s_, r_, c_, z_)          /* job round r_ into register set s_ */                 \
   {                                                                                               \
     const int zz_ = (z_);                                                                         \
     const bool zok_ = (unsigned)zz_ < (unsigned)k.D && !((M3_KO & 2) && k.D > 0);                 \
     const unsigned zb_ = zok_ ? (unsigned)zz_ * hw4 : 0u;                                         \
     const unsigned vo_ = zok_ ? jvo[r_] : OOB;                                                    \
-    if (jquad[r_]) rq[r_][c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
-    else if (jpos[r_] >= 0) rq[r_][c_][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
+    if (jquad[r_]) rq[s_][c_] = __builtin_amdgcn_raw_buffer_load_b128(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
+    else if (jpos[r_] >= 0) rq[s_][c_][0] = __builtin_amdgcn_raw_buffer_load_b32(x_src, vo_, zb_ + (unsigned)(c_) * s4, 0); \
   }
 #define M3_AVLOAD(e_, P_)                  /* activation source of the plane whose epilogue comes next */ \
   {                                                                                               \
@@ -401,10 +447,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   // the set leaves zeroed
 #define M3_EPI_ONE(a_, e_, p_)                                                                    \
   {                                                                                               \
-    constexpr int ea_ = (a_), ee_ = (e_);                                                         \
+    constexpr int eg_ = (a_), ea_ = FLOW ? 0 : eg_, ee_ = (e_);                                   \
     constexpr int r = B32 ? (ee_ >> 2) : (ee_ >> 1), h = B32 ? 0 : (ee_ & 1), q4 = B32 ? 4 * (ee_ & 3) : 0; \
     const int pp_ = (p_);                                                                         \
-    const bool ok = pp_ >= zs && pp_ < ze && evo[ee_] != OOB;                                     \
+    const bool mine_ = !FLOW || (l15 >> 2) == eg_;      /* FLOW: the finished plane is column group eg_ */ \
+    const bool ok = pp_ >= zs && pp_ < ze && evo[ee_] != OOB && mine_;                            \
     u32x4 out;                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
       float v = acc[ea_][r][h][q4 + i] * osc + (RC ? sbias[(8 * (ee_ & 3) + 4 * lhi + i) & 31] : bv);  \
@@ -412,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       if (ACTG) v = __uint_as_float(av[ACTG ? ee_ : 0][i]) > 0.f ? v : v * k.act_slope;            \
       out[i] = __float_as_uint(v);                                                                \
       pm = fmaxf(pm, ok ? fabsf(v) : 0.f);                                                        \
-      acc[ea_][r][h][q4 + i] = 0.f;                                                               \
+      acc[ea_][r][h][q4 + i] = mine_ ? 0.f : acc[ea_][r][h][q4 + i];                              \
     }                                                                                             \
     /* plane offset in the VGPR, soffset literal 0: with an SGPR soffset hipcc assumes that a 16-byte store's */ \
     /* data registers may be overwritten by the next VALU instruction -- on gfx950 they may not (dword 0 of   */ \
@@ -424,23 +471,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       __builtin_amdgcn_raw_buffer_store_b128(out, y_dst, (ok && !((M3_KO & 8) && k.D > 0)) ? evo[ee_] + (unsigned)pp_ * hw4 : OOB, 0, 0); \
     }                                                                                             \
   }
-#define M3_ATOMS(t, PH_, P_, sl_, st_, ld_)                                                            \
+#define M3_ATOMS(t, PH_, P_, sl_, st_, ld_, SET_)                                                 \
   {                                                                                               \
     if constexpr (SLOTS == 2) {                                                                   \
       if constexpr (t < 8) {                                                                      \
         if ((st_) && ko_st) {                                                                     \
           constexpr int e = t >> 1;                                                               \
-          M3_CONV_HALF(0, e, t & 1, cvh, cvr)                                                     \
+          M3_CONV_HALF(SET_, e, t & 1, cvh, cvr)                                                  \
           if constexpr ((t & 1) == 1) {                                                           \
-            if (jpos[0] >= 0 && (jquad[0] || e == 0)) {                                           \
+            if (FLOW ? (jpos[0] >= 0 && (jhe[0] < 0 || jhe[0] == e)) : (jpos[0] >= 0 && (jquad[0] || e == 0))) { \
               u32x4* Xd_ = Xs + ((sl_) ^ 1) * SU;                                                 \
-              Xd_[jpos[0] + e] = cvh;                                                             \
-              Xd_[NO * OP + jpos[0] + e] = cvr;                                                   \
+              const int pe_ = (FLOW && jhe[0] >= 0) ? 0 : e;                                      \
+              Xd_[jpos[0] + pe_] = cvh;                                                           \
+              Xd_[NO * OP + jpos[0] + pe_] = cvr;                                                 \
             }                                                                                     \
           }                                                                                       \
         }                                                                                         \
       }                                                                                           \
-      if constexpr (t >= 9 && t <= 23 && (t & 1) == 1) { if (ld_) M3_LOAD1(0, (t - 9) >> 1, (P_) + 2) } \
+      /* FLOW: plane P + 3 into the set whose plane P + 1 was converted in atoms 0..7 (its channel c was last read by atom 6 / 7) */ \
+      if constexpr (FLOW) { if constexpr (t >= 7 && t <= 14) { M3_LOAD1S(SET_, 0, t - 7, (ld_) ? (P_) + 3 : -1) } } \
+      else if constexpr (t >= 9 && t <= 23 && (t & 1) == 1) { if (ld_) M3_LOAD1(0, (t - 9) >> 1, (P_) + 2) } \
       if constexpr (ACTG && t >= 10 && t < 10 + 2 * NE && (t & 1) == 0) M3_AVLOAD((t - 10) >> 1, P_) \
       if constexpr (NSETS == 4 && t >= 30 && t < 30 + 3 * NE && (t - 30) % 3 == 0) M3_EPI_ONE(((PH_) + 2) % 4, (t - 30) / 3, (P_) - 2) \
     } else {                                                                                      \
@@ -449,21 +499,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       if constexpr (NSETS == 4 && t >= 33 && t < 33 + 2 * NE && (t & 1) == 1) M3_EPI_ONE(((PH_) + 2) % 4, (t - 33) >> 1, (P_) - 2) \
     }                                                                                             \
   }
-#define M3_STEP(PH_, sl_, P_, st_, ld_)                                                           \
+#define M3_STEP(PH_, sl_, P_, st_, ld_, SET_)                                                     \
   {                                                                                               \
     const u32x4* Xc = Xs + (sl_) * SU;                                                            \
     M3_KO_DECL                                                                                    \
     u32x4 av[ACTG ? NE : 1];                                                                      \
     M3_BREAD(0, 0) M3_BREAD(0, 1)                                                                 \
-    static_for_m<0, M3_ADEPTH>([&](auto dc_) __attribute__((always_inline)) { M3_AREAD(decltype(dc_)::value, decltype(dc_)::value) }); \
-    static_for_m<0, NSTEP * 9>([&](auto tc_) __attribute__((always_inline)) {                     \
-      constexpr int t = decltype(tc_)::value, jd = t / 3, p = t % 3, j = jd / 3, dz = jd % 3, cur = jd % (M3_ADEPTH + 1); \
+    static_for_m<0, M3_ADEPTH>([&](auto dc_) __attribute__((always_inline)) { M3_AREAD(decltype(dc_)::value, M3_WU(decltype(dc_)::value, PH_)) }); \
+    static_for_m<0, NSTEP * NDZ * 3>([&](auto tc_) __attribute__((always_inline)) {               \
+      constexpr int t = decltype(tc_)::value, jd = t / 3, p = t % 3, j = jd / NDZ, dz = jd % NDZ, cur = jd % (M3_ADEPTH + 1); \
       constexpr unsigned lmask = step_loads<CIN, COUT>(j);                                        \
       constexpr int qo = step_qoff<CIN, COUT>(j);                                                 \
-      constexpr int a = ((PH_) + 1 - dz + NSETS) % NSETS;                                         \
+      constexpr int a = FLOW ? 0 : ((PH_) + 1 - dz + NSETS) % NSETS;                              \
       if constexpr (p == 0) {                                                                     \
         if constexpr (M3_PRIO == 1) { if (wid >= 4) __builtin_amdgcn_s_setprio((jd + 1) & 1); else __builtin_amdgcn_s_setprio(jd & 1); } \
-        if constexpr (jd + M3_ADEPTH < NSTEP * 3) M3_AREAD((jd + M3_ADEPTH) % (M3_ADEPTH + 1), jd + M3_ADEPTH) \
+        if constexpr (jd + M3_ADEPTH < NSTEP * NDZ) M3_AREAD((jd + M3_ADEPTH) % (M3_ADEPTH + 1), M3_WU(jd + M3_ADEPTH, PH_)) \
         if constexpr (dz == 0) {                                                                  \
           static_for_m<0, 12>([&](auto bc_) __attribute__((always_inline)) {                      \
             constexpr int b = decltype(bc_)::value;                                               \
@@ -471,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
           });                                                                                     \
         }                                                                                         \
       }                                                                                           \
-      M3_ATOMS(t, PH_, P_, sl_, st_, ld_)                                                         \
+      M3_ATOMS(t, PH_, P_, sl_, st_, ld_, SET_)                                                   \
       constexpr int sb = p == 1 ? 1 : 0, sa = p == 0 ? 1 : 0;                                     \
       _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
         _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                          \
@@ -498,7 +548,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
   M3_GLOAD(P0)
   __syncthreads();                                           // slots zeroed, weights in place
   M3_LSTORE(0)
-  if (SLOTS == 2 && nst > 1) M3_GLOAD(P0 + 1)
+  if constexpr (FLOW) {                                      // plane i of the segment lives in register set i & 1
+    M3_GLOAD_S(nst > 1 ? P0 + 1 : -1, 1)
+    M3_GLOAD_S(nst > 2 ? P0 + 2 : -1, 0)
+  } else {
+    if (SLOTS == 2 && nst > 1) M3_GLOAD(P0 + 1)
+  }
   __syncthreads();
   ko_st = !((M3_KO & 4) && k.D > 0);
   M3_T(6)
@@ -508,15 +563,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
 #endif
 
   // one step of the march with its staging protocol; i = index of the input plane within the segment
-#define M3_ITER(PH_, i_)                                                                          \
+#define M3_ITER(PH_, i_) M3_ITER_S(PH_, i_, 0)
+#define M3_ITER_S(PH_, i_, SET_)           /* SET_ = (i_ + 1) & 1 in the FLOW form, else 0 */     \
   {                                                                                               \
     const int ii = (i_);                                                                          \
     if constexpr (SLOTS == 2) {                                                                   \
-      M3_STEP(PH_, ii & 1, P0 + ii, ii + 1 < nst, ii + 2 < nst)                                   \
+      M3_STEP(PH_, ii & 1, P0 + ii, ii + 1 < nst, ii + (FLOW ? 3 : 2) < nst, SET_)                \
       __syncthreads();                                                                            \
       M3_T(4)                                                                                     \
     } else {                                                                                      \
-      M3_STEP(PH_, 0, P0 + ii, ii + 1 < nst, false)                                               \
+      M3_STEP(PH_, 0, P0 + ii, ii + 1 < nst, false, 0)                                            \
       if (ii + 1 < nst) {                                                                         \
         __syncthreads();                                                                          \
         M3_T(4)                                                                                   \
@@ -527,7 +583,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
       }                                                                                           \
     }                                                                                             \
   }
-  if constexpr (NSETS == 3) {
+  if constexpr (FLOW) {
+    // (`break`, not `if (i + k < nst) step`: a step that is reachable around its predecessor makes the compiler place the
+    // s_waitcnt of its conversion for the path on which the predecessor's loads were never issued)
+    for (int i = 0; i < nst; i += 6) {                       // phase x register set: period 6
+      M3_ITER_S(0, i, 1)
+      if (i + 1 >= nst) break;
+      M3_ITER_S(1, i + 1, 0)
+      if (i + 2 >= nst) break;
+      M3_ITER_S(2, i + 2, 1)
+      if (i + 3 >= nst) break;
+      M3_ITER_S(0, i + 3, 0)
+      if (i + 4 >= nst) break;
+      M3_ITER_S(1, i + 4, 1)
+      if (i + 5 >= nst) break;
+      M3_ITER_S(2, i + 5, 0)
+    }
+  } else if constexpr (NSETS == 3) {
     for (int i = 0; i < nst; i += 3) {
       M3_ITER(0, i)
       if (i + 1 < nst) M3_ITER(1, i + 1)
@@ -558,18 +630,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_march_k(const float* __restrict
     }
   }
 #undef M3_ITER
+#undef M3_ITER_S
 #undef M3_STEP
 #undef M3_ATOMS
 #undef M3_EPI_ONE
 #undef M3_AVLOAD
 #undef M3_LOAD1
+#undef M3_LOAD1S
 #undef M3_CONV_HALF
 #undef M3_KO_DECL
 #undef M3_KO_RD
 #undef M3_AREAD
+#undef M3_WU
 #undef M3_BREAD
 #undef M3_LSTORE
+#undef M3_LSTORE_S
 #undef M3_GLOAD
+#undef M3_GLOAD_S
   if (y_amax) {
     __syncthreads();
     publish_block_absmax_acc(pm, &smax, y_amax);
@@ -581,7 +658,8 @@ bool march_off() {
   return a.get() || b.get() || c.get();
 }
 bool march_geom_ok(const DfConvGeom* g) {
-  const bool shape = (g->Cin == 32 && g->Cout == 16) || (g->Cin == 16 && (g->Cout == 16 || g->Cout == 32));
+  const bool shape = (g->Cin == 32 && g->Cout == 16) || (g->Cin == 16 && (g->Cout == 16 || g->Cout == 32)) ||
+                     (g->Cin == 16 && g->Cout == 3 && g->act == 0);
   return shape && g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 1 && g->pd == 1 && g->ph == 1 &&
          g->pw == 1 && g->pad_mode == 0 && g->Do == g->Di && g->Ho == g->Hi && g->Wo == g->Wi && (g->act == 0 || g->act == 1) &&
          g->Di >= 4 && g->Hi >= 8 && g->Wi >= 16 && (g->Wi % 4) == 0 &&
@@ -628,7 +706,11 @@ extern "C" int dfmir_conv3d_march_fwd(const DfConvGeom* g, const float* x, const
     if (act_src) conv3d_march_k<CI_, CO_, true><<<grid, 512, 0, st>>>(x, x_amax, w_tcc, bias, y, y_amax, k);  \
     else conv3d_march_k<CI_, CO_, false><<<grid, 512, 0, st>>>(x, x_amax, w_tcc, bias, y, y_amax, k);         \
   }
-  if (g->Cin == 32) M3_LAUNCH(32, 16)
+  if (g->Cout == 3) {
+    DF_ARG_CHECK(!act_src);
+    conv3d_march_k<16, 3, false><<<grid, 512, 0, st>>>(x, x_amax, w_tcc, bias, y, y_amax, k);
+  }
+  else if (g->Cin == 32) M3_LAUNCH(32, 16)
   else if (g->Cout == 16) M3_LAUNCH(16, 16)
   else M3_LAUNCH(16, 32)
 #undef M3_LAUNCH

@@ -267,6 +267,19 @@ __global__ void act_bwd_k(const float* __restrict__ dy, const float* __restrict_
     dx[i] = (act == 2) ? g * (1.f - yv * yv) : (yv > 0.f ? g : g * slope);
   }
 }
+// 16-byte accesses (n % 4 == 0, aligned pointers)
+__global__ __launch_bounds__(256) void act_bwd_v4_k(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                    float4* __restrict__ dx, long long n4, int act, float slope) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 yv = y[i], g = dy[i];
+    float4 o;
+    o.x = (act == 2) ? g.x * (1.f - yv.x * yv.x) : (yv.x > 0.f ? g.x : g.x * slope);
+    o.y = (act == 2) ? g.y * (1.f - yv.y * yv.y) : (yv.y > 0.f ? g.y : g.y * slope);
+    o.z = (act == 2) ? g.z * (1.f - yv.z * yv.z) : (yv.z > 0.f ? g.z : g.z * slope);
+    o.w = (act == 2) ? g.w * (1.f - yv.w * yv.w) : (yv.w > 0.f ? g.w : g.w * slope);
+    dx[i] = o;
+  }
+}
 
 // the same, 4 elements per thread, leaving the range probe of dx (DF_PROBE_SLOTS accumulating slots) for the split
 // convolutions that consume it (dgrad / wgrad of the layer in front of the activation)
@@ -840,20 +853,23 @@ __global__ void upcat_fwd_k(const float* __restrict__ a, const float* __restrict
     y[i] = v;
   }
 }
-// the same, 4 x-consecutive outputs per thread (Wa even): one float2 of `a` (or one float4 of `b`) -> one float4 store
+// the same, 4 x-consecutive outputs per thread (Wa even): one float2 of `a` (or one float4 of `b`) -> one float4 store.
+// IDX = unsigned when the element count is below 2^31 (these kernels and the three below): the 64-bit division chain of
+// the coordinate decode was most of a thread's instructions
+template <typename IDX>
 __global__ __launch_bounds__(256) void upcat_fwd_v4_k(const float* __restrict__ a, const float* __restrict__ b,
                                                       float* __restrict__ y, int N, int Ca, int Cb, int Da, int Ha,
                                                       int Wa, int sd) {
   const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb, Wq = Wo >> 2;
   const long long So = (long long)Do * Ho * Wo, Sa = (long long)Da * Ha * Wa;
-  const long long total = (long long)N * C * Do * Ho * Wq;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int xq = (int)(i % Wq);
-    long long r = i / Wq;
-    const int yy = (int)(r % Ho); r /= Ho;
-    const int z = (int)(r % Do); r /= Do;
-    const int c = (int)(r % C);
-    const long long n = r / C;
+  const IDX total = (IDX)((long long)N * C * Do * Ho * Wq);
+  for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+    const int xq = (int)(i % (IDX)Wq);
+    IDX r = i / (IDX)Wq;
+    const int yy = (int)(r % (IDX)Ho); r /= (IDX)Ho;
+    const int z = (int)(r % (IDX)Do); r /= (IDX)Do;
+    const int c = (int)(r % (IDX)C);
+    const long long n = (long long)(r / (IDX)C);
     float4 v;
     if (c < Ca) {
       const float2 t = *reinterpret_cast<const float2*>(a + (n * Ca + c) * Sa + ((long long)(z / sd) * Ha + (yy >> 1)) * Wa + 2 * xq);
@@ -864,56 +880,71 @@ __global__ __launch_bounds__(256) void upcat_fwd_v4_k(const float* __restrict__ 
     *reinterpret_cast<float4*>(y + ((n * C + c) * Do + z) * (long long)Ho * Wo + (long long)yy * Wo + 4 * xq) = v;
   }
 }
-__global__ void upcat_bwd_a_k(const float* __restrict__ dy, float* __restrict__ da, int N, int Ca, int Cb,
-                              int Da, int Ha, int Wa, int sd) {
-  const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb;
-  const long long So = (long long)Do * Ho * Wo, Sa = (long long)Da * Ha * Wa;
-  const long long total = (long long)N * Ca * Sa;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % Wa);
-    long long r = i / Wa;
-    const int yy = (int)(r % Ha); r /= Ha;
-    const int z = (int)(r % Da); r /= Da;
-    const int c = (int)(r % Ca);
-    const long long n = r / Ca;
+// d(a)[n][c][z][y][x] = the sum of dy over the sd x 2 x 2 outputs that copied it; V2: a thread owns two x-consecutive
+// inputs (one float4 of dy per output row)
+template <typename IDX, bool V2>
+__global__ __launch_bounds__(256) void upcat_bwd_a_k(const float* __restrict__ dy, float* __restrict__ da, int N, int Ca, int Cb,
+                                                     int Da, int Ha, int Wa, int sd) {
+  const int Do = Da * sd, Ho = Ha * 2, Wo = Wa * 2, C = Ca + Cb, Wh = V2 ? (Wa >> 1) : Wa;
+  const long long So = (long long)Do * Ho * Wo;
+  const IDX total = (IDX)((long long)N * Ca * Da * Ha * Wh);
+  for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+    const int x = (int)(i % (IDX)Wh);
+    IDX r = i / (IDX)Wh;
+    const int yy = (int)(r % (IDX)Ha); r /= (IDX)Ha;
+    const int z = (int)(r % (IDX)Da); r /= (IDX)Da;
+    const int c = (int)(r % (IDX)Ca);
+    const long long n = (long long)(r / (IDX)Ca);
     const float* gp = dy + (n * C + c) * So;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f;
     for (int dz = 0; dz < sd; ++dz)
+#pragma unroll
       for (int dyy = 0; dyy < 2; ++dyy) {
-        const float* row = gp + ((long long)(z * sd + dz) * Ho + (2 * yy + dyy)) * Wo + 2 * x;
-        s += row[0] + row[1];
+        const float* row = gp + ((long long)(z * sd + dz) * Ho + (2 * yy + dyy)) * Wo;
+        if (V2) {
+          const float4 t = *reinterpret_cast<const float4*>(row + 4 * x);
+          s0 += t.x + t.y; s1 += t.z + t.w;
+        } else {
+          s0 += row[2 * x] + row[2 * x + 1];
+        }
       }
-    da[i] = s;
+    float* o = da + (((n * Ca + c) * Da + z) * (long long)Ha + yy) * Wa;
+    if (V2) *reinterpret_cast<float2*>(o + 2 * x) = make_float2(s0, s1);
+    else o[x] = s0;
   }
 }
-__global__ void upcat_bwd_b_k(const float* __restrict__ dy, float* __restrict__ db, int N, int Ca, int Cb,
-                              long long So) {
-  const int C = Ca + Cb;
-  const long long total = (long long)N * Cb * So;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long s = i % So;
-    long long r = i / So;
-    const int c = (int)(r % Cb);
-    const long long n = r / Cb;
-    db[i] = dy[(n * C + Ca + c) * So + s];
+// y[n] = cat(a[n], b[n]) along channels (dir 0) or its two slice copies (dir 1; a NULL destination is skipped); SA = Ca*S,
+// SB = Cb*S per-sample element counts IN UNITS OF V floats.  upcat's d(b) is the b slice of this copy.
+template <typename IDX, int V>
+__global__ __launch_bounds__(256) void cat_channels_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                      long long N, long long SA, long long SB, int dir) {
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const IDX ST = (IDX)(SA + SB), total = (IDX)(N * (SA + SB));
+  const vec_t* av = reinterpret_cast<const vec_t*>(a);
+  const vec_t* bv = reinterpret_cast<const vec_t*>(b);
+  vec_t* yv = reinterpret_cast<vec_t*>(y);
+  vec_t* aw = const_cast<vec_t*>(av);
+  vec_t* bw = const_cast<vec_t*>(bv);
+  for (IDX i = (IDX)blockIdx.x * 256 + threadIdx.x; i < total; i += (IDX)gridDim.x * 256) {
+    const IDX n = i / ST, r = i - n * ST;
+    if (dir == 0) yv[i] = r < (IDX)SA ? av[(long long)n * SA + r] : bv[(long long)n * SB + (r - (IDX)SA)];
+    else if (r < (IDX)SA) { if (aw) aw[(long long)n * SA + r] = yv[i]; }
+    else { if (bw) bw[(long long)n * SB + (r - (IDX)SA)] = yv[i]; }
   }
 }
-
-// y[n] = cat(a[n], b[n]) along channels; bwd = the two slice copies.  `scale`: y = mult*x.
-__global__ void cat_channels_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                               long long N, long long SA, long long SB, int dir) {
-  // SA = Ca*S, SB = Cb*S (per-sample element counts); dir 0: a,b -> y ; dir 1: y -> a,b
-  const long long ST = SA + SB, total = N * ST;
-  float* aw = const_cast<float*>(a);
-  float* bw = const_cast<float*>(b);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / ST, r = i - n * ST;
-    if (dir == 0) y[i] = r < SA ? a[n * SA + r] : b[n * SB + (r - SA)];
-    else if (r < SA) { if (aw) aw[n * SA + r] = y[i]; }
-    else { if (bw) bw[n * SB + (r - SA)] = y[i]; }
+static void cat_channels_launch(const float* a, const float* b, float* y, long long N, long long SA, long long SB, int dir,
+                                hipStream_t st) {
+  const bool v4 = ((SA | SB) & 3) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  const long long V = v4 ? 4 : 1, total = N * (SA + SB) / V;
+  const unsigned grid = df_grid(total, 256, 16384);
+  const bool small = total < 0x7FFFFFFFLL;
+  if (v4) {
+    if (small) cat_channels_k<unsigned, 4><<<grid, 256, 0, st>>>(a, b, y, N, SA / 4, SB / 4, dir);
+    else cat_channels_k<long long, 4><<<grid, 256, 0, st>>>(a, b, y, N, SA / 4, SB / 4, dir);
+  } else {
+    if (small) cat_channels_k<unsigned, 1><<<grid, 256, 0, st>>>(a, b, y, N, SA, SB, dir);
+    else cat_channels_k<long long, 1><<<grid, 256, 0, st>>>(a, b, y, N, SA, SB, dir);
   }
 }
 __global__ void scale_k(const float* __restrict__ x, float* __restrict__ y, long long n, float mult) {
@@ -1034,7 +1065,11 @@ extern "C" int dfmir_in_relu_blurdown_bwd(const float* dz, const float* x, const
 extern "C" int dfmir_act_bwd(const float* dy, const float* y, float* dx, long long n, int act,
                              float slope, void* stream) {
   DF_ARG_CHECK(dy && y && dx && n > 0 && (act == 1 || act == 2));
-  act_bwd_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, slope);
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0)
+    act_bwd_v4_k<<<df_grid(n / 4, 256, 8192), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y), reinterpret_cast<float4*>(dx), n / 4, act, slope);
+  else
+    act_bwd_k<<<df_grid(n, 256, 4096), 256, 0, (hipStream_t)stream>>>(dy, y, dx, n, act, slope);
   DF_LAUNCH_CHECK();
   return 0;
 }
@@ -1136,8 +1171,12 @@ extern "C" int dfmir_upcat_fwd(const float* a, const float* b, float* y, int N, 
   DF_ARG_CHECK(a && b && y && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));
   const long long total = (long long)N * (Ca + Cb) * Da * sd * Ha * 2 * Wa * 2;
   if ((Wa & 1) == 0 && ((reinterpret_cast<uintptr_t>(a) & 7) | (reinterpret_cast<uintptr_t>(b) & 15) | (reinterpret_cast<uintptr_t>(y) & 15)) == 0)
-    upcat_fwd_v4_k<<<df_grid(total / 4, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
-  else
+  {
+    if (total / 4 < 0x7FFFFFFFLL)
+      upcat_fwd_v4_k<unsigned><<<df_grid(total / 4, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
+    else
+      upcat_fwd_v4_k<long long><<<df_grid(total / 4, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
+  } else
     upcat_fwd_k<<<df_grid(total, 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, Ca, Cb, Da, Ha, Wa, sd);
   DF_LAUNCH_CHECK();
   return 0;
@@ -1146,14 +1185,23 @@ extern "C" int dfmir_upcat_bwd(const float* dy, float* da, float* db, int N, int
                                int Ha, int Wa, int sd, void* stream) {
   DF_ARG_CHECK(dy && (da || db) && N > 0 && Ca > 0 && Cb > 0 && (sd == 1 || sd == 2));   // NULL: that gradient is not wanted
   const long long Sa = (long long)Da * Ha * Wa, So = Sa * sd * 4;
+  hipStream_t st = (hipStream_t)stream;
   if (da) {
-    upcat_bwd_a_k<<<df_grid((long long)N * Ca * Sa, 256, 16384), 256, 0, (hipStream_t)stream>>>(
-        dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+    const bool v2 = (Wa & 1) == 0 && ((reinterpret_cast<uintptr_t>(dy) & 15) | (reinterpret_cast<uintptr_t>(da) & 7)) == 0;
+    const long long total = (long long)N * Ca * Sa / (v2 ? 2 : 1);
+    const unsigned grid = df_grid(total, 256, 16384);
+    const bool small = total < 0x7FFFFFFFLL;
+    if (v2) {
+      if (small) upcat_bwd_a_k<unsigned, true><<<grid, 256, 0, st>>>(dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+      else upcat_bwd_a_k<long long, true><<<grid, 256, 0, st>>>(dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+    } else {
+      if (small) upcat_bwd_a_k<unsigned, false><<<grid, 256, 0, st>>>(dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+      else upcat_bwd_a_k<long long, false><<<grid, 256, 0, st>>>(dy, da, N, Ca, Cb, Da, Ha, Wa, sd);
+    }
     DF_LAUNCH_CHECK();
   }
   if (db) {
-    upcat_bwd_b_k<<<df_grid((long long)N * Cb * So, 256, 16384), 256, 0, (hipStream_t)stream>>>(
-        dy, db, N, Ca, Cb, So);
+    cat_channels_launch(nullptr, db, const_cast<float*>(dy), N, (long long)Ca * So, (long long)Cb * So, 1, st);
     DF_LAUNCH_CHECK();
   }
   return 0;
@@ -1161,15 +1209,14 @@ extern "C" int dfmir_upcat_bwd(const float* dy, float* da, float* db, int N, int
 extern "C" int dfmir_cat_channels_fwd(const float* a, const float* b, float* y, long long N, long long SA,
                                       long long SB, void* stream) {
   DF_ARG_CHECK(a && b && y && N > 0 && SA > 0 && SB > 0);
-  cat_channels_k<<<df_grid(N * (SA + SB), 256, 16384), 256, 0, (hipStream_t)stream>>>(a, b, y, N, SA, SB, 0);
+  cat_channels_launch(a, b, y, N, SA, SB, 0, (hipStream_t)stream);
   DF_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int dfmir_cat_channels_bwd(const float* dy, float* da, float* db, long long N, long long SA,
                                       long long SB, void* stream) {
   DF_ARG_CHECK(dy && N > 0 && SA > 0 && SB > 0);
-  cat_channels_k<<<df_grid(N * (SA + SB), 256, 16384), 256, 0, (hipStream_t)stream>>>(
-      da, db, const_cast<float*>(dy), N, SA, SB, 1);
+  cat_channels_launch(da, db, const_cast<float*>(dy), N, SA, SB, 1, (hipStream_t)stream);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -281,7 +281,10 @@ __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x,
   y[i] = mult * v;
 }
 // Wo % 4 == 0: a thread writes 4 x-consecutive outputs (one 16-B store; the z / y terms are shared, the <= 5 distinct
-// input columns of the quad come from L1) -- the x2 flow up-sampling writes 83 MB per call at 160x192x224
+// input columns of the quad come from L1) -- the x2 flow up-sampling writes 83 MB per call at 160x192x224.
+// IDX = unsigned when the quad count fits 32 bits: the three 64-bit divisions of the coordinate decode were ~600 of the
+// thread's ~800 instructions (66 us per call for 92 MB)
+template <typename IDX>
 __global__ __launch_bounds__(256) void resize_fwd_v4_k(const float* __restrict__ x, float* __restrict__ y,
                                                        int planes, int Di, int Hi, int Wi, int Do, int Ho,
                                                        int Wo, float sd, float sh, float sw, float mult) {
@@ -290,11 +293,11 @@ __global__ __launch_bounds__(256) void resize_fwd_v4_k(const float* __restrict__
   const long long total = (long long)planes * Do * Ho * Wq;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  long long r = i;
-  const int oq = (int)(r % Wq); r /= Wq;
-  const int oy = (int)(r % Ho); r /= Ho;
-  const int oz = (int)(r % Do);
-  const long long pl = r / Do;
+  IDX r = (IDX)i;
+  const int oq = (int)(r % (IDX)Wq); r /= (IDX)Wq;
+  const int oy = (int)(r % (IDX)Ho); r /= (IDX)Ho;
+  const int oz = (int)(r % (IDX)Do);
+  const long long pl = (long long)(r / (IDX)Do);
   int z0, z1, y0, y1;
   float lz, ly;
   lin_src(oz, sd, Di, z0, z1, lz);
@@ -317,6 +320,64 @@ __global__ __launch_bounds__(256) void resize_fwd_v4_k(const float* __restrict__
     o[e] = mult * ((1.f - lz) * ((1.f - ly) * a0 + ly * a1) + lz * ((1.f - ly) * b0 + ly * b1));
   }
   *reinterpret_cast<float4*>(y + ((pl * Do + oz) * Ho + oy) * (long long)Wo + 4 * oq) = make_float4(o[0], o[1], o[2], o[3]);
+}
+// Row form of the same (Wi % 4 == 0, Wo % 4 == 0, Wi <= RF_MAXW): one WAVE per output row (plane, oz, oy).  Its four source
+// rows (z0 | z1) x (y0 | y1) are copied to LDS with one 16-byte load per lane and row, then every lane interpolates four
+// outputs along x from LDS -- the same expression in the same order as the kernels above (bit-identical results), but the
+// 32 four-byte gathers per thread are gone: the x2 up-sampling of the flow at 160x192x224 took 82 us for 93 MB.
+constexpr int RF_MAXW = 512;
+__global__ __launch_bounds__(256) void resize_rows_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                         int planes, int Di, int Hi, int Wi, int Do, int Ho,
+                                                         int Wo, float sd, float sh, float sw, float mult) {
+  __shared__ __attribute__((aligned(16))) float buf[4][4][RF_MAXW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long Si = (long long)Di * Hi * Wi;
+  const unsigned nrow = (unsigned)planes * (unsigned)Do * (unsigned)Ho;
+  const int Wiq = Wi >> 2, Woq = Wo >> 2;
+  float (*b)[RF_MAXW] = buf[wv];
+  for (unsigned row = blockIdx.x * 4u + (unsigned)wv; row < nrow; row += gridDim.x * 4u) {
+    const unsigned rz = row / (unsigned)Ho;
+    const int oy = (int)(row - rz * (unsigned)Ho), oz = (int)(rz % (unsigned)Do);
+    const long long pl = (long long)(rz / (unsigned)Do);
+    int z0, z1, y0, y1;
+    float lz, ly;
+    lin_src(oz, sd, Di, z0, z1, lz);
+    lin_src(oy, sh, Hi, y0, y1, ly);
+    const float* xp = x + pl * Si;
+    const float* r00 = xp + ((long long)z0 * Hi + y0) * Wi;
+    const float* r01 = xp + ((long long)z0 * Hi + y1) * Wi;
+    const float* r10 = xp + ((long long)z1 * Hi + y0) * Wi;
+    const float* r11 = xp + ((long long)z1 * Hi + y1) * Wi;
+    for (int q = lane; q < Wiq; q += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(r00 + 4 * q), v1 = *reinterpret_cast<const float4*>(r01 + 4 * q);
+      const float4 v2 = *reinterpret_cast<const float4*>(r10 + 4 * q), v3 = *reinterpret_cast<const float4*>(r11 + 4 * q);
+      *reinterpret_cast<float4*>(&b[0][4 * q]) = v0; *reinterpret_cast<float4*>(&b[1][4 * q]) = v1;
+      *reinterpret_cast<float4*>(&b[2][4 * q]) = v2; *reinterpret_cast<float4*>(&b[3][4 * q]) = v3;
+    }
+    // (one wave: its LDS operations complete in order; the fence keeps the compiler from moving the reads up)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* yrow = y + ((pl * Do + oz) * Ho + oy) * (long long)Wo;
+    for (int oq = lane; oq < Woq; oq += 64) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int x0, x1;
+        float lx;
+        lin_src(4 * oq + e, sw, Wi, x0, x1, lx);
+        const float a0 = (1.f - lx) * b[0][x0] + lx * b[0][x1];
+        const float a1 = (1.f - lx) * b[1][x0] + lx * b[1][x1];
+        const float b0 = (1.f - lx) * b[2][x0] + lx * b[2][x1];
+        const float b1 = (1.f - lx) * b[3][x0] + lx * b[3][x1];
+        o[e] = mult * ((1.f - lz) * ((1.f - ly) * a0 + ly * a1) + lz * ((1.f - ly) * b0 + ly * b1));
+      }
+      *reinterpret_cast<float4*>(yrow + 4 * oq) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 // Adjoint in GATHER form: input sample i collects from the outputs o whose interpolation window
 // touches it (o in [(i-1)/scale, (i+1)/scale]); the weight is recomputed with the forward's own
@@ -408,7 +469,7 @@ __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy
 // coefficients.  The one-pass kernel above visits up to 7^3 candidates per input voxel (0.19 ms per call on the x2
 // flow up-sampling at 160x192x224); the three passes move 82.6 + 2 (41.3 + 20.6) + 10.3 MB.
 // in [outer][olen][inner] -> out [outer][ilen][inner];  V = floats per thread along `inner`
-template <int V>
+template <int V, typename IDX>
 __global__ __launch_bounds__(256) void resize_axis_bwd_k(const float* __restrict__ in, float* __restrict__ out,
                                                          long long outer, int ilen, int olen, long long inner,
                                                          float scale, float mult) {
@@ -416,16 +477,17 @@ __global__ __launch_bounds__(256) void resize_axis_bwd_k(const float* __restrict
   const long long total = outer * ilen * nin;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
-  const long long q = t % nin;
-  long long r = t / nin;
-  const int i = (int)(r % ilen);
-  const long long ou = r / ilen;
+  // (IDX = unsigned when the thread count fits 32 bits: see resize_fwd_v4_k)
+  const IDX q = (IDX)t % (IDX)nin;
+  IDX r = (IDX)t / (IDX)nin;
+  const int i = (int)(r % (IDX)ilen);
+  const long long ou = (long long)(r / (IDX)ilen);
   int lo, hi;
   lin_range(i, scale, olen, lo, hi);
   float acc[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) acc[e] = 0.f;
-  const float* base = in + ou * olen * inner + q * V;
+  const float* base = in + ou * olen * inner + (long long)q * V;
   for (int o = lo; o <= hi; ++o) {
     const float w = lin_weight(o, scale, ilen, i);
     if (w == 0.f) continue;
@@ -437,9 +499,45 @@ __global__ __launch_bounds__(256) void resize_axis_bwd_k(const float* __restrict
       acc[0] += w * p[0];
     }
   }
-  float* op = out + (ou * ilen + i) * inner + q * V;
+  float* op = out + (ou * ilen + i) * inner + (long long)q * V;
   if (V == 4) *reinterpret_cast<float4*>(op) = make_float4(mult * acc[0], mult * acc[1], mult * acc[V > 2 ? 2 : 0], mult * acc[V > 3 ? 3 : 0]);
   else op[0] = mult * acc[0];
+}
+
+// The W pass with FOUR consecutive inputs per thread (ilen % 4 == 0): the candidate outputs of the four windows are walked
+// once, in ascending order, and each adds to the (<= 2) inputs its interpolation touched -- the same weights and the same
+// order of additions per input as resize_axis_bwd_k<1>, i.e. bit-identical results, for a third of the instructions (one
+// lin_src() per candidate instead of one per candidate and input: that pass was bound by the vector ALUs, 50 us for 31 MB).
+template <typename IDX>
+__global__ __launch_bounds__(256) void resize_w_bwd4_k(const float* __restrict__ in, float* __restrict__ out,
+                                                       long long rows, int ilen, int olen, float scale, float mult) {
+  const IDX nin = (IDX)(ilen >> 2);
+  const IDX total = (IDX)rows * nin;
+  const long long tt = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (tt >= (long long)total) return;
+  const IDX t = (IDX)tt;
+  const int ib = 4 * (int)(t % nin);
+  const long long row = (long long)(t / nin);
+  int lo, hi, lo3, hi0;
+  lin_range(ib, scale, olen, lo, hi0);
+  lin_range(ib + 3, scale, olen, lo3, hi);
+  lo = lo < lo3 ? lo : lo3;
+  hi = hi > hi0 ? hi : hi0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* p = in + row * olen;
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1;
+    float l1;
+    lin_src(o, scale, ilen, i0, i1, l1);
+    const float g = p[o];
+    const int d0 = i0 - ib, d1 = i1 - ib;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float w = (d0 == k ? 1.f - l1 : 0.f) + (d1 == k ? l1 : 0.f);
+      if (w != 0.f) acc[k] += w * g;
+    }
+  }
+  *reinterpret_cast<float4*>(out + row * ilen + ib) = make_float4(mult * acc[0], mult * acc[1], mult * acc[2], mult * acc[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -531,9 +629,19 @@ extern "C" int dfmir_resize_fwd(const float* x, float* y, int planes, int Di, in
                                 int Ho, int Wo, float mult, void* stream) {
   DF_ARG_CHECK(x && y && planes > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0);
   const long long total = (long long)planes * Do * Ho * Wo;
-  if ((Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && total / 4 < (1LL << 31) * 256) {
-    resize_fwd_v4_k<<<(unsigned)((total / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+  static DfOptFlag no_rows{"DFMIR_RESIZE_NO_ROWS"};          // A/B: the per-thread gather kernels
+  if (!no_rows.get() && (Wo & 3) == 0 && (Wi & 3) == 0 && Wi <= RF_MAXW &&
+      ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && (long long)planes * Do * Ho < 0x7FFFFFFFLL) {
+    const long long nrow = (long long)planes * Do * Ho;
+    resize_rows_fwd_k<<<df_grid(nrow, 4, 256 * 20), 256, 0, (hipStream_t)stream>>>(
         x, y, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
+  } else if ((Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && total / 4 < (1LL << 31) * 256) {
+    if (total / 4 < 0xFFFFFFFFLL)
+      resize_fwd_v4_k<unsigned><<<(unsigned)((total / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+          x, y, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
+    else
+      resize_fwd_v4_k<long long><<<(unsigned)((total / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+          x, y, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
   } else {
     resize_fwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         x, y, planes, Di, Hi, Wi, Do, Ho, Wo, lin_scale(Di, Do), lin_scale(Hi, Ho), lin_scale(Wi, Wo), mult);
@@ -550,7 +658,10 @@ template <int V>
 static void resize_axis_launch(const float* in, float* out, long long outer, int ilen, int olen, long long inner,
                                float scale, float mult, hipStream_t st) {
   const long long total = outer * ilen * (inner / V);
-  resize_axis_bwd_k<V><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(in, out, outer, ilen, olen, inner, scale, mult);
+  if (total < 0xFFFFFFFFLL && inner / V < 0xFFFFFFFFLL)
+    resize_axis_bwd_k<V, unsigned><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(in, out, outer, ilen, olen, inner, scale, mult);
+  else
+    resize_axis_bwd_k<V, long long><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(in, out, outer, ilen, olen, inner, scale, mult);
 }
 extern "C" int dfmir_resize_bwd_sep(const float* dy, float* dx, int planes, int Di, int Hi, int Wi, int Do,
                                     int Ho, int Wo, float mult, float* ws, void* stream) {
@@ -559,7 +670,15 @@ extern "C" int dfmir_resize_bwd_sep(const float* dy, float* dx, int planes, int 
   hipStream_t st = (hipStream_t)stream;
   float* t1 = ws;                                               // [planes][Do][Ho][Wi]
   float* t2 = ws + (((long long)planes * Do * Ho * Wi + 3) & ~3LL);   // [planes][Do][Hi][Wi]
-  resize_axis_launch<1>(dy, t1, (long long)planes * Do * Ho, Wi, Wo, 1, lin_scale(Wi, Wo), 1.f, st);
+  static DfOptFlag no_rows{"DFMIR_RESIZE_NO_ROWS"};
+  const long long wrows = (long long)planes * Do * Ho;
+  if ((Wi & 3) == 0 && !no_rows.get()) {
+    const long long total = wrows * (Wi / 4);
+    if (total < 0xFFFFFFFFLL) resize_w_bwd4_k<unsigned><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, t1, wrows, Wi, Wo, lin_scale(Wi, Wo), 1.f);
+    else resize_w_bwd4_k<long long><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, t1, wrows, Wi, Wo, lin_scale(Wi, Wo), 1.f);
+  } else {
+    resize_axis_launch<1>(dy, t1, wrows, Wi, Wo, 1, lin_scale(Wi, Wo), 1.f, st);
+  }
   if ((Wi & 3) == 0) {
     resize_axis_launch<4>(t1, t2, (long long)planes * Do, Hi, Ho, Wi, lin_scale(Hi, Ho), 1.f, st);
     resize_axis_launch<4>(t2, dx, (long long)planes, Di, Do, (long long)Hi * Wi, lin_scale(Di, Do), mult, st);

@@ -226,6 +226,9 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     # the flow head / its data gradient (16 -> 3, 3 -> 16): plain fp32 FMAs (csrc/conv3dt.hip)
     tiny3d = (tuple(K) == (3, 3, 3) and res is None and ring is None and not _NO_TINY3D
               and (cout_used is None or cout_used == Cout) and bool(lib().dfmir_conv3d_tiny_ok(ctypes.byref(g))))
+    # ... the head itself on the z-marching kernel's FLOW form when the volume is large enough for it (csrc/conv3dm.hip)
+    flow_march = (tiny3d and Cin == 16 and Cout == 3 and act == 0 and act_src is None and x_amax is not None
+                  and not _NO_FLOW_MARCH and Wi % 4 == 0 and bool(lib().dfmir_conv3d_march_ok(ctypes.byref(g))))
     # the first encoder level (2 -> 16, stride 2) from an LDS-staged patch (csrc/conv3dt.hip)
     s2c2 = (not tiny3d and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and res is None and ring is None and not _NO_TINY3D
             and cout_used is None and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
@@ -244,7 +247,13 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         _audit_probe(x5, x_amax, "conv input %s -> %d ch, k=%s" % (tuple(x5.shape), Cout, tuple(K)))
 
     def launch():
-        if tiny3d:
+        if flow_march:
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_march_fwd(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(bias),
+                                               _p(y), _p(slot), None, 0.0, _st()))
+            tag_amax(y, slot)
+            _LAST_CONV_AMAX[0] = slot
+        elif tiny3d:
             slot = amax_slot(x5.device, PROBE_SLOTS)
             check(lib().dfmir_conv3d_tiny_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _p(act_src),
                                               float(act_slope), _st()))
@@ -328,6 +337,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
 _LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
 _NO_TINY3D = _env_on("DFMIR_CONV3D_NO_TINY")  # A/B switch: the flow head on the split kernels
+_NO_FLOW_MARCH = _env_on("DFMIR_CONV3D_NO_FLOW_MARCH")  # A/B switch: the flow head's forward on the fp32-FMA kernel
 _NO_ACTGRAD = _env_on("DFMIR_NO_ACTGRAD")     # A/B switch: LeakyReLU backward always as its own pass
 
 

@@ -3,6 +3,8 @@ plain torch fp32 ops on the same seeded inputs, forward and backward.  Bar: 1e-4
 tensor's max magnitude (fp32; summation order differs), 1e-3 on long-reduction gradients.
 Run on the MI355X box:  python -m pytest tests -m gpu -q
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -452,7 +454,48 @@ def test_conv3d_march_kernel(ops, cfg, nseg):
     assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)     # the epilogue's range probe of its output
 
 
-@pytest.mark.parametrize("cfg", [(32, 16), (16, 16), (16, 32)], ids=["32to16", "16to16", "16to32"])
+@pytest.mark.parametrize("cfg", [(1, 11, 24, 64), (2, 7, 16, 32), (1, 10, 33, 48), (1, 6, 40, 100)],
+                         ids=["11x24x64", "batch2-7x16x32", "ragged-10x33x48", "ragged-6x40x100"])
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_conv3d_flow_head_forward_on_the_march_kernel(ops, cfg, nseg):
+    """The flow head Conv3d(16, 3, 3, padding=1) (torchvoxelmorph/networks.py:1076-1080) on conv3d_march_k's FLOW form
+    (columns = (open plane, channel), one accumulator set, weights pre-rotated per phase of the march): against torch
+    fp64 and against the fp32-FMA kernel it replaces (csrc/conv3dt.hip); range probe of the result."""
+    from dfmir_amd import _lib
+    N, D, H, W = cfg
+    x = C.randn(321, N, 16, D, H, W)
+    w = C.randn(322, 3, 16, 3, 3, 3) / (16 * 27) ** 0.5
+    b = C.randn(323, 3) * 0.1
+    yr = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    xg, wg, bg = x.to(DEV).contiguous(), w.to(DEV), b.to(DEV)
+    wt = ops.weight_pack(wg, 0)
+
+    def run():
+        y = ops.conv_raw(xg, wt, bg, 3, (3, 3, 3), 1, (1, 1, 1), 1, 0, 0, 0.0, (D, H, W), x_amax=ops.absmax(xg))
+        probe = float(ops.amax_of(y).max())
+        torch.cuda.synchronize()
+        return y, probe
+
+    g = ops.DfConvGeom(N, 16, 3, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 0, 0, 0.0)
+    assert ops.lib().dfmir_conv3d_march_ok(ctypes.byref(g))
+    _lib.set_option("DFMIR_MARCH_NSEG", str(nseg))
+    try:
+        y1, probe = run()
+    finally:
+        _lib.set_option("DFMIR_MARCH_NSEG", None)
+    keep = ops._NO_FLOW_MARCH
+    ops._NO_FLOW_MARCH = True
+    try:
+        y0, _ = run()
+    finally:
+        ops._NO_FLOW_MARCH = keep
+    close(y1, yr.float(), rtol=2e-5, what="flow head vs fp64")
+    close(y1, y0, rtol=2e-6, what="march FLOW form vs the fp32-FMA kernel")
+    true = float(y1.abs().max())
+    assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)
+
+
+@pytest.mark.parametrize("cfg", [(32, 16), (16, 16), (16, 32), (16, 3)], ids=["32to16", "16to16", "16to32", "16to3-flow"])
 def test_conv3d_march_writes_every_voxel_and_is_reproducible(ops, cfg):
     """150 launches of conv3d_march_k into NaN-filled outputs (batch 2, 20 x 80 x 96: 30 columns, three z segments, with and
     without the folded LeakyReLU derivative): every voxel written, every launch bit-identical to the first.  This loop is
@@ -469,7 +512,7 @@ def test_conv3d_march_writes_every_voxel_and_is_reproducible(ops, cfg):
     xa = ops.absmax(x)
     g = DfConvGeom(N, Cin, Cout, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 0, 0, 0.0)
     assert lib().dfmir_conv3d_march_ok(ctypes.byref(g))
-    for actg in (False, True):
+    for actg in ((False,) if Cout == 3 else (False, True)):
         ref = None
         for rep in range(75):
             y = torch.full((N, Cout, D, H, W), float("nan"), device=DEV)
@@ -809,9 +852,10 @@ def test_blur_reflect_golden(ops, golden):
         close(out, xr.grad + add.cpu(), what="dpad + skip")
 
 
+@pytest.mark.parametrize("even", [False, True], ids=["odd-width", "even-width"])   # even: the 8- / 16-byte forms
 @pytest.mark.parametrize("nd", [2, 3])
-def test_upcat_cat_scale(ops, nd):
-    sp = (5, 7) if nd == 2 else (3, 4, 5)
+def test_upcat_cat_scale(ops, nd, even):
+    sp = ((6, 8) if even else (5, 7)) if nd == 2 else ((3, 4, 8) if even else (3, 4, 5))
     a = C.randn(41, 2, 6, *sp)
     b = C.randn(42, 2, 3, *[2 * s for s in sp])
     ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
@@ -922,6 +966,38 @@ def test_vecint_resize_golden(ops, golden):
         dbl = ops.resize_linear(x2, [s * 2 for s in shp], 2.0)
         (dbl * C.randn(26, *dbl.shape).to(DEV)).sum().backward()
         close(dbl, g["double_" + tag], what="double"); close(x2.grad, g["ddouble_" + tag], what="ddouble")
+
+
+@pytest.mark.parametrize("shp", [(12, 16, 24), (20, 32), (9, 10, 40)], ids=["3d", "2d", "3d-odd-depth"])
+def test_resize_row_kernels_equal_the_gather_kernels(ops, shp):
+    """resize_rows_fwd_k / resize_w_bwd4_k (csrc/warp.hip: one wave per output row from LDS; four inputs per thread in the
+    adjoint's W pass) evaluate the expressions of the per-thread gather kernels in the same order: BIT-identical results,
+    forward and adjoint, x0.5 and x2 (ResizeTransform, torchvoxelmorph/layers.py:71-97), and equal to F.interpolate."""
+    from dfmir_amd import _lib
+    nd = len(shp)
+    mode = "trilinear" if nd == 3 else "bilinear"
+    for factor in (0.5, 2.0):
+        out_sp = [int(s * factor) for s in shp]
+        x = C.randn(27, 2, nd, *shp).to(DEV)
+        cot = C.randn(28, 2, nd, *out_sp).to(DEV)
+        res = []
+        for off in (None, "1"):
+            _lib.set_option("DFMIR_RESIZE_NO_ROWS", off)
+            try:
+                xg = x.clone().requires_grad_()
+                y = ops.resize_linear(xg, out_sp, factor)
+                (y * cot).sum().backward()
+                torch.cuda.synchronize()
+                res.append((y.detach(), xg.grad))
+            finally:
+                _lib.set_option("DFMIR_RESIZE_NO_ROWS", None)
+        assert torch.equal(res[0][0], res[1][0]), "forward differs from the gather kernel (x%g)" % factor
+        assert torch.equal(res[0][1], res[1][1]), "adjoint differs from the gather kernel (x%g)" % factor
+        xr = x.cpu().double().requires_grad_()
+        yr = factor * F.interpolate(xr, size=out_sp, mode=mode, align_corners=True)
+        (yr * cot.cpu().double()).sum().backward()
+        close(res[0][0], yr.detach().float(), rtol=1e-5, what="resize x%g vs F.interpolate" % factor)
+        close(res[0][1], xr.grad.float(), rtol=1e-5, what="resize x%g adjoint vs autograd" % factor)
 
 
 # ---------------------------------------------------------------------------------------- PatchNCE
