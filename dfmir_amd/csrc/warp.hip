@@ -540,6 +540,50 @@ __global__ __launch_bounds__(256) void resize_w_bwd4_k(const float* __restrict__
   *reinterpret_cast<float4*>(out + row * ilen + ib) = make_float4(mult * acc[0], mult * acc[1], mult * acc[2], mult * acc[3]);
 }
 
+// The W pass from a TABLE: the candidate window of input i and its weights depend on i only, not on the row.  A workgroup
+// builds (first candidate with a non-zero weight, RT_NC weights) for all ilen inputs in LDS once -- with lin_range() /
+// lin_weight(), i.e. the same numbers as the kernels above -- and then walks rows: per input RT_NC independent loads and
+// multiply-adds, zero weights skipped, ascending candidates: bit-identical to resize_axis_bwd_k<1>.  (resize_w_bwd4_k's
+// candidate loop waits for one 4-byte load per trip: 75 us for the x2 adjoint at 160x192x224.)  The host takes this form
+// when every window fits: floor(2 / scale) + 2 <= RT_NC.
+constexpr int RT_NC = 6, RT_MAXW = 512;
+__global__ __launch_bounds__(256) void resize_w_bwd_tab_k(const float* __restrict__ in, float* __restrict__ out,
+                                                          unsigned rows, int ilen, int olen, float scale, float mult) {
+  __shared__ float tw[RT_MAXW][RT_NC];
+  __shared__ int tlo[RT_MAXW];
+  for (int i = threadIdx.x; i < ilen; i += 256) {
+    int lo, hi;
+    lin_range(i, scale, olen, lo, hi);
+    int first = hi;                                       // first candidate with a non-zero weight (hi if there is none)
+    for (int o = hi; o >= lo; --o)
+      if (lin_weight(o, scale, ilen, i) != 0.f) first = o;
+    tlo[i] = first;
+#pragma unroll
+    for (int c = 0; c < RT_NC; ++c) tw[i][c] = (first + c <= hi) ? lin_weight(first + c, scale, ilen, i) : 0.f;
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (unsigned row = blockIdx.x * 4u + (unsigned)wv; row < rows; row += gridDim.x * 4u) {
+    const float* p = in + (long long)row * olen;
+    float* q = out + (long long)row * ilen;
+    for (int i = lane; i < ilen; i += 64) {
+      const int first = tlo[i];
+      float g[RT_NC], w[RT_NC];
+#pragma unroll
+      for (int c = 0; c < RT_NC; ++c) {
+        w[c] = tw[i][c];
+        const int o = first + c < olen ? first + c : olen - 1;
+        g[c] = p[o];
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < RT_NC; ++c)
+        if (w[c] != 0.f) acc += w[c] * g[c];
+      q[i] = mult * acc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-windowed kernels (warp_win.hip): taken whenever W % 4 == 0 in linear mode.
 int df_warp_win_fwd_try(int nd, const float* src, const float* flow, float* out, int B, int C, int D, int H, int W,
@@ -672,7 +716,10 @@ extern "C" int dfmir_resize_bwd_sep(const float* dy, float* dx, int planes, int 
   float* t2 = ws + (((long long)planes * Do * Ho * Wi + 3) & ~3LL);   // [planes][Do][Hi][Wi]
   static DfOptFlag no_rows{"DFMIR_RESIZE_NO_ROWS"};
   const long long wrows = (long long)planes * Do * Ho;
-  if ((Wi & 3) == 0 && !no_rows.get()) {
+  const float wscale = lin_scale(Wi, Wo);
+  if (!no_rows.get() && Wi <= RT_MAXW && wscale > 0.f && (int)(2.f / wscale) + 2 <= RT_NC && wrows < 0x7FFFFFFFLL) {
+    resize_w_bwd_tab_k<<<df_grid(wrows, 4 * 16, 256 * 8), 256, 0, st>>>(dy, t1, (unsigned)wrows, Wi, Wo, wscale, 1.f);
+  } else if ((Wi & 3) == 0 && !no_rows.get()) {
     const long long total = wrows * (Wi / 4);
     if (total < 0xFFFFFFFFLL) resize_w_bwd4_k<unsigned><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, t1, wrows, Wi, Wo, lin_scale(Wi, Wo), 1.f);
     else resize_w_bwd4_k<long long><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dy, t1, wrows, Wi, Wo, lin_scale(Wi, Wo), 1.f);
