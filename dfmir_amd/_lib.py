@@ -59,6 +59,11 @@ _SIGS = {
     "dfmir_conv3d_s2c2_ok": [_GP],
     "dfmir_conv3d_s2c2_fwd": [_GP, P, P, P, P, P, P],
     "dfmir_conv3d_s2c2_wgrad": [_GP, P, P, P, P],
+    "dfmir_conv3d_s2_ok": [_GP],
+    "dfmir_conv3d_s2_fwd": [_GP, P, P, P, P, P, P],
+    "dfmir_conv3d_s2_wgrad": [_GP, P, P, P, P],
+    "dfmir_conv3d_s2_dgrad_ok": [_GP],
+    "dfmir_conv3d_s2_dgrad": [_GP, P, P, P, P],
     "dfmir_conv3d_up_ws_floats": [c_int, c_int],
     "dfmir_conv3d_up_fwd": [P, P, c_int, P, c_int, P, P] + [c_int] * 6 + [P],
     "dfmir_conv3d_up_skip2_fwd": [P, P, c_int, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 7 + [c_float, P],

@@ -232,6 +232,11 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
     # the first encoder level (2 -> 16, stride 2) from an LDS-staged patch (csrc/conv3dt.hip)
     s2c2 = (not tiny3d and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and res is None and ring is None and not _NO_TINY3D
             and cout_used is None and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
+    # the deeper stride-2 encoder levels and their data gradients (fp32 MFMA from LDS-staged patches: csrc/conv3ds2.hip)
+    plain = res is None and ring is None and cout_used is None and act_src is None and tuple(K) == (3, 3, 3) and not _NO_S2
+    s2m = plain and not s2c2 and stride == 2 and dil == 1 and bool(lib().dfmir_conv3d_s2_ok(ctypes.byref(g)))
+    s2d = (plain and stride == 1 and dil == 2 and bias is None and act == 0
+           and bool(lib().dfmir_conv3d_s2_dgrad_ok(ctypes.byref(g))))
     split3d = (not tiny3d and not s2c2 and x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
     if cout_used is not None and not split3d:
@@ -264,6 +269,13 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
             check(lib().dfmir_conv3d_s2c2_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _st()))
             tag_amax(y, slot)
             _LAST_CONV_AMAX[0] = slot
+        elif s2m:
+            slot = amax_slot(x5.device, PROBE_SLOTS)
+            check(lib().dfmir_conv3d_s2_fwd(ctypes.byref(g), _p(x5), _p(w_tcc), _p(bias), _p(y), _p(slot), _st()))
+            tag_amax(y, slot)
+            _LAST_CONV_AMAX[0] = slot
+        elif s2d:
+            check(lib().dfmir_conv3d_s2_dgrad(ctypes.byref(g), _p(x5), _p(w_tcc), _p(y), _st()))
         elif march3d:
             slot = amax_slot(x5.device, PROBE_SLOTS)
             check(lib().dfmir_conv3d_march_fwd(ctypes.byref(g), _p(x5), _p(x_amax), x_amax.numel(), _p(w_tcc), _p(bias),
@@ -315,7 +327,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and dil == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0
                 and not (Cout <= 4 and Cin < 8))          # what csrc/conv3d.hip::df_conv3d_fwd_try takes
         kind = ("conv3x3_" if is3x3 else (("conv3ds_" if split3d else "conv3d_") if is3d else "conv_mfma_")) + size
-        if tiny3d or s2c2:
+        if tiny3d or s2c2 or s2m or s2d:
             kind = "conv3dt_" + size
         if split3d:
             # 16-bit products the kernel ISSUES per algorithmic MAC: 3 (a0b0 + a0b1 + a1b0) x the padding of its tiling --
@@ -337,6 +349,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
 _LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
 _NO_TINY3D = _env_on("DFMIR_CONV3D_NO_TINY")  # A/B switch: the flow head on the split kernels
+_NO_S2 = _env_on("DFMIR_CONV3D_NO_S2")        # A/B switch: the stride-2 encoder levels on the generic gather kernels
 _NO_FLOW_MARCH = _env_on("DFMIR_CONV3D_NO_FLOW_MARCH")  # A/B switch: the flow head's forward on the fp32-FMA kernel
 _NO_ACTGRAD = _env_on("DFMIR_NO_ACTGRAD")     # A/B switch: LeakyReLU backward always as its own pass
 
@@ -445,6 +458,8 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
            and bool(lib().dfmir_conv3d_upwgrad_ok(ctypes.byref(g), parts[0].shape[1])))
     s2c2 = (parts is None and tuple(K) == (3, 3, 3) and stride == 2 and Cin == 2 and not _NO_TINY3D
             and bool(lib().dfmir_conv3d_s2c2_ok(ctypes.byref(g))))
+    s2m = (parts is None and not s2c2 and tuple(K) == (3, 3, 3) and stride == 2 and not _NO_S2
+           and bool(lib().dfmir_conv3d_s2_ok(ctypes.byref(g))))
     # deterministic mode: the kernels add 64-bit fixed-point sums into a scratch, never a bias gradient (its own pass below)
     det = _DetAcc(dw.numel(), Cout if db is not None else 0, N * Do * Ho * Wo, x5 if parts is None else None, x_amax,
                   dy5, dy_amax) if _DET["on"] else None
@@ -457,6 +472,11 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             if db is not None:
                 check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, Do * Ho * Wo, _st()))   # accumulates
             check(lib().dfmir_conv3d_s2c2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+            return
+        if s2m:
+            if db is not None:
+                check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, Do * Ho * Wo, _st()))   # accumulates
+            check(lib().dfmir_conv3d_s2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
             return
         if parts is not None:
             if upw:
@@ -497,7 +517,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
         is3d = (tuple(K) == (3, 3, 3) and stride == 1 and tuple(pad) == (1, 1, 1) and pad_mode == 0 and Cout <= 32
                 and Wi % 4 == 0)                          # csrc/conv3d.hip::df_conv3d_wgrad_try
         flops = 2.0 * N * Cout * Do * Ho * Wo * Cin * T
-        kind = ("wgrad3dt_S" if s2c2 else
+        kind = ("wgrad3dt_S" if (s2c2 or s2m) else
                 ("wgrad3x3_" if is3x3 else (("wgrad3ds_" if split3d else "wgrad3d_") if is3d else "conv_wgrad_")) + size)
         if split3d and is3d and not s2c2 and getattr(prof, "accepts_issued", False):
             # 16-bit products the kernel ISSUES per algorithmic MAC (cf. conv_raw): 3 x the padding of its tiling

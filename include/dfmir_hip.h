@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 12
+#define DFMIR_ABI_VERSION 13
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -52,7 +52,7 @@ const char* dfmir_last_error(void);
  *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (lab builds with -DDFMIR_BUILD_W1 only),
  *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad),
  *     DFMIR_NCC_NO_WH_FUSE, DFMIR_CONV3D_NO_WGRAD_MARCH, DFMIR_WGRAD_MARCH_NSEG=n, DFMIR_NO_TINYVOL,
- *     DFMIR_NO_1X1_WGRAD, DFMIR_CONV3D_NO_FLOW_WGRAD.
+ *     DFMIR_NO_1X1_WGRAD, DFMIR_CONV3D_NO_FLOW_WGRAD, DFMIR_CONV3D_NO_S2, DFMIR_RESIZE_NO_ROWS.
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);
@@ -176,6 +176,18 @@ int dfmir_conv3d_s2c2_ok(const DfConvGeom* g);
 int dfmir_conv3d_s2c2_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y, float* y_amax,
                           void* stream);
 int dfmir_conv3d_s2c2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream);
+/* The deeper stride-2 encoder levels (torchvoxelmorph/networks.py:66-71,1506-1521: ConvBlock(ndims, prev_nf, nf, stride=2),
+ * Cin a multiple of 4, Cout a multiple of 16 up to 64) on fp32 MFMA from LDS-staged patches (csrc/conv3ds2.hip).
+ * _fwd: y = act(conv(x) + bias), y_amax NULL or the 64 accumulating range-probe slots of y; _wgrad: dw_tcc [27][Cin][Cout]
+ * accumulates (honours dfmir_det_begin); _dgrad: g = the geometry of the data-gradient call as a convolution of dy (Cin =
+ * channels of dy, Cout = channels of dx, stride 1, dil 2, pad 1), w_tcc = the dgrad packing (dfmir_weight_pack mode 1),
+ * evaluated in the 8 parity classes of the dx voxels (nothing multiplies an inserted zero). */
+int dfmir_conv3d_s2_ok(const DfConvGeom* g);
+int dfmir_conv3d_s2_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y, float* y_amax,
+                        void* stream);
+int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream);
+int dfmir_conv3d_s2_dgrad_ok(const DfConvGeom* g);
+int dfmir_conv3d_s2_dgrad(const DfConvGeom* g, const float* dy, const float* w_tcc, float* dx, void* stream);
 long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);
 int dfmir_conv3d_up_fwd(const float* a, const float* a_amax, int a_amax_n, const float* w_tcc, int Ktot, float* ws,
                         float* y, int N, int Ca, int Cout, int D, int H, int W, void* stream);

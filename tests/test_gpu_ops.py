@@ -454,6 +454,48 @@ def test_conv3d_march_kernel(ops, cfg, nseg):
     assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)     # the epilogue's range probe of its output
 
 
+@pytest.mark.parametrize("cfg", [(16, 32, 1, 12, 20, 36), (32, 32, 2, 9, 11, 14), (32, 64, 1, 8, 8, 8), (64, 64, 1, 5, 6, 7),
+                                 (16, 32, 1, 20, 48, 56), (8, 16, 2, 6, 10, 33)],
+                         ids=["16to32", "32to32-odd-batch2", "32to64-8cube", "64to64-odd", "16to32-many-patches", "8to16-odd-width"])
+def test_conv3d_stride2_kernels(ops, cfg):
+    """ConvBlock(stride 2) of the U-Net encoder (torchvoxelmorph/networks.py:66-71,1506-1521) on csrc/conv3ds2.hip: forward
+    (+ LeakyReLU, range probe), data gradient in parity classes, weight / bias gradient -- against torch fp64 and against the
+    generic gather kernels (DFMIR_CONV3D_NO_S2); even and odd extents (Do = ceil(Di / 2)), batch 2."""
+    Cin, Cout, N, D, H, W = cfg
+    x = C.randn(331, N, Cin, D, H, W)
+    w = C.randn(332, Cout, Cin, 3, 3, 3) / (Cin * 27) ** 0.5
+    b = C.randn(333, Cout) * 0.1
+    xr, wr, br = (t.double().clone().requires_grad_() for t in (x, w, b))
+    yr = F.leaky_relu(F.conv3d(xr, wr, br, stride=2, padding=1), 0.2)
+    cot = C.randn(334, *yr.shape)
+    (yr * cot.double()).sum().backward()
+    g = ops.DfConvGeom(N, Cin, Cout, D, H, W, yr.shape[2], yr.shape[3], yr.shape[4], 3, 3, 3, 2, 1, 1, 1, 1, 0, 1, 0.2)
+    assert ops.lib().dfmir_conv3d_s2_ok(ctypes.byref(g))
+    res = []
+    for off in (False, True):
+        keep = ops._NO_S2
+        ops._NO_S2 = off
+        try:
+            xg, wg, bg = (t.clone().to(DEV).requires_grad_() for t in (x, w, b))
+            yg = ops.conv(xg, wg, bg, None, 2, 1, 0, 1, 0.2)
+            probe = float(ops.amax_of(yg).max())
+            yg.backward(cot.to(DEV))
+            torch.cuda.synchronize()
+            res.append((yg.detach(), xg.grad, wg.grad, bg.grad, probe))
+        finally:
+            ops._NO_S2 = keep
+    y1, dx1, dw1, db1, probe = res[0]
+    close(y1, yr.detach().float(), rtol=2e-5, what="y vs fp64")
+    close(dx1, xr.grad.float(), rtol=1e-4, what="dx vs fp64")
+    close(dw1, wr.grad.float(), rtol=1e-4, what="dw vs fp64")
+    close(db1, br.grad.float(), rtol=1e-4, what="db vs fp64")
+    close(y1, res[1][0], rtol=2e-5, what="y vs the generic kernel")
+    close(dx1, res[1][1], rtol=1e-4, what="dx vs the generic kernel")
+    close(dw1, res[1][2], rtol=1e-4, what="dw vs the generic kernel")
+    true = float(y1.abs().max())
+    assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)
+
+
 @pytest.mark.parametrize("cfg", [(1, 11, 24, 64), (2, 7, 16, 32), (1, 10, 33, 48), (1, 6, 40, 100)],
                          ids=["11x24x64", "batch2-7x16x32", "ragged-10x33x48", "ragged-6x40x100"])
 @pytest.mark.parametrize("nseg", [1, 3])
