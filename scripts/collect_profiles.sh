@@ -69,3 +69,10 @@ bash scripts/prof_cmd.sh "python $R/scripts/bench_conv1x1.py" conv1x1_wgrad_k co
 ONLY=16-3 bash scripts/prof_cmd.sh "python $R/scripts/bench_conv3d.py" conv3d_flow_wgrad_k flow > $O/pmc_flow_wgrad.txt 2>&1
 rm -rf $R/gpurun_out/prof_conv1x1 $R/gpurun_out/prof_flow
 
+# ---- round 6, second half: the 3-D step's switches (flow head on the march kernel, stride-2 levels, resize by rows) under the
+# graph (bench.py's also_3d / also_3d_128), the flow head / helper micro-benchmarks, the HBM-side bytes of every kernel of the step
+for sw in NONE DFMIR_CONV3D_NO_S2 DFMIR_CONV3D_NO_FLOW_MARCH DFMIR_RESIZE_NO_ROWS NONE DFMIR_CONV3D_NO_S2 DFMIR_CONV3D_NO_FLOW_MARCH DFMIR_RESIZE_NO_ROWS; do
+  env $sw=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pil-workers 0 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', '3-D 160x192x224 %.3f ms | 128^3 %.3f ms | 2-D %.2f ms' % (r['also_3d']['ms_per_step'], r['also_3d_128']['ms_per_step'], r['ms_per_step']))"
+done > $O/ab_3d_round6.txt 2>&1
+python scripts/bench_flow_head.py 2>&1 | grep -v amdgpu.ids > $O/bench_flow_head.txt
+ONLY=160x192 bash scripts/prof_cmd.sh "python $R/scripts/bench_3d.py" "" step3d > $O/pmc_step3d.txt 2>&1; rm -rf $R/gpurun_out/prof_step3d
