@@ -411,7 +411,9 @@ extern "C" int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const 
   k.npatch = (long long)g->N * g->Do * k.ny * k.nx;
   long long want = 512 / k.ngroups;                          // two workgroups per CU
   if (want < 1) want = 1;
-  long long maxs = (k.npatch + 1) / 2;                       // at least two patches per workgroup (the prefetch)
+  static DfOptInt minp_o{"DFMIR_S2W_MINP", 2};               // patches per workgroup at least (every workgroup ends in 27 Cin Cout atomics)
+  const long long minp = minp_o.get() > 0 ? minp_o.get() : 2;
+  long long maxs = (k.npatch + minp - 1) / minp;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   k.per_block = (k.npatch + want - 1) / want;
