@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256) void conv3d_s2_fwd_k(const float* __restrict__
   }
 }
 
+// Below this many output voxels per image (dgrad: voxels of dy) the layers stay where they were: the deepest levels of the
+// 6-level U-Net (8^3, 4^3, 2^3) are one or two patches here -- a single workgroup walking all of Cin x 27 taps -- and
+// conv_tinyvol_k's one-voxel workgroups win (128^3 step with them on these kernels: 3.16 ms, without: 3.06).
+constexpr long long S2_MIN_VOX = 512;
 bool s2m_off() {
   static DfOptFlag o{"DFMIR_CONV3D_NO_S2"};
   return o.get();
@@ -196,7 +200,7 @@ bool s2m_off() {
 bool s2m_geom_ok(const DfConvGeom* g) {
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 2 && g->dil == 1 && g->pd == 1 && g->ph == 1 && g->pw == 1 &&
          g->pad_mode == 0 && (g->act == 0 || g->act == 1) && g->Di > 1 && g->Do == (g->Di + 1) / 2 && g->Ho == (g->Hi + 1) / 2 &&
-         g->Wo == (g->Wi + 1) / 2 && g->Cin >= 4 && (g->Cin % 4) == 0 && g->Cout >= 16 && (g->Cout % 16) == 0 && g->Cout <= 64 &&
+         g->Wo == (g->Wi + 1) / 2 && (long long)g->Do * g->Ho * g->Wo > S2_MIN_VOX && g->Cin >= 4 && (g->Cin % 4) == 0 && g->Cout >= 16 && (g->Cout % 16) == 0 && g->Cout <= 64 &&
          (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Di * g->Hi * g->Wi * 4 < 0x7FFFFFFFLL;
 }
 }  // namespace
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict
                                                          float* __restrict__ dwt, S2wP k) {
   constexpr int PY = 4, PX = 16, BP = PY * PX, HY = 2 * PY + 1, HX = 2 * PX + 1;
   constexpr int NPOS = 3 * HY * HX;                 // 891 (odd: see conv3d_s2_fwd_k)
+  static_assert(256 / HX + 1 < HY, "one row carry per element step");
   constexpr int DSTR = (NCT == 1) ? 16 : ((16 * NCT) % 32 == 16 ? 16 * NCT : 16 * NCT + 16);
   constexpr int CGMAX = 16;
   constexpr int NXL = (CGMAX * NPOS + 255) / 256;   // halo loads per thread (56)
@@ -304,17 +309,23 @@ __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict
         const_cast<float*>(dy + (long long)n_ * k.Cout * So), 0, (unsigned)(k.Cout * So) * 4u, 0x00020000);   \
     int tq_ = tid;                                                                               \
     asm volatile("" : "+v"(tq_));   /* opaque: keeps the address decode inside the patch loop */  \
+    /* element e = tid + 256 i of the group's [c][hz][hy][hx] halo image; its coordinates are ADVANCED (256 = 7 rows of 33 */ \
+    /* + 25), not decoded: four divisions per element were 2 200 instructions per thread and patch, more than its MFMAs   */ \
+    int hx_ = tq_ % HX, r0_ = tq_ / HX, hy_ = r0_ % HY, r1_ = r0_ / HY, hz_ = r1_ % 3, c_ = r1_ / 3;  \
     _Pragma("unroll") for (int i = 0; i < NXL; ++i) {                                            \
-      const int e = tq_ + 256 * i;                                                               \
       unsigned o = S2_OOB;                                                                       \
-      if (e < nelem) {                                                                           \
-        const int c = e / NPOS, pos = e - c * NPOS;                                              \
-        const int hx = pos % HX, t = pos / HX, hy = t % HY, hz = t / HY;                         \
-        const int gz = 2 * z_ - 1 + hz, gy = 2 * y0_ - 1 + hy, gx = 2 * x0_ - 1 + hx;            \
-        if ((unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
-          o = (unsigned)c * si4 + (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                   \
+      {                                                                                          \
+        const int gz = 2 * z_ - 1 + hz_, gy = 2 * y0_ - 1 + hy_, gx = 2 * x0_ - 1 + hx_;         \
+        if (c_ < cgn && (unsigned)gz < (unsigned)k.D && (unsigned)gy < (unsigned)k.H && (unsigned)gx < (unsigned)k.W) \
+          o = (unsigned)c_ * si4 + (unsigned)((gz * k.H + gy) * k.W + gx) * 4u;                  \
       }                                                                                          \
       rxv[i] = __builtin_amdgcn_raw_buffer_load_b32(xs_, o, 0, 0);                               \
+      hx_ += 256 % HX;                                                                           \
+      const int cx_ = hx_ >= HX ? 1 : 0;                                                         \
+      hx_ -= cx_ * HX;                                                                           \
+      hy_ += 256 / HX + cx_;                                                                     \
+      if (hy_ >= HY) { hy_ -= HY; ++hz_; }                                                       \
+      if (hz_ >= 3) { hz_ -= 3; ++c_; }                                                          \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < ND4; ++i) {                                            \
       const int e = tid + 256 * i;              /* (co, py, x4): x4 fastest */                   \
@@ -612,7 +623,7 @@ bool s2d_geom_ok(const DfConvGeom* g) {
   // the dgrad call of a 3x3x3 stride-2 pad-1 convolution: in = dy, out = dx with Do = the forward input's size
   return g->KD == 3 && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->dil == 2 && g->pd == 1 && g->ph == 1 && g->pw == 1 &&
          g->pad_mode == 0 && g->act == 0 && g->Di > 1 && g->Di == (g->Do + 1) / 2 && g->Hi == (g->Ho + 1) / 2 &&
-         g->Wi == (g->Wo + 1) / 2 && g->Cin >= 8 && (g->Cin % 4) == 0 && g->Cout >= 16 && (g->Cout % 16) == 0 && g->Cout <= 64 &&
+         g->Wi == (g->Wo + 1) / 2 && (long long)g->Di * g->Hi * g->Wi > S2_MIN_VOX && g->Cin >= 8 && (g->Cin % 4) == 0 && g->Cout >= 16 && (g->Cout % 16) == 0 && g->Cout <= 64 &&
          (long long)(g->Cin > g->Cout ? g->Cin : g->Cout) * g->Do * g->Ho * g->Wo * 4 < 0x7FFFFFFFLL;
 }
 }  // namespace

@@ -454,9 +454,9 @@ def test_conv3d_march_kernel(ops, cfg, nseg):
     assert probe >= true and probe <= true * (1 + 1e-6), (probe, true)     # the epilogue's range probe of its output
 
 
-@pytest.mark.parametrize("cfg", [(16, 32, 1, 12, 20, 36), (32, 32, 2, 9, 11, 14), (32, 64, 1, 8, 8, 8), (64, 64, 1, 5, 6, 7),
-                                 (16, 32, 1, 20, 48, 56), (8, 16, 2, 6, 10, 33)],
-                         ids=["16to32", "32to32-odd-batch2", "32to64-8cube", "64to64-odd", "16to32-many-patches", "8to16-odd-width"])
+@pytest.mark.parametrize("cfg", [(16, 32, 1, 12, 20, 36), (32, 32, 2, 17, 19, 22), (32, 64, 1, 16, 16, 18), (64, 64, 1, 15, 18, 17),
+                                 (16, 32, 1, 20, 48, 56), (8, 16, 2, 12, 18, 33)],
+                         ids=["16to32", "32to32-odd-batch2", "32to64", "64to64-odd", "16to32-many-patches", "8to16-odd-width"])
 def test_conv3d_stride2_kernels(ops, cfg):
     """ConvBlock(stride 2) of the U-Net encoder (torchvoxelmorph/networks.py:66-71,1506-1521) on csrc/conv3ds2.hip: forward
     (+ LeakyReLU, range probe), data gradient in parity classes, weight / bias gradient -- against torch fp64 and against the
@@ -471,6 +471,8 @@ def test_conv3d_stride2_kernels(ops, cfg):
     (yr * cot.double()).sum().backward()
     g = ops.DfConvGeom(N, Cin, Cout, D, H, W, yr.shape[2], yr.shape[3], yr.shape[4], 3, 3, 3, 2, 1, 1, 1, 1, 0, 1, 0.2)
     assert ops.lib().dfmir_conv3d_s2_ok(ctypes.byref(g))
+    g_small = ops.DfConvGeom(N, Cin, Cout, 8, 8, 8, 4, 4, 4, 3, 3, 3, 2, 1, 1, 1, 1, 0, 1, 0.2)
+    assert not ops.lib().dfmir_conv3d_s2_ok(ctypes.byref(g_small))     # the deepest levels stay on conv_tinyvol_k
     res = []
     for off in (False, True):
         keep = ops._NO_S2
