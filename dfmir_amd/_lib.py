@@ -61,7 +61,7 @@ _SIGS = {
     "dfmir_conv3d_s2c2_wgrad": [_GP, P, P, P, P],
     "dfmir_conv3d_s2_ok": [_GP],
     "dfmir_conv3d_s2_fwd": [_GP, P, P, P, P, P, P],
-    "dfmir_conv3d_s2_wgrad": [_GP, P, P, P, P],
+    "dfmir_conv3d_s2_wgrad": [_GP, P, P, P, P, P],
     "dfmir_conv3d_s2_dgrad_ok": [_GP],
     "dfmir_conv3d_s2_dgrad": [_GP, P, P, P, P],
     "dfmir_conv3d_up_ws_floats": [c_int, c_int],

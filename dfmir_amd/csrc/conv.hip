@@ -800,11 +800,17 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
   DF_ARG_CHECK(check_geom(g) == 0 && x && w_tcc && y);
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)g->N * g->Do * g->Ho * g->Wo;
+  static DfOptFlag tinyvol_o{"DFMIR_NO_TINYVOL"};             // A/B: the deepest levels on conv_mfma_k
+  // chosen by the PER-IMAGE volume, 3-D only: the kernel a sample runs on must not depend on the batch it arrives in
+  // (tests/test_gpu_models.py::test_batch16_equals_per_sample_runs), and the 2-D deep levels keep their tuned path.
+  // Ahead of the fp32-MFMA 3x3x3 kernel too: its 2 x 8 x 16 patches are one or two workgroups at these volumes (0.14-0.27 ms)
+  const bool tinyvol = !use_generic_only() && g->Do > 1 && (long long)g->Do * g->Ho * g->Wo <= 512 && P <= 8192 && g->Cout <= 64 &&
+                       g->Cout > 4 && !tinyvol_o.get();
   if (!use_generic_only()) {
     int rc = 0;
     if (df_conv3x3_split_fwd_try(g, x, x_amax, x_n, w_tcc, bias, nullptr, nullptr, 0, y, st, &rc)) return rc;
     if (df_conv3x3_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
-    if (df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
+    if (!tinyvol && df_conv3d_fwd_try(g, x, w_tcc, bias, y, st, &rc)) return rc;
   }
   if (g->Cout <= 4) {
     const unsigned grid = (unsigned)((P + 255) / 256);
@@ -814,10 +820,7 @@ static int conv_fwd_impl(const DfConvGeom* g, const float* x, const float* x_ama
     DF_LAUNCH_CHECK();
     return 0;
   }
-  static DfOptFlag tinyvol_o{"DFMIR_NO_TINYVOL"};             // A/B: the deepest levels on conv_mfma_k
-  // chosen by the PER-IMAGE volume, 3-D only: the kernel a sample runs on must not depend on the batch it arrives in
-  // (tests/test_gpu_models.py::test_batch16_equals_per_sample_runs), and the 2-D deep levels keep their tuned path
-  if (!use_generic_only() && g->Do > 1 && (long long)g->Do * g->Ho * g->Wo <= 512 && P <= 8192 && g->Cout <= 64 && !tinyvol_o.get()) {
+  if (tinyvol) {
     if (g->Cout <= 8) conv_tinyvol_k<8><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else if (g->Cout <= 16) conv_tinyvol_k<16><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);
     else if (g->Cout <= 32) conv_tinyvol_k<32><<<(unsigned)P, 256, 0, st>>>(x, w_tcc, bias, y, *g);

@@ -245,7 +245,7 @@ struct S2wP {
 
 template <int NCT, int RT>
 __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ dwt, S2wP k) {
+                                                         float* __restrict__ dwt, float* __restrict__ db, S2wP k) {
   constexpr int PY = 4, PX = 16, BP = PY * PX, HY = 2 * PY + 1, HX = 2 * PX + 1;
   constexpr int NPOS = 3 * HY * HX;                 // 891 (odd: see conv3d_s2_fwd_k)
   static_assert(256 / HX + 1 < HY, "one row carry per element step");
@@ -290,6 +290,11 @@ __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[r][c][e] = 0.f;
 
+  // bias gradient (db != NULL, channel group 0): wave 0 sums the dY operands it reads anyway (every wave reads them all)
+  const bool do_db = db != nullptr && grp == 0 && wid == 0;
+  float bsum[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) bsum[c] = 0.f;
   const unsigned si4 = (unsigned)Si * 4u, so4 = (unsigned)So * 4u;
   unsigned rxv[NXL];
   u32x4_s2 rd[ND4];
@@ -373,6 +378,10 @@ __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict
       float b[NCT];
 #pragma unroll
       for (int c = 0; c < NCT; ++c) b[c] = Ds[kp * DSTR + c * 16 + l15];
+      if (do_db) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bsum[c] += b[c];
+      }
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         const float a = Xs[aoff[r] + pp];
@@ -405,13 +414,24 @@ __global__ __launch_bounds__(256) void conv3d_s2_wgrad_k(const float* __restrict
       }
     }
   }
+  if (do_db) {                                   // lane (l15 = channel, lk = voxel mod 4): fold the four voxel classes
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int co = c * 16 + l15;
+      if (lk == 0 && co < k.Cout) df_acc(db, co, v, k.fx);
+    }
+  }
 }
 }  // namespace
 
 const float* df_det_fx();
 
-// dw_tcc[27][Cin][Cout] += the weight gradient of the stride-2 convolution y = conv(x) for the output gradient dy.
-extern "C" int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream) {
+// dw_tcc[27][Cin][Cout] += the weight gradient of the stride-2 convolution y = conv(x) for the output gradient dy;
+// db (may be NULL) [Cout] += the bias gradient, summed from the dY tiles as they pass (no separate pass over dY).
+extern "C" int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, float* db, void* stream) {
   DF_ARG_CHECK(g && x && dy && dw_tcc && dfmir_conv3d_s2_ok(g));
   S2wP k{};
   k.fx = df_det_fx();
@@ -432,10 +452,10 @@ extern "C" int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const 
   dim3 grid(nbx, (unsigned)k.ngroups);
   hipStream_t st = (hipStream_t)stream;
   // 27 cg <= 432 rows = 27 row tiles: 7 per wave
-  if (g->Cout <= 16) conv3d_s2_wgrad_k<1, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
-  else if (g->Cout <= 32) conv3d_s2_wgrad_k<2, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
-  else if (g->Cout <= 48) conv3d_s2_wgrad_k<3, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
-  else conv3d_s2_wgrad_k<4, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, k);
+  if (g->Cout <= 16) conv3d_s2_wgrad_k<1, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, db, k);
+  else if (g->Cout <= 32) conv3d_s2_wgrad_k<2, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, db, k);
+  else if (g->Cout <= 48) conv3d_s2_wgrad_k<3, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, db, k);
+  else conv3d_s2_wgrad_k<4, 7><<<grid, 256, 0, st>>>(x, dy, dw_tcc, db, k);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -239,6 +239,11 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
            and bool(lib().dfmir_conv3d_s2_dgrad_ok(ctypes.byref(g))))
     split3d = (not tiny3d and not s2c2 and x_amax is not None and tuple(K) == (3, 3, 3) and res is None and ring is None
                and bool(lib().dfmir_conv3d_split_ok(ctypes.byref(g))))
+    # <= 512 output voxels per image (the deepest levels of the 6-level U-Net: 8^3, 4^3, 2^3): a split launch costs its
+    # 45-80 us of prologue whatever the volume; conv_tinyvol_k (behind dfmir_conv_fwd_scaled) takes 20-30
+    if (split3d and cout_used is None and not _NO_TINYVOL and Cout <= 64
+            and out_sp[0] * out_sp[1] * out_sp[2] <= 512 and N * out_sp[0] * out_sp[1] * out_sp[2] <= 8192):
+        split3d = False
     if cout_used is not None and not split3d:
         cout_used = None                                     # only the split 3-D kernel computes a channel subset
     # the full-resolution layers with Cin x Cout <= 512: the z-marching kernel (csrc/conv3dm.hip)
@@ -349,6 +354,7 @@ def conv_raw(x5, w_tcc, bias, Cout, K, stride, pad, dil, pad_mode, act, slope, o
 
 _LAST_ACTGRAD = [False]     # did the last conv_raw() apply an activation derivative in its epilogue?
 _NO_TINY3D = _env_on("DFMIR_CONV3D_NO_TINY")  # A/B switch: the flow head on the split kernels
+_NO_TINYVOL = _env_on("DFMIR_NO_TINYVOL")     # A/B switch (also read by the library): no conv_tinyvol_k
 _NO_S2 = _env_on("DFMIR_CONV3D_NO_S2")        # A/B switch: the stride-2 encoder levels on the generic gather kernels
 _NO_FLOW_MARCH = _env_on("DFMIR_CONV3D_NO_FLOW_MARCH")  # A/B switch: the flow head's forward on the fp32-FMA kernel
 _NO_ACTGRAD = _env_on("DFMIR_NO_ACTGRAD")     # A/B switch: LeakyReLU backward always as its own pass
@@ -474,9 +480,7 @@ def conv_wgrad_raw(x5, dy5, K, stride, pad, pad_mode, out=None, x_amax=None, dy_
             check(lib().dfmir_conv3d_s2c2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
             return
         if s2m:
-            if db is not None:
-                check(lib().dfmir_bias_grad(_p(dy5), _p(db), dy5.shape[0], Cout, Do * Ho * Wo, _st()))   # accumulates
-            check(lib().dfmir_conv3d_s2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _st()))
+            check(lib().dfmir_conv3d_s2_wgrad(ctypes.byref(g), _p(x5), _p(dy5), _p(dw), _p(db), _st()))   # db fused
             return
         if parts is not None:
             if upw:

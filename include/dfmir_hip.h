@@ -179,13 +179,13 @@ int dfmir_conv3d_s2c2_wgrad(const DfConvGeom* g, const float* x, const float* dy
 /* The deeper stride-2 encoder levels (torchvoxelmorph/networks.py:66-71,1506-1521: ConvBlock(ndims, prev_nf, nf, stride=2),
  * Cin a multiple of 4, Cout a multiple of 16 up to 64) on fp32 MFMA from LDS-staged patches (csrc/conv3ds2.hip).
  * _fwd: y = act(conv(x) + bias), y_amax NULL or the 64 accumulating range-probe slots of y; _wgrad: dw_tcc [27][Cin][Cout]
- * accumulates (honours dfmir_det_begin); _dgrad: g = the geometry of the data-gradient call as a convolution of dy (Cin =
+ * and db [Cout] (may be NULL) accumulate (honours dfmir_det_begin); _dgrad: g = the geometry of the data-gradient call as a convolution of dy (Cin =
  * channels of dy, Cout = channels of dx, stride 1, dil 2, pad 1), w_tcc = the dgrad packing (dfmir_weight_pack mode 1),
  * evaluated in the 8 parity classes of the dx voxels (nothing multiplies an inserted zero). */
 int dfmir_conv3d_s2_ok(const DfConvGeom* g);
 int dfmir_conv3d_s2_fwd(const DfConvGeom* g, const float* x, const float* w_tcc, const float* bias, float* y, float* y_amax,
                         void* stream);
-int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, void* stream);
+int dfmir_conv3d_s2_wgrad(const DfConvGeom* g, const float* x, const float* dy, float* dw_tcc, float* db, void* stream);
 int dfmir_conv3d_s2_dgrad_ok(const DfConvGeom* g);
 int dfmir_conv3d_s2_dgrad(const DfConvGeom* g, const float* dy, const float* w_tcc, float* dx, void* stream);
 long long dfmir_conv3d_up_ws_floats(int Ca, int Cout);

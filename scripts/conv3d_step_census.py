@@ -3,13 +3,16 @@ sys.path.insert(0, os.getcwd())
 import torch
 from dfmir_amd import ops
 from dfmir_amd.registration3d import Registration3DModel
-shape=(160,192,224)
+PLUGIN = [[16, 32, 32, 64, 64, 64], [64, 64, 64, 32, 32, 32, 16]]
+small = os.environ.get("CENSUS") == "128"          # CENSUS=128: the 128^3 volume with the plugin's 6-level features
+shape=(128,128,128) if small else (160,192,224)
 torch.manual_seed(0)
-m=Registration3DModel(shape,None)
+m=Registration3DModel(shape, PLUGIN if small else None)
 A=torch.rand(1,1,*shape,device="cuda")*2-1; B=0.5*A+0.5*(torch.rand(1,1,*shape,device="cuda")*2-1)
 recs=[]
 def prof(kind, flops, launch):
     s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()                                   # (an eager step is host-bound at 128^3: time each launch alone)
     s.record(); launch(); e.record(); recs.append((kind,flops,s,e))
 for _ in range(2):
     m.set_input({"A":A,"B":B}); m.optimize_parameters()
