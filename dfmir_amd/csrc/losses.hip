@@ -642,6 +642,54 @@ __global__ __launch_bounds__(256) void ncc_fields_boxwh_k(const float* __restric
     }
   }
 }
+// The backward's last two passes in one: the box sums of the three gradient fields along the strided axis (D) as
+// box_axis_march_k forms them -- same ring, same order of additions -- and, per output, the combination of ncc_combine_k.
+// The three summed fields (82 MB written and read back at 160x192x224) are never stored; results are bit-identical.
+template <int R, int SEG>
+__global__ __launch_bounds__(256) void ncc_boxd_combine_k(const float* __restrict__ in, const float* __restrict__ I,
+                                                          const float* __restrict__ J, float* __restrict__ dI,
+                                                          long long N, long long stride, int len) {
+  constexpr int WN = 2 * R + 1;
+  static_assert(SEG % WN == 0, "segment = whole turns of the ring");
+  const long long nline = N / len;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nseg = (len + SEG - 1) / SEG;
+  if (t >= nline * nseg) return;
+  const int sg = (int)(t / nline);
+  const long long l = t - (long long)sg * nline;
+  const long long outer = l / stride, inner = l - outer * stride;
+  const long long base = outer * len * stride + inner;
+  const float* p = in + base;
+  const int c0 = sg * SEG;
+  float ring[3][WN];
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int j = 0; j < WN - 1; ++j) {
+      const int cc = c0 - R + j;
+      ring[f][j] = ((unsigned)cc < (unsigned)len) ? p[(long long)f * N + (long long)cc * stride] : 0.f;
+    }
+  for (int k0 = 0; k0 < SEG; k0 += WN) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int c = c0 + k0 + j;
+      if (c < len) {
+        const int cc = c + R;
+        float sacc[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          ring[f][(WN - 1 + j) % WN] = (cc < len) ? p[(long long)f * N + (long long)cc * stride] : 0.f;
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < WN; ++w) a += ring[f][w];
+          sacc[f] = a;
+        }
+        const long long i = base + (long long)c * stride;
+        dI[i] = J[i] * sacc[0] + 2.f * I[i] * sacc[1] + sacc[2];
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void ncc_combine_k(const float* __restrict__ I, const float* __restrict__ J,
                                                      const float* __restrict__ bx, float* __restrict__ dI,
                                                      long long N) {
@@ -845,6 +893,14 @@ extern "C" int dfmir_ncc_bwd_m(const float* I, const float* J, const float* mask
     DF_LAUNCH_CHECK();
   }
   const float* fin = tmp;
+  static DfOptFlag nofuse_d{"DFMIR_NCC_NO_D_FUSE"};          // A/B: the D pass and the combination as separate launches
+  if (D > 1 && r == 4 && (long long)H * W > 1 && !nofuse_d.get()) {
+    constexpr int SEG = 36;
+    const long long thr = ((long long)B * H * W) * ((D + SEG - 1) / SEG);
+    ncc_boxd_combine_k<4, SEG><<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(tmp, I, J, dI, N, (long long)H * W, D);
+    DF_LAUNCH_CHECK();
+    return 0;
+  }
   if (D > 1) {
     box_axis_launch(tmp, tmp2, 3, N, (long long)H * W, D, r, st);
     DF_LAUNCH_CHECK();

@@ -1208,6 +1208,24 @@ def test_ncc_fused_box_passes_match_the_separate_ones(ops):
         set_option("DFMIR_NCC_NO_WH_FUSE", None)
     close(res[0][0], res[1][0], rtol=1e-6, what="ncc fused vs separate")
     close(res[0][1], res[1][1], rtol=2e-5, what="dncc fused vs separate")
+    # the backward's D pass + combination in one launch (ncc_boxd_combine_k): the same ring and order of additions as
+    # box_axis_march_k, the same expression as ncc_combine_k -- BIT-identical to the two launches, depth of one segment,
+    # of several segments (D = 6, 80) and with a mask
+    for shape, masked in (((2, 1, 6, 70, 150), False), ((1, 1, 80, 20, 24), False), ((1, 1, 40, 12, 20), True)):
+        I2 = C.rand(173, *shape)
+        J2 = (0.6 * I2 + 0.4 * C.rand(174, *shape)).to(DEV)
+        mask = (C.rand(175, *shape) > 0.3).float().to(DEV) if masked else None
+        out = []
+        try:
+            for off in (None, "1"):
+                set_option("DFMIR_NCC_NO_D_FUSE", off)
+                Ig = I2.clone().to(DEV).requires_grad_()
+                l = ops.ncc_loss(Ig, J2, 9, 1e-5, mask=mask) if masked else ops.ncc_loss(Ig, J2, 9, 1e-5)
+                l.backward()
+                out.append(Ig.grad.clone())
+        finally:
+            set_option("DFMIR_NCC_NO_D_FUSE", None)
+        assert torch.equal(out[0], out[1]), "fused D pass differs from box_axis_march_k + ncc_combine_k %s" % (shape,)
 
 
 def test_adam_matches_torch(ops):
