@@ -263,6 +263,16 @@ def bench_3d(dev, pmc, shape=(160, 192, 224), feats=None, gflop_step=2393.0, lab
         m.optimize_parameters()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if dt * steps < 0.25 and graphed:
+        # a 3 ms step timed over 20 steps is 60 ms of wall clock: one host hiccup is 10 % (3.28 ms on the line of a run whose
+        # A/B processes measured 2.81 three times).  Short timed regions are repeated over five times the steps.
+        steps *= 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.set_input({"A": A, "B": B})
+            m.optimize_parameters()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
     timer.enabled = False
     if graphed:
         m._graph['force_eager'] = True
