@@ -155,6 +155,8 @@ int dfmir_conv3d_split_is_pair(int cout_used);
  * arithmetic as dfmir_conv3d_split_fwd (scaled fp16x2 products, fp32 accumulation); x_amax as there; y_amax
  * (DFMIR_PROBE_SLOTS floats, zeroed by the caller, or NULL) receives the range probe of y.  act_src != NULL (g->act == 0):
  * the result is multiplied by the LeakyReLU derivative act_src > 0 ? 1 : act_slope, as dfmir_conv3d_split_fwd_actgrad.
+ * Cin = 16, Cout = 3, g->act == 0, act_src == NULL: the flow head (torchvoxelmorph/networks.py:1076-1080) in the FLOW form --
+ * MFMA columns = (open output plane, channel), one accumulator set for the three planes of the march.
  * Needs W % 4 == 0 and 16-byte aligned x, y, act_src, w_tcc; dfmir_conv3d_march_ok says whether the geometry is taken
  * (0 under DFMIR_CONV3D_NO_MARCH / DFMIR_CONV3D_FP32 / DFMIR_CONV_FP32). */
 int dfmir_conv3d_march_ok(const DfConvGeom* g);
