@@ -132,6 +132,7 @@ _SIGS = {
     "dfmir_patchnce_bwd": [P, P, P, P, c_longlong, c_int, c_int, c_float, P],
     "dfmir_masked_l1_fwd": [P, P, P, c_float, P, P, c_longlong, P],
     "dfmir_masked_l1_bwd": [P, P, P, c_float, P, P, P, P, c_longlong, P],
+    "dfmir_flow_smooth_ws_floats": [],
     "dfmir_flow_smooth_fwd": [P, P, P] + [c_int] * 5 + [P],
     "dfmir_flow_smooth_bwd": [P, P, P] + [c_int] * 5 + [P],
     "dfmir_flow_smooth_fwd_p": [P, P, P] + [c_int] * 6 + [P],
@@ -186,6 +187,7 @@ def lib():
         h.dfmir_conv3d_up_ws_floats.restype = c_longlong
         h.dfmir_conv3d_up_dgrad_ws_floats.restype = c_longlong
         h.dfmir_conv3d_upwgrad_ws_floats.restype = c_longlong
+        h.dfmir_flow_smooth_ws_floats.restype = c_longlong
         h.dfmir_warp_bwd_own_ws_floats.restype = c_longlong
         h.dfmir_resize_bwd_ws_floats.restype = c_longlong
         h.dfmir_last_error.argtypes = []

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void masked_l1_bwd_k(const float* __restrict__
 // row with wave-uniform arithmetic, lanes run along x -- no per-element divisions (they used to cost more than the
 // memory traffic), every load a contiguous run.  <= 2048 workgroups: each ends in three same-address atomics.
 // L1: sum |d| instead of sum d^2 (Grad_Loss / vxm Grad with penalty 'l1': util/losses.py:92-117, torchvoxelmorph/losses.py:102-112)
+constexpr int FS_PART = 8, FS_MAXWG = 2048;     // ws: [0..7] the sums, then 3 x FS_MAXWG per-workgroup partials
 template <bool L1>
 __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict__ f, float* __restrict__ ws,
                                                          long long planes, int D, int H, int W, int RB) {
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(256) void flow_smooth_fwd_k(const float* __restrict
   sd = block_sum(sd, sm);
   sh = block_sum(sh, sm);
   sw = block_sum(sw, sm);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[0], sd);
-    atomicAdd(&ws[1], sh);
-    atomicAdd(&ws[2], sw);
+  if (threadIdx.x == 0) {          // per-workgroup partials (flow_smooth_fin_k adds them in index order)
+    ws[FS_PART + blockIdx.x] = sd;
+    ws[FS_PART + FS_MAXWG + blockIdx.x] = sh;
+    ws[FS_PART + 2 * FS_MAXWG + blockIdx.x] = sw;
   }
 }
 // W % 4 == 0: a thread owns 16-B quads (grid-stride), one float4 load each for the quad, its y + 1 and z + 1 neighbours and
@@ -134,10 +135,10 @@ __global__ __launch_bounds__(1024) void flow_smooth_fwd_v4_k(const float* __rest
   sd = block_sum(sd, sm);
   sh = block_sum(sh, sm);
   sw = block_sum(sw, sm);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[0], sd);
-    atomicAdd(&ws[1], sh);
-    atomicAdd(&ws[2], sw);
+  if (threadIdx.x == 0) {          // per-workgroup partials (flow_smooth_fin_k adds them in index order)
+    ws[FS_PART + blockIdx.x] = sd;
+    ws[FS_PART + FS_MAXWG + blockIdx.x] = sh;
+    ws[FS_PART + 2 * FS_MAXWG + blockIdx.x] = sw;
   }
 }
 template <int TPR>
@@ -174,7 +175,17 @@ __global__ __launch_bounds__(256) void flow_smooth_bwd_v4_k(const float* __restr
     *reinterpret_cast<float4*>(df + (long long)row * W + 4 * q) = o;
   }
 }
-__global__ void flow_smooth_fin_k(const float* ws, float* out, float cd, float ch, float cw, float nd) {
+__global__ __launch_bounds__(256) void flow_smooth_fin_k(float* ws, float* out, float cd, float ch, float cw, float nd, int nwg) {
+  // the partials in a FIXED order (thread t adds slots t, t + 256, ...; the block tree is the same every run): the loss is
+  // bit-reproducible, and 512 x 3 same-address atomics at the end of the forward kernel were a third of its 46 us
+  __shared__ float sm[17];
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nwg; i += 256) {
+    a += ws[FS_PART + i]; b += ws[FS_PART + FS_MAXWG + i]; c += ws[FS_PART + 2 * FS_MAXWG + i];
+  }
+  a = block_sum(a, sm); b = block_sum(b, sm); c = block_sum(c, sm);
+  if (threadIdx.x) return;
+  ws[0] = a; ws[1] = b; ws[2] = c;
   float s = 0.f;
   if (cd > 0.f) s += ws[0] / cd;
   if (ch > 0.f) s += ws[1] / ch;
@@ -750,33 +761,38 @@ extern "C" int dfmir_masked_l1_bwd(const float* a, const float* b, const unsigne
   DF_LAUNCH_CHECK();
   return 0;
 }
+// floats of `ws` (dfmir_flow_smooth_fwd / _fwd_p): the three sums + one slot per workgroup and axis
+extern "C" long long dfmir_flow_smooth_ws_floats(void) { return FS_PART + 3LL * FS_MAXWG; }
 extern "C" int dfmir_flow_smooth_fwd_p(const float* flow, float* ws, float* out, int B, int C, int D, int H,
                                        int W, int penalty, void* stream) {
   DF_ARG_CHECK(flow && ws && out && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (penalty == 1 || penalty == 2));
   const bool l1 = penalty == 1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = df_zero_async(ws, 8, st);
-  if (e != hipSuccess) return df_set_error((int)e, __FILE__, __LINE__);
   const long long planes = (long long)B * C;
   const long long nrow = planes * D * H;
+  unsigned nwg;                                              // workgroups of the pass = partials the finaliser adds (<= FS_MAXWG)
   if (l1) {
     const int rb = (int)((nrow + 2047) / 2048);
-    flow_smooth_fwd_k<true><<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
+    nwg = (unsigned)((nrow + rb - 1) / rb);
+    flow_smooth_fwd_k<true><<<nwg, 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
   } else if ((W & 3) == 0 && W <= 256 && nrow < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(flow) & 15) == 0) {
     const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);
-    const unsigned grid = 8 * ((df_grid(nrow * tpr, 8 * 1024, 512) + 7) / 8);      // >= 8 rows per thread: few workgroups, few atomics
+    const unsigned grid = 8 * ((df_grid(nrow * tpr, 8 * 1024, 512) + 7) / 8);      // >= 8 rows per thread: few workgroups
+    nwg = grid;
     if (tpr == 16) flow_smooth_fwd_v4_k<16><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
     else if (tpr == 32) flow_smooth_fwd_v4_k<32><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
     else flow_smooth_fwd_v4_k<64><<<grid, 1024, 0, st>>>(flow, ws, planes, D, H, W);
   } else {
     const int rb = (int)((nrow + 2047) / 2048);
-    flow_smooth_fwd_k<false><<<(unsigned)((nrow + rb - 1) / rb), 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
+    nwg = (unsigned)((nrow + rb - 1) / rb);
+    flow_smooth_fwd_k<false><<<nwg, 256, 0, st>>>(flow, ws, planes, D, H, W, rb);
   }
   DF_LAUNCH_CHECK();
+  DF_ARG_CHECK(nwg <= (unsigned)FS_MAXWG);
   const float cd = (float)((double)planes * (D - 1) * H * W), ch = (float)((double)planes * D * (H - 1) * W),
               cw = (float)((double)planes * D * H * (W - 1));
   const float nd = (D > 1) ? 3.f : 2.f;
-  flow_smooth_fin_k<<<1, 1, 0, st>>>(ws, out, cd, ch, cw, nd);
+  flow_smooth_fin_k<<<1, 256, 0, st>>>(ws, out, cd, ch, cw, nd, (int)nwg);
   DF_LAUNCH_CHECK();
   return 0;
 }

@@ -2278,7 +2278,7 @@ class FlowSmoothFn(Function):
         nd = flow.dim() - 2
         B, C = flow.shape[0], flow.shape[1]
         D, H, W = flow.shape[2:] if nd == 3 else (1,) + tuple(flow.shape[2:])
-        ws = torch.empty(8, device=flow.device, dtype=torch.float32)
+        ws = torch.empty(int(lib().dfmir_flow_smooth_ws_floats()), device=flow.device, dtype=torch.float32)
         out = torch.empty((), device=flow.device, dtype=torch.float32)
         if penalty == 2:
             check(lib().dfmir_flow_smooth_fwd(_p(flow), _p(ws), _p(out), B, C, D, H, W, _st()))

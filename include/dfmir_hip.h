@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFMIR_ABI_VERSION 13
+#define DFMIR_ABI_VERSION 14
 
 int dfmir_abi_version(void);
 const char* dfmir_last_error(void);
@@ -539,7 +539,10 @@ int dfmir_masked_l1_bwd(const float* a, const float* b, const unsigned char* mas
                         const float* ws, const float* gout, float* da, float* db, long long n,
                         void* stream);
 /* smooothing_loss (registration_model.py:25-32) / Grad_Loss l2 (util/losses.py:81-130):
- * mean over axes of mean(squared forward difference) (D==1: 2 axes). flow [B,C,D,H,W]. */
+ * mean over axes of mean(squared forward difference) (D==1: 2 axes). flow [B,C,D,H,W].
+ * ws: dfmir_flow_smooth_ws_floats() floats of scratch (need not be zeroed): every workgroup leaves its three partial sums in
+ * its own slots and the finaliser adds them in index order -- the loss is bit-reproducible. */
+long long dfmir_flow_smooth_ws_floats(void);
 int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, int B, int C, int D, int H,
                           int W, void* stream);
 int dfmir_flow_smooth_bwd(const float* flow, const float* gout, float* dflow, int B, int C, int D,

@@ -30,7 +30,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
     h = dfmir_amd.lib()
-    assert h.dfmir_abi_version() == 13
+    assert h.dfmir_abi_version() == 14
     # a bad-argument call must fail loudly without touching a device
     rc = h.dfmir_scale(None, None, 0, 1.0, None)
     assert rc != 0
