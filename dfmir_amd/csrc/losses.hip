@@ -175,6 +175,101 @@ __global__ __launch_bounds__(256) void flow_smooth_bwd_v4_k(const float* __restr
     *reinterpret_cast<float4*>(df + (long long)row * W + 4 * q) = o;
   }
 }
+// The same gradient, MARCHING along z (D > 1).  flow_smooth_bwd_v4_k reads five rows per output row; four of them hit in L2,
+// but every one is a fill of the CU's vector cache, and the kernel ran at the rate of those fills (413 MB for 165 MB of HBM
+// traffic: 0.088 ms; without the neighbour loads: 0.032).  Here a workgroup owns a strip of FS_RY rows of one plane stack and
+// walks a segment of z: a thread keeps its two rows' quads of planes z - 1, z, z + 1 in registers (the z neighbours are its
+// own earlier loads), the y neighbours come from the other waves through LDS, only the two halo rows of the strip are loaded
+// a second time -- 1.25 row fills per output row (x the segment's two halo planes).  Loads are issued two planes ahead.  The
+// expression is flow_smooth_bwd_v4_k's, operand for operand: bit-identical results.
+constexpr int FS_RY = 8;
+struct FsmP { int D, H, W, nstrip, nseg, zlen; long long nitem; float kd, kh, kw; };
+__global__ __launch_bounds__(256) void flow_smooth_bwd_march_k(const float* __restrict__ f, const float* __restrict__ gout,
+                                                               float* __restrict__ df, FsmP k) {
+  typedef float fsv4 __attribute__((ext_vector_type(4)));     // (HIP's float4 struct is rebuilt element by element from a
+  typedef unsigned u32x4_fs __attribute__((ext_vector_type(4))); //  buffer load's result: a copy that waits for the load at once)
+  __shared__ __attribute__((aligned(16))) fsv4 rows[2][FS_RY + 2][64];    // [step parity][strip row + 1][quad]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Wq = k.W >> 2;
+  const float g = gout[0];
+  // item -> (plane stack, z segment, strip): ids with the same residue mod 8 (one XCD) walk a contiguous eighth of the list,
+  // strips fastest (neighbouring strips share their halo rows in one L2)
+  const long long per = (k.nitem + 7) / 8;
+  const long long item = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((long long)(blockIdx.x >> 3) >= per || item >= k.nitem) return;
+  const int strip = (int)(item % k.nstrip);
+  const int seg = (int)((item / k.nstrip) % k.nseg);
+  const long long pc = item / ((long long)k.nstrip * k.nseg);
+  const int y0 = strip * FS_RY, zs = seg * k.zlen, ze = (zs + k.zlen < k.D) ? zs + k.zlen : k.D;
+  const long long HW = (long long)k.H * k.W;
+  const float* fp = f + pc * k.D * HW;
+  float* dp = df + pc * k.D * HW;
+  const bool act = lane < Wq;
+  const int ya = y0 + 2 * wv, yb = ya + 1;                   // this wave's two rows
+  const bool oka = act && ya < k.H, okb = act && yb < k.H;
+  // halo rows of the strip: wave 0 carries row y0 - 1, wave 3 row y0 + FS_RY
+  const int yh = wv == 0 ? y0 - 1 : y0 + FS_RY;
+  const bool okh = act && (wv == 0 || wv == 3) && yh >= 0 && yh < k.H;
+  // every load unconditional, with an out-of-range offset where there is nothing to fetch (a bounds-checked buffer load returns
+  // 0 and moves nothing): under `cond ? *p : 0` each load was a branch with its own s_waitcnt vmcnt(0) -- no prefetch at all
+  const __amdgpu_buffer_rsrc_t f_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fp), 0, (unsigned)(k.D * HW * 4), 0x00020000);
+  auto fsm_ld = [&](int z_, int y_, bool ok_) __attribute__((always_inline)) {
+    const unsigned off = (ok_ && z_ >= 0 && z_ < k.D) ? (unsigned)((z_ * HW + (long long)y_ * k.W + 4 * lane) * 4) : 0x80000000u;
+    return __builtin_bit_cast(fsv4, __builtin_amdgcn_raw_buffer_load_b128(f_src, off, 0, 0));
+  };
+#define FSM_LD(z_, y_, ok_) fsm_ld((z_), (y_), (ok_))
+  // four register sets {row a, row b, halo row} hold planes z - 1, z, z + 1 and the one in flight (z + 2); the plane loop is
+  // unrolled by four so that the rotation is a renaming (a register move would wait for the load it moves), and the steps are
+  // separated by `break` (DESIGN.md hardware fact 11)
+  fsv4 Aa = FSM_LD(zs - 1, ya, oka), Ab = FSM_LD(zs - 1, yb, okb), Ah = fsv4{0.f, 0.f, 0.f, 0.f};
+  fsv4 Ba = FSM_LD(zs, ya, oka), Bb = FSM_LD(zs, yb, okb), Bh = FSM_LD(zs, yh, okh);
+  fsv4 Ca = FSM_LD(zs + 1, ya, oka), Cb = FSM_LD(zs + 1, yb, okb), Ch = FSM_LD(zs + 1, yh, okh);
+  fsv4 Ea, Eb, Eh;
+  // LDS only between the waves: wait for the LDS writes, not for the global loads / stores in flight (__syncthreads() is a
+  // fence over both and drained the prefetch at every plane)
+#define FSM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define FSM_STEP(Ua, Ub, Va, Vb, Vh, Da, Db, Na, Nb, Nh, zz_, par_)                                                     \
+  {                                                                                                                      \
+    const int z = (zz_);                                                                                                 \
+    Na = FSM_LD(z + 2, ya, oka && z + 2 <= ze); Nb = FSM_LD(z + 2, yb, okb && z + 2 <= ze);                              \
+    Nh = FSM_LD(z + 2, yh, okh && z + 2 <= ze);                                                                          \
+    rows[par_][1 + 2 * wv][lane] = Va;                                                                                   \
+    rows[par_][2 + 2 * wv][lane] = Vb;                                                                                   \
+    if (wv == 0) rows[par_][0][lane] = Vh;                                                                               \
+    if (wv == 3) rows[par_][FS_RY + 1][lane] = Vh;                                                                       \
+    FSM_BARRIER();                                           /* (the other parity is rewritten two steps later) */       \
+    const bool hzu = z > 0, hzd = z + 1 < k.D;                                                                           \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                      \
+      const int y = r ? yb : ya;                                                                                         \
+      if (!(r ? okb : oka)) continue;                                                                                    \
+      const fsv4 v = r ? Vb : Va;                                                                                      \
+      const fsv4 zu = hzu ? (r ? Ub : Ua) : v, zd = hzd ? (r ? Db : Da) : v;                                           \
+      const fsv4 yu = y > 0 ? (r ? Va : rows[par_][2 * wv][lane]) : v;                                                 \
+      const fsv4 yd = y + 1 < k.H ? (r ? rows[par_][3 + 2 * wv][lane] : Vb) : v;                                       \
+      const float lsh = __shfl_up(v.w, 1, 64), rsh = __shfl_down(v.x, 1, 64);                                            \
+      const float xl = lane > 0 ? lsh : v.x, xr = lane + 1 < Wq ? rsh : v.w;                                             \
+      fsv4 o;                                                                                                            \
+      o.x = g * (k.kw * ((v.x - xl) - (v.y - v.x)) + k.kh * ((v.x - yu.x) - (yd.x - v.x)) + k.kd * ((v.x - zu.x) - (zd.x - v.x))); \
+      o.y = g * (k.kw * ((v.y - v.x) - (v.z - v.y)) + k.kh * ((v.y - yu.y) - (yd.y - v.y)) + k.kd * ((v.y - zu.y) - (zd.y - v.y))); \
+      o.z = g * (k.kw * ((v.z - v.y) - (v.w - v.z)) + k.kh * ((v.z - yu.z) - (yd.z - v.z)) + k.kd * ((v.z - zu.z) - (zd.z - v.z))); \
+      o.w = g * (k.kw * ((v.w - v.z) - (xr - v.w)) + k.kh * ((v.w - yu.w) - (yd.w - v.w)) + k.kd * ((v.w - zu.w) - (zd.w - v.w))); \
+      *reinterpret_cast<fsv4*>(dp + (long long)z * HW + (long long)y * k.W + 4 * lane) = o;                            \
+    }                                                                                                                    \
+  }
+  (void)Ah;
+  for (int z0 = zs; z0 < ze; z0 += 4) {
+    FSM_STEP(Aa, Ab, Ba, Bb, Bh, Ca, Cb, Ea, Eb, Eh, z0, 0)
+    if (z0 + 1 >= ze) break;
+    FSM_STEP(Ba, Bb, Ca, Cb, Ch, Ea, Eb, Aa, Ab, Ah, z0 + 1, 1)
+    if (z0 + 2 >= ze) break;
+    FSM_STEP(Ca, Cb, Ea, Eb, Eh, Aa, Ab, Ba, Bb, Bh, z0 + 2, 0)
+    if (z0 + 3 >= ze) break;
+    FSM_STEP(Ea, Eb, Aa, Ab, Ah, Ba, Bb, Ca, Cb, Ch, z0 + 3, 1)
+  }
+#undef FSM_STEP
+#undef FSM_BARRIER
+#undef FSM_LD
+}
 __global__ __launch_bounds__(256) void flow_smooth_fin_k(float* ws, float* out, float cd, float ch, float cw, float nd, int nwg) {
   // the partials in a FIXED order (thread t adds slots t, t + 256, ...; the block tree is the same every run): the loss is
   // bit-reproducible, and 512 x 3 same-address atomics at the end of the forward kernel were a third of its 46 us
@@ -800,6 +895,10 @@ extern "C" int dfmir_flow_smooth_fwd(const float* flow, float* ws, float* out, i
                                      int W, void* stream) {
   return dfmir_flow_smooth_fwd_p(flow, ws, out, B, C, D, H, W, 2, stream);
 }
+static bool fs_no_march() {
+  static DfOptFlag o{"DFMIR_SMOOTH_NO_MARCH"};               // A/B: the backward as five row loads per output row
+  return o.get();
+}
 extern "C" int dfmir_flow_smooth_bwd_p(const float* flow, const float* gout, float* dflow, int B, int C, int D,
                                        int H, int W, int penalty, void* stream) {
   DF_ARG_CHECK(flow && gout && dflow && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && (penalty == 1 || penalty == 2));
@@ -817,6 +916,19 @@ extern "C" int dfmir_flow_smooth_bwd_p(const float* flow, const float* gout, flo
     else
       flow_smooth_bwd_k<long long, true><<<df_grid(planes * D * H * W, 256, 4096), 256, 0, (hipStream_t)stream>>>(
           flow, gout, dflow, planes, D, H, W, kd, kh, kw);
+  } else if ((W & 3) == 0 && W <= 256 && D >= 8 && H >= FS_RY && !fs_no_march() && (long long)D * H * W * 4 < 0x7FFFFFFFLL &&
+             ((reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(dflow)) & 15) == 0) {
+    FsmP k{D, H, W, (H + FS_RY - 1) / FS_RY, 1, D, 0, kd, kh, kw};
+    // z segments: enough items for ~4 workgroups per CU, at least 8 planes each (two halo planes per segment are read again)
+    const long long cols = planes * k.nstrip;
+    int nseg = (int)((1024 + cols - 1) / cols);              // (768 ... 1024 workgroups measured best: 0.083 / 0.087 / 0.070 / 0.072 / 0.084 ms at 256 / 512 / 768 / 1024 / 1536)
+    if (nseg > D / 8) nseg = D / 8;
+    if (nseg < 1) nseg = 1;
+    k.zlen = (D + nseg - 1) / nseg;
+    k.nseg = (D + k.zlen - 1) / k.zlen;
+    k.nitem = cols * k.nseg;
+    const unsigned grid = (unsigned)(8 * ((k.nitem + 7) / 8));
+    flow_smooth_bwd_march_k<<<grid, 256, 0, (hipStream_t)stream>>>(flow, gout, dflow, k);
   } else if ((W & 3) == 0 && W <= 256 && planes * D * H < 0x7FFFFFFFLL &&
       ((reinterpret_cast<uintptr_t>(flow) | reinterpret_cast<uintptr_t>(dflow)) & 15) == 0) {
     const int tpr = W <= 64 ? 16 : (W <= 128 ? 32 : 64);

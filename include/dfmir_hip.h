@@ -52,7 +52,7 @@ const char* dfmir_last_error(void);
  *     DFMIR_MARCH_NSEG=n, DFMIR_CS_DEPHASE=n, DFMIR_CONV_W1 (lab builds with -DDFMIR_BUILD_W1 only),
  *     DFMIR_UPWGRAD_DIRECT, DFMIR_UPWGRAD_NO_FUSEB, DFMIR_UPWGRAD_8WAVE, DFMIR_UPWGRAD_NSEG=n (dfmir_conv3d_upwgrad),
  *     DFMIR_NCC_NO_WH_FUSE, DFMIR_CONV3D_NO_WGRAD_MARCH, DFMIR_WGRAD_MARCH_NSEG=n, DFMIR_NO_TINYVOL,
- *     DFMIR_NO_1X1_WGRAD, DFMIR_CONV3D_NO_FLOW_WGRAD, DFMIR_CONV3D_NO_S2, DFMIR_RESIZE_NO_ROWS, DFMIR_NCC_NO_D_FUSE.
+ *     DFMIR_NO_1X1_WGRAD, DFMIR_CONV3D_NO_FLOW_WGRAD, DFMIR_CONV3D_NO_S2, DFMIR_RESIZE_NO_ROWS, DFMIR_NCC_NO_D_FUSE, DFMIR_SMOOTH_NO_MARCH.
  * ---------------------------------------------------------------------------------------- */
 int dfmir_set_option(const char* name, const char* value);
 int dfmir_get_option(const char* name, char* buf, int buf_len);

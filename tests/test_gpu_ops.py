@@ -1188,6 +1188,30 @@ def test_edge_branches_golden(ops, golden):
                   what="%s-negatives dfeat%d" % (name, i))
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 16, 24, 32), (2, 3, 9, 21, 64), (1, 3, 20, 40, 224), (1, 3, 33, 8, 40), (1, 2, 50, 19, 12)],
+                         ids=["16x24x32", "batch2-9x21x64-ragged", "20x40x224", "33x8x40-segments", "50x19x12"])
+def test_flow_smoothness_backward_marching_kernel(ops, shape):
+    """Grad_Loss l2 backward (util/losses.py:81-130) on flow_smooth_bwd_march_k -- a strip of 8 rows marched along z, z
+    neighbours from registers, y neighbours through LDS -- against the five-loads-per-row kernel (DFMIR_SMOOTH_NO_MARCH):
+    BIT-identical (the same expression), ragged strips, several z segments, batch; and against autograd."""
+    from dfmir_amd._lib import set_option
+    flow = C.randn(341, *shape)
+    out = []
+    try:
+        for off in (None, "1"):
+            set_option("DFMIR_SMOOTH_NO_MARCH", off)
+            fg = flow.clone().to(DEV).requires_grad_()
+            (ops.flow_smoothness(fg, 'l2') * 3.0).backward()
+            out.append(fg.grad.clone())
+    finally:
+        set_option("DFMIR_SMOOTH_NO_MARCH", None)
+    assert torch.equal(out[0], out[1]), "marching kernel differs from flow_smooth_bwd_v4_k"
+    fr = flow.double().requires_grad_()
+    dz, dy, dx = fr[:, :, 1:] - fr[:, :, :-1], fr[:, :, :, 1:] - fr[:, :, :, :-1], fr[..., 1:] - fr[..., :-1]
+    (3.0 * ((dz ** 2).mean() + (dy ** 2).mean() + (dx ** 2).mean()) / 3.0).backward()
+    close(out[0], fr.grad.float(), rtol=1e-5, what="d smoothness vs autograd")
+
+
 def test_ncc_fused_box_passes_match_the_separate_ones(ops):
     """NCC[9,9,9] (torchvoxelmorph/losses.py NCC: 5 box-filtered product fields forward, 3 gradient fields backward): the
     launches that fuse the W and H box passes (with the products / with the field evaluation) through one LDS tile against
