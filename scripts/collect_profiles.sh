@@ -75,4 +75,5 @@ for sw in NONE DFMIR_CONV3D_NO_S2 DFMIR_CONV3D_NO_FLOW_MARCH DFMIR_RESIZE_NO_ROW
   env $sw=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pil-workers 0 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=1', '3-D 160x192x224 %.3f ms | 128^3 %.3f ms | 2-D %.2f ms' % (r['also_3d']['ms_per_step'], r['also_3d_128']['ms_per_step'], r['ms_per_step']))"
 done > $O/ab_3d_round6.txt 2>&1
 python scripts/bench_flow_head.py 2>&1 | grep -v amdgpu.ids > $O/bench_flow_head.txt
+for sw in NONE DFMIR_SMOOTH_NO_MARCH NONE DFMIR_SMOOTH_NO_MARCH; do env $sw=1 python scripts/bench_3d.py 2>/dev/null | cut -c1-64 | sed "s/^/$sw  /"; done > $O/ab_smooth.txt; python scripts/bench_flow_smooth.py 2>&1 | tail -n 1 >> $O/ab_smooth.txt; DFMIR_SMOOTH_NO_MARCH=1 python scripts/bench_flow_smooth.py 2>&1 | tail -n 1 | sed 's/^/DFMIR_SMOOTH_NO_MARCH=1: /' >> $O/ab_smooth.txt
 ONLY=160x192 bash scripts/prof_cmd.sh "python $R/scripts/bench_3d.py" "" step3d > $O/pmc_step3d.txt 2>&1; rm -rf $R/gpurun_out/prof_step3d

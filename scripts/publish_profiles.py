@@ -18,7 +18,7 @@ cp = {'bench.json': TAG + '_bench_b16.json', 'bench_eager.json': TAG + '_bench_b
       'ab_staged.txt': TAG + '_ab_staged.txt', 'ab_1x1_wgrad.txt': TAG + '_ab_1x1_wgrad.txt', 'ab_deterministic.txt': TAG + '_ab_deterministic.txt',
       'ab_flow_wgrad.txt': TAG + '_ab_flow_wgrad.txt', 'graph_split_probe.txt': TAG + '_graph_split_probe.txt', 'parity_margins.txt': TAG + '_parity_margins.txt', 'bench_conv1x1.txt': TAG + '_bench_conv1x1.txt',
       'pmc_conv1x1.txt': TAG + '_conv1x1_pmc_raw.txt', 'pmc_flow_wgrad.txt': TAG + '_flow_wgrad_pmc_raw.txt',
-      'ab_3d_round6.txt': TAG + '_ab_3d_round6.txt', 'bench_flow_head.txt': TAG + '_bench_flow_head.txt', 'pmc_step3d.txt': TAG + '_step3d_pmc_raw.txt'}
+      'ab_3d_round6.txt': TAG + '_ab_3d_round6.txt', 'bench_flow_head.txt': TAG + '_bench_flow_head.txt', 'pmc_step3d.txt': TAG + '_step3d_pmc_raw.txt', 'ab_smooth.txt': TAG + '_ab_smooth.txt'}
 def clean(txt):
     txt = txt.replace("(anonymous namespace)::", "")
     return "\n".join(l for l in txt.splitlines() if not re.match(r'^[WEI]\d{8} ', l) and 'amdgpu.ids' not in l and 'UserWarning' not in l and '_warn_once' not in l)
